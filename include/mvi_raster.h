@@ -1,0 +1,130 @@
+/*
+ * mvi_raster.h — C-ABI of the MI355X (gfx950) Gaussian-splat rasterizer-with-depth.
+ *
+ * Drop-in boundary: these entry points are what a binding of the reference's rasterizer plug-in
+ * binds. The reference imports the plug-in as a Python package,
+ *     gs-simp/gaussian_renderer/__init__.py:14
+ *         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+ * and calls it at gs-simp/gaussian_renderer/__init__.py:85-93 (forward; returns color, radii,
+ * depth) and through loss.backward() at gs-simp/train.py:93, gs-simp/inpaint_rec.py:125,
+ * gs-simp/sds_train.py:130 (backward). That package's native module (rasterize_gaussians /
+ * rasterize_gaussians_backward / mark_visible) is what this library replaces; the Python side
+ * that binds it with ctypes is multiview_inpaint_amd/raster/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all arrays are dense, row-major, fp32 unless stated; shapes as in the reference call:
+ *       means3D [P,3], scales [P,3], rotations [P,4] (w,x,y,z), opacities [P], shs [P,M,3],
+ *       colors_precomp [P,3], cov3D_precomp [P,6] (xx,xy,xz,yy,yz,zz),
+ *       viewmatrix/projmatrix [16] in Camera.world_view_transform / full_proj_transform memory
+ *       order (gs-simp/scene/cameras.py:60-62), campos [3], bg [3];
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it. Only
+ *     mvi_raster_forward_geom synchronises it (once, to return num_rendered to the host);
+ *   - the library owns no memory: scratch comes from the caller (sizes from the *_bytes queries),
+ *     and the caller keeps geom/binning/image alive from forward to backward (the reference's
+ *     autograd Function keeps them in ctx);
+ *   - every function returns 0 on success, a negative MVI_E* code otherwise;
+ *     mvi_raster_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef MVI_RASTER_H
+#define MVI_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVI_OK 0
+#define MVI_EINVAL (-1)   /* bad argument combination (mirrors the Python layer's Exception) */
+#define MVI_EHIP (-2)     /* a HIP call or kernel launch failed */
+#define MVI_ENOMEM (-3)   /* a caller-provided scratch buffer is too small */
+
+#define MVI_TILE 16       /* tile edge in pixels; block = MVI_TILE x MVI_TILE threads = 4 wave64 */
+
+typedef struct mvi_raster_settings {
+    int32_t image_height;       /* GaussianRasterizationSettings.image_height */
+    int32_t image_width;        /* .image_width */
+    float tanfovx;              /* .tanfovx */
+    float tanfovy;              /* .tanfovy */
+    float scale_modifier;       /* .scale_modifier */
+    int32_t sh_degree;          /* .sh_degree (active degree 0..3) */
+    int32_t prefiltered;        /* .prefiltered */
+    const float* bg;            /* .bg         device [3]  */
+    const float* viewmatrix;    /* .viewmatrix device [16] */
+    const float* projmatrix;    /* .projmatrix device [16] */
+    const float* campos;        /* .campos     device [3]  */
+} mvi_raster_settings;
+
+/* Scratch sizes. geom: per-Gaussian SoA; image: per-pixel + per-tile; binning: per (tile,Gaussian)
+ * pair, needs num_rendered which mvi_raster_forward_geom returns. */
+size_t mvi_raster_geom_bytes(int32_t P);
+size_t mvi_raster_image_bytes(int32_t image_width, int32_t image_height);
+size_t mvi_raster_binning_bytes(int64_t num_rendered, int32_t image_width, int32_t image_height);
+
+/* Forward, stage 1: per-Gaussian preprocess (cull, cov3D, EWA cov2D, conic, radius, tile rect,
+ * SH colour) + scan of tiles touched. Exactly one of shs | colors_precomp and one of
+ * (scales, rotations) | cov3D_precomp must be non-NULL. M = SH coefficients per channel in shs.
+ * Writes radii [P] int32 and *num_rendered_host. */
+int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, void* geom, size_t geom_bytes,
+                            int32_t* radii, int64_t* num_rendered_host, void* stream);
+
+/* Forward, stage 2: key emission, radix sort by (tile, depth), tile ranges, per-tile
+ * front-to-back compositing. out_color [3,H,W], out_depth [1,H,W] (15.0f where nothing composites,
+ * gs-simp/gen_seq.py:50). */
+int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t num_rendered,
+                              const int32_t* radii, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                              void* image, size_t image_bytes, float* out_color, float* out_depth,
+                              void* stream);
+
+/* Backward. dL_dout_color [3,H,W]. Gradient outputs are overwritten (not accumulated):
+ * dL_dmeans3D [P,3], dL_dmeans2D [P,3] (x,y = NDC-scaled screen gradient, z = 0; consumer
+ * gs-simp/scene/gaussian_model.py:482-484), dL_dopacity [P], and
+ * dL_dshs [P,M,3] | dL_dcolors [P,3], dL_dscales [P,3] + dL_drotations [P,4] | dL_dcov3D [P,6]
+ * (pass NULL for the member of each pair that was not a forward input).
+ * dL_dconic_scratch: [P,4] fp32 scratch. */
+int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t num_rendered,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* scales, const float* rotations, const float* cov3D_precomp,
+                        const int32_t* radii, const void* geom, const void* binning,
+                        const void* image, const float* dL_dout_color, float* dL_dmeans3D,
+                        float* dL_dmeans2D, float* dL_dopacity, float* dL_dshs, float* dL_dcolors,
+                        float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                        float* dL_dconic_scratch, void* stream);
+
+/* visible [P] uint8 = 1 where view-space z > 0.2 (the plug-in's markVisible; unused by the
+ * reference but part of the plug-in surface). */
+int mvi_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                            const float* projmatrix, uint8_t* visible, void* stream);
+
+/* Introspection used by the parity tests: copies of intermediate device arrays' addresses.
+ * Pointers alias the caller's scratch buffers; valid while those are. */
+typedef struct mvi_raster_views {
+    const float* depths;          /* [P] */
+    const float* means2D;         /* [P,2] pixel centres */
+    const float* cov3D;           /* [P,6] */
+    const float* conic_opacity;   /* [P,4] */
+    const float* rgb;             /* [P,3] */
+    const uint32_t* tiles_touched;/* [P] */
+    const uint8_t* clamped;       /* [P,3] */
+    const uint64_t* keys_sorted;  /* [D] tile<<32 | depth bits */
+    const uint32_t* point_list;   /* [D] Gaussian index per sorted pair */
+    const uint32_t* ranges;       /* [tiles,2] */
+    const float* final_T;         /* [H,W] */
+    const uint32_t* n_contrib;    /* [H,W] */
+} mvi_raster_views;
+int mvi_raster_get_views(int32_t P, int64_t num_rendered, int32_t image_width, int32_t image_height,
+                         const void* geom, const void* binning, const void* image,
+                         mvi_raster_views* out);
+
+const char* mvi_raster_last_error(void);
+const char* mvi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVI_RASTER_H */

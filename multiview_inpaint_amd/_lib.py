@@ -1,0 +1,95 @@
+"""ctypes binding of the C-ABI HIP library (include/mvi_raster.h, include/mvi_unet_ops.h).
+
+There is NO fallback: if libmvi_hip.so is missing or does not export a declared symbol this
+module raises, and every op of the package fails with it."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvi_hip.so")
+INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
+
+
+class RasterSettings(C.Structure):
+    """struct mvi_raster_settings (include/mvi_raster.h)"""
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("prefiltered", C.c_int32),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+    ]
+
+
+class RasterViews(C.Structure):
+    """struct mvi_raster_views"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "depths", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "clamped",
+        "keys_sorted", "point_list", "ranges", "final_T", "n_contrib")]
+
+
+def declared_symbols():
+    """Every function name declared in include/*.h."""
+    names = []
+    for fn in sorted(os.listdir(INCLUDE_DIR)):
+        if fn.endswith(".h"):
+            src = open(os.path.join(INCLUDE_DIR, fn)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names += re.findall(r"\b(mvi_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m multiview_inpaint_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for this path.")
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} does not export {missing}; rebuild it")
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    L.mvi_raster_last_error.restype = C.c_char_p
+    L.mvi_version.restype = C.c_char_p
+    L.mvi_raster_geom_bytes.restype = sz
+    L.mvi_raster_geom_bytes.argtypes = [i32]
+    L.mvi_raster_image_bytes.restype = sz
+    L.mvi_raster_image_bytes.argtypes = [i32, i32]
+    L.mvi_raster_binning_bytes.restype = sz
+    L.mvi_raster_binning_bytes.argtypes = [i64, i32, i32]
+    L.mvi_raster_forward_geom.restype = C.c_int
+    L.mvi_raster_forward_geom.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 7 + [vp, sz, vp, C.POINTER(i64), vp]
+    L.mvi_raster_forward_render.restype = C.c_int
+    L.mvi_raster_forward_render.argtypes = [C.POINTER(RasterSettings), i32, i64, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp]
+    L.mvi_raster_backward.restype = C.c_int
+    L.mvi_raster_backward.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 21
+    L.mvi_raster_mark_visible.restype = C.c_int
+    L.mvi_raster_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.mvi_raster_get_views.restype = C.c_int
+    L.mvi_raster_get_views.argtypes = [i32, i64, i32, i32, vp, vp, vp, C.POINTER(RasterViews)]
+    _bind_unet_ops(L)
+    _lib = L
+    return L
+
+
+def _bind_unet_ops(L):
+    # filled in by the UNet-ops section once include/mvi_unet_ops.h exists
+    try:
+        from . import _unet_ops_bind
+    except ImportError:
+        return
+    _unet_ops_bind.bind(L)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mvi_raster_last_error().decode(errors="replace")
+        if rc == -1:
+            raise Exception(msg)            # argument-combination errors: plain Exception like the plug-in
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")

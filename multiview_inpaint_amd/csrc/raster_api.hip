@@ -1,0 +1,180 @@
+// C-ABI of the rasterizer (include/mvi_raster.h). Host-side only: argument checks, scratch carving,
+// kernel sequencing on the caller's stream. Mirrors the error behaviour of the plug-in the
+// reference imports (gs-simp/gaussian_renderer/__init__.py:14): argument-combination errors are
+// reported, never silently repaired.
+#include <cstdio>
+#include <cstring>
+
+#include "raster_common.h"
+
+namespace mvi {
+int launch_scan_block_sums(GeomView g, int P, hipStream_t st);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+static int hip_fail(const char* where, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return MVI_EHIP;
+}
+
+static int make_frame(const mvi_raster_settings* s, int P, int M, mvi::Frame& f) {
+    if (!s) return fail(MVI_EINVAL, "settings is NULL%s");
+    if (s->image_width < 0 || s->image_height < 0 || P < 0)
+        return fail(MVI_EINVAL, "negative size%s (P=%lld, W=%lld)", "", P, s->image_width);
+    if (s->sh_degree < 0 || s->sh_degree > 3) return fail(MVI_EINVAL, "sh_degree must be 0..3%s (got %lld)", "", s->sh_degree);
+    if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
+        return fail(MVI_EINVAL, "bg/viewmatrix/projmatrix/campos must be device pointers%s");
+    f.P = P; f.M = M; f.deg = s->sh_degree; f.W = s->image_width; f.H = s->image_height;
+    f.gx = (f.W + mvi::kTile - 1) / mvi::kTile;
+    f.gy = (f.H + mvi::kTile - 1) / mvi::kTile;
+    f.tanfovx = s->tanfovx; f.tanfovy = s->tanfovy;
+    f.fx = (float)f.W / (2.0f * s->tanfovx);
+    f.fy = (float)f.H / (2.0f * s->tanfovy);
+    f.scale_modifier = s->scale_modifier;
+    f.view = s->viewmatrix; f.proj = s->projmatrix; f.campos = s->campos; f.bg = s->bg;
+    return MVI_OK;
+}
+
+extern "C" {
+
+const char* mvi_raster_last_error(void) { return g_err; }
+const char* mvi_version(void) { return "multiview_inpaint_amd 0.1.0 (gfx950)"; }
+
+size_t mvi_raster_geom_bytes(int32_t P) { return mvi::carve_geom(nullptr, P).bytes; }
+size_t mvi_raster_image_bytes(int32_t W, int32_t H) { return mvi::carve_image(nullptr, W, H).bytes; }
+size_t mvi_raster_binning_bytes(int64_t D, int32_t W, int32_t H) { return mvi::carve_binning(nullptr, D, W, H).bytes; }
+
+int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* opacities,
+                            const float* scales, const float* rotations, const float* cov3D_precomp,
+                            void* geom, size_t geom_bytes, int32_t* radii, int64_t* num_rendered_host,
+                            void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, M, f)) return rc;
+    if (!num_rendered_host) return fail(MVI_EINVAL, "num_rendered_host is NULL%s");
+    *num_rendered_host = 0;
+    if (P == 0) return MVI_OK;
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(MVI_EINVAL, "Please provide excatly one of either SHs or precomputed colors!%s");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(MVI_EINVAL, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!%s");
+    if (!means3D || !opacities || !geom || !radii) return fail(MVI_EINVAL, "NULL means3D/opacities/geom/radii%s");
+    if (shs && M < (s->sh_degree + 1) * (s->sh_degree + 1))
+        return fail(MVI_EINVAL, "shs holds %s%lld coefficients per channel, sh_degree needs %lld", "", M,
+                    (s->sh_degree + 1) * (s->sh_degree + 1));
+    mvi::GeomView g = mvi::carve_geom(geom, P);
+    if (geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s: %lld < %lld", "", (long long)geom_bytes, (long long)g.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mvi::launch_preprocess_forward(f, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                                cov3D_precomp, g, radii, st))
+        return hip_fail("preprocess_forward", hipGetLastError());
+    if (int rc = mvi::launch_scan_block_sums(g, P, st)) return hip_fail("scan_block_sums", hipGetLastError());
+    int nblk = (P + mvi::kBlock - 1) / mvi::kBlock;
+    uint32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, g.block_offsets + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_fail("copy num_rendered", e);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail("forward_geom sync", e);
+    *num_rendered_host = (int64_t)total;
+    return MVI_OK;
+}
+
+int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii,
+                              void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
+                              size_t image_bytes, float* out_color, float* out_depth, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, 0, f)) return rc;
+    if (!image || !out_color || !out_depth) return fail(MVI_EINVAL, "NULL image/out_color/out_depth%s");
+    if (D < 0 || D > 0xFFFFFFFFll) return fail(MVI_EINVAL, "num_rendered out of range%s: %lld", "", D);
+    if (D > 0 && (!geom || !binning || !radii)) return fail(MVI_EINVAL, "NULL geom/binning/radii with num_rendered > 0%s");
+    mvi::GeomView g = mvi::carve_geom(geom, P);
+    mvi::ImageView im = mvi::carve_image(image, f.W, f.H);
+    mvi::BinningView b = mvi::carve_binning(binning, D, f.W, f.H);
+    if (image_bytes < im.bytes) return fail(MVI_ENOMEM, "image scratch too small%s: %lld < %lld", "", (long long)image_bytes, (long long)im.bytes);
+    if (D > 0 && binning_bytes < b.bytes) return fail(MVI_ENOMEM, "binning scratch too small%s: %lld < %lld", "", (long long)binning_bytes, (long long)b.bytes);
+    if (D > 0 && geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mvi::launch_binning(f, g, radii, b, im, D, st)) return hip_fail("binning", hipGetLastError());
+    if (int rc = mvi::launch_render_forward(f, g, b, im, D, out_color, out_depth, st))
+        return hip_fail("render_forward", hipGetLastError());
+    return MVI_OK;
+}
+
+int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t D, const float* means3D,
+                        const float* shs, const float* colors_precomp, const float* scales,
+                        const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                        const void* geom, const void* binning, const void* image,
+                        const float* dL_dout_color, float* dL_dmeans3D, float* dL_dmeans2D,
+                        float* dL_dopacity, float* dL_dshs, float* dL_dcolors, float* dL_dscales,
+                        float* dL_drotations, float* dL_dcov3D, float* dL_dconic_scratch, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, M, f)) return rc;
+    if (P == 0) return MVI_OK;
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(MVI_EINVAL, "Please provide excatly one of either SHs or precomputed colors!%s");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(MVI_EINVAL, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!%s");
+    if (!means3D || !radii || !geom || !image || !dL_dout_color || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity ||
+        !dL_dcolors || !dL_dconic_scratch)
+        return fail(MVI_EINVAL, "NULL required pointer in backward%s");
+    if (shs && !dL_dshs) return fail(MVI_EINVAL, "dL_dshs is NULL but shs was a forward input%s");
+    if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
+        return fail(MVI_EINVAL, "missing covariance gradient output%s");
+    if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
+    mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
+    mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), f.W, f.H);
+    mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, f.W, f.H);
+    hipStream_t st = (hipStream_t)stream;
+    float4* dconic_op = reinterpret_cast<float4*>(dL_dconic_scratch);
+    hipError_t e;
+    if ((e = hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
+    if ((e = hipMemsetAsync(dconic_op, 0, sizeof(float) * 4 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
+    if ((e = hipMemsetAsync(dL_dcolors, 0, sizeof(float) * 3 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
+    if (int rc = mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, dL_dmeans2D, dconic_op, dL_dcolors, st))
+        return hip_fail("render_backward", hipGetLastError());
+    if (int rc = mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g,
+                                                 dL_dmeans2D, dconic_op, dL_dcolors, dL_dmeans3D, dL_dshs, dL_dcov3D,
+                                                 dL_dscales, dL_drotations, st))
+        return hip_fail("preprocess_backward", hipGetLastError());
+    // dL/dopacity is the .w lane of the float4 scratch
+    e = hipMemcpy2DAsync(dL_dopacity, sizeof(float), reinterpret_cast<const float*>(dconic_op) + 3, sizeof(float4),
+                         sizeof(float), (size_t)P, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return hip_fail("copy dL_dopacity", e);
+    return MVI_OK;
+}
+
+int mvi_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                            uint8_t* visible, void* stream) {
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !visible))) return fail(MVI_EINVAL, "bad arguments to mark_visible%s");
+    if (mvi::launch_mark_visible(P, means3D, viewmatrix, visible, (hipStream_t)stream)) return hip_fail("mark_visible", hipGetLastError());
+    return MVI_OK;
+}
+
+int mvi_raster_get_views(int32_t P, int64_t D, int32_t W, int32_t H, const void* geom, const void* binning,
+                         const void* image, mvi_raster_views* out) {
+    if (!out) return fail(MVI_EINVAL, "views is NULL%s");
+    memset(out, 0, sizeof(*out));
+    if (geom) {
+        mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
+        out->depths = g.depths; out->means2D = reinterpret_cast<const float*>(g.xy); out->cov3D = g.cov3D;
+        out->conic_opacity = reinterpret_cast<const float*>(g.conic_opacity); out->rgb = g.rgb;
+        out->tiles_touched = g.tiles_touched; out->clamped = g.clamped;
+    }
+    if (binning) {
+        mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, W, H);
+        int fin = b.passes & 1;
+        out->keys_sorted = b.keys[fin]; out->point_list = b.vals[fin];
+    }
+    if (image) {
+        mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), W, H);
+        out->ranges = im.ranges; out->final_T = im.final_T; out->n_contrib = im.n_contrib;
+    }
+    return MVI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+// Tile binning for gfx950: scan of tiles touched, (tile|depth) key emission, stable LSD radix sort
+// of (u64 key, u32 value) pairs, per-tile ranges. Replaces the plug-in's
+// InclusiveSum / duplicateWithKeys / DeviceRadixSort::SortPairs / identifyTileRanges stages behind
+// gs-simp/gaussian_renderer/__init__.py:85-93. Keys and sorted order are integer data and must be
+// bit-exact against the oracle.
+#include "raster_common.h"
+
+namespace mvi {
+
+// ---- exclusive scan of the per-block sums the preprocess kernel produced (one block) ----------
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ sums,
+                                                               uint32_t* __restrict__ offsets, int n) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        uint32_t v = i < n ? sums[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+        uint32_t carry = s_carry;
+        if (i < n) offsets[i] = carry + wave_off + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wave_off + inc;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[n] = s_carry;
+}
+
+// ---- key emission: block = 256 Gaussians; output slots of the block are written coalesced -----
+__global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(Frame f, GeomView g,
+                                                                const int32_t* __restrict__ radii,
+                                                                uint64_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ vals) {
+    __shared__ uint32_t s_off[kBlock];     // exclusive offsets inside the block
+    __shared__ uint32_t s_wave[4];
+    __shared__ int s_x0[kBlock], s_y0[kBlock], s_w[kBlock];
+    __shared__ uint32_t s_depth[kBlock];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    uint32_t t = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (i < f.P && radii[i] > 0) {
+        float2 p = g.xy[i];
+        tile_rect(p.x, p.y, radii[i], f.gx, f.gy, x0, y0, x1, y1);
+        t = (uint32_t)((x1 - x0) * (y1 - y0));
+        s_depth[tid] = __float_as_uint(g.depths[i]);
+    }
+    s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
+    uint32_t inc = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    s_off[tid] = wave_off + inc - t;
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    const uint32_t base = g.block_offsets[blockIdx.x];
+    for (uint32_t j = tid; j < total; j += kBlock) {
+        // largest gi with s_off[gi] <= j (that Gaussian has tiles_touched > 0 by construction)
+        int lo = 0, hi = kBlock - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        uint32_t k = j - s_off[lo];
+        int w = s_w[lo];
+        int y = s_y0[lo] + (int)(k / (uint32_t)w), x = s_x0[lo] + (int)(k % (uint32_t)w);
+        uint64_t key = ((uint64_t)(uint32_t)(y * f.gx + x) << 32) | (uint64_t)s_depth[lo];
+        keys[base + j] = key;
+        vals[base + j] = (uint32_t)(blockIdx.x * kBlock + lo);
+    }
+}
+
+// ---- radix sort: 8-bit LSD passes, three kernels per pass -------------------------------------
+// count: per-block digit histogram, stored digit-major: block_hist[d * nblk + b]
+__global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint64_t* __restrict__ keys, int64_t D,
+                                                             int shift, uint32_t mask,
+                                                             uint32_t* __restrict__ block_hist, int nblk) {
+    __shared__ uint32_t s_hist[256];
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+        int64_t idx = base + it * kBlock + tid;
+        if (idx < D) atomicAdd(&s_hist[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    block_hist[(size_t)tid * nblk + blockIdx.x] = s_hist[tid];
+}
+
+// scan: block d turns row d of block_hist into exclusive offsets inside digit d; digit_tot[d] = sum
+__global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restrict__ block_hist, int nblk,
+                                                               uint32_t* __restrict__ digit_tot) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    uint32_t* row = block_hist + (size_t)blockIdx.x * nblk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        int i = base + tid;
+        uint32_t v = i < nblk ? row[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+        uint32_t carry = s_carry;
+        if (i < nblk) row[i] = carry + wave_off + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wave_off + inc;
+        __syncthreads();
+    }
+    if (tid == 0) digit_tot[blockIdx.x] = s_carry;
+}
+
+// scatter: stable. Wave w of a block owns 512 consecutive keys, item `it` of lane l is key
+// w*512 + it*64 + l, so ranking items in `it` order inside a wave and waves in order keeps the
+// input order among equal digits.
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask,
+    const uint32_t* __restrict__ block_hist, int nblk, const uint32_t* __restrict__ digit_tot) {
+    __shared__ uint32_t s_wave_hist[4][256];
+    __shared__ uint32_t s_digit_base[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0;
+    // exclusive scan of the 256 digit totals -> start of each digit in the output
+    {
+        uint32_t v = digit_tot[tid];
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        __shared__ uint32_t s_w4[4];
+        if (lane == 63) s_w4[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += s_w4[w];
+        s_digit_base[tid] = wave_off + inc - v + block_hist[(size_t)tid * nblk + blockIdx.x];
+    }
+    __syncthreads();
+
+    const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * (kSortItems * 64);
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems], rank[kSortItems], dig[kSortItems];
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+        int64_t idx = base + it * 64 + lane;
+        bool valid = idx < D;
+        key[it] = valid ? keys_in[idx] : 0ull;
+        val[it] = valid ? vals_in[idx] : 0u;
+        uint32_t d = (uint32_t)(key[it] >> shift) & mask;
+        dig[it] = valid ? d : 0xFFFFFFFFu;
+        // lanes of this wave holding the same digit
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bit = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bit : ~bit;
+        }
+        uint32_t before = (uint32_t)__popcll(peers & lanemask_lt);
+        uint32_t prev = 0;
+        if (valid) {
+            prev = s_wave_hist[wave][d];
+            // one writer per digit: the highest peer lane stores the new running count
+            if ((peers >> lane) == 1ull) s_wave_hist[wave][d] = prev + (uint32_t)__popcll(peers);
+        }
+        rank[it] = prev + before;
+    }
+    __syncthreads();
+    // offset of each wave inside the block for every digit
+    {
+        uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid], c2 = s_wave_hist[2][tid];
+        __syncthreads();
+        s_wave_hist[0][tid] = 0;
+        s_wave_hist[1][tid] = c0;
+        s_wave_hist[2][tid] = c0 + c1;
+        s_wave_hist[3][tid] = c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+        if (dig[it] != 0xFFFFFFFFu) {
+            uint32_t d = dig[it];
+            uint32_t dst = s_digit_base[d] + s_wave_hist[wave][d] + rank[it];
+            keys_out[dst] = key[it];
+            vals_out[dst] = val[it];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint64_t* __restrict__ keys, int64_t D,
+                                                             uint32_t* __restrict__ ranges) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= D) return;
+    uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[2 * t] = 0;
+    else {
+        uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        if (t != tp) { ranges[2 * tp + 1] = (uint32_t)i; ranges[2 * t] = (uint32_t)i; }
+    }
+    if (i == D - 1) ranges[2 * t + 1] = (uint32_t)D;
+}
+
+int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
+    int nblk = (P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_offsets, nblk);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+// After this call the sorted pairs are in b.keys[b.passes & 1], b.vals[b.passes & 1].
+int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
+                   int64_t D, hipStream_t st) {
+    size_t tiles = (size_t)f.gx * f.gy;
+    if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
+    if (D <= 0 || f.P <= 0) return 0;
+    int nblk = (f.P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, radii, b.keys[0], b.vals[0]);
+    int cur = 0;
+    for (int p = 0; p < b.passes; ++p) {
+        int shift = 8 * p;
+        int nb = b.key_bits - shift < 8 ? b.key_bits - shift : 8;
+        uint32_t mask = (1u << nb) - 1u;
+        hipLaunchKernelGGL(radix_count_kernel, dim3(b.nsort), dim3(kBlock), 0, st, b.keys[cur], D, shift, mask,
+                           b.block_hist, b.nsort);
+        hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, b.block_hist, b.nsort, b.digit_tot);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(b.nsort), dim3(kBlock), 0, st, b.keys[cur], b.vals[cur],
+                           b.keys[cur ^ 1], b.vals[cur ^ 1], D, shift, mask, b.block_hist, b.nsort, b.digit_tot);
+        cur ^= 1;
+    }
+    int nrb = (int)((D + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(nrb), dim3(kBlock), 0, st, b.keys[cur], D, im.ranges);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+}  // namespace mvi

@@ -1,0 +1,186 @@
+// Shared declarations of the gfx950 rasterizer kernels (device helpers + scratch layouts).
+// Plug-in being replaced: diff_gaussian_rasterization, called at
+// gs-simp/gaussian_renderer/__init__.py:85-93. Written for CDNA4 only (wave64, 256-thread blocks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/mvi_raster.h"
+
+namespace mvi {
+
+constexpr int kTile = MVI_TILE;            // 16x16 pixels per tile, one 256-thread block (4 wave64)
+constexpr int kBlock = 256;
+constexpr float kNearZ = 0.2f;             // view-space z cull
+constexpr float kLowpass = 0.3f;           // cov2D diagonal dilation
+constexpr float kFrustumClamp = 1.3f;
+constexpr float kLambdaFloor = 0.1f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTEps = 0.0001f;
+constexpr float kDepthSentinel = 15.0f;    // gs-simp/gen_seq.py:50
+
+constexpr int kSortTile = 2048;            // keys per block in one radix pass (256 threads x 8)
+constexpr int kSortItems = 8;
+
+// Per-call constants every kernel needs, passed by value (lives in SGPRs).
+struct Frame {
+    int P, M, deg, W, H, gx, gy;
+    float tanfovx, tanfovy, fx, fy, scale_modifier;
+    const float* view;   // [16] device
+    const float* proj;   // [16] device
+    const float* campos; // [3]  device
+    const float* bg;     // [3]  device
+};
+
+// ---- scratch layouts (all offsets 256-B aligned) ---------------------------------------------
+struct GeomView {
+    float* depths;            // [P]
+    float2* xy;               // [P]
+    float* cov3D;             // [6P]
+    float4* conic_opacity;    // [P]
+    float* rgb;               // [3P]
+    uint32_t* tiles_touched;  // [P]
+    uint8_t* clamped;         // [3P]
+    uint32_t* block_sums;     // [nblk]   tiles touched per 256-Gaussian block
+    uint32_t* block_offsets;  // [nblk+1] exclusive scan of block_sums; [nblk] = D
+    size_t bytes;
+};
+struct ImageView {
+    uint32_t* ranges;     // [2*tiles]
+    float* final_T;       // [H*W]
+    uint32_t* n_contrib;  // [H*W]
+    size_t bytes;
+};
+struct BinningView {
+    uint64_t* keys[2];    // ping-pong [D]
+    uint32_t* vals[2];    // ping-pong [D]
+    uint32_t* block_hist; // [256 * nsort]  digit-major per-block digit counts / offsets
+    uint32_t* digit_tot;  // [256]
+    int nsort;            // blocks per radix pass
+    int passes;           // 8-bit passes over 32 + tile bits
+    int key_bits;
+    size_t bytes;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline GeomView carve_geom(void* base, int P) {
+    GeomView g;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t n = (size_t)(P > 0 ? P : 1);
+    int nblk = (int)((n + kBlock - 1) / kBlock);
+    auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
+    g.depths = (float*)take(4 * n);
+    g.xy = (float2*)take(8 * n);
+    g.cov3D = (float*)take(24 * n);
+    g.conic_opacity = (float4*)take(16 * n);
+    g.rgb = (float*)take(12 * n);
+    g.tiles_touched = (uint32_t*)take(4 * n);
+    g.clamped = (uint8_t*)take(3 * n);
+    g.block_sums = (uint32_t*)take(4 * (size_t)nblk);
+    g.block_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
+    g.bytes = o;
+    return g;
+}
+inline ImageView carve_image(void* base, int W, int H) {
+    ImageView v;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t tiles = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    size_t px = (size_t)W * H;
+    auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
+    v.ranges = (uint32_t*)take(8 * (tiles ? tiles : 1));
+    v.final_T = (float*)take(4 * (px ? px : 1));
+    v.n_contrib = (uint32_t*)take(4 * (px ? px : 1));
+    v.bytes = o;
+    return v;
+}
+inline int tile_bits(int W, int H) {
+    unsigned tiles = (unsigned)(((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile));
+    int b = 0;
+    while ((1u << b) < tiles && b < 31) ++b;
+    return b > 0 ? b : 1;
+}
+inline BinningView carve_binning(void* base, int64_t D, int W, int H) {
+    BinningView v;
+    char* p = (char*)base;
+    size_t o = 0;
+    size_t n = (size_t)(D > 0 ? D : 1);
+    v.nsort = (int)((n + kSortTile - 1) / kSortTile);
+    v.key_bits = 32 + tile_bits(W, H);
+    v.passes = (v.key_bits + 7) / 8;
+    auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
+    v.keys[0] = (uint64_t*)take(8 * n);
+    v.keys[1] = (uint64_t*)take(8 * n);
+    v.vals[0] = (uint32_t*)take(4 * n);
+    v.vals[1] = (uint32_t*)take(4 * n);
+    v.block_hist = (uint32_t*)take(4 * 256 * (size_t)v.nsort);
+    v.digit_tot = (uint32_t*)take(4 * 256);
+    v.bytes = o;
+    return v;
+}
+
+// ---- device helpers ---------------------------------------------------------------------------
+// Arithmetic contract shared with oracle/raster_oracle.c: explicit fma chains, no other fusion in
+// the functions that feed integer outputs (those are compiled under `#pragma clang fp contract(off)`).
+__device__ __forceinline__ float affine3(float m0, float m1, float m2, float m3, float x, float y, float z) {
+    return __builtin_fmaf(m2, z, __builtin_fmaf(m1, y, __builtin_fmaf(m0, x, m3)));
+}
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, a0 * b0));
+}
+
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0,
+                                          int& y0, int& x1, int& y1) {
+#pragma clang fp contract(off)
+    x0 = min(gx, max(0, (int)((px - (float)radius) / (float)kTile)));
+    y0 = min(gy, max(0, (int)((py - (float)radius) / (float)kTile)));
+    x1 = min(gx, max(0, (int)((px + (float)radius + (float)(kTile - 1)) / (float)kTile)));
+    y1 = min(gy, max(0, (int)((py + (float)radius + (float)(kTile - 1)) / (float)kTile)));
+}
+
+// Sum over the 64 lanes of a wave with DPP moves; the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// launchers (defined in the .hip files; all enqueue on `st`, none synchronise)
+int launch_preprocess_forward(const Frame& f, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* opacities, const float* scales,
+                              const float* rotations, const float* cov3D_precomp, GeomView g,
+                              int32_t* radii, hipStream_t st);
+int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
+                               const float* scales, const float* rotations, const float* cov3D_precomp,
+                               const int32_t* radii, GeomView g, const float* dL_dmean2D_ndc,
+                               const float4* dL_dconic_op, const float* dL_dcolor, float* dL_dmeans3D,
+                               float* dL_dshs, float* dL_dcov3D, float* dL_dscales, float* dL_drots,
+                               hipStream_t st);
+int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
+                   int64_t D, hipStream_t st);
+int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
+                          float* out_color, float* out_depth, hipStream_t st);
+int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
+                           const float* dL_dpix, float* dL_dmean2D, float4* dL_dconic_op,
+                           float* dL_dcolor, hipStream_t st);
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st);
+
+}  // namespace mvi

@@ -1,0 +1,437 @@
+// Per-Gaussian preprocess, forward and backward, for gfx950.
+// Replaces the plug-in's preprocess stages behind gs-simp/gaussian_renderer/__init__.py:85-93:
+// frustum cull, cov3D from scale/quaternion (gs-simp/utils/general_utils.py:66-112 conventions),
+// EWA cov2D, conic, 3-sigma radius, tile rectangle, SH colour (gs-simp/utils/sh_utils.py:57-112).
+// One thread per Gaussian, 256-thread blocks; each block also emits the sum of tiles touched so
+// the binning stage only has to scan ceil(P/256) block sums.
+#include "raster_common.h"
+
+namespace mvi {
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b) {
+#pragma clang fp contract(off)
+    b[0] = SH_C0;
+    if (deg > 0) {
+        b[1] = -SH_C1 * y;
+        b[2] = SH_C1 * z;
+        b[3] = -SH_C1 * x;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy;
+            b[5] = SH_C2[1] * yz;
+            b[6] = SH_C2[2] * (2.0f * zz - xx - yy);
+            b[7] = SH_C2[3] * xz;
+            b[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = SH_C3[0] * y * (3.0f * xx - yy);
+                b[10] = SH_C3[1] * xy * z;
+                b[11] = SH_C3[2] * y * (4.0f * zz - xx - yy);
+                b[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                b[13] = SH_C3[4] * x * (4.0f * zz - xx - yy);
+                b[14] = SH_C3[5] * z * (xx - yy);
+                b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void quat_to_rot(float r, float x, float y, float z, float R[3][3]) {
+#pragma clang fp contract(off)
+    R[0][0] = __builtin_fmaf(-2.0f, __builtin_fmaf(y, y, z * z), 1.0f);
+    R[0][1] = 2.0f * __builtin_fmaf(x, y, -(r * z));
+    R[0][2] = 2.0f * __builtin_fmaf(x, z, r * y);
+    R[1][0] = 2.0f * __builtin_fmaf(x, y, r * z);
+    R[1][1] = __builtin_fmaf(-2.0f, __builtin_fmaf(x, x, z * z), 1.0f);
+    R[1][2] = 2.0f * __builtin_fmaf(y, z, -(r * x));
+    R[2][0] = 2.0f * __builtin_fmaf(x, z, -(r * y));
+    R[2][1] = 2.0f * __builtin_fmaf(y, z, r * x);
+    R[2][2] = __builtin_fmaf(-2.0f, __builtin_fmaf(x, x, y * y), 1.0f);
+}
+
+struct Ewa {
+    float Tm[2][3];
+    float tx, ty, tz, xmul, ymul;
+};
+
+__device__ __forceinline__ void ewa_setup(const Frame& f, const float* V, float vx, float vy, float vz, Ewa& e) {
+#pragma clang fp contract(off)
+    float limx = kFrustumClamp * f.tanfovx, limy = kFrustumClamp * f.tanfovy;
+    float txtz = vx / vz, tytz = vy / vz;
+    e.xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    e.ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    e.tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+    e.ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+    e.tz = vz;
+    float J00 = f.fx / vz, J02 = -(f.fx * e.tx) / (vz * vz);
+    float J11 = f.fy / vz, J12 = -(f.fy * e.ty) / (vz * vz);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        e.Tm[0][j] = __builtin_fmaf(J02, V[2 + 4 * j], J00 * V[0 + 4 * j]);
+        e.Tm[1][j] = __builtin_fmaf(J12, V[2 + 4 * j], J11 * V[1 + 4 * j]);
+    }
+}
+
+__device__ __forceinline__ void cov2d_from_cov3d(const Ewa& e, const float* c6, float& a, float& b, float& c) {
+#pragma clang fp contract(off)
+    float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float t0[3], t1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t0[j] = dot3(e.Tm[0][0], e.Tm[0][1], e.Tm[0][2], S[0][j], S[1][j], S[2][j]);
+        t1[j] = dot3(e.Tm[1][0], e.Tm[1][1], e.Tm[1][2], S[0][j], S[1][j], S[2][j]);
+    }
+    a = dot3(t0[0], t0[1], t0[2], e.Tm[0][0], e.Tm[0][1], e.Tm[0][2]) + kLowpass;
+    b = dot3(t0[0], t0[1], t0[2], e.Tm[1][0], e.Tm[1][1], e.Tm[1][2]);
+    c = dot3(t1[0], t1[1], t1[2], e.Tm[1][0], e.Tm[1][1], e.Tm[1][2]) + kLowpass;
+}
+
+__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
+    Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii) {
+#pragma clang fp contract(off)
+    __shared__ uint32_t s_sum;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = f.view[k]; PM[k] = f.proj[k]; }
+
+    uint32_t touched = 0;
+    int rad_out = 0;
+    if (i < f.P) {
+        do {
+            float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+            float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
+            float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
+            float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
+            if (vz <= kNearZ) break;
+            float hx = affine3(PM[0], PM[4], PM[8], PM[12], px, py, pz);
+            float hy = affine3(PM[1], PM[5], PM[9], PM[13], px, py, pz);
+            float hw = affine3(PM[3], PM[7], PM[11], PM[15], px, py, pz);
+            float pw = 1.0f / (hw + 0.0000001f);
+            float ndx = hx * pw, ndy = hy * pw;
+
+            float c6[6];
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+            } else {
+                float R[3][3], Mx[3][3];
+                const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * i);
+                quat_to_rot(q.x, q.y, q.z, q.w, R);
+                float s[3] = {f.scale_modifier * scales[3 * i], f.scale_modifier * scales[3 * i + 1],
+                              f.scale_modifier * scales[3 * i + 2]};
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) Mx[r][j] = R[r][j] * s[j];
+                c6[0] = dot3(Mx[0][0], Mx[0][1], Mx[0][2], Mx[0][0], Mx[0][1], Mx[0][2]);
+                c6[1] = dot3(Mx[0][0], Mx[0][1], Mx[0][2], Mx[1][0], Mx[1][1], Mx[1][2]);
+                c6[2] = dot3(Mx[0][0], Mx[0][1], Mx[0][2], Mx[2][0], Mx[2][1], Mx[2][2]);
+                c6[3] = dot3(Mx[1][0], Mx[1][1], Mx[1][2], Mx[1][0], Mx[1][1], Mx[1][2]);
+                c6[4] = dot3(Mx[1][0], Mx[1][1], Mx[1][2], Mx[2][0], Mx[2][1], Mx[2][2]);
+                c6[5] = dot3(Mx[2][0], Mx[2][1], Mx[2][2], Mx[2][0], Mx[2][1], Mx[2][2]);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g.cov3D[6 * (size_t)i + k] = c6[k];
+
+            Ewa e;
+            ewa_setup(f, V, vx, vy, vz, e);
+            float a, b, c;
+            cov2d_from_cov3d(e, c6, a, b, c);
+            float det = __builtin_fmaf(a, c, -(b * b));
+            if (det == 0.0f) break;
+            float det_inv = 1.0f / det;
+            float mid = 0.5f * (a + c);
+            float disc = sqrtf(fmaxf(kLambdaFloor, __builtin_fmaf(mid, mid, -det)));
+            float lam1 = mid + disc, lam2 = mid - disc;
+            int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+            float pix_x = ((ndx + 1.0f) * (float)f.W - 1.0f) * 0.5f;
+            float pix_y = ((ndy + 1.0f) * (float)f.H - 1.0f) * 0.5f;
+            int x0, y0, x1, y1;
+            tile_rect(pix_x, pix_y, rad, f.gx, f.gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) == 0) break;
+
+            if (colors_precomp) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    g.rgb[3 * (size_t)i + ch] = colors_precomp[3 * (size_t)i + ch];
+                    g.clamped[3 * (size_t)i + ch] = 0;
+                }
+            } else {
+                float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
+                float len = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+                dx = dx / len; dy = dy / len; dz = dz / len;
+                float bs[16];
+                sh_basis(f.deg, dx, dy, dz, bs);
+                const int nb = (f.deg + 1) * (f.deg + 1);
+                const float* sh = shs + (size_t)i * f.M * 3;
+                float r0 = bs[0] * sh[0], r1 = bs[0] * sh[1], r2 = bs[0] * sh[2];
+                for (int k = 1; k < nb; ++k) {
+                    r0 = __builtin_fmaf(bs[k], sh[3 * k], r0);
+                    r1 = __builtin_fmaf(bs[k], sh[3 * k + 1], r1);
+                    r2 = __builtin_fmaf(bs[k], sh[3 * k + 2], r2);
+                }
+                r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+                g.clamped[3 * (size_t)i] = r0 < 0.0f;
+                g.clamped[3 * (size_t)i + 1] = r1 < 0.0f;
+                g.clamped[3 * (size_t)i + 2] = r2 < 0.0f;
+                g.rgb[3 * (size_t)i] = fmaxf(r0, 0.0f);
+                g.rgb[3 * (size_t)i + 1] = fmaxf(r1, 0.0f);
+                g.rgb[3 * (size_t)i + 2] = fmaxf(r2, 0.0f);
+            }
+            g.depths[i] = vz;
+            g.xy[i] = make_float2(pix_x, pix_y);
+            g.conic_opacity[i] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
+            rad_out = rad;
+            touched = (uint32_t)((x1 - x0) * (y1 - y0));
+        } while (false);
+        radii[i] = rad_out;
+        g.tiles_touched[i] = touched;
+    }
+    uint32_t wsum = wave_sum_u32(touched);
+    if ((tid & 63) == 0 && wsum) atomicAdd(&s_sum, wsum);
+    __syncthreads();
+    if (tid == 0) g.block_sums[blockIdx.x] = s_sum;
+}
+
+int launch_preprocess_forward(const Frame& f, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* opacities, const float* scales,
+                              const float* rotations, const float* cov3D_precomp, GeomView g,
+                              int32_t* radii, hipStream_t st) {
+    if (f.P <= 0) return 0;
+    int nblk = (f.P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nblk), dim3(kBlock), 0, st, f, means3D, shs,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+// ------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* dx, float* dy, float* dz) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dx[k] = dy[k] = dz[k] = 0.0f;
+    if (deg > 0) {
+        dy[1] = -SH_C1; dz[2] = SH_C1; dx[3] = -SH_C1;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            dx[4] = SH_C2[0] * y; dy[4] = SH_C2[0] * x;
+            dy[5] = SH_C2[1] * z; dz[5] = SH_C2[1] * y;
+            dx[6] = SH_C2[2] * (-2.0f * x); dy[6] = SH_C2[2] * (-2.0f * y); dz[6] = SH_C2[2] * (4.0f * z);
+            dx[7] = SH_C2[3] * z; dz[7] = SH_C2[3] * x;
+            dx[8] = SH_C2[4] * (2.0f * x); dy[8] = SH_C2[4] * (-2.0f * y);
+            if (deg > 2) {
+                dx[9] = SH_C3[0] * (6.0f * x * y); dy[9] = SH_C3[0] * (3.0f * xx - 3.0f * yy);
+                dx[10] = SH_C3[1] * (y * z); dy[10] = SH_C3[1] * (x * z); dz[10] = SH_C3[1] * (x * y);
+                dx[11] = SH_C3[2] * (-2.0f * x * y); dy[11] = SH_C3[2] * (4.0f * zz - xx - 3.0f * yy);
+                dz[11] = SH_C3[2] * (8.0f * y * z);
+                dx[12] = SH_C3[3] * (-6.0f * x * z); dy[12] = SH_C3[3] * (-6.0f * y * z);
+                dz[12] = SH_C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+                dx[13] = SH_C3[4] * (4.0f * zz - 3.0f * xx - yy); dy[13] = SH_C3[4] * (-2.0f * x * y);
+                dz[13] = SH_C3[4] * (8.0f * x * z);
+                dx[14] = SH_C3[5] * (2.0f * x * z); dy[14] = SH_C3[5] * (-2.0f * y * z);
+                dz[14] = SH_C3[5] * (xx - yy);
+                dx[15] = SH_C3[6] * (3.0f * xx - 3.0f * yy); dy[15] = SH_C3[6] * (-6.0f * x * y);
+            }
+        }
+    }
+}
+
+// One thread per Gaussian. Inputs: dL_dmean2D_ndc [P,3] (x,y used), dL_dconic_op [P] float4 =
+// (dL/dA, dL/dB, dL/dC, dL/dopacity) of power = -0.5(A dx^2 + C dy^2) - B dx dy, dL_dcolor [P,3].
+// Outputs are written for every Gaussian (zeros where radii == 0).
+__global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
+    Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii, GeomView g,
+    const float* __restrict__ dL_dmean2D, const float4* __restrict__ dL_dconic_op,
+    const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= f.P) return;
+    const bool live = radii[i] > 0;
+    float dm[3] = {0, 0, 0};
+    float g6[6] = {0, 0, 0, 0, 0, 0};
+    const int nb = (f.deg + 1) * (f.deg + 1);
+    if (live) {
+        float V[16], PM[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { V[k] = f.view[k]; PM[k] = f.proj[k]; }
+        float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
+        float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
+        float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = g.cov3D[6 * (size_t)i + k];
+        Ewa e;
+        ewa_setup(f, V, vx, vy, vz, e);
+        float a, b, c;
+        cov2d_from_cov3d(e, c6, a, b, c);
+        float denom = a * c - b * b;
+        float d2inv = 1.0f / (denom * denom + 0.0000001f);
+        float4 gc = dL_dconic_op[i];
+        float da = 0, db = 0, dc = 0;
+        if (d2inv != 0.0f) {
+            da = d2inv * (-c * c * gc.x + b * c * gc.y + (denom - a * c) * gc.z);
+            dc = d2inv * (-a * a * gc.z + a * b * gc.y + (denom - a * c) * gc.x);
+            db = d2inv * (2.0f * b * c * gc.x - (denom + 2.0f * b * b) * gc.y + 2.0f * a * b * gc.z);
+            const float(*Tm)[3] = e.Tm;
+            g6[0] = Tm[0][0] * Tm[0][0] * da + Tm[0][0] * Tm[1][0] * db + Tm[1][0] * Tm[1][0] * dc;
+            g6[3] = Tm[0][1] * Tm[0][1] * da + Tm[0][1] * Tm[1][1] * db + Tm[1][1] * Tm[1][1] * dc;
+            g6[5] = Tm[0][2] * Tm[0][2] * da + Tm[0][2] * Tm[1][2] * db + Tm[1][2] * Tm[1][2] * dc;
+            g6[1] = 2 * Tm[0][0] * Tm[0][1] * da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * db +
+                    2 * Tm[1][0] * Tm[1][1] * dc;
+            g6[2] = 2 * Tm[0][0] * Tm[0][2] * da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * db +
+                    2 * Tm[1][0] * Tm[1][2] * dc;
+            g6[4] = 2 * Tm[0][2] * Tm[0][1] * da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * db +
+                    2 * Tm[1][1] * Tm[1][2] * dc;
+        }
+        float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float st0 = S[k][0] * e.Tm[0][0] + S[k][1] * e.Tm[0][1] + S[k][2] * e.Tm[0][2];
+            float st1 = S[k][0] * e.Tm[1][0] + S[k][1] * e.Tm[1][1] + S[k][2] * e.Tm[1][2];
+            float dT0 = 2.0f * da * st0 + db * st1;
+            float dT1 = 2.0f * dc * st1 + db * st0;
+            dJ00 += dT0 * V[0 + 4 * k];
+            dJ02 += dT0 * V[2 + 4 * k];
+            dJ11 += dT1 * V[1 + 4 * k];
+            dJ12 += dT1 * V[2 + 4 * k];
+        }
+        float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        float dtx = e.xmul * -f.fx * tz2 * dJ02;
+        float dty = e.ymul * -f.fy * tz2 * dJ12;
+        float dtz = -f.fx * tz2 * dJ00 - f.fy * tz2 * dJ11 + (2 * f.fx * e.tx) * tz3 * dJ02 +
+                    (2 * f.fy * e.ty) * tz3 * dJ12;
+        dm[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+        dm[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+        dm[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+
+        float hx = affine3(PM[0], PM[4], PM[8], PM[12], px, py, pz);
+        float hy = affine3(PM[1], PM[5], PM[9], PM[13], px, py, pz);
+        float hw = affine3(PM[3], PM[7], PM[11], PM[15], px, py, pz);
+        float mw = 1.0f / (hw + 0.0000001f);
+        float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+        float g2x = dL_dmean2D[3 * (size_t)i], g2y = dL_dmean2D[3 * (size_t)i + 1];
+        dm[0] += (PM[0] * mw - PM[3] * mul1) * g2x + (PM[1] * mw - PM[3] * mul2) * g2y;
+        dm[1] += (PM[4] * mw - PM[7] * mul1) * g2x + (PM[5] * mw - PM[7] * mul2) * g2y;
+        dm[2] += (PM[8] * mw - PM[11] * mul1) * g2x + (PM[9] * mw - PM[11] * mul2) * g2y;
+
+        if (shs) {
+            float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];
+            float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float dx = ox / len, dy = oy / len, dz = oz / len;
+            float bs[16], bx[16], by[16], bz[16];
+            sh_basis(f.deg, dx, dy, dz, bs);
+            sh_basis_grad(f.deg, dx, dy, dz, bx, by, bz);
+            const float* sh = shs + (size_t)i * f.M * 3;
+            float* dsh = dL_dshs + (size_t)i * f.M * 3;
+            float gcol[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                gcol[ch] = g.clamped[3 * (size_t)i + ch] ? 0.0f : dL_dcolor[3 * (size_t)i + ch];
+            float ddx = 0, ddy = 0, ddz = 0;
+            for (int k = 0; k < nb; ++k) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    dsh[3 * k + ch] = bs[k] * gcol[ch];
+                    float w = sh[3 * k + ch] * gcol[ch];
+                    ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+                }
+            }
+            for (int k = nb; k < f.M; ++k) { dsh[3 * k] = 0; dsh[3 * k + 1] = 0; dsh[3 * k + 2] = 0; }
+            float dotp = dx * ddx + dy * ddy + dz * ddz;
+            dm[0] += (ddx - dx * dotp) / len;
+            dm[1] += (ddy - dy * dotp) / len;
+            dm[2] += (ddz - dz * dotp) / len;
+        }
+    } else if (shs) {
+        float* dsh = dL_dshs + (size_t)i * f.M * 3;
+        for (int k = 0; k < 3 * f.M; ++k) dsh[k] = 0.0f;
+    }
+    dL_dmeans3D[3 * (size_t)i] = dm[0];
+    dL_dmeans3D[3 * (size_t)i + 1] = dm[1];
+    dL_dmeans3D[3 * (size_t)i + 2] = dm[2];
+
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = g6[k];
+    } else {
+        float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        if (live) {
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * i);
+            float R[3][3];
+            quat_to_rot(q.x, q.y, q.z, q.w, R);
+            float s[3] = {f.scale_modifier * scales[3 * i], f.scale_modifier * scales[3 * i + 1],
+                          f.scale_modifier * scales[3 * i + 2]};
+            float Gf[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
+                              {0.5f * g6[1], g6[3], 0.5f * g6[4]},
+                              {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
+            float dR[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float acc_s = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float dMrj = 2.0f * (Gf[r][0] * R[0][j] + Gf[r][1] * R[1][j] + Gf[r][2] * R[2][j]) * s[j];
+                    acc_s += dMrj * R[r][j];
+                    dR[r][j] = dMrj * s[j];
+                }
+                ds[j] = acc_s * f.scale_modifier;
+            }
+            float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+            dq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+            dq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2 * qx * dR[1][1] - qr * dR[1][2] +
+                            qz * dR[2][0] + qr * dR[2][1] - 2 * qx * dR[2][2]);
+            dq[2] = 2.0f * (-2 * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
+                            qr * dR[2][0] + qz * dR[2][1] - 2 * qy * dR[2][2]);
+            dq[3] = 2.0f * (-2 * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2 * qz * dR[1][1] +
+                            qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] = ds[k];
+        *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+}
+
+int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
+                               const float* scales, const float* rotations, const float* cov3D_precomp,
+                               const int32_t* radii, GeomView g, const float* dL_dmean2D,
+                               const float4* dL_dconic_op, const float* dL_dcolor, float* dL_dmeans3D,
+                               float* dL_dshs, float* dL_dcov3D, float* dL_dscales, float* dL_drots,
+                               hipStream_t st) {
+    if (f.P <= 0) return 0;
+    int nblk = (f.P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), 0, st, f, means3D, shs, scales,
+                       rotations, cov3D_precomp, radii, g, dL_dmean2D, dL_dconic_op, dL_dcolor,
+                       dL_dmeans3D, dL_dshs, dL_dcov3D, dL_dscales, dL_drots);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
+                                    uint8_t* __restrict__ visible) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    float vz = affine3(view[2], view[6], view[10], view[14], means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    visible[i] = vz > kNearZ;
+}
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, P, means3D, view, visible);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+}  // namespace mvi

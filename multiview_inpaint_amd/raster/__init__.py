@@ -1,0 +1,222 @@
+"""Host-side mirror of the rasterizer plug-in the reference imports
+(`from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer`,
+gs-simp/gaussian_renderer/__init__.py:14), bound to the HIP C-ABI library with ctypes.
+
+Call contract reproduced (gs-simp/gaussian_renderer/__init__.py:36-51, :85-93):
+    settings = GaussianRasterizationSettings(image_height=..., image_width=..., tanfovx=..., tanfovy=...,
+                                             bg=..., scale_modifier=..., viewmatrix=..., projmatrix=...,
+                                             sh_degree=..., campos=..., prefiltered=...)      # 11 fields, no `debug`
+    color, radii, depth = GaussianRasterizer(raster_settings=settings)(
+        means3D=..., means2D=..., shs=..., colors_precomp=..., opacities=..., scales=..., rotations=...,
+        cov3D_precomp=...)
+backward returns gradients for means3D, means2D, shs|colors_precomp, opacities, scales+rotations|
+cov3D_precomp; `means2D.grad[:, :2]` is what gs-simp/scene/gaussian_model.py:482-484 consumes.
+
+PyTorch is used here only for device memory, the current stream and autograd plumbing.
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from .. import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be on the GPU (got {t.device}); the rasterizer has no CPU path")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Frame:
+    """ctypes settings struct + the tensors it points into (kept alive together)."""
+
+    def __init__(self, rs: GaussianRasterizationSettings):
+        self.keep = [_dev_f32(rs.bg, "bg").reshape(-1), _dev_f32(rs.viewmatrix, "viewmatrix").reshape(-1),
+                     _dev_f32(rs.projmatrix, "projmatrix").reshape(-1), _dev_f32(rs.campos, "campos").reshape(-1)]
+        if self.keep[0].numel() != 3 or self.keep[1].numel() != 16 or self.keep[2].numel() != 16 or self.keep[3].numel() != 3:
+            raise Exception("bg/campos must have 3 elements, viewmatrix/projmatrix 16")
+        s = _lib.RasterSettings()
+        s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+        s.tanfovx, s.tanfovy, s.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+        s.sh_degree, s.prefiltered = int(rs.sh_degree), int(bool(rs.prefiltered))
+        s.bg, s.viewmatrix, s.projmatrix, s.campos = (t.data_ptr() for t in self.keep)
+        self.c = s
+
+
+class RasterState:
+    """Scratch buffers one forward leaves behind for its backward (and for the parity tests)."""
+    __slots__ = ("P", "M", "D", "W", "H", "geom", "binning", "image", "radii")
+
+    def views(self):
+        L = _lib.lib()
+        v = _lib.RasterViews()
+        _lib.check(L.mvi_raster_get_views(self.P, self.D, self.W, self.H, _ptr(self.geom), _ptr(self.binning),
+                                          _ptr(self.image), C.byref(v)), "get_views")
+        return v
+
+    def tensor(self, name, shape, dtype):
+        """Copy of one intermediate array as a torch tensor (tests only)."""
+        addr = getattr(self.views(), name)
+        n = 1
+        for s in shape:
+            n *= s
+        out = torch.empty(shape, dtype=dtype, device=self.geom.device)
+        if n:
+            nbytes = n * out.element_size()
+            for buf in (self.geom, self.binning, self.image):
+                if buf is not None and buf.numel() and buf.data_ptr() <= addr < buf.data_ptr() + buf.numel():
+                    off = addr - buf.data_ptr()
+                    out.view(torch.uint8).reshape(-1).copy_(buf[off:off + nbytes])
+                    return out
+            raise RuntimeError(f"view {name} not inside a scratch buffer")
+        return out
+
+
+def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
+                      scales=None, rotations=None, cov3D_precomp=None):
+    """Runs the HIP forward. Returns (color [3,H,W], radii [P] int32, depth [1,H,W], RasterState)."""
+    L = _lib.lib()
+    fr = _Frame(rs)
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("means3D must be on the GPU; the rasterizer has no CPU path")
+    P = int(means3D.shape[0])
+    H, W = int(rs.image_height), int(rs.image_width)
+    M = int(shs.shape[1]) if shs is not None and shs.numel() else 0
+    st = RasterState()
+    st.P, st.M, st.W, st.H = P, M, W, H
+    u8 = dict(dtype=torch.uint8, device=dev)
+    st.geom = torch.empty(L.mvi_raster_geom_bytes(P), **u8)
+    st.image = torch.empty(L.mvi_raster_image_bytes(W, H), **u8)
+    st.radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    D = C.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_forward_geom(C.byref(fr.c), P, M, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                                             _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                             _ptr(st.geom), st.geom.numel(), _ptr(st.radii), C.byref(D), stream),
+                   "rasterize forward (geom)")
+        st.D = int(D.value)
+        st.binning = torch.empty(L.mvi_raster_binning_bytes(st.D, W, H) if st.D else 0, **u8)
+        _lib.check(L.mvi_raster_forward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), st.geom.numel(),
+                                               _ptr(st.binning), st.binning.numel(), _ptr(st.image), st.image.numel(),
+                                               _ptr(color), _ptr(depth), stream), "rasterize forward (render)")
+    return color, st.radii, depth, st
+
+
+def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_color, means3D, shs=None,
+                       colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    """Runs the HIP backward. Returns dict of gradients (None for inputs that were not given)."""
+    L = _lib.lib()
+    fr = _Frame(rs)
+    dev = means3D.device
+    P = st.P
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = dict(means3D=torch.empty(P, 3, **f32), means2D=torch.empty(P, 3, **f32), opacities=torch.empty(P, 1, **f32),
+             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+    dcolors = torch.empty(P, 3, **f32)                   # output in colours mode, scratch in SH mode
+    if shs is not None:
+        g["shs"] = torch.empty(P, st.M, 3, **f32)
+    else:
+        g["colors_precomp"] = dcolors
+    if cov3D_precomp is not None:
+        g["cov3D_precomp"] = torch.empty(P, 6, **f32)
+    else:
+        g["scales"], g["rotations"] = torch.empty(P, 3, **f32), torch.empty(P, 4, **f32)
+    scratch = torch.empty(P, 4, **f32)
+    grad_color = grad_color.to(torch.float32).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_backward(
+            C.byref(fr.c), P, st.M, st.D, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(scales), _ptr(rotations),
+            _ptr(cov3D_precomp), _ptr(st.radii), _ptr(st.geom), _ptr(st.binning), _ptr(st.image), _ptr(grad_color),
+            _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(dcolors),
+            _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(scratch), stream),
+            "rasterize backward")
+    return g
+
+
+def _opt(t):
+    """None or empty -> None; otherwise contiguous fp32."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.to(torch.float32).contiguous()
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs):
+        a = dict(means3D=_opt(means3D), shs=_opt(shs), colors_precomp=_opt(colors_precomp), opacities=_opt(opacities),
+                 scales=_opt(scales), rotations=_opt(rotations), cov3D_precomp=_opt(cov3D_precomp))
+        if a["means3D"] is None:
+            a["means3D"] = means3D.to(torch.float32).reshape(0, 3)
+        color, radii, depth, st = rasterize_forward(rs, a["means3D"], a["opacities"], a["shs"], a["colors_precomp"],
+                                                    a["scales"], a["rotations"], a["cov3D_precomp"])
+        ctx.rs, ctx.st, ctx.a = rs, st, a
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, _grad_depth):
+        a, st = ctx.a, ctx.st
+        if st.P == 0:
+            z = lambda t: None if t is None else torch.zeros_like(t)
+            return (z(a["means3D"]), None, z(a["shs"]), z(a["colors_precomp"]), z(a["opacities"]), z(a["scales"]),
+                    z(a["rotations"]), z(a["cov3D_precomp"]), None)
+        g = rasterize_backward(ctx.rs, st, grad_color, a["means3D"], a["shs"], a["colors_precomp"], a["scales"],
+                               a["rotations"], a["cov3D_precomp"])
+        return (g["means3D"], g["means2D"], g["shs"], g["colors_precomp"], g["opacities"], g["scales"],
+                g["rotations"], g["cov3D_precomp"], None)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """bool [P]: view-space z > 0.2 (part of the plug-in surface; no caller in the reference)."""
+        L = _lib.lib()
+        rs = self.raster_settings
+        p = _dev_f32(positions, "positions")
+        out = torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device)
+        fr = _Frame(rs)
+        stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+        with torch.cuda.device(p.device):
+            _lib.check(L.mvi_raster_mark_visible(p.shape[0], _ptr(p), _ptr(fr.keep[1]), _ptr(fr.keep[2]), _ptr(out), stream),
+                       "mark_visible")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        return _Rasterize.apply(means3D, means2D,
+                                empty if shs is None else shs, empty if colors_precomp is None else colors_precomp,
+                                opacities, empty if scales is None else scales, empty if rotations is None else rotations,
+                                empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

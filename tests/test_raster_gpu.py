@@ -1,0 +1,255 @@
+"""GPU parity tests of the HIP rasterizer (through the C-ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): bit-exact on integer outputs (radii, tiles touched, sort keys,
+sorted order, tile ranges) — and, because the per-Gaussian arithmetic contract is shared, bit-exact
+on the per-Gaussian floats too; 1e-4 relative on RGB-D and on every gradient.
+
+The compositing loop takes three hard decisions per (pixel, Gaussian) pair (power > 0,
+alpha < 1/255, T(1-alpha) < 1e-4) and one for the median depth (T crossing 0.5). exp() differs by
+~1 ulp between v_exp_f32 and glibc, so a handful of pairs per 10^8 can take the other branch; such a
+pixel then differs by up to alpha*T*c <= 4e-3 in colour (or picks the neighbouring Gaussian's depth).
+FLIP_FRAC bounds the fraction of pixels allowed outside the 1e-4 band for that reason; every other
+pixel must be inside it."""
+import numpy as np
+import pytest
+import torch
+
+from multiview_inpaint_amd import synthetic as syn
+from raster_helpers import oracle_params, rel_err, small_scene
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+FLIP_FRAC = 2e-4
+
+
+@pytest.fixture(scope="module")
+def R():
+    from multiview_inpaint_amd import raster
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return raster
+
+
+@pytest.fixture(scope="module")
+def ro():
+    from oracle import raster_oracle
+    return raster_oracle
+
+
+def _settings(R, cam, bg, deg, scale_modifier=1.0):
+    d = "cuda"
+    return R.GaussianRasterizationSettings(
+        image_height=cam["H"], image_width=cam["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+        bg=torch.tensor(bg, device=d), scale_modifier=scale_modifier,
+        viewmatrix=torch.tensor(cam["viewmatrix"], device=d), projmatrix=torch.tensor(cam["projmatrix"], device=d),
+        sh_degree=deg, campos=torch.tensor(cam["campos"], device=d), prefiltered=False)
+
+
+def _to_dev(sc):
+    return {k: torch.tensor(v, device="cuda") for k, v in sc.items() if k != "sh_degree"}
+
+
+def _close_frac(a, b, rtol=RTOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = np.abs(b).max() + 1e-12
+    bad = np.abs(a - b) > rtol * scale
+    return bad.mean(), np.abs(a - b).max() / scale
+
+
+def _check_forward(R, ro, cam, sc, bg, full=True):
+    deg = sc["sh_degree"]
+    p = oracle_params(ro, cam, sc, bg)
+    f = ro.forward(p, sc["means3D"], sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    t = _to_dev(sc)
+    rs = _settings(R, cam, bg, deg)
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                  rotations=t["rotations"])
+    torch.cuda.synchronize()
+    P, D, W, H = st.P, st.D, cam["W"], cam["H"]
+    # ---- integer outputs: bit-exact
+    assert D == f["num_rendered"]
+    assert np.array_equal(radii.cpu().numpy(), f["radii"])
+    vis = f["radii"] > 0
+    tt = st.tensor("tiles_touched", (P,), torch.int32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(tt, f["tiles_touched"])
+    keys = st.tensor("keys_sorted", (D,), torch.int64).cpu().numpy().view(np.uint64)
+    assert np.array_equal(keys, f["keys_sorted"]), "sort keys differ"
+    plist = st.tensor("point_list", (D,), torch.int32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(plist, f["point_list"]), "sorted order differs"
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    ranges = st.tensor("ranges", (tiles, 2), torch.int32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(ranges, f["ranges"])
+    # ---- per-Gaussian floats: shared arithmetic contract -> bit-exact where visible
+    for name, shape, ref in (("depths", (P,), f["depths"]), ("means2D", (P, 2), f["xy"]), ("cov3D", (P, 6), f["cov3D"]),
+                             ("conic_opacity", (P, 4), f["conic_opacity"]), ("rgb", (P, 3), f["rgb"])):
+        got = st.tensor(name, shape, torch.float32).cpu().numpy()
+        assert np.array_equal(got[vis], ref[vis]), name
+    cl = st.tensor("clamped", (P, 3), torch.uint8).cpu().numpy()
+    assert np.array_equal(cl[vis], f["clamped"][vis])
+    # ---- image outputs: 1e-4 rel outside threshold flips
+    frac, worst = _close_frac(color.cpu().numpy(), f["color"])
+    assert frac <= FLIP_FRAC and worst < 2e-2, (frac, worst)
+    nc = st.tensor("n_contrib", (H, W), torch.int32).cpu().numpy().view(np.uint32)
+    assert (nc != f["n_contrib"]).mean() <= FLIP_FRAC
+    dfrac, _ = _close_frac(depth.cpu().numpy(), f["depth"])
+    assert dfrac <= FLIP_FRAC
+    assert (depth.cpu().numpy()[0][f["n_contrib"] == 0] == 15.0).all()
+    ft = st.tensor("final_T", (H, W), torch.float32).cpu().numpy()
+    tfrac, _ = _close_frac(ft, f["final_T"])
+    assert tfrac <= FLIP_FRAC
+    return f, p, rs, t, st
+
+
+@pytest.mark.parametrize("seed,deg,pose,N,W,H", [(0, 3, True, 400, 100, 70), (1, 0, True, 3000, 200, 120),
+                                                 (2, 1, False, 2000, 129, 67), (3, 2, True, 5000, 320, 240)])
+def test_forward_parity_small(R, ro, seed, deg, pose, N, W, H):
+    cam, sc, bg = small_scene(seed, N=N, W=W, H=H, deg=deg, pose=pose, log_scale=np.log(0.04))
+    _check_forward(R, ro, cam, sc, bg)
+
+
+@pytest.mark.parametrize("seed,deg,mode", [(0, 3, "sh"), (4, 1, "sh"), (5, 2, "precomp"), (6, 0, "sh")])
+def test_backward_parity_small(R, ro, seed, deg, mode):
+    cam, sc, bg = small_scene(seed, N=1500, W=160, H=112, deg=deg, log_scale=np.log(0.05))
+    t = _to_dev(sc)
+    p = oracle_params(ro, cam, sc, bg)
+    rs = _settings(R, cam, bg, deg)
+    g_img = np.random.default_rng(seed).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
+    if mode == "precomp":
+        f0 = ro.forward(p, sc["means3D"], sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], render=False)
+        c6, cp = f0["cov3D"].copy(), np.abs(np.random.default_rng(9).normal(0.5, 0.3, (p.P, 3))).astype(np.float32)
+        okw = dict(colors_precomp=cp, cov3D_precomp=c6)
+        gkw = dict(colors_precomp=torch.tensor(cp, device="cuda"), cov3D_precomp=torch.tensor(c6, device="cuda"))
+    else:
+        okw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+        gkw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    f = ro.forward(p, sc["means3D"], sc["opacities"], **okw)
+    b = ro.backward(p, f, g_img, sc["means3D"], **okw)
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **gkw)
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], **gkw)
+    torch.cuda.synchronize()
+    for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        if b[k] is None:
+            assert g[k] is None, k
+            continue
+        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
+        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+
+
+def test_autograd_module_contract(R, ro):
+    """The nn.Module surface the reference calls (gaussian_renderer/__init__.py:85-101)."""
+    cam, sc, bg = small_scene(7, N=800, W=96, H=64, deg=1, log_scale=np.log(0.06))
+    t = {k: v.requires_grad_(True) for k, v in _to_dev(sc).items()}
+    rs = _settings(R, cam, bg, 1)
+    screen = torch.zeros_like(t["means3D"], requires_grad=True) + 0
+    screen.retain_grad()
+    rast = R.GaussianRasterizer(raster_settings=rs)
+    out = rast(means3D=t["means3D"], means2D=screen, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+               scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    assert isinstance(out, tuple) and len(out) == 3
+    color, radii, depth = out
+    assert color.shape == (3, 64, 96) and depth.shape == (1, 64, 96) and radii.shape == (800,) and radii.dtype == torch.int32
+    assert not depth.requires_grad and color.requires_grad
+    target = torch.rand_like(color)
+    (color - target).abs().mean().backward()
+    assert screen.grad is not None and screen.grad.shape == (800, 3) and (screen.grad[:, 2] == 0).all()
+    vis = radii > 0
+    assert (screen.grad[~vis] == 0).all() and screen.grad[vis].abs().sum() > 0
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        assert t[k].grad is not None and t[k].grad.shape == t[k].shape and torch.isfinite(t[k].grad).all()
+    # no-grad forward (gen_seq.py:65) and the argument-combination errors of the plug-in
+    with torch.no_grad():
+        c2, r2, d2 = rast(means3D=t["means3D"], means2D=screen, shs=t["shs"], opacities=t["opacities"],
+                          scales=t["scales"], rotations=t["rotations"])
+    assert torch.equal(c2, color.detach())
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(means3D=t["means3D"], means2D=screen, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=t["means3D"], means2D=screen, shs=t["shs"], opacities=t["opacities"])
+    assert torch.equal(rast.markVisible(t["means3D"].detach()).cpu(),
+                       torch.tensor((sc["means3D"] @ cam["viewmatrix"][:3, 2] + cam["viewmatrix"][3, 2]) > 0.2))
+
+
+def test_empty_and_culled(R):
+    cam = syn.make_camera(48, 32, 60.0)
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    rs = _settings(R, cam, bg, 0)
+    rast = R.GaussianRasterizer(rs)
+    N = 16
+    means = torch.zeros(N, 3, device="cuda")
+    means[:, 2] = torch.linspace(-3, 0.2, N)
+    kw = dict(means2D=torch.zeros(N, 3, device="cuda"), shs=torch.ones(N, 1, 3, device="cuda"),
+              opacities=torch.full((N, 1), 0.9, device="cuda"), scales=torch.full((N, 3), 0.1, device="cuda"),
+              rotations=torch.tensor([[1.0, 0, 0, 0]], device="cuda").repeat(N, 1))
+    means.requires_grad_(True)
+    color, radii, depth = rast(means3D=means, **kw)
+    assert (radii == 0).all() and (depth == 15.0).all()
+    assert torch.allclose(color, torch.tensor(bg, device="cuda")[:, None, None].expand_as(color))
+    color.sum().backward()
+    assert (means.grad == 0).all()
+    # P = 0
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    color, radii, depth = rast(means3D=z(0, 3), means2D=z(0, 3), shs=z(0, 1, 3), opacities=z(0, 1), scales=z(0, 3), rotations=z(0, 4))
+    assert radii.numel() == 0 and (depth == 15.0).all()
+    assert torch.allclose(color, torch.tensor(bg, device="cuda")[:, None, None].expand_as(color))
+
+
+def test_bringup_config_100k_800(R, ro):
+    """BASELINE.json configs[1]: 100k synthetic Gaussians, 800x800, fwd+bwd vs the oracle."""
+    cam = syn.make_camera(800, 800, 50.0)
+    sc = syn.make_scene(100_000, cam, 3, seed=0)
+    bg = np.zeros(3, np.float32)
+    f, p, rs, t, st = _check_forward(R, ro, cam, sc, bg)
+    g_img = np.random.default_rng(0).normal(size=(3, 800, 800)).astype(np.float32)
+    b = ro.backward(p, f, g_img, sc["means3D"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
+                             rotations=t["rotations"])
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
+        assert frac <= 5e-4, (k, frac, worst)
+
+
+def test_full_size_properties_1p5M_1080p(R):
+    """BASELINE.json configs[2] size (1.5M Gaussians, 1920x1080): size-independent properties."""
+    cam = syn.make_camera(1920, 1080, 50.0)
+    sc = syn.make_scene(1_500_000, cam, 3, seed=0)
+    t = _to_dev(sc)
+    W, H = 1920, 1080
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    bg0, bg1 = np.zeros(3, np.float32), np.array([0.25, 0.5, 1.0], np.float32)
+    c0, radii, d0, st = R.rasterize_forward(_settings(R, cam, bg0, 3), t["means3D"], t["opacities"], **kw)
+    P, D = st.P, st.D
+    keys = st.tensor("keys_sorted", (D,), torch.int64)
+    plist = st.tensor("point_list", (D,), torch.int32).long()
+    tt = st.tensor("tiles_touched", (P,), torch.int32).long()
+    depths = st.tensor("depths", (P,), torch.float32)
+    # sortedness (keys are non-negative as int64: tile < 2^31) and key <-> payload consistency
+    assert (keys[1:] >= keys[:-1]).all()
+    assert D == int(tt.sum()) and ((radii > 0) == (tt > 0)).all()
+    assert torch.equal((keys & 0xFFFFFFFF).int(), depths[plist].view(torch.int32))
+    # the sorted payload is a permutation of "Gaussian i repeated tiles_touched[i] times"
+    assert torch.equal(torch.bincount(plist, minlength=P), tt)
+    # stability: equal keys keep ascending Gaussian index
+    same = keys[1:] == keys[:-1]
+    assert (plist[1:][same] > plist[:-1][same]).all()
+    # ranges partition [0, D) in tile order
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    ranges = st.tensor("ranges", (tiles, 2), torch.int32).long()
+    tile_of = keys >> 32
+    cnt = torch.bincount(tile_of, minlength=tiles)
+    assert torch.equal(ranges[:, 1] - ranges[:, 0], cnt)
+    nz = cnt > 0
+    assert torch.equal(ranges[nz][:, 0], (torch.cumsum(cnt, 0) - cnt)[nz])
+    # background linearity: color(bg) - color(0) == final_T * bg ; depth independent of bg
+    c1, _, d1, st1 = R.rasterize_forward(_settings(R, cam, bg1, 3), t["means3D"], t["opacities"], **kw)
+    ft = st1.tensor("final_T", (H, W), torch.float32)
+    assert torch.allclose(c1 - c0, ft[None] * torch.tensor(bg1, device="cuda")[:, None, None], atol=1e-6)
+    assert torch.equal(d0, d1)
+    assert ((d0 == 15.0) | ((d0 > 0.2) & (d0 < 9.0))).all()
+    # gradient linearity in the upstream gradient (atomics reorder sums: tolerance, not bit-exact)
+    g_img = torch.randn(3, H, W, device="cuda")
+    ga = R.rasterize_backward(_settings(R, cam, bg0, 3), st, g_img, t["means3D"], **kw)
+    gb = R.rasterize_backward(_settings(R, cam, bg0, 3), st, 2 * g_img, t["means3D"], **kw)
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        assert torch.isfinite(ga[k]).all()
+        err = (gb[k] - 2 * ga[k]).abs().max() / (gb[k].abs().max() + 1e-12)
+        assert err < 1e-4, (k, float(err))
+        assert (ga[k][radii == 0] == 0).all()
