@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric).
+
+A step = one forward + backward pass of the Gaussian-splat rasterizer-with-depth over one camera
+view: 1.5 M synthetic Gaussians (SURVEY.md §8d recipe, seed 0), 1920x1080, sh_degree 3, upstream
+gradient dL/dcolor ~ N(0,1). Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...`: one process per GPU, every rank renders a DIFFERENT view of the replicated scene
+(weak scaling: one view per GPU per step) and the Gaussian gradients are summed with one RCCL
+all-reduce of a flat bucket per step. value = pixels of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(N, V, D, M, P, T, n_pass=1):
+    """SURVEY.md §8d closed form, per stage (bytes of compulsory traffic)."""
+    fwd = dict(
+        preprocess_forward=N * (44 + 12 * M) + N * 8 + V * 67,
+        scan_block_sums=N * 8,
+        duplicate_keys=V * 20 + D * 12,
+        radix_sort=D * 24 * n_pass,
+        tile_ranges=D * 8 + T * 8,
+        render_forward=T * 8 + D * 44 + P * 24,
+    )
+    bwd = dict(
+        render_backward=P * 20 + D * 40 + V * 44,
+        preprocess_backward=N * (75 + 12 * M) + V * 44 + N * (40 + 12 * M),
+    )
+    return fwd, bwd
+
+
+def view_camera(rank, W, H):
+    """Rank r looks at the scene from a slightly different pose (yaw r*4 degrees about the scene centre)."""
+    from multiview_inpaint_amd import synthetic as syn
+    if rank == 0:
+        return syn.make_camera(W, H, 50.0)
+    a = math.radians(4.0 * rank)
+    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    centre = np.array([0.0, 0.0, 4.5])
+    cam_pos = centre - R @ np.array([0.0, 0.0, 4.5])       # orbit at the same distance
+    T = -R.T @ cam_pos
+    return syn.make_camera(W, H, 50.0, R, T)
+
+
+def cpu_baseline():
+    """The oracle (a port: the reference has no CPU rasterizer) on a bounded sample: fwd+bwd of one
+    800x800 view at N=100k (BASELINE.json configs[1]), one host core."""
+    from multiview_inpaint_amd import synthetic as syn
+    from oracle import raster_oracle as ro
+    W = H = 800
+    N = 100_000
+    cam = syn.make_camera(W, H, 50.0)
+    sc = syn.make_scene(N, cam, 3, seed=0)
+    p = ro.make_params(N, 3, 16, W, H, cam["tanfovx"], cam["tanfovy"], 1.0, cam["viewmatrix"], cam["projmatrix"],
+                       cam["campos"], np.zeros(3, np.float32))
+    kw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    g_img = np.random.default_rng(0).normal(size=(3, H, W)).astype(np.float32)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        f = ro.forward(p, sc["means3D"], sc["opacities"], **kw)
+        ro.backward(p, f, g_img, sc["means3D"], **kw)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 20:
+            break
+    return dict(value=round(reps * W * H / dt / 1e6, 4), unit="Mpix/s", cores=1, kind="port",
+                sample=f"{reps} x (fwd+bwd, N=100k Gaussians, 800x800, sh_degree 3, D={f['num_rendered']}) "
+                       f"with oracle/raster_oracle.c on 1 of {os.cpu_count()} host cores, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=1_500_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch under torch.distributed.run as a child (never exec after GPU init)
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    from multiview_inpaint_amd import _lib, raster as R, synthetic as syn
+    from multiview_inpaint_amd import dist as mdist
+    L = _lib.lib()                                        # fails loudly if the HIP library is missing
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)
+
+    W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
+    M = (deg + 1) ** 2
+    cam0 = syn.make_camera(W, H, 50.0)
+    sc = syn.make_scene(N, cam0, deg, seed=0)             # identical on every rank (replicated scene)
+    cam = view_camera(rank, W, H)
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items() if k != "sh_degree"}
+    rs = R.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=torch.tensor(cam["viewmatrix"], device=dev),
+        projmatrix=torch.tensor(cam["projmatrix"], device=dev), sh_degree=deg,
+        campos=torch.tensor(cam["campos"], device=dev), prefiltered=False)
+    g_img = torch.randn(3, H, W, device=dev, generator=torch.Generator(dev).manual_seed(rank))
+    bucket = mdist.GradBucket(N, M, dev)
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+    def step():
+        color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+        R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, **kw)
+        if world > 1:
+            bucket.all_reduce()
+        return st, radii
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st, radii = step()
+    barrier()
+    L.mvi_raster_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, radii = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    L.mvi_raster_timing_enable(0)
+    ms = (C.c_float * 8)()
+    calls = (C.c_int32 * 8)()
+    _lib.check(L.mvi_raster_timing_read(ms, calls), "timing_read")
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        D = st.D
+        V = int((radii > 0).sum().item())
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        Ppix = W * H
+        fwd_b, bwd_b = algorithmic_bytes(N, V, D, M, Ppix, T, n_pass=1)
+        stage_bytes = {**fwd_b, **bwd_b}
+        stages = {}
+        for i in range(8):
+            name = L.mvi_raster_stage_name(i).decode()
+            if calls[i]:
+                avg_ms = ms[i] / calls[i]
+                stages[name] = dict(ms=round(avg_ms, 4), GBs=round(stage_bytes[name] / avg_ms / 1e6, 1))
+        dom = max(stages, key=lambda k: stages[k]["ms"])
+        ms_step = dt / args.steps * 1e3
+        total_bytes = sum(stage_bytes.values())
+        ranges = st.tensor("ranges", (T, 2), torch.int32).long()
+        lens = (ranges[:, 1] - ranges[:, 0]).float()
+        out = {
+            "metric": "Mpix/s fwd+bwd @1.5M Gauss 1080p",
+            "value": round(world * Ppix / (dt / args.steps) / 1e6, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"rasterizer-with-depth fwd+bwd, one {W}x{H} view per GPU per step, "
+                                   f"N={N} Gaussians, sh_degree {deg} (BASELINE.json configs[2] size, SURVEY.md §8d scene)",
+                       "gaussians": N, "visible": V, "num_rendered_D": D, "tiles": T,
+                       "tile_list_mean": round(float(lens.mean()), 1), "tile_list_max": int(lens.max()),
+                       "parallelism": f"views x{world}" + (" + RCCL all-reduce of the gradient bucket" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom,
+                         "achieved": stages[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(stage_bytes[dom]),
+                         "whole_step": {"algorithmic_bytes": int(total_bytes),
+                                        "GBs": round(total_bytes / ms_step / 1e6, 1),
+                                        "frac": round(total_bytes / ms_step / 1e6 / HBM_PEAK_GBS, 5)}},
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,15 @@ int mvi_raster_get_views(int32_t P, int64_t num_rendered, int32_t image_width, i
                          const void* geom, const void* binning, const void* image,
                          mvi_raster_views* out);
 
+/* Stage timing (measurement aid for bench.py): while enabled, every kernel stage the library
+ * enqueues is bracketed by hipEvents on the caller's stream. mvi_raster_timing_read waits for the
+ * recorded events, adds the elapsed milliseconds and launch counts per stage into ms_sum/calls
+ * ([MVI_RASTER_NSTAGES] each, caller-zeroed) and forgets them. Not thread-safe. */
+#define MVI_RASTER_NSTAGES 8
+int mvi_raster_timing_enable(int enable);
+int mvi_raster_timing_read(float* ms_sum_host, int32_t* calls_host);
+const char* mvi_raster_stage_name(int stage);
+
 const char* mvi_raster_last_error(void);
 const char* mvi_version(void);
 

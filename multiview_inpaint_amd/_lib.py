@@ -73,6 +73,12 @@ def lib():
     L.mvi_raster_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     L.mvi_raster_get_views.restype = C.c_int
     L.mvi_raster_get_views.argtypes = [i32, i64, i32, i32, vp, vp, vp, C.POINTER(RasterViews)]
+    L.mvi_raster_timing_enable.restype = C.c_int
+    L.mvi_raster_timing_enable.argtypes = [C.c_int]
+    L.mvi_raster_timing_read.restype = C.c_int
+    L.mvi_raster_timing_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.mvi_raster_stage_name.restype = C.c_char_p
+    L.mvi_raster_stage_name.argtypes = [C.c_int]
     _bind_unet_ops(L)
     _lib = L
     return L

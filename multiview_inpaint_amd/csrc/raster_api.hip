@@ -13,6 +13,33 @@ int launch_scan_block_sums(GeomView g, int P, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
+// ---- stage timing ------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct Rec { int stage; hipEvent_t a, b; };
+bool g_timing = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_open[MVI_RASTER_NSTAGES];
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+namespace mvi {
+void stage_begin(int stage, hipStream_t st) {
+    if (!g_timing) return;
+    g_open[stage] = get_event();
+    (void)hipEventRecord(g_open[stage], st);
+}
+void stage_end(int stage, hipStream_t st) {
+    if (!g_timing) return;
+    hipEvent_t b = get_event();
+    (void)hipEventRecord(b, st);
+    g_recs.push_back({stage, g_open[stage], b});
+}
+}  // namespace mvi
+
 static int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
     snprintf(g_err, sizeof(g_err), fmt, a, b, c);
     return code;
@@ -43,6 +70,28 @@ static int make_frame(const mvi_raster_settings* s, int P, int M, mvi::Frame& f)
 extern "C" {
 
 const char* mvi_raster_last_error(void) { return g_err; }
+
+int mvi_raster_timing_enable(int enable) { g_timing = enable != 0; return MVI_OK; }
+int mvi_raster_timing_read(float* ms_sum, int32_t* calls) {
+    if (!ms_sum || !calls) return fail(MVI_EINVAL, "NULL timing outputs%s");
+    for (auto& r : g_recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return hip_fail("timing sync", e);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        ms_sum[r.stage] += ms;
+        calls[r.stage] += 1;
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return MVI_OK;
+}
+const char* mvi_raster_stage_name(int i) {
+    static const char* n[MVI_RASTER_NSTAGES] = {"preprocess_forward", "scan_block_sums", "duplicate_keys", "radix_sort",
+                                                "tile_ranges", "render_forward", "render_backward", "preprocess_backward"};
+    return (i >= 0 && i < MVI_RASTER_NSTAGES) ? n[i] : "";
+}
 const char* mvi_version(void) { return "multiview_inpaint_amd 0.1.0 (gfx950)"; }
 
 size_t mvi_raster_geom_bytes(int32_t P) { return mvi::carve_geom(nullptr, P).bytes; }
@@ -70,10 +119,16 @@ int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, 
     mvi::GeomView g = mvi::carve_geom(geom, P);
     if (geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s: %lld < %lld", "", (long long)geom_bytes, (long long)g.bytes);
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = mvi::launch_preprocess_forward(f, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                                cov3D_precomp, g, radii, st))
-        return hip_fail("preprocess_forward", hipGetLastError());
-    if (int rc = mvi::launch_scan_block_sums(g, P, st)) return hip_fail("scan_block_sums", hipGetLastError());
+    {
+        mvi::StageTimer tm(mvi::kStPreFwd, st);
+        if (mvi::launch_preprocess_forward(f, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                           cov3D_precomp, g, radii, st))
+            return hip_fail("preprocess_forward", hipGetLastError());
+    }
+    {
+        mvi::StageTimer tm(mvi::kStScan, st);
+        if (mvi::launch_scan_block_sums(g, P, st)) return hip_fail("scan_block_sums", hipGetLastError());
+    }
     int nblk = (P + mvi::kBlock - 1) / mvi::kBlock;
     uint32_t total = 0;
     hipError_t e = hipMemcpyAsync(&total, g.block_offsets + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
@@ -100,8 +155,11 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D
     if (D > 0 && geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s", "");
     hipStream_t st = (hipStream_t)stream;
     if (int rc = mvi::launch_binning(f, g, radii, b, im, D, st)) return hip_fail("binning", hipGetLastError());
-    if (int rc = mvi::launch_render_forward(f, g, b, im, D, out_color, out_depth, st))
-        return hip_fail("render_forward", hipGetLastError());
+    {
+        mvi::StageTimer tm(mvi::kStRenderFwd, st);
+        if (mvi::launch_render_forward(f, g, b, im, D, out_color, out_depth, st))
+            return hip_fail("render_forward", hipGetLastError());
+    }
     return MVI_OK;
 }
 
@@ -135,8 +193,12 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
     if ((e = hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
     if ((e = hipMemsetAsync(dconic_op, 0, sizeof(float) * 4 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
     if ((e = hipMemsetAsync(dL_dcolors, 0, sizeof(float) * 3 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
-    if (int rc = mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, dL_dmeans2D, dconic_op, dL_dcolors, st))
-        return hip_fail("render_backward", hipGetLastError());
+    {
+        mvi::StageTimer tm(mvi::kStRenderBwd, st);
+        if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, dL_dmeans2D, dconic_op, dL_dcolors, st))
+            return hip_fail("render_backward", hipGetLastError());
+    }
+    mvi::StageTimer tm(mvi::kStPreBwd, st);
     if (int rc = mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g,
                                                  dL_dmeans2D, dconic_op, dL_dcolors, dL_dmeans3D, dL_dshs, dL_dcov3D,
                                                  dL_dscales, dL_drotations, st))

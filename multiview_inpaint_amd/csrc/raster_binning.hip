@@ -243,8 +243,12 @@ int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView
     if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
     if (D <= 0 || f.P <= 0) return 0;
     int nblk = (f.P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, radii, b.keys[0], b.vals[0]);
+    {
+        StageTimer tm(kStDup, st);
+        hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, radii, b.keys[0], b.vals[0]);
+    }
     int cur = 0;
+    stage_begin(kStSort, st);
     for (int p = 0; p < b.passes; ++p) {
         int shift = 8 * p;
         int nb = b.key_bits - shift < 8 ? b.key_bits - shift : 8;
@@ -256,7 +260,9 @@ int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView
                            b.keys[cur ^ 1], b.vals[cur ^ 1], D, shift, mask, b.block_hist, b.nsort, b.digit_tot);
         cur ^= 1;
     }
+    stage_end(kStSort, st);
     int nrb = (int)((D + kBlock - 1) / kBlock);
+    StageTimer tm(kStRanges, st);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(nrb), dim3(kBlock), 0, st, b.keys[cur], D, im.ranges);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }

@@ -163,6 +163,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return v;
 }
 
+// Stage timing (include/mvi_raster.h: mvi_raster_timing_*). A StageTimer brackets the launches
+// enqueued during its lifetime with two hipEvents when timing is enabled; otherwise it is free.
+enum Stage { kStPreFwd = 0, kStScan, kStDup, kStSort, kStRanges, kStRenderFwd, kStRenderBwd, kStPreBwd };
+void stage_begin(int stage, hipStream_t st);
+void stage_end(int stage, hipStream_t st);
+struct StageTimer {
+    int stage; hipStream_t st;
+    StageTimer(int s, hipStream_t q) : stage(s), st(q) { stage_begin(stage, st); }
+    ~StageTimer() { stage_end(stage, st); }
+};
+
 // launchers (defined in the .hip files; all enqueue on `st`, none synchronise)
 int launch_preprocess_forward(const Frame& f, const float* means3D, const float* shs,
                               const float* colors_precomp, const float* opacities, const float* scales,

@@ -126,24 +126,34 @@ def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs
 
 
 def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_color, means3D, shs=None,
-                       colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
-    """Runs the HIP backward. Returns dict of gradients (None for inputs that were not given)."""
+                       colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, out=None):
+    """Runs the HIP backward. Returns dict of gradients (None for inputs that were not given).
+    `out` may hold preallocated contiguous fp32 tensors (e.g. dist.GradBucket.views) to write into."""
     L = _lib.lib()
     fr = _Frame(rs)
     dev = means3D.device
     P = st.P
     f32 = dict(dtype=torch.float32, device=dev)
-    g = dict(means3D=torch.empty(P, 3, **f32), means2D=torch.empty(P, 3, **f32), opacities=torch.empty(P, 1, **f32),
+    out = out or {}
+
+    def buf(name, *shape):
+        t = out.get(name)
+        if t is None:
+            return torch.empty(*shape, **f32)
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"out[{name!r}] must be a contiguous fp32 {shape} tensor on {dev}")
+        return t
+    g = dict(means3D=buf("means3D", P, 3), means2D=buf("means2D", P, 3), opacities=buf("opacities", P, 1),
              shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
-    dcolors = torch.empty(P, 3, **f32)                   # output in colours mode, scratch in SH mode
+    dcolors = buf("colors_precomp", P, 3)                # output in colours mode, scratch in SH mode
     if shs is not None:
-        g["shs"] = torch.empty(P, st.M, 3, **f32)
+        g["shs"] = buf("shs", P, st.M, 3)
     else:
         g["colors_precomp"] = dcolors
     if cov3D_precomp is not None:
-        g["cov3D_precomp"] = torch.empty(P, 6, **f32)
+        g["cov3D_precomp"] = buf("cov3D_precomp", P, 6)
     else:
-        g["scales"], g["rotations"] = torch.empty(P, 3, **f32), torch.empty(P, 4, **f32)
+        g["scales"], g["rotations"] = buf("scales", P, 3), buf("rotations", P, 4)
     scratch = torch.empty(P, 4, **f32)
     grad_color = grad_color.to(torch.float32).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU) of the view-parallel exchange step (multiview_inpaint_amd/dist.py).
+The rasterizer itself needs the GPU; here the per-view gradients are stand-ins and the checks are on
+the exchange: bucket sum == sum of per-rank gradients, identical on every rank, densification stats
+reduced as per-view norms."""
+import os
+import socket
+
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from multiview_inpaint_amd import dist as md
+    P, M = 1000, 4
+    views = list(range(7))
+    mine = md.shard_views(views, rank, world)
+    assert mine == [v for v in views if v % world == rank]
+    # 1. GradBucket: one flat all-reduce equals the sum of the per-rank SoA gradients
+    bucket = md.GradBucket(P, M, "cpu")
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    per_rank = [{k: torch.randn(v.shape, generator=gens[r]) for k, v in sorted(bucket.views.items()) if k != "means2D"}
+                for r in range(world)]
+    for k, v in per_rank[rank].items():
+        bucket.views[k].copy_(v)
+    bucket.all_reduce()
+    for k in per_rank[0]:
+        want = sum(per_rank[r][k] for r in range(world))
+        assert torch.allclose(bucket.views[k], want, rtol=1e-5, atol=1e-6), k
+    assert bucket.flat.numel() == P * (11 + 3 * M)
+    # 2. parameter-gradient exchange over the reference's six parameter groups
+    shapes = [(P, 3), (P, 1, 3), (P, M - 1, 3), (P, 1), (P, 3), (P, 4)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    g2 = [torch.Generator().manual_seed(200 + r) for r in range(world)]
+    grads = [[torch.randn(s, generator=g2[r]) for s in shapes] for r in range(world)]
+    for p, g in zip(params, grads[rank]):
+        p.grad = g.clone()
+    if rank == 1:
+        params[3].grad = None                             # a rank whose view saw nothing for that group
+    md.all_reduce_param_grads(params)
+    for i, p in enumerate(params):
+        want = sum(grads[r][i] for r in range(world) if not (r == 1 and i == 3))
+        assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), i
+    # 3. densification side channel: per-view norms are summed, radii are max-ed
+    g3 = [torch.Generator().manual_seed(300 + r) for r in range(world)]
+    vg = [torch.randn(P, 3, generator=g3[r]) for r in range(world)]
+    vis = [torch.rand(P, generator=g3[r]) > 0.4 for r in range(world)]
+    rad = [torch.randint(0, 50, (P,), generator=g3[r], dtype=torch.int32) for r in range(world)]
+    accum, denom, mx = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+    md.reduce_densification_stats(vg[rank], vis[rank], rad[rank], accum, denom, mx)
+    want_a = sum(torch.where(vis[r][:, None], vg[r][:, :2].norm(dim=-1, keepdim=True), torch.zeros(P, 1)) for r in range(world))
+    want_d = sum(vis[r].float()[:, None] for r in range(world))
+    want_m = torch.stack([torch.where(vis[r], rad[r].float(), torch.zeros(P)) for r in range(world)]).max(0).values
+    assert torch.allclose(accum, want_a, atol=1e-6) and torch.equal(denom, want_d) and torch.equal(mx, want_m)
+    torch.save(dict(flat=bucket.flat, accum=accum), os.path.join(out_dir, f"r{rank}.pt"))
+    td.destroy_process_group()
+
+
+def test_view_parallel_exchange_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(tmp_path / f"r{r}.pt") for r in range(world))
+    assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["accum"], b["accum"])   # ranks agree bit for bit
