@@ -1,0 +1,99 @@
+"""Network wrappers and the Lightning-free counterpart of the reference's sampling engine.
+
+Reference: sgm/modules/diffusionmodules/wrappers.py:9-34 (IdentityWrapper / OpenAIWrapper),
+models/csvd.py:1086-1152 (SVDEngine.apply_model), :1258-1277 (SVDEngine.sample), stock path
+sgm/models/diffusion.py:313-328. The reference engines are pytorch-lightning modules that also
+own the VAE, the conditioner and checkpoint plumbing (out of scope); this
+harness owns exactly the per-step hot path: ControlNet -> scaled residuals -> ControlledVideoUNet,
+wrapped by Denoiser and driven by the sampler.
+"""
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from .schedule import Denoiser, instantiate_from_config
+
+OPENAIUNETWRAPPER = "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper"
+
+
+class IdentityWrapper(nn.Module):
+    def __init__(self, diffusion_model, compile_model: bool = False):
+        super().__init__()
+        if compile_model:
+            raise NotImplementedError("no tracing compiler on this path: hot ops are hand-written HIP kernels")
+        self.diffusion_model = diffusion_model
+
+    def forward(self, *args, **kwargs):
+        return self.diffusion_model(*args, **kwargs)
+
+
+class OpenAIWrapper(IdentityWrapper):
+    """x || c['concat'] on channels; crossattn -> context, vector -> y (wrappers.py:23-34)."""
+
+    def forward(self, x, t, c: dict, **kwargs):
+        cc = c.get("concat")
+        if cc is not None and cc.numel():
+            x = torch.cat((x, cc.type_as(x)), dim=1)
+        return self.diffusion_model(x, timesteps=t, context=c.get("crossattn"), y=c.get("vector"), **kwargs)
+
+
+class SVDInpaintEngine(nn.Module):
+    """`model.diffusion_model` (ControlledVideoUNet) + `control_model` (ControlNet) + denoiser + sampler.
+    Attribute names follow the reference engine so its checkpoints' key prefixes line up."""
+
+    def __init__(self, network: nn.Module, control_model: Optional[nn.Module], denoiser: Denoiser, sampler=None,
+                 control_scales: Optional[Sequence[float]] = None, global_average_pooling: bool = False):
+        super().__init__()
+        self.model = OpenAIWrapper(network)
+        self.control_model = control_model
+        self.denoiser = denoiser
+        self.sampler = sampler
+        self.control_scales = list(control_scales) if control_scales is not None else [1.0] * 13
+        self.global_average_pooling = global_average_pooling
+
+    @classmethod
+    def from_configs(cls, network_config, control_config, denoiser_config, sampler_config=None, **kw):
+        return cls(instantiate_from_config(network_config),
+                   instantiate_from_config(control_config) if control_config else None,
+                   instantiate_from_config(denoiser_config),
+                   instantiate_from_config(sampler_config) if sampler_config else None, **kw)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def apply_model(self, x, timesteps, cond: Dict, time_context=None, num_video_frames=None, image_only_indicator=None):
+        cc = cond.get("concat")
+        if cc is None:
+            cc = x.new_zeros(x.shape[0], 0, *x.shape[2:])
+        if "concat_scale" in cond:
+            cc = cc * cond["concat_scale"]
+        xin = torch.cat([x, cc.type_as(x)], dim=1)
+        context = cond.get("crossattn")
+        if "crossattn_scale" in cond:
+            context = context * cond["crossattn_scale"]
+        y = cond.get("vector")
+        hint = cond.get("control_hint")
+        if "palette" in cond:
+            hint = [hint, cond["palette"]]
+        controls = None
+        if hint is not None and self.control_model is not None:
+            controls = self.control_model(x=xin, hint=hint, timesteps=timesteps, context=context, y=y,
+                                          time_context=time_context, num_video_frames=num_video_frames,
+                                          image_only_indicator=image_only_indicator)
+            controls = [c * s for c, s in zip(controls, self.control_scales)]
+            if self.global_average_pooling:
+                controls = [c.mean(dim=(2, 3), keepdim=True) for c in controls]
+        return self.model.diffusion_model(x=xin, timesteps=timesteps, context=context, y=y, time_context=time_context,
+                                          control=controls, num_video_frames=num_video_frames,
+                                          image_only_indicator=image_only_indicator)
+
+    def denoise(self, x, sigma, cond, **kwargs):
+        """One denoise step = Denoiser.forward over apply_model (csvd.py:1271-1273)."""
+        return self.denoiser(self.apply_model, x, sigma, cond, **kwargs)
+
+    @torch.no_grad()
+    def sample(self, x, cond: Dict, uc: Optional[Dict] = None, batch_size: int = 16, shape=None, **kwargs):
+        randn = torch.randn(batch_size, *shape).to(self.device)     # global torch RNG, as csvd.py:1269
+        return self.sampler(lambda inp, sigma, c: self.denoise(inp, sigma, c, **kwargs), randn, cond, uc=uc)

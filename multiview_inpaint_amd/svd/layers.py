@@ -1,0 +1,290 @@
+"""Convolutional building blocks of the video UNet: GroupNorm32(+SiLU), sinusoidal embeddings,
+alpha blending of spatial/temporal branches, up/down-sampling, the spatial ResBlock and its
+spatial+temporal VideoResBlock.
+
+Reference: sgm/modules/diffusionmodules/util.py:207-231 (timestep_embedding), :259-276
+(normalization/GroupNorm32), :312-372 (AlphaBlender); openaimodel.py:72-104
+(TimestepEmbedSequential), :107-207 (Upsample/Downsample), :210-354 (ResBlock);
+video_model.py:12-81 (VideoResBlock). Parameter names (state-dict keys) are identical to the
+reference so svd.safetensors / ControlNet checkpoints load (sgm/models/diffusion.py:105).
+"""
+import math
+from dataclasses import dataclass
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint as _torch_checkpoint
+
+from . import ops
+
+
+def zero_module(m: nn.Module) -> nn.Module:
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+def conv_nd(dims, *a, **k):
+    return {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}[dims](*a, **k)
+
+
+def avg_pool_nd(dims, *a, **k):
+    return {1: nn.AvgPool1d, 2: nn.AvgPool2d, 3: nn.AvgPool3d}[dims](*a, **k)
+
+
+def linear(*a, **k):
+    return nn.Linear(*a, **k)
+
+
+def maybe_checkpoint(fn, enabled, *args):
+    """Activation checkpointing only matters when a graph is being recorded."""
+    if enabled and torch.is_grad_enabled():
+        return _torch_checkpoint(fn, *args, use_reentrant=False)
+    return fn(*args)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    """[N] -> [N, dim], cosine half first, then sine (util.py:207-231)."""
+    if repeat_only:
+        return timesteps[:, None].expand(-1, dim)
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(timesteps.device)
+    ang = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+class GroupNorm32(nn.GroupNorm):
+    """GroupNorm computed in fp32 and cast back (util.py:274-276); HIP kernel on the GPU."""
+
+    def forward(self, x, silu: bool = False):
+        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, silu=silu)
+
+
+def normalization(channels):
+    return GroupNorm32(32, channels)
+
+
+def norm_act(seq: nn.Sequential, x):
+    """Runs a `[GroupNorm32, SiLU, ...]` prefix as ONE fused op; returns the activated tensor."""
+    return seq[0](x, silu=True)
+
+
+class Timestep(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, t):
+        return timestep_embedding(t, self.dim)
+
+
+class AlphaBlender(nn.Module):
+    """alpha * spatial + (1 - alpha) * temporal with alpha = sigmoid(mix_factor), forced to 1 for
+    image-only frames (util.py:312-372), including the CFG patch that repeats alpha when the batch
+    was doubled after image_only_indicator was built (:365-367)."""
+    strategies = ["learned", "fixed", "learned_with_images"]
+
+    def __init__(self, alpha: float, merge_strategy: str = "learned_with_images",
+                 rearrange_pattern: str = "b t -> (b t) 1 1"):
+        super().__init__()
+        assert merge_strategy in self.strategies, f"merge_strategy needs to be in {self.strategies}"
+        self.merge_strategy, self.rearrange_pattern = merge_strategy, rearrange_pattern
+        if merge_strategy == "fixed":
+            self.register_buffer("mix_factor", torch.tensor([float(alpha)]))
+        else:
+            self.register_parameter("mix_factor", nn.Parameter(torch.tensor([float(alpha)])))
+
+    def get_alpha(self, image_only_indicator):
+        if self.merge_strategy == "fixed":
+            return self.mix_factor
+        if self.merge_strategy == "learned":
+            return torch.sigmoid(self.mix_factor)
+        assert image_only_indicator is not None, "need image_only_indicator ..."
+        ind = image_only_indicator.bool()
+        a = torch.where(ind, torch.ones(1, 1, device=ind.device), torch.sigmoid(self.mix_factor)[..., None])
+        b, t = a.shape
+        if self.rearrange_pattern == "b t -> (b t) 1 1":
+            return a.reshape(b * t, 1, 1)
+        if self.rearrange_pattern == "b t -> b 1 t 1 1":
+            return a.reshape(b, 1, t, 1, 1)
+        from einops import rearrange
+        return rearrange(a, self.rearrange_pattern)
+
+    def forward(self, x_spatial, x_temporal, image_only_indicator=None):
+        a = self.get_alpha(image_only_indicator)
+        if a.size(0) != x_spatial.size(0):
+            a = torch.cat([a] * 2)
+        a = a.to(x_spatial.dtype)
+        return a * x_spatial + (1.0 - a) * x_temporal
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_up=False,
+                 kernel_size=3, scale_factor=2):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.use_conv, self.dims, self.third_up, self.scale_factor = use_conv, dims, third_up, scale_factor
+        if use_conv:
+            self.conv = conv_nd(dims, self.channels, self.out_channels, kernel_size, padding=padding)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        s = self.scale_factor
+        if self.dims == 3:
+            x = F.interpolate(x, ((s if self.third_up else 1) * x.shape[2], x.shape[3] * s, x.shape[4] * s), mode="nearest")
+        else:
+            x = F.interpolate(x, scale_factor=s, mode="nearest")
+        return self.conv(x) if self.use_conv else x
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_down=False):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.use_conv, self.dims = use_conv, dims
+        stride = 2 if dims != 3 else ((2, 2, 2) if third_down else (1, 2, 2))
+        if use_conv:
+            self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=stride, padding=padding)
+        else:
+            assert self.channels == self.out_channels
+            self.op = avg_pool_nd(dims, kernel_size=stride, stride=stride)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return self.op(x)
+
+
+@dataclass
+class BlockArgs:
+    """What a TimestepEmbedSequential hands to each member that wants more than `x`."""
+    emb: Optional[torch.Tensor] = None
+    context: Optional[torch.Tensor] = None
+    image_only_indicator: Optional[torch.Tensor] = None
+    time_context: Optional[torch.Tensor] = None
+    num_video_frames: Optional[int] = None
+
+
+class TimestepBlock(nn.Module):
+    """Marker: forward(x, emb)."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Sequential whose members declare, through `takes`, which conditioning they consume
+    (openaimodel.py:72-104 dispatches on isinstance instead; same call signature)."""
+
+    def forward(self, x, emb=None, context=None, image_only_indicator=None, time_context=None, num_video_frames=None):
+        a = BlockArgs(emb, context, image_only_indicator, time_context, num_video_frames)
+        for layer in self:
+            kind = getattr(layer, "takes", None)
+            if kind == "video_res":
+                x = layer(x, a.emb, a.num_video_frames, a.image_only_indicator)
+            elif kind == "video_attn":
+                x = layer(x, a.context, a.time_context, a.num_video_frames, a.image_only_indicator)
+            elif kind == "attn":
+                x = layer(x, a.context)
+            elif kind == "emb" or isinstance(layer, TimestepBlock):
+                x = layer(x, a.emb)
+            else:
+                x = layer(x)
+        return x
+
+
+class ResBlock(TimestepBlock):
+    """GN-SiLU-conv, + Linear(SiLU(emb)), GN-SiLU-(dropout)-conv, + skip (openaimodel.py:210-354).
+    GN+SiLU pairs run as one fused op."""
+    takes = "emb"
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False,
+                 kernel_size=3, exchange_temb_dims=False, skip_t_emb=False):
+        super().__init__()
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_conv, self.use_checkpoint = use_conv, use_checkpoint
+        self.use_scale_shift_norm, self.exchange_temb_dims = use_scale_shift_norm, exchange_temb_dims
+        pad = [k // 2 for k in kernel_size] if isinstance(kernel_size, Iterable) else kernel_size // 2
+
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(),
+                                       conv_nd(dims, channels, self.out_channels, kernel_size, padding=pad))
+        self.updown = up or down
+        if up:
+            self.h_upd, self.x_upd = Upsample(channels, False, dims), Upsample(channels, False, dims)
+        elif down:
+            self.h_upd, self.x_upd = Downsample(channels, False, dims), Downsample(channels, False, dims)
+        else:
+            self.h_upd = self.x_upd = nn.Identity()
+
+        self.skip_t_emb = skip_t_emb
+        self.emb_out_channels = 2 * self.out_channels if use_scale_shift_norm else self.out_channels
+        if skip_t_emb:
+            assert not use_scale_shift_norm
+            self.emb_layers, self.exchange_temb_dims = None, False
+        else:
+            self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.emb_out_channels))
+        self.out_layers = nn.Sequential(
+            normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+            zero_module(conv_nd(dims, self.out_channels, self.out_channels, kernel_size, padding=pad)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, kernel_size, padding=pad)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def forward(self, x, emb):
+        return maybe_checkpoint(self._forward, self.use_checkpoint, x, emb)
+
+    def _forward(self, x, emb):
+        h = norm_act(self.in_layers, x)
+        if self.updown:
+            h, x = self.h_upd(h), self.x_upd(x)
+        h = self.in_layers[2](h)
+        if self.skip_t_emb:
+            e = torch.zeros_like(h)
+        else:
+            e = self.emb_layers(emb).type(h.dtype)
+        e = e.reshape(e.shape + (1,) * (h.ndim - e.ndim))
+        if self.use_scale_shift_norm:
+            scale, shift = e.chunk(2, dim=1)
+            h = self.out_layers[0](h) * (1 + scale) + shift
+            h = self.out_layers[3](self.out_layers[2](F.silu(h)))
+        else:
+            if self.exchange_temb_dims:
+                e = e.transpose(1, 2)                       # b t c ... -> b c t ...
+            h = norm_act(self.out_layers, h + e)
+            h = self.out_layers[3](self.out_layers[2](h))
+        return self.skip_connection(x) + h
+
+
+class VideoResBlock(ResBlock):
+    """Spatial ResBlock on (b t) c h w, then a temporal ResBlock (Conv3d kernel (3,1,1)) on
+    b c t h w, blended by AlphaBlender (video_model.py:12-81)."""
+    takes = "video_res"
+
+    def __init__(self, channels, emb_channels, dropout, video_kernel_size=3, merge_strategy="fixed",
+                 merge_factor=0.5, out_channels=None, use_conv=False, use_scale_shift_norm=False, dims=2,
+                 use_checkpoint=False, up=False, down=False):
+        super().__init__(channels, emb_channels, dropout, out_channels=out_channels, use_conv=use_conv,
+                         use_scale_shift_norm=use_scale_shift_norm, dims=dims, use_checkpoint=use_checkpoint,
+                         up=up, down=down)
+        oc = out_channels if out_channels is not None else channels
+        self.time_stack = ResBlock(oc, emb_channels, dropout=dropout, dims=3, out_channels=oc,
+                                   use_scale_shift_norm=False, use_conv=False, up=False, down=False,
+                                   kernel_size=video_kernel_size, use_checkpoint=use_checkpoint,
+                                   exchange_temb_dims=True)
+        self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy,
+                                       rearrange_pattern="b t -> b 1 t 1 1")
+
+    def forward(self, x, emb, num_video_frames, image_only_indicator=None):
+        x = super().forward(x, emb)
+        t = int(num_video_frames)
+        bt, c, h, w = x.shape
+        xs = x.reshape(bt // t, t, c, h, w).transpose(1, 2)          # b c t h w (view)
+        xt = self.time_stack(xs, emb.reshape(bt // t, t, *emb.shape[1:]))
+        out = self.time_mixer(x_spatial=xs, x_temporal=xt, image_only_indicator=image_only_indicator)
+        return out.transpose(1, 2).reshape(bt, c, h, w)

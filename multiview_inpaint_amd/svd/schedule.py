@@ -1,0 +1,364 @@
+"""Sigma schedule, denoiser preconditioning, guidance and the Euler EDM sampler.
+
+Reference call stack: EulerEDMSampler.__call__ (sampling.py:110-131) ->
+sampler_step (:94-108) -> denoise (:55-58) -> guider.prepare_inputs (guiders.py:88-99) ->
+Denoiser.forward (denoiser.py:23-38) with VScalingWithEDMcNoise (denoiser_scaling.py:51-59) ->
+network -> guider.__call__ (guiders.py:78-86) -> to_d / Euler update (sampling_utils.py:34-35,
+sampling.py:79-80). Sigma grid: EDMDiscretization (discretizer.py:28-39).
+All paths are relative to svd_inpaint1/sgm/modules/diffusionmodules/.
+"""
+import importlib
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+
+# ------------------------------------------------------------------ config plumbing (sgm/util.py:168-199)
+def get_obj_from_str(name: str, reload: bool = False):
+    mod, attr = name.rsplit(".", 1)
+    m = importlib.import_module(mod)
+    if reload:
+        m = importlib.reload(m)
+    return getattr(m, attr)
+
+
+def instantiate_from_config(config):
+    if "target" not in config:
+        if config in ("__is_first_stage__", "__is_unconditional__"):
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(config["target"])(**dict(config.get("params", {}) or {}))
+
+
+def default(value, fallback):
+    if value is not None:
+        return value
+    return fallback() if callable(fallback) else fallback
+
+
+def append_dims(x: torch.Tensor, ndim: int) -> torch.Tensor:
+    extra = ndim - x.ndim
+    if extra < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {ndim}, which is less")
+    return x.reshape(x.shape + (1,) * extra)
+
+
+def append_zero(x: torch.Tensor) -> torch.Tensor:
+    return torch.cat([x, x.new_zeros(1)])
+
+
+# ------------------------------------------------------------------ sigma grids
+class Discretization:
+    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
+        sig = self.get_sigmas(n, device=device)
+        if do_append_zero:
+            sig = append_zero(sig)
+        return torch.flip(sig, (0,)) if flip else sig
+
+    def get_sigmas(self, n, device):
+        raise NotImplementedError
+
+
+class EDMDiscretization(Discretization):
+    """Karras rho-grid from sigma_max down to sigma_min (discretizer.py:28-39)."""
+
+    def __init__(self, sigma_min=0.002, sigma_max=80.0, rho=7.0):
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def get_sigmas(self, n, device="cpu"):
+        u = torch.linspace(0, 1, n, device=device)
+        lo, hi = self.sigma_min ** (1 / self.rho), self.sigma_max ** (1 / self.rho)
+        return (hi + u * (lo - hi)) ** self.rho
+
+
+# ------------------------------------------------------------------ preconditioning (c_skip, c_out, c_in, c_noise)
+class DenoiserScaling:
+    def __call__(self, sigma):
+        raise NotImplementedError
+
+
+class EDMScaling(DenoiserScaling):
+    def __init__(self, sigma_data: float = 0.5):
+        self.sigma_data = sigma_data
+
+    def __call__(self, sigma):
+        sd, tot = self.sigma_data, sigma ** 2 + self.sigma_data ** 2
+        return sd ** 2 / tot, sigma * sd / tot ** 0.5, 1 / tot ** 0.5, 0.25 * sigma.log()
+
+
+class EpsScaling(DenoiserScaling):
+    def __call__(self, sigma):
+        return torch.ones_like(sigma), -sigma, 1 / (sigma ** 2 + 1.0) ** 0.5, sigma.clone()
+
+
+class VScaling(DenoiserScaling):
+    def __call__(self, sigma):
+        tot = sigma ** 2 + 1.0
+        return 1.0 / tot, -sigma / tot ** 0.5, 1.0 / tot ** 0.5, sigma.clone()
+
+
+class VScalingWithEDMcNoise(DenoiserScaling):
+    """v-prediction with the EDM noise embedding 0.25 ln(sigma) (denoiser_scaling.py:51-59)."""
+
+    def __call__(self, sigma):
+        tot = sigma ** 2 + 1.0
+        return 1.0 / tot, -sigma / tot ** 0.5, 1.0 / tot ** 0.5, 0.25 * sigma.log()
+
+
+class Denoiser(nn.Module):
+    """D(x; sigma) = c_out * F(c_in * x, c_noise, cond) + c_skip * x (denoiser.py:12-38)."""
+
+    def __init__(self, scaling_config: Dict):
+        super().__init__()
+        self.scaling: DenoiserScaling = instantiate_from_config(scaling_config)
+
+    def possibly_quantize_sigma(self, sigma):
+        return sigma
+
+    def possibly_quantize_c_noise(self, c_noise):
+        return c_noise
+
+    def _precondition(self, x, sigma):
+        sigma = self.possibly_quantize_sigma(sigma)
+        shape = sigma.shape
+        c_skip, c_out, c_in, c_noise = self.scaling(append_dims(sigma, x.ndim))
+        return c_skip, c_out, c_in, self.possibly_quantize_c_noise(c_noise.reshape(shape))
+
+    def forward(self, network, input, sigma, cond, **additional_model_inputs):
+        c_skip, c_out, c_in, c_noise = self._precondition(input, sigma)
+        return network(input * c_in, c_noise, cond, **additional_model_inputs) * c_out + input * c_skip
+
+    def inv_sample(self, network, input, sigma, cond, **additional_model_inputs):
+        """Raw network output (denoiser.py:40-56; used only by the unshipped inversion engine)."""
+        _, _, c_in, c_noise = self._precondition(input, sigma)
+        return network(input * c_in, c_noise, cond, **additional_model_inputs)
+
+
+class DiscreteDenoiser(Denoiser):
+    def __init__(self, scaling_config, num_idx, discretization_config, do_append_zero=False,
+                 quantize_c_noise=True, flip=True):
+        super().__init__(scaling_config)
+        self.discretization = instantiate_from_config(discretization_config)
+        self.register_buffer("sigmas", self.discretization(num_idx, do_append_zero=do_append_zero, flip=flip))
+        self.quantize_c_noise, self.num_idx = quantize_c_noise, num_idx
+
+    def sigma_to_idx(self, sigma):
+        return (sigma - self.sigmas[:, None]).abs().argmin(dim=0).view(sigma.shape)
+
+    def idx_to_sigma(self, idx):
+        return self.sigmas[idx]
+
+    def possibly_quantize_sigma(self, sigma):
+        return self.idx_to_sigma(self.sigma_to_idx(sigma))
+
+    def possibly_quantize_c_noise(self, c_noise):
+        return self.sigma_to_idx(c_noise) if self.quantize_c_noise else c_noise
+
+
+# ------------------------------------------------------------------ guidance
+_BATCHED_KEYS = ("vector", "crossattn", "concat")
+
+
+class Guider:
+    def __call__(self, x, sigma):
+        raise NotImplementedError
+
+    def prepare_inputs(self, x, s, c, uc):
+        raise NotImplementedError
+
+
+def _double_cond(c: Dict, uc: Dict, keys: Sequence[str]) -> Dict:
+    out = {}
+    for k, v in c.items():
+        if k in keys:
+            out[k] = torch.cat((uc[k], v), 0)
+        else:
+            assert v == uc[k]
+            out[k] = v
+    return out
+
+
+class IdentityGuider(Guider):
+    def __call__(self, x, sigma):
+        return x
+
+    def prepare_inputs(self, x, s, c, uc):
+        return x, s, dict(c)
+
+
+class VanillaCFG(Guider):
+    def __init__(self, scale: float):
+        self.scale = scale
+
+    def __call__(self, x, sigma):
+        x_u, x_c = x.chunk(2)
+        return x_u + self.scale * (x_c - x_u)
+
+    def prepare_inputs(self, x, s, c, uc):
+        return torch.cat([x] * 2), torch.cat([s] * 2), _double_cond(c, uc, _BATCHED_KEYS)
+
+
+class LinearPredictionGuider(Guider):
+    """Per-frame guidance scale linspace(min_scale, max_scale, num_frames) (guiders.py:60-99)."""
+
+    def __init__(self, max_scale: float, num_frames: int, min_scale: float = 1.0,
+                 additional_cond_keys: Optional[Union[List[str], str]] = None):
+        self.min_scale, self.max_scale, self.num_frames = min_scale, max_scale, num_frames
+        self.scale = torch.linspace(min_scale, max_scale, num_frames).unsqueeze(0)
+        extra = default(additional_cond_keys, [])
+        self.additional_cond_keys = [extra] if isinstance(extra, str) else list(extra)
+
+    def __call__(self, x, sigma):
+        x_u, x_c = x.chunk(2)
+        t = self.num_frames
+        x_u = x_u.reshape(-1, t, *x_u.shape[1:])
+        x_c = x_c.reshape(-1, t, *x_c.shape[1:])
+        scale = append_dims(self.scale.expand(x_u.shape[0], t), x_u.ndim).to(x_u.device)
+        out = x_u + scale * (x_c - x_u)
+        return out.reshape(-1, *out.shape[2:])
+
+    def prepare_inputs(self, x, s, c, uc):
+        keys = list(_BATCHED_KEYS) + self.additional_cond_keys
+        return torch.cat([x] * 2), torch.cat([s] * 2), _double_cond(c, uc, keys)
+
+
+class LinearPredictionGuider2(LinearPredictionGuider):
+    """Pass-through variant of the unshipped inversion experiments (guiders.py:102-148)."""
+
+    def __call__(self, x, sigma):
+        return x
+
+    def prepare_inputs(self, x, s, c, uc):
+        keys = list(_BATCHED_KEYS) + self.additional_cond_keys
+        for k in c:
+            if k not in keys:
+                assert c[k] == uc[k]
+        return x, s, dict(c)
+
+    prepare_inv_inputs = prepare_inputs
+
+
+# ------------------------------------------------------------------ sampler
+def to_d(x, sigma, denoised):
+    return (x - denoised) / append_dims(sigma, x.ndim)
+
+
+DEFAULT_GUIDER = {"target": "sgm.modules.diffusionmodules.guiders.IdentityGuider"}
+
+
+class BaseDiffusionSampler:
+    def __init__(self, discretization_config, num_steps=None, guider_config=None, verbose=False, device="cuda"):
+        self.num_steps = num_steps
+        self.discretization = instantiate_from_config(discretization_config)
+        self.guider = instantiate_from_config(default(guider_config, DEFAULT_GUIDER))
+        self.verbose, self.device = verbose, device
+
+    def prepare_sampling_loop(self, x, cond, uc=None, num_steps=None):
+        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps, device=self.device)
+        uc = default(uc, cond)
+        x *= torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        return x, x.new_ones([x.shape[0]]), sigmas, len(sigmas), cond, uc
+
+    def denoise(self, x, denoiser, sigma, cond, uc):
+        return self.guider(denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc)), sigma)
+
+    def get_sigma_gen(self, num_sigmas):
+        steps = range(num_sigmas - 1)
+        if self.verbose:
+            from tqdm import tqdm
+            steps = tqdm(steps, total=num_sigmas, desc=f"Sampling with {type(self).__name__} for {num_sigmas} steps")
+        return steps
+
+
+class SingleStepDiffusionSampler(BaseDiffusionSampler):
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc, *args, **kwargs):
+        raise NotImplementedError
+
+    def euler_step(self, x, d, dt):
+        return x + dt * d
+
+
+class EDMSampler(SingleStepDiffusionSampler):
+    def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+
+    def _gamma(self, sigma_i, num_sigmas):
+        if self.s_tmin <= sigma_i <= self.s_tmax:
+            return min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1)
+        return 0.0
+
+    def _churn(self, x, sigma, gamma):
+        sigma_hat = sigma * (gamma + 1.0)
+        if gamma > 0:
+            x = x + torch.randn_like(x) * self.s_noise * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
+        return x, sigma_hat
+
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, gamma=0.0):
+        x, sigma_hat = self._churn(x, sigma, gamma)
+        denoised = self.denoise(x, denoiser, sigma_hat, cond, uc)
+        d = to_d(x, sigma_hat, denoised)
+        dt = append_dims(next_sigma - sigma_hat, x.ndim)
+        return self.possible_correction_step(self.euler_step(x, d, dt), x, d, dt, next_sigma, denoiser, cond, uc)
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
+        x, s_in, sigmas, n, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(n):
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc,
+                                  self._gamma(sigmas[i], n))
+        return x
+
+
+class EulerEDMSampler(EDMSampler):
+    def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
+        return euler_step
+
+
+class HeunEDMSampler(EDMSampler):
+    def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
+        if torch.sum(next_sigma) < 1e-14:
+            return euler_step
+        d_new = to_d(euler_step, next_sigma, self.denoise(euler_step, denoiser, next_sigma, cond, uc))
+        d_prime = (d + d_new) / 2.0
+        return torch.where(append_dims(next_sigma, x.ndim) > 0.0, x + d_prime * dt, euler_step)
+
+
+class EDMSampler2(EDMSampler):
+    """Latent-mask blending variant (sampling.py:134-191): before every step the known region is
+    replaced by the re-noised reference latent, x = x*mask + (z + eps*sigma)*(1-mask). Not referenced
+    by any shipped config; kept importable, not optimised."""
+
+    def sampler_step(self, sigma, next_sigma, denoiser, z, mask, masked_z, x, cond, uc=None, gamma=0.0):
+        x, sigma_hat = self._churn(x, sigma, gamma)
+        x = x * mask + (z + torch.randn_like(z) * append_dims(sigma_hat, z.ndim)) * (1.0 - mask)
+        denoised = self.denoise(x, denoiser, sigma_hat, cond, uc)
+        d = to_d(x, sigma_hat, denoised)
+        dt = append_dims(next_sigma - sigma_hat, x.ndim)
+        return self.possible_correction_step(self.euler_step(x, d, dt), x, d, dt, next_sigma, denoiser, cond, uc)
+
+    def __call__(self, denoiser, z, mask, masked_z, x, cond, uc=None, num_steps=None):
+        x, s_in, sigmas, n, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(n):
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, z, mask, masked_z, x, cond, uc,
+                                  self._gamma(sigmas[i], n))
+        return x
+
+
+class EDMSampler3(EDMSampler2):
+    """Placeholder for the reference's Euler-inversion experiment (sampling.py:193-356), which dumps
+    np.save debug files into logs/demo_out and is referenced by no shipped config. Importable only."""
+
+    def __call__(self, *args, **kwargs):
+        raise NotImplementedError("EDMSampler3 (inversion experiment) is outside the shipped hot path; "
+                                  "see SURVEY.md §8a-B10")
+
+
+class EulerEDMSampler2(EDMSampler2):
+    def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
+        return euler_step
+
+
+class EulerEDMSampler3(EDMSampler3):
+    def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
+        return euler_step

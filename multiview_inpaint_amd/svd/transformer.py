@@ -1,0 +1,281 @@
+"""Attention blocks of the video UNet: CrossAttention, GEGLU feed-forward, the spatial
+BasicTransformerBlock / SpatialTransformer and the temporal VideoTransformerBlock /
+SpatialVideoTransformer.
+
+Reference: sgm/modules/attention.py:87-113 (GEGLU/FeedForward), :255-344 (CrossAttention),
+:347-453 (MemoryEfficientCrossAttention), :456-572 (BasicTransformerBlock), :619-723
+(SpatialTransformer); sgm/modules/video_attention.py:16-141 (VideoTransformerBlock), :147-302
+(SpatialVideoTransformer). State-dict keys are identical to the reference.
+
+Both attention-mode strings ("softmax", "softmax-xformers") map to the same CrossAttention, whose
+softmax(QK^T/sqrt(d))V runs in ops.attention (HIP on the GPU). No mask is ever passed on the hot
+path; a mask is rejected rather than ignored.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import AlphaBlender, linear, maybe_checkpoint, timestep_embedding, zero_module
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        a, gate = self.proj(x).chunk(2, dim=-1)
+        return a * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0):
+        super().__init__()
+        inner = int(dim * mult)
+        first = GEGLU(dim, inner) if glu else nn.Sequential(nn.Linear(dim, inner), nn.GELU())
+        self.net = nn.Sequential(first, nn.Dropout(dropout), nn.Linear(inner, dim if dim_out is None else dim_out))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, backend=None, **_ignored):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale, self.heads, self.dim_head = dim_head ** -0.5, heads, dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+        self.backend = backend
+
+    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
+        if mask is not None:
+            raise NotImplementedError("attention masks are not part of the SVD denoise path")
+        n_extra = 0
+        if additional_tokens is not None:
+            n_extra = additional_tokens.shape[1]
+            x = torch.cat([additional_tokens, x], dim=1)
+        ctx = x if context is None else context
+        if ctx.shape[1] == 1 and not n_times_crossframe_attn_in_self:
+            # one key: softmax over a single score is exactly 1, so every query receives the value
+            # row. to_q / to_k never influence the result (SURVEY.md §7 "S_k = 1 cross-attention":
+            # 32 of the 64 attention calls of a UNet eval attend to the single CLIP token).
+            out = self.to_v(ctx).expand(-1, x.shape[1], -1)
+        else:
+            q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+            if n_times_crossframe_attn_in_self:
+                n = n_times_crossframe_attn_in_self
+                assert x.shape[0] % n == 0
+                k = k[::n].repeat_interleave(x.shape[0] // n, dim=0)
+                v = v[::n].repeat_interleave(x.shape[0] // n, dim=0)
+            out = ops.attention(q, k, v, self.heads)
+        if n_extra:
+            out = out[:, n_extra:]
+        return self.to_out(out)
+
+
+# the xformers-backed class of the reference; same maths, same parameters
+MemoryEfficientCrossAttention = CrossAttention
+
+
+class BasicTransformerBlock(nn.Module):
+    ATTENTION_MODES = {"softmax": CrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False, attn_mode="softmax", sdp_backend=None):
+        super().__init__()
+        assert attn_mode in self.ATTENTION_MODES
+        cls = self.ATTENTION_MODES[attn_mode]
+        self.disable_self_attn = disable_self_attn
+        self.attn1 = cls(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                         context_dim=context_dim if disable_self_attn else None, backend=sdp_backend)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                         backend=sdp_backend)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+    def forward(self, x, context=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
+        if additional_tokens is None and not n_times_crossframe_attn_in_self:
+            return maybe_checkpoint(self._forward, self.checkpoint, x, context)
+        return self._forward(x, context, additional_tokens, n_times_crossframe_attn_in_self)
+
+    def _forward(self, x, context=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
+        x = self.attn1(self.norm1(x), context=context if self.disable_self_attn else None,
+                       additional_tokens=additional_tokens,
+                       n_times_crossframe_attn_in_self=0 if self.disable_self_attn else n_times_crossframe_attn_in_self) + x
+        x = self.attn2(self.norm2(x), context=context, additional_tokens=additional_tokens) + x
+        return self.ff(self.norm3(x)) + x
+
+
+def Normalize(in_channels):
+    """GroupNorm(32, eps=1e-6) of the transformer stem (attention.py:125-128) — not followed by SiLU."""
+    from .layers import GroupNorm32
+    return GroupNorm32(32, in_channels, eps=1e-6, affine=True)
+
+
+class SpatialTransformer(nn.Module):
+    """GN -> proj_in -> depth x BasicTransformerBlock over the h*w tokens -> proj_out -> + input."""
+    takes = "attn"
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None,
+                 disable_self_attn=False, use_linear=False, attn_type="softmax", use_checkpoint=True,
+                 sdp_backend=None):
+        super().__init__()
+        if context_dim is not None and not isinstance(context_dim, (list, tuple)):
+            context_dim = [context_dim]
+        if context_dim is None:
+            context_dim = [None] * depth
+        elif len(context_dim) != depth:
+            assert all(c == context_dim[0] for c in context_dim), "need homogenous context_dim to match depth automatically"
+            context_dim = depth * [context_dim[0]]
+        self.in_channels, self.use_linear = in_channels, use_linear
+        inner = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.proj_in = nn.Linear(in_channels, inner) if use_linear else nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim[d],
+                                  disable_self_attn=disable_self_attn, attn_mode=attn_type,
+                                  checkpoint=use_checkpoint, sdp_backend=sdp_backend) for d in range(depth)])
+        self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1))
+
+    def _tokens_in(self, x):
+        h = self.norm(x)
+        if not self.use_linear:
+            h = self.proj_in(h)
+        h = h.flatten(2).transpose(1, 2)                     # b c h w -> b (h w) c
+        return self.proj_in(h) if self.use_linear else h
+
+    def _tokens_out(self, t, x_in):
+        b, c, h, w = x_in.shape
+        if self.use_linear:
+            t = self.proj_out(t)
+        t = t.transpose(1, 2).reshape(b, -1, h, w)
+        if not self.use_linear:
+            t = self.proj_out(t)
+        return t + x_in
+
+    def forward(self, x, context=None):
+        ctxs = context if isinstance(context, list) else [context]
+        t = self._tokens_in(x)
+        for i, blk in enumerate(self.transformer_blocks):
+            t = blk(t, context=ctxs[0 if len(ctxs) == 1 else i])
+        return self._tokens_out(t, x)
+
+
+class VideoTransformerBlock(nn.Module):
+    """Transformer block over the time axis: tokens are regrouped `(b t) s c -> (b s) t c`
+    (video_attention.py:110-141)."""
+    ATTENTION_MODES = {"softmax": CrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True,
+                 timesteps=None, ff_in=False, inner_dim=None, attn_mode="softmax", disable_self_attn=False,
+                 disable_temporal_crossattention=False, switch_temporal_ca_to_sa=False):
+        super().__init__()
+        cls = self.ATTENTION_MODES[attn_mode]
+        self.ff_in = ff_in or inner_dim is not None
+        inner_dim = dim if inner_dim is None else inner_dim
+        assert int(n_heads * d_head) == inner_dim
+        self.is_res = inner_dim == dim
+        if self.ff_in:
+            self.norm_in = nn.LayerNorm(dim)
+            self.ff_in = FeedForward(dim, dim_out=inner_dim, dropout=dropout, glu=gated_ff)
+        self.timesteps, self.disable_self_attn = timesteps, disable_self_attn
+        if disable_self_attn:
+            self.attn1 = cls(query_dim=inner_dim, heads=n_heads, dim_head=d_head, context_dim=context_dim, dropout=dropout)
+        else:
+            self.attn1 = cls(query_dim=inner_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(inner_dim, dim_out=dim, dropout=dropout, glu=gated_ff)
+        if disable_temporal_crossattention:
+            if switch_temporal_ca_to_sa:
+                raise ValueError
+            self.attn2 = None
+        else:
+            self.norm2 = nn.LayerNorm(inner_dim)
+            if switch_temporal_ca_to_sa:
+                self.attn2 = cls(query_dim=inner_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+            else:
+                self.attn2 = cls(query_dim=inner_dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1, self.norm3 = nn.LayerNorm(inner_dim), nn.LayerNorm(inner_dim)
+        self.switch_temporal_ca_to_sa, self.checkpoint = switch_temporal_ca_to_sa, checkpoint
+
+    def forward(self, x, context=None, timesteps=None):
+        return maybe_checkpoint(lambda a, c: self._forward(a, c, timesteps), self.checkpoint, x, context)
+
+    def _forward(self, x, context=None, timesteps=None):
+        assert self.timesteps or timesteps
+        assert not (self.timesteps and timesteps) or self.timesteps == timesteps
+        t = int(self.timesteps or timesteps)
+        B, S, C = x.shape
+        x = x.reshape(B // t, t, S, C).transpose(1, 2).reshape(-1, t, C)      # (b t) s c -> (b s) t c
+        if self.ff_in:
+            skip = x
+            x = self.ff_in(self.norm_in(x))
+            if self.is_res:
+                x = x + skip
+        x = self.attn1(self.norm1(x), context=context if self.disable_self_attn else None) + x
+        if self.attn2 is not None:
+            x = self.attn2(self.norm2(x), context=None if self.switch_temporal_ca_to_sa else context) + x
+        skip = x
+        x = self.ff(self.norm3(x))
+        if self.is_res:
+            x = x + skip
+        return x.reshape(B // t, S, t, C).transpose(1, 2).reshape(B, S, C)    # (b s) t c -> (b t) s c
+
+    def get_last_layer(self):
+        return self.ff.net[-1].weight
+
+
+class SpatialVideoTransformer(SpatialTransformer):
+    """Per depth: spatial block, + frame-index embedding, temporal block, alpha blend
+    (video_attention.py:147-302)."""
+    takes = "video_attn"
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, use_linear=False, context_dim=None,
+                 use_spatial_context=False, timesteps=None, merge_strategy="fixed", merge_factor=0.5,
+                 time_context_dim=None, ff_in=False, checkpoint=False, time_depth=1, attn_mode="softmax",
+                 disable_self_attn=False, disable_temporal_crossattention=False, max_time_embed_period=10000):
+        super().__init__(in_channels, n_heads, d_head, depth=depth, dropout=dropout, attn_type=attn_mode,
+                         use_checkpoint=checkpoint, context_dim=context_dim, use_linear=use_linear,
+                         disable_self_attn=disable_self_attn)
+        self.time_depth, self.depth, self.max_time_embed_period = time_depth, depth, max_time_embed_period
+        inner = n_heads * d_head
+        if use_spatial_context:
+            time_context_dim = context_dim
+        self.time_stack = nn.ModuleList([
+            VideoTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=time_context_dim,
+                                  timesteps=timesteps, checkpoint=checkpoint, ff_in=ff_in, inner_dim=inner,
+                                  attn_mode=attn_mode, disable_self_attn=disable_self_attn,
+                                  disable_temporal_crossattention=disable_temporal_crossattention)
+            for _ in range(depth)])
+        assert len(self.time_stack) == len(self.transformer_blocks)
+        self.use_spatial_context = use_spatial_context
+        self.time_pos_embed = nn.Sequential(linear(in_channels, in_channels * 4), nn.SiLU(),
+                                            linear(in_channels * 4, in_channels))
+        self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy)
+
+    def forward(self, x, context=None, time_context=None, timesteps=None, image_only_indicator=None):
+        _, _, h, w = x.shape
+        T = int(timesteps)
+        if self.use_spatial_context:
+            assert context.ndim == 3, f"n dims of spatial context should be 3 but are {context.ndim}"
+            time_context = context[::T].repeat_interleave(h * w, dim=0)        # first frame's context per pixel
+        elif time_context is not None:
+            time_context = time_context.repeat_interleave(h * w, dim=0)
+            if time_context.ndim == 2:
+                time_context = time_context[:, None]
+        t = self._tokens_in(x)
+        frame_idx = torch.arange(T, device=x.device).repeat(x.shape[0] // T)
+        pe = timestep_embedding(frame_idx, self.in_channels, repeat_only=False, max_period=self.max_time_embed_period)
+        emb = self.time_pos_embed(pe.to(self.time_pos_embed[0].weight.dtype))[:, None, :]
+        for blk, mix in zip(self.transformer_blocks, self.time_stack):
+            t = blk(t, context=context)
+            t = self.time_mixer(x_spatial=t, x_temporal=mix(t + emb, context=time_context, timesteps=T),
+                                image_only_indicator=image_only_indicator)
+        return self._tokens_out(t, x)

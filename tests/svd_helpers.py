@@ -1,0 +1,48 @@
+"""Shared by tools/gen_golden_sgm.py (reference side, build container only) and the sgm parity tests:
+the small network configuration, seeded weights and seeded inputs. Weights are regenerated from the
+seed on both sides (same state-dict keys and shapes by construction), so fixtures hold only inputs'
+seeds and the reference's outputs."""
+import torch
+
+SMALL_UNET = dict(in_channels=8, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[2, 1],
+                  channel_mult=[1, 2], num_head_channels=16, transformer_depth=1, context_dim=24, adm_in_channels=12,
+                  num_classes="sequential", use_linear_in_transformer=True, extra_ff_mix_layer=True,
+                  use_spatial_context=True, merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1],
+                  use_checkpoint=False, spatial_transformer_attn_type="softmax")
+SMALL_CTRL = {k: v for k, v in SMALL_UNET.items() if k != "out_channels"}
+SMALL_CTRL["hint_channels"] = 7
+T_FRAMES = 3
+LATENT_HW = (16, 8)
+
+
+def seeded_state_dict(module, seed):
+    """Every parameter/buffer re-drawn (zero-initialised ones too, SURVEY.md §8c caveat) in sorted-key order."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k in sorted(module.state_dict().keys()):
+        v = module.state_dict()[k]
+        if not v.dtype.is_floating_point:
+            sd[k] = v.clone()
+            continue
+        r = torch.randn(v.shape, generator=g)
+        if k.endswith("mix_factor"):
+            sd[k] = r
+        elif v.ndim >= 2:
+            fan_in = v[0].numel()
+            sd[k] = r / fan_in ** 0.5
+        elif k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * r                       # norm scales
+        else:
+            sd[k] = 0.1 * r                             # biases
+    return sd
+
+
+def seeded_inputs(seed, T=T_FRAMES, hw=LATENT_HW, cfg=SMALL_UNET, cfg_doubled=True):
+    g = torch.Generator().manual_seed(seed)
+    B = (2 if cfg_doubled else 1) * T
+    h, w = hw
+    r = lambda *s: torch.randn(*s, generator=g)
+    return dict(
+        x=r(B, 4, h, w), concat=r(B, 4, h, w), crossattn=r(B, 1, cfg["context_dim"]), vector=r(B, cfg["adm_in_channels"]),
+        control_hint=torch.rand(B, 7, 8 * h, 8 * w, generator=g), sigma=torch.exp(r(B) * 1.2),
+        image_only_indicator=torch.zeros(1, T), num_video_frames=T)

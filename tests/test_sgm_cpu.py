@@ -1,0 +1,199 @@
+"""CPU parity of the denoise-loop restatement (multiview_inpaint_amd.svd, imported through the
+drop-in `sgm` / `models.csvd` names) against golden outputs of the REFERENCE modules
+(tests/golden/sgm_small.npz, made by tools/gen_golden_sgm.py from /root/reference).
+Tolerance 1e-4 relative (BASELINE.json north_star); fp32 CPU results agree to ~1e-6."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import svd_helpers as H
+
+DROPIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiview_inpaint_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+from sgm.util import instantiate_from_config  # noqa: E402
+
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "sgm_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def nets():
+    unet = instantiate_from_config({"target": "sgm.modules.diffusionmodules.video_model.VideoUNet", "params": H.SMALL_UNET}).eval()
+    cunet = instantiate_from_config({"target": "models.csvd.ControlledVideoUNet", "params": H.SMALL_UNET}).eval()
+    cnet = instantiate_from_config({"target": "models.csvd.ControlNet", "params": H.SMALL_CTRL}).eval()
+    unet.load_state_dict(H.seeded_state_dict(unet, 11), strict=True)
+    cunet.load_state_dict(H.seeded_state_dict(cunet, 11), strict=True)
+    cnet.load_state_dict(H.seeded_state_dict(cnet, 12), strict=True)
+    return unet, cunet, cnet
+
+
+def test_scalar_known_answers(G):
+    from sgm.modules.diffusionmodules.discretizer import EDMDiscretization
+    from sgm.modules.diffusionmodules.denoiser_scaling import VScalingWithEDMcNoise
+    from sgm.modules.diffusionmodules.guiders import LinearPredictionGuider
+    from sgm.modules.diffusionmodules.util import timestep_embedding
+    sig = EDMDiscretization(sigma_min=0.002, sigma_max=700.0, rho=7.0)(25)
+    np.testing.assert_allclose(sig.numpy(), G["sigmas25"], rtol=1e-6)
+    # SURVEY.md §8c captured values
+    assert sig.shape == (26,) and sig[-1] == 0
+    np.testing.assert_allclose(sig[[0, 1, 2, 12, 23, 24]].numpy(),
+                               [700.000122, 545.729492, 421.569122, 15.589973, 0.007883, 0.002], rtol=2e-4)
+    s = torch.tensor(G["scaling_sigma"])
+    np.testing.assert_allclose(torch.stack(VScalingWithEDMcNoise()(s)).numpy(), G["scaling_out"], rtol=1e-6)
+    np.testing.assert_allclose([float(v[0]) for v in VScalingWithEDMcNoise()(torch.tensor([700.0]))],
+                               [2.0408122e-06, -0.99999893, 1.4285699e-03, 1.63777006], rtol=1e-5)
+    g = LinearPredictionGuider(max_scale=2.5, num_frames=14, min_scale=1.0)
+    np.testing.assert_array_equal(g.scale.numpy(), G["guider_scale14"])
+    e = timestep_embedding(torch.tensor([0.25 * np.log(700.0), 0.0, -1.3]).float(), 320)
+    np.testing.assert_allclose(e.numpy(), G["temb_320"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(e[0, :3].numpy(), [-0.0669237, 0.0246392, 0.1109036], atol=2e-6)   # cos half first
+    np.testing.assert_allclose(timestep_embedding(torch.tensor([3.0, 0.5]), 33, max_period=100).numpy(), G["temb_odd"],
+                               rtol=1e-6, atol=1e-7)
+
+
+def test_state_dict_keys_match_reference(G, nets):
+    unet, cunet, cnet = nets
+    assert sorted(unet.state_dict().keys()) == list(G["unet_keys"])
+    assert sorted(cunet.state_dict().keys()) == list(G["unet_keys"])
+    assert sorted(cnet.state_dict().keys()) == list(G["cnet_keys"])
+
+
+def test_videounet_and_activations(G, nets):
+    unet, _, _ = nets
+    inp = H.seeded_inputs(21)
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    tt = 0.25 * inp["sigma"].log()
+    acts = {}
+    hooks = [unet.input_blocks[1].register_forward_hook(lambda m, i, o: acts.__setitem__("in1", o)),
+             unet.input_blocks[3].register_forward_hook(lambda m, i, o: acts.__setitem__("in3", o)),
+             unet.middle_block.register_forward_hook(lambda m, i, o: acts.__setitem__("mid", o)),
+             unet.output_blocks[0].register_forward_hook(lambda m, i, o: acts.__setitem__("out0", o))]
+    with torch.no_grad():
+        y = unet(xin, tt, inp["crossattn"], inp["vector"], **kw)
+        for h in hooks:
+            h.remove()
+        y1 = unet(xin, tt, inp["crossattn"], inp["vector"], num_video_frames=H.T_FRAMES,
+                  image_only_indicator=torch.ones(1, H.T_FRAMES))
+    for k, v in acts.items():
+        assert rel(v.numpy(), G["unet_act_" + k]) < RTOL, k
+    assert rel(y.numpy(), G["unet_out"]) < RTOL
+    assert rel(y1.numpy(), G["unet_out_imageonly"]) < RTOL
+
+
+def test_controlnet_and_controlled_unet(G, nets):
+    _, cunet, cnet = nets
+    inp = H.seeded_inputs(21)
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    tt = 0.25 * inp["sigma"].log()
+    with torch.no_grad():
+        ctrls = cnet(xin, inp["control_hint"], tt, inp["crossattn"], inp["vector"], **kw)
+        n = len(ctrls)
+        for i, c in enumerate(ctrls):
+            assert rel(c.numpy(), G[f"ctrl_{i}"]) < RTOL, i
+        lst = [c.clone() for c in ctrls]
+        y = cunet(xin, tt, inp["crossattn"], inp["vector"], control=lst, **kw)
+    assert len(lst) == 0 and n == 5                       # the caller's list is consumed (csvd.py:80,91)
+    assert rel(y.numpy(), G["cunet_out"]) < RTOL
+
+
+def test_denoiser_forward(G, nets):
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    unet, _, _ = nets
+    inp = H.seeded_inputs(21)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    cond = dict(crossattn=inp["crossattn"], vector=inp["vector"], concat=inp["concat"])
+    with torch.no_grad():
+        d = den(OpenAIWrapper(unet), inp["x"], inp["sigma"], cond, num_video_frames=H.T_FRAMES,
+                image_only_indicator=inp["image_only_indicator"])
+    assert rel(d.numpy(), G["denoiser_out"]) < RTOL
+
+
+def test_euler_sampler_trajectory_with_controlnet(G, nets):
+    """5 Euler steps, per-frame linear guidance, control_hint doubled with the batch — through the
+    Lightning-free engine that stands in for SVDEngine.apply_model/sample (csvd.py:1086-1152)."""
+    from models.csvd import SVDInpaintEngine
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    _, cunet, cnet = nets
+    T = H.T_FRAMES
+    one = H.seeded_inputs(22, cfg_doubled=False)
+    sampler = instantiate_from_config({
+        "target": "sgm.modules.diffusionmodules.sampling.EulerEDMSampler",
+        "params": {"num_steps": 5, "device": "cpu",
+                   "discretization_config": {"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                                             "params": {"sigma_max": 700.0}},
+                   "guider_config": {"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                                     "params": {"max_scale": 2.5, "min_scale": 1.0, "num_frames": T,
+                                                "additional_cond_keys": ["control_hint"]}}}})
+    eng = SVDInpaintEngine(cunet, cnet, Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}),
+                           sampler, control_scales=[1.0] * 5)
+    c = dict(crossattn=one["crossattn"], vector=one["vector"], concat=one["concat"], control_hint=one["control_hint"])
+    uc = dict(crossattn=torch.zeros_like(one["crossattn"]), vector=torch.zeros_like(one["vector"]),
+              concat=torch.zeros_like(one["concat"]), control_hint=one["control_hint"])
+    traj = []
+
+    def denoiser(x, sigma, cc):
+        d = eng.denoise(x, sigma, cc, num_video_frames=T, image_only_indicator=one["image_only_indicator"])
+        traj.append(d.clone())
+        return d
+    with torch.no_grad():
+        xs = sampler(denoiser, one["x"].clone(), c, uc=uc)
+    assert len(traj) == 5 and traj[0].shape[0] == 2 * T
+    assert rel(traj[0].numpy(), G["sample_denoised_step0"]) < RTOL
+    assert rel(traj[4].numpy(), G["sample_denoised_step4"]) < 5 * RTOL
+    assert rel(xs.numpy(), G["sample_final"]) < 5 * RTOL
+
+
+def test_full_size_parameter_counts_on_meta():
+    """The SVD configuration of the reference YAMLs: 1 524 623 082 UNet and
+    682 022 113 ControlNet parameters — counted on the meta device, nothing is allocated."""
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    from models.csvd import ControlNet
+    cfg = dict(in_channels=8, out_channels=4, model_channels=320, channel_mult=[1, 2, 4, 4], num_res_blocks=2,
+               attention_resolutions=[4, 2, 1], num_head_channels=64, transformer_depth=1, context_dim=1024,
+               adm_in_channels=768, num_classes="sequential", use_linear_in_transformer=True, extra_ff_mix_layer=True,
+               use_spatial_context=True, merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1],
+               use_checkpoint=True, spatial_transformer_attn_type="softmax-xformers")
+    with torch.device("meta"):
+        unet = VideoUNet(**cfg)
+        ccfg = {k: v for k, v in cfg.items() if k != "out_channels"}
+        cnet = ControlNet(hint_channels=7, **ccfg)
+    assert sum(p.numel() for p in unet.parameters()) == 1_524_623_082
+    assert sum(p.numel() for p in cnet.parameters()) == 682_022_113
+    assert len(cnet.zero_convs) == 12
+    n_attn = sum(1 for m in unet.modules() if type(m).__name__ == "SpatialVideoTransformer")
+    n_res = sum(1 for m in unet.modules() if type(m).__name__ == "VideoResBlock")
+    assert (n_attn, n_res) == (16, 22)
+
+
+def test_single_key_cross_attention_shortcut_is_exact():
+    """S_k = 1: the value-row shortcut equals softmax attention bit for bit up to the out-projection."""
+    from sgm.modules.attention import CrossAttention
+    torch.manual_seed(0)
+    att = CrossAttention(query_dim=32, context_dim=24, heads=4, dim_head=8).eval()
+    x, ctx = torch.randn(3, 10, 32), torch.randn(3, 1, 24)
+    with torch.no_grad():
+        fast = att(x, context=ctx)
+        q, k, v = att.to_q(x), att.to_k(ctx), att.to_v(ctx)
+        qh, kh, vh = (t.reshape(3, -1, 4, 8).transpose(1, 2) for t in (q, k, v))
+        ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(3, 10, 32)
+        ref = att.to_out(ref)
+    assert torch.allclose(fast, ref, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        att(x, context=ctx, mask=torch.ones(3, 10, 1, dtype=torch.bool))
