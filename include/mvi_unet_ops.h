@@ -1,0 +1,56 @@
+/*
+ * mvi_unet_ops.h — C-ABI of the MI355X (gfx950) device ops of the SVD temporal-UNet denoise loop.
+ *
+ * Drop-in boundary: the reference's denoise loop is PyTorch modules whose only hand-optimised
+ * device ops are reached through
+ *   - xformers.ops.memory_efficient_attention      svd_inpaint1/sgm/modules/attention.py:427-439
+ *   - F.scaled_dot_product_attention               svd_inpaint1/sgm/modules/attention.py:332-336
+ *   - GroupNorm32 (+ SiLU), Normalize              svd_inpaint1/sgm/modules/diffusionmodules/util.py:259-276,
+ *                                                  openaimodel.py:257-261,292-305, attention.py:125-128
+ * These entry points replace those calls; the Python side that binds them with ctypes is
+ * multiview_inpaint_amd/svd/hip_ops.py behind the same module classes.
+ *
+ * Conventions: every pointer is a DEVICE pointer; `stream` is a hipStream_t passed as void*;
+ * nothing synchronises; the library owns no memory. Returns 0 or a negative MVI_E* code
+ * (include/mvi_raster.h); mvi_unet_last_error() gives the message.
+ */
+#ifndef MVI_UNET_OPS_H
+#define MVI_UNET_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVI_DT_F32 0
+#define MVI_DT_BF16 1
+#define MVI_DT_F16 2
+
+/* GroupNorm over groups of C/groups channels x `spatial` positions of x [N, C, spatial] (contiguous;
+ * spatial = H*W or T*H*W), statistics and affine in fp32, optional fused SiLU, y has x's dtype.
+ * weight/bias: fp32 [C]. workspace: mvi_groupnorm_workspace_bytes(...) bytes. */
+size_t mvi_groupnorm_workspace_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups);
+int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float* bias, int64_t N,
+                       int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                       int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out = softmax(q k^T * scale) v per (batch, head). Token-major layout, as the Linear projections
+ * produce it: q/out [B, Sq, H, D], k/v [B, Sk, H, D], contiguous. No mask (none is used on the
+ * denoise path). dtype selects the I/O type; fp32 I/O computes in fp32 (validation mode, 1e-4
+ * parity), bf16/f16 I/O with D == 64 and Sk > 32 runs the MFMA flash kernel (fp32 accumulate,
+ * fp32 softmax, P rounded to the I/O type before P.V), everything else an fp32-math kernel. */
+int mvi_attention_forward(const void* q, const void* k, const void* v, void* out, int32_t B,
+                          int32_t H, int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype,
+                          void* stream);
+
+/* Which kernel mvi_attention_forward would pick: 0 = rowtile fp32-math, 1 = MFMA flash. */
+int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);
+
+const char* mvi_unet_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVI_UNET_OPS_H */

@@ -1,0 +1,15 @@
+"""ctypes signatures of include/mvi_unet_ops.h (bound by _lib.lib())."""
+import ctypes as C
+
+
+def bind(L):
+    vp, i32, i64, sz, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+    L.mvi_groupnorm_workspace_bytes.restype = sz
+    L.mvi_groupnorm_workspace_bytes.argtypes = [i64, i32, i64, i32]
+    L.mvi_groupnorm_silu.restype = C.c_int
+    L.mvi_groupnorm_silu.argtypes = [vp, vp, vp, vp, i64, i32, i64, i32, f32, i32, i32, vp, sz, vp]
+    L.mvi_attention_forward.restype = C.c_int
+    L.mvi_attention_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.mvi_attention_kernel_kind.restype = C.c_int
+    L.mvi_attention_kernel_kind.argtypes = [i32, i32, i32, i32]
+    L.mvi_unet_last_error.restype = C.c_char_p

@@ -1,0 +1,262 @@
+// bf16/f16 MFMA flash attention (forward) for gfx950, head dim 64 — the only dense contraction of
+// the SVD denoise loop that is hand-written (BASELINE.json north_star). Replaces
+// xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention
+// (svd_inpaint1/sgm/modules/attention.py:427-439, :332-336) for the spatial self-attention calls:
+// (B*H, S) = (140, 9216), (280, 2304), (560, 576), (560, 144) at 14 x 576x1024.
+//
+// Layout: q/out [B, Sq, H, 64], k/v [B, Sk, H, 64] token-major, contiguous.
+// Block = 4 wave64 = 128 query rows of one (batch, head); each wave owns 32 rows. KV tile = 64 keys.
+// Per wave and KV tile (v_mfma_f32_32x32x16, fp32 accumulate):
+//   S^T[key][query] = K Q^T    : 2 key blocks x 4 d-steps  = 8 MFMA   (A = K rows from LDS, B = Q in regs)
+//   online softmax in registers: the query sits on the lane (col = lane & 31), its 64 scores are 2 x 16
+//                                registers in this lane and in lane ^ 32 -> one cross-lane max, no LDS
+//   O^T[d][query]  += V^T P^T  : 2 d blocks x 4 key-steps   = 8 MFMA   (A = V^T from LDS, B = P from the
+//                                S^T accumulators, converted in place: MFMA C/D layout == next B layout
+//                                up to the fixed key permutation the V^T fragment read follows)
+// K tile rows are padded to 72 elements (b128 reads conflict-free), V is stored transposed with a
+// row of 68 elements (b64 reads conflict-free). Global loads of tile t+1 are issued before the
+// MFMAs of tile t and written to LDS after them.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+
+namespace mvi {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int kFD = 64;          // head dim
+constexpr int kFQ = 128;         // query rows per block
+constexpr int kFK = 64;          // keys per tile
+constexpr int kKStride = 72;     // elements per K row in LDS
+constexpr int kVStride = 68;     // elements per V^T row in LDS
+
+template <typename T> struct Mma;
+template <> struct Mma<__hip_bfloat16> {
+    using frag = bf16x8;
+    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+        return (uint32_t) * reinterpret_cast<uint16_t*>(&a) | ((uint32_t) * reinterpret_cast<uint16_t*>(&b) << 16);
+    }
+};
+template <> struct Mma<__half> {
+    using frag = f16x8;
+    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        __half2 h = __floats2half2_rn(lo, hi);
+        return *reinterpret_cast<uint32_t*>(&h);
+    }
+};
+
+template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                         const T* __restrict__ v, T* __restrict__ out, int H, int Sq,
+                                                         int Sk, float scale_log2e, int q_blocks, int total_blocks) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    __shared__ __attribute__((aligned(16))) uint16_t s_k[kFK * kKStride];
+    __shared__ __attribute__((aligned(16))) uint16_t s_vt[kFD * kVStride];
+
+    // XCD-aware block order: the 8 XCDs get contiguous runs of blocks, so the q-blocks that share one
+    // (batch, head)'s K/V stream hit the same L2 (speed only; any placement is correct)
+    int bid = blockIdx.x;
+    if ((total_blocks & 7) == 0) bid = (bid & 7) * (total_blocks >> 3) + (bid >> 3);
+    const int qb = bid % q_blocks;
+    const int bh = bid / q_blocks;
+    const int h = bh % H;
+    const int64_t b = bh / H;
+    const int64_t hd = (int64_t)H * kFD;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qcol = lane & 31, hh = lane >> 5;
+    const int q0 = qb * kFQ + wave * 32;
+    const int qrow = q0 + qcol;
+
+    // Q fragments (B operand of S^T = K Q^T): element j of step s is Q[qrow][16 s + 8 hh + j]
+    frag qf[4];
+    {
+        const T* qp = q + ((b * Sq + (qrow < Sq ? qrow : 0)) * hd + (int64_t)h * kFD + 8 * hh);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 raw = qrow < Sq ? *reinterpret_cast<const u32x4*>(qp + 16 * s) : u32x4{0, 0, 0, 0};
+            qf[s] = as_frag<frag>(raw);
+        }
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    // staging: thread -> (K row kr, 16-element segment ks) and (V key pair vp, 8-element segment vs)
+    const int kr = tid >> 2, ks = tid & 3;
+    const int vp = tid >> 3, vs = tid & 7;
+    const T* kbase = k + (b * Sk * hd + (int64_t)h * kFD);
+    const T* vbase = v + (b * Sk * hd + (int64_t)h * kFD);
+    u32x4 rk0, rk1, rv0, rv1;
+    auto load_tile = [&](int k0) {
+        const u32x4 z = {0, 0, 0, 0};
+        int r = k0 + kr;
+        const T* p = kbase + (int64_t)r * hd + 16 * ks;
+        rk0 = r < Sk ? *reinterpret_cast<const u32x4*>(p) : z;
+        rk1 = r < Sk ? *reinterpret_cast<const u32x4*>(p + 8) : z;
+        int r0 = k0 + 2 * vp;
+        const T* pv = vbase + (int64_t)r0 * hd + 8 * vs;
+        rv0 = r0 < Sk ? *reinterpret_cast<const u32x4*>(pv) : z;
+        rv1 = r0 + 1 < Sk ? *reinterpret_cast<const u32x4*>(pv + hd) : z;
+    };
+    auto store_tile = [&]() {
+        *reinterpret_cast<u32x4*>(&s_k[kr * kKStride + 16 * ks]) = rk0;
+        *reinterpret_cast<u32x4*>(&s_k[kr * kKStride + 16 * ks + 8]) = rk1;
+        // transpose: (V[key0][d], V[key0+1][d]) -> one dword at V^T[d][key0]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t a = rv0[i], c = rv1[i];
+            uint32_t lo = (a & 0xFFFFu) | (c << 16), hi = (a >> 16) | (c & 0xFFFF0000u);
+            *reinterpret_cast<uint32_t*>(&s_vt[(8 * vs + 2 * i) * kVStride + 2 * vp]) = lo;
+            *reinterpret_cast<uint32_t*>(&s_vt[(8 * vs + 2 * i + 1) * kVStride + 2 * vp]) = hi;
+        }
+    };
+
+    const int n_tiles = (Sk + kFK - 1) / kFK;
+    load_tile(0);
+    for (int t = 0; t < n_tiles; ++t) {
+        __syncthreads();                                   // every wave is done reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (t + 1 < n_tiles) load_tile((t + 1) * kFK);      // in flight during this tile's MFMAs
+        const int k0 = t * kFK;
+
+        // ---- S^T = K Q^T
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                u32x4 raw = *reinterpret_cast<const u32x4*>(&s_k[(kb * 32 + qcol) * kKStride + 16 * s + 8 * hh]);
+                st[kb] = M::mfma(as_frag<frag>(raw), qf[s], st[kb]);
+            }
+        }
+        // st[kb][r] is key k0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hh for query qrow
+        float rmax = -INFINITY;
+        const bool tail = k0 + kFK > Sk;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = st[kb][r] * scale_log2e;
+                if (tail && (k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) s = -INFINITY;
+                st[kb][r] = s;
+                rmax = fmaxf(rmax, s);
+            }
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+        const float m_new = fmaxf(m, rmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float rsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                st[kb][r] = p;
+                rsum += p;
+            }
+        l = l * alpha + rsum;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+        // ---- O^T += V^T P^T ; P fragment of key-step (kb, s2) = registers 8 s2 .. 8 s2 + 7 of st[kb]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 pr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pr[i] = M::pack2(st[kb][8 * s2 + 2 * i], st[kb][8 * s2 + 2 * i + 1]);
+                const frag pf = as_frag<frag>(pr);
+                const int koff = 32 * kb + 16 * s2 + 4 * hh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const uint16_t* row = &s_vt[(32 * db + qcol) * kVStride + koff];
+                    u32x2 a0 = *reinterpret_cast<const u32x2*>(row);
+                    u32x2 a1 = *reinterpret_cast<const u32x2*>(row + 8);
+                    u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+                    o[db] = M::mfma(as_frag<frag>(av), pf, o[db]);
+                }
+            }
+    }
+    l += __shfl_xor(l, 32);
+    if (qrow < Sq) {
+        const float inv = 1.0f / l;
+        T* op = out + ((b * Sq + qrow) * hd + (int64_t)h * kFD);
+        // o[db][r] is channel 32 db + (r & 3) + 8 (r >> 2) + 4 hh: four consecutive channels per 8-byte store
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w = {M::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                           M::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
+                *reinterpret_cast<u32x2*>(op + 32 * db + 8 * g + 4 * hh) = w;
+            }
+    }
+}
+
+template <typename T>
+int attn_flash_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
+                      float scale, hipStream_t st) {
+    const int q_blocks = (Sq + kFQ - 1) / kFQ;
+    const int64_t total = (int64_t)B * H * q_blocks;
+    if (total > 0x7FFFFFFFll) return MVI_EINVAL;
+    hipLaunchKernelGGL((attn_flash_kernel<T>), dim3((unsigned)total), dim3(256), 0, st, (const T*)q, (const T*)k,
+                       (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+template int attn_flash_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template int attn_flash_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
+
+// rowtile kernel (attn_rowtile.hip)
+template <typename T>
+int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
+                        float scale, hipStream_t st);
+int unet_fail(int code, const char* msg);
+
+}  // namespace mvi
+
+extern "C" int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype) {
+    return (dtype != MVI_DT_F32 && D == mvi::kFD && Sk > 32) ? 1 : 0;
+}
+
+extern "C" int mvi_attention_forward(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                                     int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype, void* stream) {
+    if (B < 0 || H <= 0 || Sq < 0 || Sk <= 0 || D <= 0) return mvi::unet_fail(MVI_EINVAL, "attention: bad shape");
+    if (B == 0 || Sq == 0) return MVI_OK;
+    if (!q || !k || !v || !out) return mvi::unet_fail(MVI_EINVAL, "attention: NULL pointer");
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 != 0)
+        return mvi::unet_fail(MVI_EINVAL, "attention: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (mvi_attention_kernel_kind(Sq, Sk, D, dtype) == 1) {
+        rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st)
+                                  : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st);
+    } else {
+        if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "attention: head dim must be 16, 32 or 64");
+        switch (dtype) {
+            case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, Sq, Sk, D, scale, st); break;
+            case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, D, scale, st); break;
+            case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, Sq, Sk, D, scale, st); break;
+            default: return mvi::unet_fail(MVI_EINVAL, "attention: unknown dtype");
+        }
+    }
+    return rc ? mvi::unet_fail(rc, "attention: kernel launch failed") : MVI_OK;
+}

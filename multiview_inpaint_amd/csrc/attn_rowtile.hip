@@ -1,0 +1,158 @@
+// fp32-math attention for gfx950: the validation-mode / short-sequence kernel.
+// Replaces F.scaled_dot_product_attention / xformers.memory_efficient_attention
+// (svd_inpaint1/sgm/modules/attention.py:332-336, :427-439) for
+//   * fp32 inputs  — the 1e-4-parity validation mode (no reduced-precision operand anywhere),
+//   * the temporal attention of the video transformer, S_q = S_k = T (14 or 25) with batch
+//     (b h w) x heads in the tens of thousands: HBM-bound, one wave per problem,
+//   * head dims the MFMA kernel is not built for.
+// Layout: q/out [B, Sq, H, D], k/v [B, Sk, H, D] token-major (what the Linear layers produce), so no
+// head-transpose copies exist on either side.
+//
+// One wave64 = 16 query rows x 4 lanes per row; each lane owns D/4 interleaved channels
+// (d = 4*p + 16*i + c: a lane's 4-vectors are 16 B apart from its neighbours', so LDS reads of a
+// K/V row are conflict-free b128). K/V tiles of up to 32 keys are staged in LDS per wave.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+
+namespace mvi {
+
+int unet_fail(int code, const char* msg);
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
+
+constexpr int kRtKeys = 32;      // keys per LDS tile
+constexpr int kRtWaves = 4;      // waves (= independent problems) per block
+
+// DV = D / 16 : number of 4-channel vectors a lane owns (D in {16, 32, 64, 128})
+template <typename T, int DV>
+__global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                     const T* __restrict__ v, T* __restrict__ out,
+                                                                     int B, int H, int Sq, int Sk, float scale,
+                                                                     int64_t n_problems, int q_tiles) {
+    constexpr int D = DV * 16;
+    __shared__ float s_k[kRtWaves][kRtKeys][D];
+    __shared__ float s_v[kRtWaves][kRtKeys][D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t prob = (int64_t)blockIdx.x * kRtWaves + wave;        // (b, h, q_tile)
+    if (prob >= n_problems) return;                                     // whole wave exits together
+    const int qt = (int)(prob % q_tiles);
+    const int64_t bh = prob / q_tiles;
+    const int h = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int row = qt * 16 + (lane >> 2), p = lane & 3;
+    const bool row_ok = row < Sq;
+    const int64_t hd = (int64_t)H * D;
+
+    float qr[DV][4], acc[DV][4];
+#pragma unroll
+    for (int i = 0; i < DV; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[i][c] = 0.f;
+            qr[i][c] = row_ok ? to_f<T>(q[(b * Sq + row) * hd + (int64_t)h * D + 16 * i + 4 * p + c]) * scale : 0.f;
+        }
+    float m = -INFINITY, l = 0.f;
+
+    for (int k0 = 0; k0 < Sk; k0 += kRtKeys) {
+        const int nk = min(kRtKeys, Sk - k0);
+        // stage K and V rows of this head: lane l copies 4-vectors l, l+64, ... of the nk x D tile
+        for (int e = lane; e < nk * (D / 4); e += 64) {
+            int kr = e / (D / 4), dv = e % (D / 4);
+            const T* kp = k + ((b * Sk + k0 + kr) * hd + (int64_t)h * D + 4 * dv);
+            const T* vp = v + ((b * Sk + k0 + kr) * hd + (int64_t)h * D + 4 * dv);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s_k[wave][kr][4 * dv + c] = to_f<T>(kp[c]);
+                s_v[wave][kr][4 * dv + c] = to_f<T>(vp[c]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): this wave's LDS writes have landed
+        float s[kRtKeys];
+        float tile_max = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kRtKeys; ++j) {
+            float d = 0.f;
+            if (j < nk) {
+#pragma unroll
+                for (int i = 0; i < DV; ++i) {
+                    const float4 kv = *reinterpret_cast<const float4*>(&s_k[wave][j][16 * i + 4 * p]);
+                    d += qr[i][0] * kv.x + qr[i][1] * kv.y + qr[i][2] * kv.z + qr[i][3] * kv.w;
+                }
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                tile_max = fmaxf(tile_max, d);
+            } else {
+                d = -INFINITY;
+            }
+            s[j] = d;
+        }
+        const float m_new = fmaxf(m, tile_max);
+        const float alpha = __expf(m - m_new);             // m = -inf on the first tile -> 0
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < DV; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][c] *= alpha;
+#pragma unroll
+        for (int j = 0; j < kRtKeys; ++j) {
+            if (j < nk) {
+                const float pj = __expf(s[j] - m_new);
+                l += pj;
+#pragma unroll
+                for (int i = 0; i < DV; ++i) {
+                    const float4 vv = *reinterpret_cast<const float4*>(&s_v[wave][j][16 * i + 4 * p]);
+                    acc[i][0] += pj * vv.x; acc[i][1] += pj * vv.y; acc[i][2] += pj * vv.z; acc[i][3] += pj * vv.w;
+                }
+            }
+        }
+        m = m_new;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (row_ok) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int i = 0; i < DV; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                out[(b * Sq + row) * hd + (int64_t)h * D + 16 * i + 4 * p + c] = from_f<T>(acc[i][c] * inv);
+    }
+}
+
+template <typename T>
+int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
+                        float scale, hipStream_t st) {
+    const int q_tiles = (Sq + 15) / 16;
+    const int64_t n = (int64_t)B * H * q_tiles;
+    const int64_t blocks = (n + kRtWaves - 1) / kRtWaves;
+    if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+    dim3 grid((unsigned)blocks), blk(64 * kRtWaves);
+#define MVI_RT(DVV)                                                                                              \
+    hipLaunchKernelGGL((attn_rowtile_kernel<T, DVV>), grid, blk, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, \
+                       B, H, Sq, Sk, scale, n, q_tiles)
+    switch (D) {
+        case 16: MVI_RT(1); break;
+        case 32: MVI_RT(2); break;
+        case 64: MVI_RT(4); break;
+        default: return MVI_EINVAL;
+    }
+#undef MVI_RT
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+template int attn_rowtile_launch<float>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
+template int attn_rowtile_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
+template int attn_rowtile_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
+
+}  // namespace mvi

@@ -1,0 +1,265 @@
+// Fused GroupNorm(+SiLU) for gfx950 — HBM-bound: 2 reads + 1 write of the tensor.
+// Replaces nn.GroupNorm -> nn.SiLU pairs of the reference UNet
+// (svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:257-261,292-305; GroupNorm32 fp32
+// upcast util.py:274-276; attention.py:125-128 for the eps=1e-6, no-SiLU stem norm).
+//
+// x [N, C, S] contiguous: one group = Cg*S contiguous elements. Two launches:
+//   stats : grid (chunks, N*G); each 256-thread block holds its chunk in registers, computes the
+//           chunk mean and the centred second moment M2 exactly (two passes over registers) and
+//           writes (count, mean, M2);
+//   apply : same grid; every block merges its group's partials with Chan's formula (fp32), then
+//           normalises its chunk with per-channel affine (+SiLU) and writes y in x's dtype.
+// Loads/stores are 16 B per lane. The chunk partition is identical in both launches.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+
+namespace mvi {
+
+constexpr int kGnBlock = 256;
+constexpr int kGnVecPerThread = 8;                        // 8 x 16 B per thread
+
+template <typename T> struct Io;
+template <> struct Io<float> {
+    static constexpr int kVec = 4;                        // elements per 16 B
+    __device__ static void load(const float* p, float* o) { float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    __device__ static void store(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+    __device__ static float ld1(const float* p) { return *p; }
+    __device__ static void st1(float* p, float v) { *p = v; }
+};
+template <> struct Io<__hip_bfloat16> {
+    static constexpr int kVec = 8;
+    __device__ static void load(const __hip_bfloat16* p, float* o) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
+    }
+    __device__ static void store(__hip_bfloat16* p, const float* o) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __hip_bfloat16 a = __float2bfloat16(o[2 * i]), b = __float2bfloat16(o[2 * i + 1]);
+            w[i] = (uint32_t) * reinterpret_cast<uint16_t*>(&a) | ((uint32_t) * reinterpret_cast<uint16_t*>(&b) << 16);
+        }
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ static float ld1(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+    __device__ static void st1(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+};
+template <> struct Io<__half> {
+    static constexpr int kVec = 8;
+    __device__ static void load(const __half* p, float* o) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        const __half2* h = reinterpret_cast<const __half2*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { float2 f = __half22float2(h[i]); o[2 * i] = f.x; o[2 * i + 1] = f.y; }
+    }
+    __device__ static void store(__half* p, const float* o) {
+        uint4 v;
+        __half2* h = reinterpret_cast<__half2*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = __floats2half2_rn(o[2 * i], o[2 * i + 1]);
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+    __device__ static float ld1(const __half* p) { return __half2float(*p); }
+    __device__ static void st1(__half* p, float v) { *p = __float2half(v); }
+};
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// chunk = kGnBlock * kGnVecPerThread * kVec elements of one group (vector path needs E % kVec == 0
+// and a 16-B aligned base, checked on the host; otherwise VEC = false walks scalars)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part,
+                                                            int64_t E, int chunks) {
+    __shared__ float s_red[4];
+    constexpr int KV = Io<T>::kVec;
+    constexpr int CH = kGnBlock * kGnVecPerThread * KV;
+    const int64_t g = blockIdx.y;
+    const int64_t e0 = (int64_t)blockIdx.x * CH;
+    const T* base = x + g * E;
+    float v[kGnVecPerThread * KV];
+    int cnt = 0;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGnVecPerThread; ++i) {
+        int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
+        if (VEC) {
+            if (e < E) { Io<T>::load(base + e, v + i * KV); cnt += KV; }
+            else {
+#pragma unroll
+                for (int k = 0; k < KV; ++k) v[i * KV + k] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                bool ok = e + k < E;
+                v[i * KV + k] = ok ? Io<T>::ld1(base + e + k) : 0.f;
+                cnt += ok;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) sum += v[i * KV + k];
+    }
+    const float total = block_sum(sum, s_red);
+    const int64_t n_chunk = (E - e0) < CH ? (E - e0) : CH;
+    const float mean = total / (float)n_chunk;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGnVecPerThread; ++i) {
+        int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            float d = v[i * KV + k] - mean;
+            if (e + k < E) m2 += d * d;
+        }
+    }
+    m2 = block_sum(m2, s_red);
+    if (threadIdx.x == 0) {
+        float* p = part + (g * chunks + blockIdx.x) * 3;
+        p[0] = (float)n_chunk; p[1] = mean; p[2] = m2;
+    }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                            const float* __restrict__ weight,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ part, int64_t E, int chunks,
+                                                            int64_t S, int Cg, int G, float eps, int silu) {
+    __shared__ float s_stat[2];
+    constexpr int KV = Io<T>::kVec;
+    constexpr int CH = kGnBlock * kGnVecPerThread * KV;
+    const int64_t g = blockIdx.y;
+    if (threadIdx.x < 64) {
+        // merge the group's partials: lanes take them round-robin, then a butterfly of Chan merges
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int c = threadIdx.x; c < chunks; c += 64) {
+            const float* p = part + (g * chunks + c) * 3;
+            float nb = p[0], mb = p[1], m2b = p[2];
+            float nt = n + nb, d = mb - mean;
+            mean += d * (nb / nt);
+            m2 += m2b + d * d * (n * nb / nt);
+            n = nt;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), m2b = __shfl_xor(m2, o);
+            float nt = n + nb;
+            if (nt > 0.f) {
+                float d = mb - mean;
+                float new_mean = mean + d * (nb / nt);
+                m2 = m2 + m2b + d * d * (n * nb / nt);
+                mean = new_mean;
+            }
+            n = nt;
+        }
+        if (threadIdx.x == 0) { s_stat[0] = mean; s_stat[1] = rsqrtf(m2 / n + eps); }
+    }
+    __syncthreads();
+    const float mean = s_stat[0], rstd = s_stat[1];
+    const int c0 = (int)(g % G) * Cg;
+    const int64_t e0 = (int64_t)blockIdx.x * CH;
+    const T* xb = x + g * E;
+    T* yb = y + g * E;
+#pragma unroll
+    for (int i = 0; i < kGnVecPerThread; ++i) {
+        int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
+        if (e >= E) continue;
+        float v[KV];
+        if (VEC) {
+            Io<T>::load(xb + e, v);
+            int c = c0 + (int)(e / S);                    // S % KV == 0 on this path: one channel per vector
+            float w = weight[c] * rstd, b = bias[c] - mean * w;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                float t = v[k] * w + b;
+                v[k] = silu ? t / (1.0f + __expf(-t)) : t;
+            }
+            Io<T>::store(yb + e, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                if (e + k >= E) break;
+                int c = c0 + (int)((e + k) / S);
+                float t = (Io<T>::ld1(xb + e + k) - mean) * rstd * weight[c] + bias[c];
+                Io<T>::st1(yb + e + k, silu ? t / (1.0f + __expf(-t)) : t);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int gn_launch(const void* x, void* y, const float* w, const float* b, int64_t N, int C, int64_t S, int G,
+                     float eps, int silu, float* part, hipStream_t st) {
+    constexpr int KV = Io<T>::kVec;
+    constexpr int CH = kGnBlock * kGnVecPerThread * KV;
+    const int Cg = C / G;
+    const int64_t E = (int64_t)Cg * S;
+    const int chunks = (int)((E + CH - 1) / CH);
+    const bool vec = (S % KV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    dim3 grid(chunks, (unsigned)(N * G));
+    if (vec) {
+        hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, E, chunks);
+        hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, E,
+                           chunks, S, Cg, G, eps, silu);
+    } else {
+        hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, E, chunks);
+        hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, E,
+                           chunks, S, Cg, G, eps, silu);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+}  // namespace mvi
+
+static thread_local char g_uerr[384] = "";
+extern "C" const char* mvi_unet_last_error(void) { return g_uerr; }
+namespace mvi {
+int unet_fail(int code, const char* msg) { snprintf(g_uerr, sizeof(g_uerr), "%s", msg); return code; }
+}
+
+static int chunks_for(int64_t E, int dtype) {
+    int kv = dtype == MVI_DT_F32 ? 4 : 8;
+    int64_t ch = (int64_t)mvi::kGnBlock * mvi::kGnVecPerThread * kv;
+    return (int)((E + ch - 1) / ch);
+}
+
+extern "C" size_t mvi_groupnorm_workspace_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups) {
+    if (N <= 0 || C <= 0 || groups <= 0 || spatial <= 0) return 0;
+    int64_t E = (int64_t)(C / groups) * spatial;
+    // sized for the dtype with the fewest elements per chunk (fp32)
+    return (size_t)(N * groups) * chunks_for(E, MVI_DT_F32) * 3 * sizeof(float);
+}
+
+extern "C" int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float* bias, int64_t N,
+                                  int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                  int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 0 || C <= 0 || groups <= 0 || spatial < 0 || C % groups != 0)
+        return mvi::unet_fail(MVI_EINVAL, "groupnorm: C must be a positive multiple of groups");
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!x || !y || !weight || !bias || !workspace) return mvi::unet_fail(MVI_EINVAL, "groupnorm: NULL pointer");
+    if (N * groups > 0x7FFFFFFFll || N * groups > 65535ll * 65535ll) return mvi::unet_fail(MVI_EINVAL, "groupnorm: N*groups too large");
+    if (N * groups > 65535) return mvi::unet_fail(MVI_EINVAL, "groupnorm: N*groups exceeds grid.y (65535)");
+    if (workspace_bytes < mvi_groupnorm_workspace_bytes(N, C, spatial, groups))
+        return mvi::unet_fail(MVI_ENOMEM, "groupnorm: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, N, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, N, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, N, C, spatial, groups, eps, fuse_silu, part, st); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "groupnorm: unknown dtype");
+    }
+    return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm: kernel launch failed") : MVI_OK;
+}

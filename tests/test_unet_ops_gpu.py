@@ -1,0 +1,165 @@
+"""GPU parity of the UNet device ops (HIP, through the C-ABI) against plain PyTorch fp32 references
+computed on the CPU, and of the whole small UNet / ControlNet / sampler running on those ops against
+the golden outputs of the imported reference (tests/golden/sgm_small.npz).
+
+Tolerances (north_star: 1e-4 relative on UNet activations):
+  * fp32 I/O: GroupNorm(+SiLU) and attention  -> 1e-4 relative (validation mode, fp32 everywhere);
+  * bf16 / f16 I/O (production): inputs are rounded to the I/O type first and the reference is
+    evaluated in fp64 on those rounded inputs; the bound is the I/O type's own rounding
+    (bf16 2^-8, f16 2^-11) on the output plus P's rounding inside the MFMA kernel."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import svd_helpers as H
+
+pytestmark = pytest.mark.gpu
+DROPIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiview_inpaint_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from multiview_inpaint_amd.svd import hip_ops
+    return hip_ops
+
+
+GN_SHAPES = [((4, 64, 24, 16), 32), ((2, 320, 9, 16), 32), ((3, 96, 5, 7), 32), ((2, 64, 3, 20, 12), 32),
+             ((28, 320, 72, 128), 32), ((2, 320, 14, 72, 128), 32), ((28, 1280, 9, 16), 32), ((1, 32, 1, 1), 32),
+             ((2, 640, 36, 64), 32)]
+
+
+@pytest.mark.parametrize("shape,groups", GN_SHAPES)
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm_fp32(ops, shape, groups, silu):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 2 + 0.7
+    x[0, :2] += 30.0                                     # a group with mean >> std
+    w, b = torch.randn(shape[1], generator=g), torch.randn(shape[1], generator=g)
+    eps = 1e-6 if not silu else 1e-5
+    ref = F.group_norm(x.double(), groups, w.double(), b.double(), eps)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.group_norm_silu(x.cuda(), groups, w.cuda(), b.cuda(), eps, silu)
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    assert rel(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_groupnorm_half_io(ops, dtype, tol):
+    g = torch.Generator().manual_seed(5)
+    for shape in [(4, 64, 24, 16), (2, 320, 14, 18, 32), (3, 96, 5, 7)]:
+        x = (torch.randn(shape, generator=g) * 1.5).to(dtype)
+        w, b = torch.randn(shape[1], generator=g), torch.randn(shape[1], generator=g)
+        ref = F.silu(F.group_norm(x.double(), 32, w.double(), b.double(), 1e-5))
+        y = ops.group_norm_silu(x.cuda(), 32, w.cuda(), b.cuda(), 1e-5, True)
+        assert y.dtype == dtype
+        assert rel(y, ref) < tol
+
+
+def _attn_ref(q, k, v, heads):
+    B, Sq, HD = q.shape
+    D = HD // heads
+    qh, kh, vh = (t.double().reshape(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * D ** -0.5, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Sq, HD)
+
+
+ATTN_SHAPES = [  # B, H, Sq, Sk, D
+    (6, 5, 14, 14, 64), (3, 2, 25, 25, 64), (2, 4, 64, 64, 16), (2, 2, 144, 144, 64), (1, 3, 100, 37, 32),
+    (2, 5, 576, 576, 64), (1, 2, 130, 200, 64), (4, 10, 14, 1, 64)]
+
+
+@pytest.mark.parametrize("B,Hh,Sq,Sk,D", ATTN_SHAPES)
+def test_attention_fp32_validation_mode(ops, B, Hh, Sq, Sk, D):
+    g = torch.Generator().manual_seed(B * 1000 + Sq)
+    q, k, v = (torch.randn(B, s, Hh * D, generator=g) for s in (Sq, Sk, Sk))
+    q[0, 0] *= 6.0                                        # a peaked row
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), Hh)
+    assert ops.attention_kernel_kind(Sq, Sk, D, torch.float32) == 0
+    assert rel(out, _attn_ref(q, k, v, Hh)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("B,Hh,Sq,Sk,D", [(2, 5, 576, 576, 64), (1, 2, 130, 200, 64), (2, 2, 144, 144, 64),
+                                            (1, 5, 2304, 2304, 64), (3, 2, 33, 65, 64), (6, 5, 14, 14, 64)])
+def test_attention_half_io(ops, dtype, tol, B, Hh, Sq, Sk, D):
+    g = torch.Generator().manual_seed(Sq + Sk)
+    q, k, v = (torch.randn(B, s, Hh * D, generator=g).to(dtype) for s in (Sq, Sk, Sk))
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), Hh)
+    assert out.dtype == dtype
+    assert ops.attention_kernel_kind(Sq, Sk, D, dtype) == (1 if Sk > 32 else 0)
+    assert rel(out, _attn_ref(q, k, v, Hh)) < tol
+
+
+def test_attention_mfma_layout_with_exact_integers(ops):
+    """Asymmetric small-integer data: every product and sum is exact in bf16/fp32, so a swapped
+    row/column map or a wrong key permutation in the P.V operand shows up as a gross error."""
+    B, Hh, S, D = 1, 1, 128, 64
+    q = torch.zeros(B, S, D)
+    k = torch.zeros(B, S, D)
+    for i in range(S):
+        q[0, i, i % D] = 8.0                              # query i looks at channel i % 64
+        k[0, i, (3 * i + 1) % D] = 8.0
+    v = (torch.arange(S)[:, None] * 2 + torch.arange(D)[None, :] % 7).float()[None]
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    out = ops.attention(qb.cuda(), kb.cuda(), vb.cuda(), Hh)
+    assert rel(out, _attn_ref(qb, kb, vb, Hh)) < 1e-2
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "sgm_small.npz"))
+
+
+def test_small_unet_on_hip_ops_matches_reference_golden(G):
+    """fp32 end to end on the GPU: HIP GroupNorm+SiLU and HIP attention inside the real module graph."""
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    from models.csvd import ControlNet, ControlledVideoUNet
+    unet = VideoUNet(**H.SMALL_UNET).eval()
+    unet.load_state_dict(H.seeded_state_dict(unet, 11))
+    cunet = ControlledVideoUNet(**H.SMALL_UNET).eval()
+    cunet.load_state_dict(H.seeded_state_dict(cunet, 11))
+    cnet = ControlNet(**H.SMALL_CTRL).eval()
+    cnet.load_state_dict(H.seeded_state_dict(cnet, 12))
+    unet, cunet, cnet = unet.cuda(), cunet.cuda(), cnet.cuda()
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(21).items()}
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    tt = 0.25 * inp["sigma"].log()
+    with torch.no_grad():
+        y = unet(xin, tt, inp["crossattn"], inp["vector"], **kw)
+        ctrls = cnet(xin, inp["control_hint"], tt, inp["crossattn"], inp["vector"], **kw)
+        yc = cunet(xin, tt, inp["crossattn"], inp["vector"], control=list(ctrls), **kw)
+    assert rel(y, torch.tensor(G["unet_out"])) < 1e-4
+    for i, c in enumerate(ctrls):
+        assert rel(c, torch.tensor(G[f"ctrl_{i}"])) < 1e-4, i
+    assert rel(yc, torch.tensor(G["cunet_out"])) < 1e-4
+
+
+def test_small_unet_bf16_autocast_error_is_reported(G):
+    """Production precision: bf16 autocast (the reference runs fp16 autocast, csvd.py:27-31). Not a
+    1e-4 claim — the measured error against the fp32 reference golden is bounded loosely and printed."""
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    unet = VideoUNet(**H.SMALL_UNET).eval()
+    unet.load_state_dict(H.seeded_state_dict(unet, 11))
+    unet = unet.cuda()
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(21).items()}
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = unet(xin, 0.25 * inp["sigma"].log(), inp["crossattn"], inp["vector"], num_video_frames=H.T_FRAMES,
+                 image_only_indicator=inp["image_only_indicator"])
+    e = rel(y.float(), torch.tensor(G["unet_out"]))
+    print(f"bf16-autocast small-UNet relative error vs fp32 reference: {e:.3e}")
+    assert e < 8e-2
