@@ -36,7 +36,7 @@ def ops():
 
 
 GN_SHAPES = [((4, 64, 24, 16), 32), ((2, 320, 9, 16), 32), ((3, 96, 5, 7), 32), ((2, 64, 3, 20, 12), 32),
-             ((28, 320, 72, 128), 32), ((2, 320, 14, 72, 128), 32), ((28, 1280, 9, 16), 32), ((1, 32, 1, 1), 32),
+             ((28, 320, 72, 128), 32), ((2, 320, 14, 72, 128), 32), ((28, 1280, 9, 16), 32), ((2, 32, 1, 3), 32),
              ((2, 640, 36, 64), 32)]
 
 
