@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", choices=["both", "raster", "svd"], default="both",
+                    help="hot-path halves to run at N=1 (the SVD denoise loop is replicas-only across GPUs)")
+    ap.add_argument("--svd-steps", type=int, default=2)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,6 +210,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and args.path in ("both", "svd"):
+            # second half of the BASELINE.json metric: SVD 14-frame 576x1024 denoise steps/s
+            del t, bucket, st, g_img
+            torch.cuda.empty_cache()
+            from multiview_inpaint_amd.svd import bench_svd
+            svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=1)
+            svd["metric"] = "SVD 14-frame 576x1024 denoise steps/s (ControlNet + ControlledVideoUNet, CFG batch 28)"
+            if not args.no_cpu_baseline:
+                svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
+            out["svd"] = svd
         print(json.dumps(out), flush=True)
     if world > 1:
         td.destroy_process_group()

@@ -1,0 +1,121 @@
+"""SVD denoise-step benchmark (BASELINE.json metric, second half: "SVD 14-frame 576x1024 denoise
+steps/s"). One step = one CFG-doubled (batch 28) evaluation of ControlNet + ControlledVideoUNet
+through Denoiser.forward, bf16 autocast, synthetic tensors of the shapes in SURVEY.md §8d, seeded
+N(0, 0.02) weights (no pretrained weights exist offline). Configuration = the reference YAML
+svd_inpaint1/configs/test/svd_f_est_ctrl_simp1.yaml:19-61."""
+import time
+
+import torch
+
+SVD_UNET = dict(in_channels=8, out_channels=4, model_channels=320, channel_mult=[1, 2, 4, 4], num_res_blocks=2,
+                attention_resolutions=[4, 2, 1], num_head_channels=64, transformer_depth=1, context_dim=1024,
+                adm_in_channels=768, num_classes="sequential", use_linear_in_transformer=True, extra_ff_mix_layer=True,
+                use_spatial_context=True, merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1],
+                use_checkpoint=True, spatial_transformer_attn_type="softmax-xformers")
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+HBM_PEAK_GBS = 8000.0
+
+
+def build(device, seed=0, with_control=True, dtype=torch.float32):
+    """Full-size networks materialised directly on `device` (meta construction, seeded N(0, 0.02))."""
+    from .engine import SVDInpaintEngine
+    from .schedule import Denoiser
+    from .unet import ControlledVideoUNet, ControlNet
+    with torch.device("meta"):
+        unet = ControlledVideoUNet(**SVD_UNET)
+        cnet = ControlNet(hint_channels=7, **{k: v for k, v in SVD_UNET.items() if k != "out_channels"}) if with_control else None
+    g = torch.Generator(device=device).manual_seed(seed)
+    for m in (unet, cnet):
+        if m is None:
+            continue
+        m.to_empty(device=device)
+        with torch.no_grad():
+            for name, p in list(m.named_parameters()) + list(m.named_buffers()):
+                if name.endswith("mix_factor"):
+                    p.fill_(0.5)
+                elif p.ndim == 1 and name.endswith("weight") and ("norm" in name or "layers.0" in name or name.startswith("out.0")):
+                    p.normal_(1.0, 0.02, generator=g)
+                else:
+                    p.normal_(0.0, 0.02, generator=g)
+        m.eval().to(dtype)
+    den = Denoiser({"target": "multiview_inpaint_amd.svd.schedule.VScalingWithEDMcNoise"})
+    return SVDInpaintEngine(unet, cnet, den)
+
+
+def inputs(device, T=14, h=72, w=128, seed=0, cfg_doubled=True):
+    g = torch.Generator(device=device).manual_seed(seed)
+    B = (2 if cfg_doubled else 1) * T
+    r = lambda *s: torch.randn(*s, device=device, generator=g)
+    cond = dict(crossattn=r(B, 1, 1024), vector=r(B, 768), concat=r(B, 4, h, w),
+                control_hint=torch.rand(B, 7, 8 * h, 8 * w, device=device, generator=g))
+    return r(B, 4, h, w), cond, torch.zeros(B // T if not cfg_doubled else B // (2 * T), T, device=device)
+
+
+def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True):
+    from . import hip_ops
+    from .schedule import EDMDiscretization
+    eng = build(device, with_control=with_control)
+    x, cond, ind = inputs(device, T, h, w)
+    if not with_control:
+        cond.pop("control_hint")
+    sig = EDMDiscretization(sigma_max=700.0)(25, device=device)
+    kw = dict(num_video_frames=T, image_only_indicator=ind)
+
+    def step(i):
+        s = sig[i % 25].expand(x.shape[0])
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return eng.denoise(x, s, cond, **kw)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    hip_ops.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    prof = hip_ops.profile_summary()
+    hip_ops.PROFILE = None
+    res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
+               controlnet=with_control, dtype="bf16 autocast (fp32 weights, fp32 GroupNorm statistics/softmax)",
+               finite=bool(torch.isfinite(out).all()))
+    ops = {}
+    for kind, (calls, ms, work) in prof.items():
+        per_step_ms = ms / steps
+        if kind.startswith("attention"):
+            tf = work / (ms * 1e-3) / 1e12
+            ops[kind] = dict(calls_per_step=calls // steps, ms_per_step=round(per_step_ms, 3), TFLOPs=round(tf, 1),
+                             frac_of_bf16_mfma_peak=round(tf / MFMA_BF16_PEAK_TFLOPS, 4))
+        else:
+            gbs = work / (ms * 1e-3) / 1e9
+            ops[kind] = dict(calls_per_step=calls // steps, ms_per_step=round(per_step_ms, 3), GBs=round(gbs, 1),
+                             frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
+    res["hip_ops"] = ops
+    return res
+
+
+def run_cpu_baseline(threads=None):
+    """BASELINE.json configs[0]: one Denoiser.forward of the full-size VideoUNet, 1 frame 256x256
+    (latent 32x32), fp32, CPU PyTorch — this package's own modules on CPU tensors (the Python
+    reference cannot travel to the GPU box; parity with it is pinned by tests/test_sgm_cpu.py)."""
+    import os
+    dev = torch.device("cpu")
+    t0 = time.perf_counter()
+    if torch.cuda.is_available():
+        eng = build(torch.device("cuda"), with_control=False).to(dev)   # draw the 1.5 B weights on the GPU, run on CPU
+    else:
+        eng = build(dev, with_control=False)
+    t_build = time.perf_counter() - t0
+    x, cond, ind = inputs(dev, T=1, h=32, w=32, cfg_doubled=False)
+    cond.pop("control_hint")
+    s = torch.full((1,), 1.5)
+    times = []
+    with torch.no_grad():
+        for _ in range(2):
+            t1 = time.perf_counter()
+            eng.denoise(x, s, cond, num_video_frames=1, image_only_indicator=ind)
+            times.append(time.perf_counter() - t1)
+    return dict(value=round(1.0 / times[-1], 4), unit="denoise steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"2 x Denoiser.forward(VideoUNet 1.52B params), 1 frame 256x256 (latent 32x32), fp32, "
+                       f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; first call {times[0]:.1f} s, "
+                       f"second {times[1]:.1f} s, model build {t_build:.1f} s")

@@ -9,6 +9,37 @@ from .. import _lib
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _ws = {}
 
+# Optional per-op timing for bench.py: when PROFILE is a list, every op appends
+# (kind, start_event, end_event, work) with events recorded on the stream the kernel runs on.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, work, dev):
+        self.on = PROFILE is not None
+        if self.on:
+            self.kind, self.work = kind, work
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.st = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        if self.on:
+            self.a.record(self.st)
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record(self.st)
+            PROFILE.append((self.kind, self.a, self.b, self.work))
+
+
+def profile_summary():
+    """{kind: (calls, total_ms, total_work)} of the recorded ops; call after torch.cuda.synchronize()."""
+    out = {}
+    for kind, a, b, work in PROFILE or []:
+        c, ms, w = out.get(kind, (0, 0.0, 0.0))
+        out[kind] = (c + 1, ms + a.elapsed_time(b), w + work)
+    return out
+
 
 def _check(rc, what):
     if rc != 0:
@@ -41,7 +72,7 @@ def group_norm_silu(x, num_groups, weight, bias, eps, silu):
     w = weight.detach().float().contiguous()
     b = bias.detach().float().contiguous()
     ws = _workspace(xc.device, L.mvi_groupnorm_workspace_bytes(N, Cc, S, num_groups))
-    with torch.cuda.device(xc.device):
+    with torch.cuda.device(xc.device), _Timed("groupnorm", 2.0 * xc.numel() * xc.element_size(), xc.device):
         _check(L.mvi_groupnorm_silu(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc, S, num_groups,
                                     float(eps), int(bool(silu)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
                                     _stream(xc.device)), "group_norm")
@@ -58,7 +89,8 @@ def attention(q, k, v, heads):
     D = HD // heads
     q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
     out = torch.empty_like(q)
-    with torch.cuda.device(q.device):
+    kind = "attention_mfma" if L.mvi_attention_kernel_kind(Sq, Sk, D, _DT[q.dtype]) == 1 else "attention_rowtile"
+    with torch.cuda.device(q.device), _Timed(kind, 4.0 * B * heads * Sq * Sk * D, q.device):
         _check(L.mvi_attention_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, Sq, Sk, D,
                                        float(D) ** -0.5, _DT[q.dtype], _stream(q.device)), "attention")
     return out

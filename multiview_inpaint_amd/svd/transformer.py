@@ -62,19 +62,20 @@ class CrossAttention(nn.Module):
             n_extra = additional_tokens.shape[1]
             x = torch.cat([additional_tokens, x], dim=1)
         ctx = x if context is None else context
-        if ctx.shape[1] == 1 and not n_times_crossframe_attn_in_self:
+        if ctx.shape[1] == 1 and not n_times_crossframe_attn_in_self and not n_extra:
             # one key: softmax over a single score is exactly 1, so every query receives the value
-            # row. to_q / to_k never influence the result (SURVEY.md §7 "S_k = 1 cross-attention":
-            # 32 of the 64 attention calls of a UNet eval attend to the single CLIP token).
-            out = self.to_v(ctx).expand(-1, x.shape[1], -1)
-        else:
-            q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
-            if n_times_crossframe_attn_in_self:
-                n = n_times_crossframe_attn_in_self
-                assert x.shape[0] % n == 0
-                k = k[::n].repeat_interleave(x.shape[0] // n, dim=0)
-                v = v[::n].repeat_interleave(x.shape[0] // n, dim=0)
-            out = ops.attention(q, k, v, self.heads)
+            # row; to_q / to_k never influence the result (SURVEY.md §7 "S_k = 1 cross-attention":
+            # 32 of the 64 attention calls of a UNet eval attend to the single CLIP token). The output
+            # projection is applied to that one row and the result broadcast over the queries (the
+            # residual add broadcasts it) — also keeps zero-stride operands out of the GEMM library.
+            return self.to_out(self.to_v(ctx)).expand(-1, x.shape[1], -1)
+        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+        if n_times_crossframe_attn_in_self:
+            n = n_times_crossframe_attn_in_self
+            assert x.shape[0] % n == 0
+            k = k[::n].repeat_interleave(x.shape[0] // n, dim=0)
+            v = v[::n].repeat_interleave(x.shape[0] // n, dim=0)
+        out = ops.attention(q, k, v, self.heads)
         if n_extra:
             out = out[:, n_extra:]
         return self.to_out(out)
