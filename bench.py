@@ -179,7 +179,7 @@ def main():
         for i in range(8):
             name = L.mvi_raster_stage_name(i).decode()
             if calls[i]:
-                avg_ms = ms[i] / calls[i]
+                avg_ms = ms[i] / args.steps                  # a stage may be bracketed more than once per step
                 stages[name] = dict(ms=round(avg_ms, 4), GBs=round(stage_bytes[name] / avg_ms / 1e6, 1))
         dom = max(stages, key=lambda k: stages[k]["ms"])
         ms_step = dt / args.steps * 1e3

@@ -86,7 +86,7 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t n
  * gs-simp/scene/gaussian_model.py:482-484), dL_dopacity [P], and
  * dL_dshs [P,M,3] | dL_dcolors [P,3], dL_dscales [P,3] + dL_drotations [P,4] | dL_dcov3D [P,6]
  * (pass NULL for the member of each pair that was not a forward input).
- * dL_dconic_scratch: [P,4] fp32 scratch. */
+ * grad_rows_scratch: [P,16] fp32 scratch (64-byte accumulation row per Gaussian). */
 int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t num_rendered,
                         const float* means3D, const float* shs, const float* colors_precomp,
                         const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -94,7 +94,7 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
                         const void* image, const float* dL_dout_color, float* dL_dmeans3D,
                         float* dL_dmeans2D, float* dL_dopacity, float* dL_dshs, float* dL_dcolors,
                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                        float* dL_dconic_scratch, void* stream);
+                        float* grad_rows_scratch, void* stream);
 
 /* visible [P] uint8 = 1 where view-space z > 0.2 (the plug-in's markVisible; unused by the
  * reference but part of the plug-in surface). */
@@ -111,7 +111,8 @@ typedef struct mvi_raster_views {
     const float* rgb;             /* [P,3] */
     const uint32_t* tiles_touched;/* [P] */
     const uint8_t* clamped;       /* [P,3] */
-    const uint64_t* keys_sorted;  /* [D] tile<<32 | depth bits */
+    const uint32_t* tile_ids_sorted; /* [D] high word of the sort key; the full key of pair i is
+                                      * tile_ids_sorted[i] << 32 | bits(depths[point_list[i]]) */
     const uint32_t* point_list;   /* [D] Gaussian index per sorted pair */
     const uint32_t* ranges;       /* [tiles,2] */
     const float* final_T;         /* [H,W] */

@@ -25,7 +25,7 @@ class RasterViews(C.Structure):
     """struct mvi_raster_views"""
     _fields_ = [(n, C.c_void_p) for n in (
         "depths", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "clamped",
-        "keys_sorted", "point_list", "ranges", "final_T", "n_contrib")]
+        "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")]
 
 
 def declared_symbols():

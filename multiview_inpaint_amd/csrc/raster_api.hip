@@ -178,9 +178,10 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
     if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
         return fail(MVI_EINVAL, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!%s");
     if (!means3D || !radii || !geom || !image || !dL_dout_color || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity ||
-        !dL_dcolors || !dL_dconic_scratch)
+        !dL_dconic_scratch)
         return fail(MVI_EINVAL, "NULL required pointer in backward%s");
     if (shs && !dL_dshs) return fail(MVI_EINVAL, "dL_dshs is NULL but shs was a forward input%s");
+    if (colors_precomp && !dL_dcolors) return fail(MVI_EINVAL, "dL_dcolors is NULL but colors_precomp was a forward input%s");
     if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
         return fail(MVI_EINVAL, "missing covariance gradient output%s");
     if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
@@ -188,25 +189,19 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
     mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), f.W, f.H);
     mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, f.W, f.H);
     hipStream_t st = (hipStream_t)stream;
-    float4* dconic_op = reinterpret_cast<float4*>(dL_dconic_scratch);
+    float* grad_rows = dL_dconic_scratch;             // [P][16] accumulation rows
     hipError_t e;
-    if ((e = hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
-    if ((e = hipMemsetAsync(dconic_op, 0, sizeof(float) * 4 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
-    if ((e = hipMemsetAsync(dL_dcolors, 0, sizeof(float) * 3 * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
+    if ((e = hipMemsetAsync(grad_rows, 0, sizeof(float) * mvi::kGradRow * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
     {
         mvi::StageTimer tm(mvi::kStRenderBwd, st);
-        if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, dL_dmeans2D, dconic_op, dL_dcolors, st))
+        if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, grad_rows, st))
             return hip_fail("render_backward", hipGetLastError());
     }
     mvi::StageTimer tm(mvi::kStPreBwd, st);
-    if (int rc = mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g,
-                                                 dL_dmeans2D, dconic_op, dL_dcolors, dL_dmeans3D, dL_dshs, dL_dcov3D,
-                                                 dL_dscales, dL_drotations, st))
+    if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, grad_rows,
+                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, colors_precomp ? dL_dcolors : nullptr,
+                                        dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, st))
         return hip_fail("preprocess_backward", hipGetLastError());
-    // dL/dopacity is the .w lane of the float4 scratch
-    e = hipMemcpy2DAsync(dL_dopacity, sizeof(float), reinterpret_cast<const float*>(dconic_op) + 3, sizeof(float4),
-                         sizeof(float), (size_t)P, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return hip_fail("copy dL_dopacity", e);
     return MVI_OK;
 }
 
@@ -230,7 +225,7 @@ int mvi_raster_get_views(int32_t P, int64_t D, int32_t W, int32_t H, const void*
     if (binning) {
         mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, W, H);
         int fin = b.passes & 1;
-        out->keys_sorted = b.keys[fin]; out->point_list = b.vals[fin];
+        out->tile_ids_sorted = b.keys[fin]; out->point_list = b.vals[fin];
     }
     if (image) {
         mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), W, H);

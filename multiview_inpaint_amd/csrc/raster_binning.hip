@@ -1,13 +1,19 @@
-// Tile binning for gfx950: scan of tiles touched, (tile|depth) key emission, stable LSD radix sort
-// of (u64 key, u32 value) pairs, per-tile ranges. Replaces the plug-in's
-// InclusiveSum / duplicateWithKeys / DeviceRadixSort::SortPairs / identifyTileRanges stages behind
-// gs-simp/gaussian_renderer/__init__.py:85-93. Keys and sorted order are integer data and must be
-// bit-exact against the oracle.
+// Tile binning for gfx950. Replaces the plug-in's InclusiveSum / duplicateWithKeys /
+// DeviceRadixSort::SortPairs / identifyTileRanges stages behind
+// gs-simp/gaussian_renderer/__init__.py:85-93 and produces the SAME sorted pair order (stable sort
+// of key = tile << 32 | depth bits, ties in Gaussian-index order) — but never materialises or moves
+// 64-bit keys:
+//   level 1  sort the P Gaussians by depth bits (32-bit keys, 4 stable 8-bit passes over P items);
+//   emit     walk the Gaussians in that order and write one (tile id, Gaussian index) pair per
+//            covered tile, coalesced per 256-Gaussian block;
+//   level 2  stable partition of the D pairs by tile id (ceil(log2 T / 8) = 2 passes).
+// HBM traffic per pair drops from 6 passes x 32 B to 2 passes x 20 B; the order is bit-identical
+// because both levels are stable. Integer data: the parity tests compare it bit for bit.
 #include "raster_common.h"
 
 namespace mvi {
 
-// ---- exclusive scan of the per-block sums the preprocess kernel produced (one block) ----------
+// ---- exclusive scan of per-block sums (one 1024-thread block) ---------------------------------
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ sums,
                                                                uint32_t* __restrict__ offsets, int n) {
     __shared__ uint32_t s_wave[16];
@@ -37,26 +43,57 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
     if (tid == 0) offsets[n] = s_carry;
 }
 
-// ---- key emission: block = 256 Gaussians; output slots of the block are written coalesced -----
-__global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(Frame f, GeomView g,
-                                                                const int32_t* __restrict__ radii,
-                                                                uint64_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ vals) {
-    __shared__ uint32_t s_off[kBlock];     // exclusive offsets inside the block
+// ---- level 1 input: (depth bits | 0xFFFFFFFF for culled, index) -------------------------------
+__global__ __launch_bounds__(kBlock) void depth_keys_kernel(int P, const float* __restrict__ depths,
+                                                            const uint32_t* __restrict__ tiles_touched,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    keys[i] = tiles_touched[i] ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;   // depth > 0.2: bits are monotonic
+    vals[i] = (uint32_t)i;
+}
+
+// tiles touched per 256 depth-ordered Gaussians
+__global__ __launch_bounds__(kBlock) void perm_block_sums_kernel(int P, const uint32_t* __restrict__ order,
+                                                                 const uint32_t* __restrict__ tiles_touched,
+                                                                 uint32_t* __restrict__ sums) {
+    __shared__ uint32_t s_sum;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    int i = blockIdx.x * kBlock + tid;
+    uint32_t t = i < P ? tiles_touched[order[i]] : 0u;
+    uint32_t w = wave_sum_u32(t);
+    if ((tid & 63) == 0 && w) atomicAdd(&s_sum, w);
+    __syncthreads();
+    if (tid == 0) sums[blockIdx.x] = s_sum;
+}
+
+// ---- pair emission in depth order: block = 256 consecutive entries of `order`; the block's output
+// slots are written coalesced (slot j finds its Gaussian by binary search over the in-block scan)
+__global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g, const uint32_t* __restrict__ order,
+                                                            const int32_t* __restrict__ radii,
+                                                            const uint32_t* __restrict__ block_offsets,
+                                                            uint32_t* __restrict__ tile_keys,
+                                                            uint32_t* __restrict__ vals) {
+    __shared__ uint32_t s_off[kBlock];
     __shared__ uint32_t s_wave[4];
     __shared__ int s_x0[kBlock], s_y0[kBlock], s_w[kBlock];
-    __shared__ uint32_t s_depth[kBlock];
+    __shared__ uint32_t s_gi[kBlock];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * kBlock + tid;
-    uint32_t t = 0;
+    const int pos = blockIdx.x * kBlock + tid;
+    uint32_t t = 0, gi = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    if (i < f.P && radii[i] > 0) {
-        float2 p = g.xy[i];
-        tile_rect(p.x, p.y, radii[i], f.gx, f.gy, x0, y0, x1, y1);
-        t = (uint32_t)((x1 - x0) * (y1 - y0));
-        s_depth[tid] = __float_as_uint(g.depths[i]);
+    if (pos < f.P) {
+        gi = order[pos];
+        const int rad = radii[gi];
+        if (rad > 0) {
+            float2 p = g.xy[gi];
+            tile_rect(p.x, p.y, rad, f.gx, f.gy, x0, y0, x1, y1);
+            t = (uint32_t)((x1 - x0) * (y1 - y0));
+        }
     }
-    s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
+    s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0; s_gi[tid] = gi;
     uint32_t inc = t;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -70,10 +107,9 @@ __global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(Frame f, GeomVie
     s_off[tid] = wave_off + inc - t;
     const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
-    const uint32_t base = g.block_offsets[blockIdx.x];
+    const uint32_t base = block_offsets[blockIdx.x];
     for (uint32_t j = tid; j < total; j += kBlock) {
-        // largest gi with s_off[gi] <= j (that Gaussian has tiles_touched > 0 by construction)
-        int lo = 0, hi = kBlock - 1;
+        int lo = 0, hi = kBlock - 1;                      // largest entry with s_off <= j (it has t > 0)
         while (lo < hi) {
             int mid = (lo + hi + 1) >> 1;
             if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
@@ -81,17 +117,15 @@ __global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(Frame f, GeomVie
         uint32_t k = j - s_off[lo];
         int w = s_w[lo];
         int y = s_y0[lo] + (int)(k / (uint32_t)w), x = s_x0[lo] + (int)(k % (uint32_t)w);
-        uint64_t key = ((uint64_t)(uint32_t)(y * f.gx + x) << 32) | (uint64_t)s_depth[lo];
-        keys[base + j] = key;
-        vals[base + j] = (uint32_t)(blockIdx.x * kBlock + lo);
+        tile_keys[base + j] = (uint32_t)(y * f.gx + x);
+        vals[base + j] = s_gi[lo];
     }
 }
 
-// ---- radix sort: 8-bit LSD passes, three kernels per pass -------------------------------------
-// count: per-block digit histogram, stored digit-major: block_hist[d * nblk + b]
-__global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint64_t* __restrict__ keys, int64_t D,
-                                                             int shift, uint32_t mask,
-                                                             uint32_t* __restrict__ block_hist, int nblk) {
+// ---- stable 8-bit LSD radix pass over (u32 key, u32 value) pairs: count / scan / scatter -------
+__global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint32_t* __restrict__ keys, int64_t D, int shift,
+                                                             uint32_t mask, uint32_t* __restrict__ block_hist,
+                                                             int nblk) {
     __shared__ uint32_t s_hist[256];
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
@@ -100,13 +134,13 @@ __global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint64_t* __r
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
         int64_t idx = base + it * kBlock + tid;
-        if (idx < D) atomicAdd(&s_hist[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+        if (idx < D) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
     block_hist[(size_t)tid * nblk + blockIdx.x] = s_hist[tid];
 }
 
-// scan: block d turns row d of block_hist into exclusive offsets inside digit d; digit_tot[d] = sum
+// block d turns row d of block_hist into exclusive offsets inside digit d; digit_tot[d] = row sum
 __global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restrict__ block_hist, int nblk,
                                                                uint32_t* __restrict__ digit_tot) {
     __shared__ uint32_t s_wave[16];
@@ -137,20 +171,20 @@ __global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restr
     if (tid == 0) digit_tot[blockIdx.x] = s_carry;
 }
 
-// scatter: stable. Wave w of a block owns 512 consecutive keys, item `it` of lane l is key
-// w*512 + it*64 + l, so ranking items in `it` order inside a wave and waves in order keeps the
-// input order among equal digits.
+// Stable scatter. Wave w of a block owns 512 consecutive pairs, item `it` of lane l is pair
+// w*512 + it*64 + l, so ranking items in `it` order inside a wave (64-bit __ballot peer masks) and
+// waves in order keeps the input order among equal digits.
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask,
-    const uint32_t* __restrict__ block_hist, int nblk, const uint32_t* __restrict__ digit_tot) {
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask, const uint32_t* __restrict__ block_hist,
+    int nblk, const uint32_t* __restrict__ digit_tot) {
     __shared__ uint32_t s_wave_hist[4][256];
     __shared__ uint32_t s_digit_base[256];
+    __shared__ uint32_t s_w4[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0;
-    // exclusive scan of the 256 digit totals -> start of each digit in the output
-    {
+    {   // exclusive scan of the 256 digit totals -> start of each digit in the output
         uint32_t v = digit_tot[tid];
         uint32_t inc = v;
 #pragma unroll
@@ -158,7 +192,6 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
             uint32_t t = __shfl_up(inc, o);
             if (lane >= o) inc += t;
         }
-        __shared__ uint32_t s_w4[4];
         if (lane == 63) s_w4[wave] = inc;
         __syncthreads();
         uint32_t wave_off = 0;
@@ -168,19 +201,17 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     __syncthreads();
 
     const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * (kSortItems * 64);
-    uint64_t key[kSortItems];
-    uint32_t val[kSortItems], rank[kSortItems], dig[kSortItems];
+    uint32_t key[kSortItems], val[kSortItems], rank[kSortItems], dig[kSortItems];
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
         int64_t idx = base + it * 64 + lane;
         bool valid = idx < D;
-        key[it] = valid ? keys_in[idx] : 0ull;
+        key[it] = valid ? keys_in[idx] : 0u;
         val[it] = valid ? vals_in[idx] : 0u;
-        uint32_t d = (uint32_t)(key[it] >> shift) & mask;
+        uint32_t d = (key[it] >> shift) & mask;
         dig[it] = valid ? d : 0xFFFFFFFFu;
-        // lanes of this wave holding the same digit
-        uint64_t peers = __ballot(valid);
+        uint64_t peers = __ballot(valid);                // lanes of this wave holding the same digit
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             uint64_t bit = __ballot((d >> b) & 1u);
@@ -196,8 +227,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
         rank[it] = prev + before;
     }
     __syncthreads();
-    // offset of each wave inside the block for every digit
-    {
+    {   // offset of each wave inside the block for every digit
         uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid], c2 = s_wave_hist[2][tid];
         __syncthreads();
         s_wave_hist[0][tid] = 0;
@@ -217,14 +247,14 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     }
 }
 
-__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint64_t* __restrict__ keys, int64_t D,
+__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t D,
                                                              uint32_t* __restrict__ ranges) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= D) return;
-    uint32_t t = (uint32_t)(keys[i] >> 32);
+    uint32_t t = tile_keys[i];
     if (i == 0) ranges[2 * t] = 0;
     else {
-        uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        uint32_t tp = tile_keys[i - 1];
         if (t != tp) { ranges[2 * tp + 1] = (uint32_t)i; ranges[2 * t] = (uint32_t)i; }
     }
     if (i == D - 1) ranges[2 * t + 1] = (uint32_t)D;
@@ -236,31 +266,48 @@ int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
-// After this call the sorted pairs are in b.keys[b.passes & 1], b.vals[b.passes & 1].
+// one stable pass over n pairs; returns the index (0/1) of the buffer holding the result
+static int radix_pass(uint32_t* const keys[2], uint32_t* const vals[2], int cur, int64_t n, int shift, int bits,
+                      uint32_t* hist, uint32_t* tot, int nsort, hipStream_t st) {
+    uint32_t mask = (1u << bits) - 1u;
+    hipLaunchKernelGGL(radix_count_kernel, dim3(nsort), dim3(kBlock), 0, st, keys[cur], n, shift, mask, hist, nsort);
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, hist, nsort, tot);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nsort), dim3(kBlock), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
+                       vals[cur ^ 1], n, shift, mask, hist, nsort, tot);
+    return cur ^ 1;
+}
+
+// After this call the sorted pairs are in b.keys[b.passes & 1] (tile ids), b.vals[b.passes & 1].
 int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
                    int64_t D, hipStream_t st) {
     size_t tiles = (size_t)f.gx * f.gy;
     if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
     if (D <= 0 || f.P <= 0) return 0;
-    int nblk = (f.P + kBlock - 1) / kBlock;
-    {
+    const int nblk = (f.P + kBlock - 1) / kBlock;
+    {   // level 1: Gaussians by depth (4 passes over P items; even count -> result back in buffer 0)
+        StageTimer tm(kStSort, st);
+        hipLaunchKernelGGL(depth_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.depths, g.tiles_touched,
+                           g.dkeys[0], g.dvals[0]);
+        int cur = 0;
+        for (int p = 0; p < 4; ++p)
+            cur = radix_pass(g.dkeys, g.dvals, cur, f.P, 8 * p, 8, g.dhist, g.dtot, g.nsortP, st);
+    }
+    {   // emission in depth order
         StageTimer tm(kStDup, st);
-        hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, radii, b.keys[0], b.vals[0]);
+        hipLaunchKernelGGL(perm_block_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.dvals[0], g.tiles_touched,
+                           g.perm_sums);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.perm_sums, g.perm_offsets, nblk);
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, g.dvals[0], radii, g.perm_offsets,
+                           b.keys[0], b.vals[0]);
     }
     int cur = 0;
-    stage_begin(kStSort, st);
-    for (int p = 0; p < b.passes; ++p) {
-        int shift = 8 * p;
-        int nb = b.key_bits - shift < 8 ? b.key_bits - shift : 8;
-        uint32_t mask = (1u << nb) - 1u;
-        hipLaunchKernelGGL(radix_count_kernel, dim3(b.nsort), dim3(kBlock), 0, st, b.keys[cur], D, shift, mask,
-                           b.block_hist, b.nsort);
-        hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, b.block_hist, b.nsort, b.digit_tot);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(b.nsort), dim3(kBlock), 0, st, b.keys[cur], b.vals[cur],
-                           b.keys[cur ^ 1], b.vals[cur ^ 1], D, shift, mask, b.block_hist, b.nsort, b.digit_tot);
-        cur ^= 1;
+    {   // level 2: stable partition by tile id
+        StageTimer tm(kStSort, st);
+        for (int p = 0; p < b.passes; ++p) {
+            int bits = b.key_bits - 8 * p < 8 ? b.key_bits - 8 * p : 8;
+            cur = radix_pass(b.keys, b.vals, cur, D, 8 * p, bits, b.block_hist, b.digit_tot, b.nsort, st);
+        }
     }
-    stage_end(kStSort, st);
     int nrb = (int)((D + kBlock - 1) / kBlock);
     StageTimer tm(kStRanges, st);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(nrb), dim3(kBlock), 0, st, b.keys[cur], D, im.ranges);

@@ -45,6 +45,14 @@ struct GeomView {
     uint8_t* clamped;         // [3P]
     uint32_t* block_sums;     // [nblk]   tiles touched per 256-Gaussian block
     uint32_t* block_offsets;  // [nblk+1] exclusive scan of block_sums; [nblk] = D
+    // depth sort of the Gaussians (binning level 1): ping-pong (depth bits, index) pairs
+    uint32_t* dkeys[2];       // [P]
+    uint32_t* dvals[2];       // [P]; after the 4 passes dvals[0] = Gaussian indices in depth order
+    uint32_t* dhist;          // [256 * nsortP]
+    uint32_t* dtot;           // [256]
+    uint32_t* perm_sums;      // [nblk]   tiles touched per 256 depth-ordered Gaussians
+    uint32_t* perm_offsets;   // [nblk+1]
+    int nsortP;
     size_t bytes;
 };
 struct ImageView {
@@ -54,13 +62,14 @@ struct ImageView {
     size_t bytes;
 };
 struct BinningView {
-    uint64_t* keys[2];    // ping-pong [D]
-    uint32_t* vals[2];    // ping-pong [D]
+    uint32_t* keys[2];    // ping-pong [D] tile ids (the 64-bit (tile|depth) key is implicit: pairs are
+                          // emitted in depth order and stably partitioned by tile)
+    uint32_t* vals[2];    // ping-pong [D] Gaussian indices
     uint32_t* block_hist; // [256 * nsort]  digit-major per-block digit counts / offsets
     uint32_t* digit_tot;  // [256]
     int nsort;            // blocks per radix pass
-    int passes;           // 8-bit passes over 32 + tile bits
-    int key_bits;
+    int passes;           // 8-bit passes over the tile bits; sorted pairs end in keys/vals[passes & 1]
+    int key_bits;         // tile bits
     size_t bytes;
 };
 
@@ -82,6 +91,12 @@ inline GeomView carve_geom(void* base, int P) {
     g.clamped = (uint8_t*)take(3 * n);
     g.block_sums = (uint32_t*)take(4 * (size_t)nblk);
     g.block_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
+    g.nsortP = (int)((n + kSortTile - 1) / kSortTile);
+    for (int i = 0; i < 2; ++i) { g.dkeys[i] = (uint32_t*)take(4 * n); g.dvals[i] = (uint32_t*)take(4 * n); }
+    g.dhist = (uint32_t*)take(4 * 256 * (size_t)g.nsortP);
+    g.dtot = (uint32_t*)take(4 * 256);
+    g.perm_sums = (uint32_t*)take(4 * (size_t)nblk);
+    g.perm_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
     g.bytes = o;
     return g;
 }
@@ -110,11 +125,11 @@ inline BinningView carve_binning(void* base, int64_t D, int W, int H) {
     size_t o = 0;
     size_t n = (size_t)(D > 0 ? D : 1);
     v.nsort = (int)((n + kSortTile - 1) / kSortTile);
-    v.key_bits = 32 + tile_bits(W, H);
+    v.key_bits = tile_bits(W, H);
     v.passes = (v.key_bits + 7) / 8;
     auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
-    v.keys[0] = (uint64_t*)take(8 * n);
-    v.keys[1] = (uint64_t*)take(8 * n);
+    v.keys[0] = (uint32_t*)take(4 * n);
+    v.keys[1] = (uint32_t*)take(4 * n);
     v.vals[0] = (uint32_t*)take(4 * n);
     v.vals[1] = (uint32_t*)take(4 * n);
     v.block_hist = (uint32_t*)take(4 * 256 * (size_t)v.nsort);
@@ -158,6 +173,14 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3
     return v;
 }
+// Sum over each 16-lane DPP row; the row total lands in lanes 15, 31, 47, 63.
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+    v = dpp_add<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
@@ -181,17 +204,16 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               int32_t* radii, hipStream_t st);
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
                                const float* scales, const float* rotations, const float* cov3D_precomp,
-                               const int32_t* radii, GeomView g, const float* dL_dmean2D_ndc,
-                               const float4* dL_dconic_op, const float* dL_dcolor, float* dL_dmeans3D,
-                               float* dL_dshs, float* dL_dcov3D, float* dL_dscales, float* dL_drots,
-                               hipStream_t st);
+                               const int32_t* radii, GeomView g, const float* grad_rows, float* dL_dmeans3D,
+                               float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors, float* dL_dshs,
+                               float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st);
 int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
                    int64_t D, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                           float* out_color, float* out_depth, hipStream_t st);
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
-                           const float* dL_dpix, float* dL_dmean2D, float4* dL_dconic_op,
-                           float* dL_dcolor, hipStream_t st);
+                           const float* dL_dpix, float* grad_rows, hipStream_t st);
+constexpr int kGradRow = 16;   // floats per Gaussian in the backward accumulation rows (64 B)
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st);
 
 }  // namespace mvi

@@ -248,19 +248,33 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
     }
 }
 
-// One thread per Gaussian. Inputs: dL_dmean2D_ndc [P,3] (x,y used), dL_dconic_op [P] float4 =
-// (dL/dA, dL/dB, dL/dC, dL/dopacity) of power = -0.5(A dx^2 + C dy^2) - B dx dy, dL_dcolor [P,3].
+// One thread per Gaussian. Input: grad_rows [P][16] from render_backward (mean2D.xy NDC-scaled,
+// dL/dA, dL/dB, dL/dC of power = -0.5(A dx^2 + C dy^2) - B dx dy, dL/dopacity, dL/drgb).
 // Outputs are written for every Gaussian (zeros where radii == 0).
 __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii, GeomView g,
-    const float* __restrict__ dL_dmean2D, const float4* __restrict__ dL_dconic_op,
-    const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
+    const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= f.P) return;
     const bool live = radii[i] > 0;
+    float gr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+        const float4* row = reinterpret_cast<const float4*>(grad_rows + (size_t)i * kGradRow);
+        float4 a = row[0], b4 = row[1];
+        gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b4.x; gr[5] = b4.y; gr[6] = b4.z; gr[7] = b4.w;
+        gr[8] = grad_rows[(size_t)i * kGradRow + 8];
+    }
+    dL_dmeans2D[3 * (size_t)i] = gr[0];
+    dL_dmeans2D[3 * (size_t)i + 1] = gr[1];
+    dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
+    dL_dopacity[i] = gr[5];
+    if (dL_dcolors) {
+        dL_dcolors[3 * (size_t)i] = gr[6]; dL_dcolors[3 * (size_t)i + 1] = gr[7]; dL_dcolors[3 * (size_t)i + 2] = gr[8];
+    }
     float dm[3] = {0, 0, 0};
     float g6[6] = {0, 0, 0, 0, 0, 0};
     const int nb = (f.deg + 1) * (f.deg + 1);
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         cov2d_from_cov3d(e, c6, a, b, c);
         float denom = a * c - b * b;
         float d2inv = 1.0f / (denom * denom + 0.0000001f);
-        float4 gc = dL_dconic_op[i];
+        const float4 gc = make_float4(gr[2], gr[3], gr[4], gr[5]);
         float da = 0, db = 0, dc = 0;
         if (d2inv != 0.0f) {
             da = d2inv * (-c * c * gc.x + b * c * gc.y + (denom - a * c) * gc.z);
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         float hw = affine3(PM[3], PM[7], PM[11], PM[15], px, py, pz);
         float mw = 1.0f / (hw + 0.0000001f);
         float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-        float g2x = dL_dmean2D[3 * (size_t)i], g2y = dL_dmean2D[3 * (size_t)i + 1];
+        float g2x = gr[0], g2y = gr[1];
         dm[0] += (PM[0] * mw - PM[3] * mul1) * g2x + (PM[1] * mw - PM[3] * mul2) * g2y;
         dm[1] += (PM[4] * mw - PM[7] * mul1) * g2x + (PM[5] * mw - PM[7] * mul2) * g2y;
         dm[2] += (PM[8] * mw - PM[11] * mul1) * g2x + (PM[9] * mw - PM[11] * mul2) * g2y;
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             float gcol[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
-                gcol[ch] = g.clamped[3 * (size_t)i + ch] ? 0.0f : dL_dcolor[3 * (size_t)i + ch];
+                gcol[ch] = g.clamped[3 * (size_t)i + ch] ? 0.0f : gr[6 + ch];
             float ddx = 0, ddy = 0, ddz = 0;
             for (int k = 0; k < nb; ++k) {
 #pragma unroll
@@ -409,15 +423,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
 
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
                                const float* scales, const float* rotations, const float* cov3D_precomp,
-                               const int32_t* radii, GeomView g, const float* dL_dmean2D,
-                               const float4* dL_dconic_op, const float* dL_dcolor, float* dL_dmeans3D,
-                               float* dL_dshs, float* dL_dcov3D, float* dL_dscales, float* dL_drots,
-                               hipStream_t st) {
+                               const int32_t* radii, GeomView g, const float* grad_rows, float* dL_dmeans3D,
+                               float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors, float* dL_dshs,
+                               float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st) {
     if (f.P <= 0) return 0;
     int nblk = (f.P + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), 0, st, f, means3D, shs, scales,
-                       rotations, cov3D_precomp, radii, g, dL_dmean2D, dL_dconic_op, dL_dcolor,
-                       dL_dmeans3D, dL_dshs, dL_dcov3D, dL_dscales, dL_drots);
+                       rotations, cov3D_precomp, radii, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
+                       dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales, dL_drots);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

@@ -145,16 +145,16 @@ def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_
         return t
     g = dict(means3D=buf("means3D", P, 3), means2D=buf("means2D", P, 3), opacities=buf("opacities", P, 1),
              shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
-    dcolors = buf("colors_precomp", P, 3)                # output in colours mode, scratch in SH mode
+    dcolors = None
     if shs is not None:
         g["shs"] = buf("shs", P, st.M, 3)
     else:
-        g["colors_precomp"] = dcolors
+        dcolors = g["colors_precomp"] = buf("colors_precomp", P, 3)
     if cov3D_precomp is not None:
         g["cov3D_precomp"] = buf("cov3D_precomp", P, 6)
     else:
         g["scales"], g["rotations"] = buf("scales", P, 3), buf("rotations", P, 4)
-    scratch = torch.empty(P, 4, **f32)
+    scratch = torch.empty(P, 16, **f32)              # 64-byte accumulation row per Gaussian
     grad_color = grad_color.to(torch.float32).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):

@@ -71,10 +71,13 @@ def _check_forward(R, ro, cam, sc, bg, full=True):
     vis = f["radii"] > 0
     tt = st.tensor("tiles_touched", (P,), torch.int32).cpu().numpy().view(np.uint32)
     assert np.array_equal(tt, f["tiles_touched"])
-    keys = st.tensor("keys_sorted", (D,), torch.int64).cpu().numpy().view(np.uint64)
-    assert np.array_equal(keys, f["keys_sorted"]), "sort keys differ"
     plist = st.tensor("point_list", (D,), torch.int32).cpu().numpy().view(np.uint32)
     assert np.array_equal(plist, f["point_list"]), "sorted order differs"
+    # the 64-bit sort key of pair i is tile_ids_sorted[i] << 32 | bits(depths[point_list[i]]) (include/mvi_raster.h)
+    tids = st.tensor("tile_ids_sorted", (D,), torch.int32).cpu().numpy().view(np.uint32)
+    dbits = st.tensor("depths", (P,), torch.float32).cpu().numpy().view(np.uint32)
+    keys = (tids.astype(np.uint64) << np.uint64(32)) | dbits[plist].astype(np.uint64)
+    assert np.array_equal(keys, f["keys_sorted"]), "sort keys differ"
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     ranges = st.tensor("ranges", (tiles, 2), torch.int32).cpu().numpy().view(np.uint32)
     assert np.array_equal(ranges, f["ranges"])
@@ -217,10 +220,11 @@ def test_full_size_properties_1p5M_1080p(R):
     bg0, bg1 = np.zeros(3, np.float32), np.array([0.25, 0.5, 1.0], np.float32)
     c0, radii, d0, st = R.rasterize_forward(_settings(R, cam, bg0, 3), t["means3D"], t["opacities"], **kw)
     P, D = st.P, st.D
-    keys = st.tensor("keys_sorted", (D,), torch.int64)
     plist = st.tensor("point_list", (D,), torch.int32).long()
     tt = st.tensor("tiles_touched", (P,), torch.int32).long()
     depths = st.tensor("depths", (P,), torch.float32)
+    tids = st.tensor("tile_ids_sorted", (D,), torch.int32).long()
+    keys = (tids << 32) | (depths[plist].view(torch.int32).long() & 0xFFFFFFFF)
     # sortedness (keys are non-negative as int64: tile < 2^31) and key <-> payload consistency
     assert (keys[1:] >= keys[:-1]).all()
     assert D == int(tt.sum()) and ((radii > 0) == (tt > 0)).all()
