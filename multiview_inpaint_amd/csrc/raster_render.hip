@@ -115,14 +115,30 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
 }
 
 // ------------------------------------------------------------------------------------ backward
-// Back-to-front replay over the entries [0, max n_contrib of the tile) only. Each lane owns a
-// pixel; per evaluated Gaussian the 9 partial gradients are summed over the wave with DPP,
-// accumulated over the block's 4 waves in LDS rows of 16 floats, and flushed once per 256-entry
-// batch with float atomics shaped as whole 64-byte rows (16 lanes per Gaussian, 4 Gaussians per
-// wave-instruction): MI355X float atomics run at the 64-B-request rate, so one dword per row would
-// be 16x slower for the same sums. Row layout of grad_rows [P][16]:
+// Back-to-front replay over the entries [0, max n_contrib of the tile) only. Each lane owns a pixel.
+// Per evaluated (quadrant, Gaussian) pair every lane produces 9 RAW moments
+//     W = o G dL/dalpha,  W dx,  W dy,  W dx^2,  W dx dy,  W dy^2,  alpha T dL/dC_{r,g,b}
+// (the per-Gaussian factors — conic coefficients, 1/o, the 0.5 W / 0.5 H screen scale — are applied
+// once per (tile, Gaussian) after the sums). The 64-lane sums take two DPP steps inside each quad,
+// then the 16 quad partials of up to 7 Gaussians x 9 moments are parked in a per-wave LDS slab
+// (rows of 16, stride 20) and summed by ONE lane per row — 63 rows per wave64 — which adds the row
+// total into the block's per-entry accumulator. That replaces 6 cross-lane steps per value by 2
+// plus ~1/7 of a 16-element row sum. Once per 256-entry batch the block turns the raw sums into
+// gradients and flushes them with float atomics shaped as whole 64-byte rows (16 lanes per
+// Gaussian): MI355X float atomics run at the 64-B-request rate. Row layout of grad_rows [P][16]:
 //   0 mean2D.x  1 mean2D.y  2 conic A  3 conic B  4 conic C  5 opacity  6 r  7 g  8 b  9..15 unused
 constexpr int kRow = 16;
+constexpr int kSlabG = 7;          // Gaussians parked per wave before a row-sum pass (7 x 9 = 63 rows)
+constexpr int kSlabStride = 20;    // floats per slab row (16 used; 80-byte rows keep b128 reads conflict-free)
+
+template <int CTRL>
+__device__ __forceinline__ float quad_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float quad_sum(float v) {   // every lane of a quad ends with the quad total
+    return quad_add<0x4e>(quad_add<0xb1>(v));
+}
 
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -134,8 +150,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     __shared__ float2 s_ext[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_rgb[kBlock];
-    __shared__ float s_acc[kBlock][kRow];
-    __shared__ uint32_t s_touched[kBlock / 32];
+    __shared__ float s_acc[kBlock][12];                               // raw moment sums per staged entry
+    __shared__ __attribute__((aligned(16))) float s_slab[4][kSlabG * 9][kSlabStride];
+    __shared__ int s_slot[4][8];
     __shared__ uint32_t s_blast[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.y * f.gx + blockIdx.x;
@@ -153,7 +170,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
     if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
     const float bg_dot = f.bg[0] * dp0 + f.bg[1] * dp1 + f.bg[2] * dp2;
-    const float ddelx_dx = 0.5f * (float)f.W, ddely_dy = 0.5f * (float)f.H;
     // deepest list position composited by any pixel of this wave / of the block
     uint32_t wave_last = last;
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
@@ -161,6 +177,18 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     __syncthreads();
     const int total = (int)max(max(s_blast[0], s_blast[1]), max(s_blast[2], s_blast[3]));
     const int rounds = (total + kBlock - 1) / kBlock;
+    // row-sum pass: lane r < 9 * parked owns slab row r = slot * 9 + moment
+    const int my_slot = (lane * 57) >> 9, my_mom = lane - 9 * my_slot;      // lane / 9, lane % 9 for lane < 64
+    float (*slab)[kSlabStride] = s_slab[wave];
+    auto drain = [&](int parked) {
+        if (lane < 9 * parked) {
+            const float4* row = reinterpret_cast<const float4*>(slab[lane]);
+            float4 a = row[0], b = row[1], c = row[2], d = row[3];
+            float sum = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) +
+                        ((d.x + d.y) + (d.z + d.w));
+            atomicAdd(&s_acc[s_slot[wave][my_slot]][my_mom], sum);
+        }
+    };
 
     for (int r = 0; r < rounds; ++r) {
         // batch r holds list positions hi-1 ... lo (descending); staged slot s <-> position hi-1-s
@@ -177,9 +205,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
             s_rgb[tid] = make_float4(rgb[3 * (size_t)id], rgb[3 * (size_t)id + 1], rgb[3 * (size_t)id + 2], 0.f);
         }
 #pragma unroll
-        for (int c = 0; c < kRow; ++c) s_acc[tid][c] = 0.0f;
-        if (tid < kBlock / 32) s_touched[tid] = 0u;
+        for (int c = 0; c < 12; ++c) s_acc[tid][c] = 0.0f;
         __syncthreads();
+        int parked = 0;                                         // wave-uniform
         for (int c = 0; c < n; c += 64) {
             const int e = c + lane;
             // position of staged slot e is hi-1-e; this wave composited positions < wave_last only
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                 const int j = c + __builtin_ctzll(mask);        // wave-uniform
                 mask &= mask - 1;
                 const uint32_t pos = (uint32_t)(hi - 1 - j);
-                float g_mx = 0.f, g_my = 0.f, g_a = 0.f, g_b = 0.f, g_c = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_bl = 0.f;
+                float m_w = 0.f, m_x = 0.f, m_y = 0.f, m_xx = 0.f, m_xy = 0.f, m_yy = 0.f, m_r = 0.f, m_g = 0.f, m_b = 0.f;
                 bool active = false;
                 if (pos < last) {
                     float2 p = s_xy[j];
@@ -211,46 +239,56 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                             acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
                             lc0 = col.x; lc1 = col.y; lc2 = col.z;
                             float dL_dalpha = (col.x - acc0) * dp0 + (col.y - acc1) * dp1 + (col.z - acc2) * dp2;
-                            g_r = dchannel * dp0; g_g = dchannel * dp1; g_bl = dchannel * dp2;
+                            m_r = dchannel * dp0; m_g = dchannel * dp1; m_b = dchannel * dp2;
                             dL_dalpha *= T;
                             last_alpha = alpha;
                             dL_dalpha += (-T_final * inv_1ma) * bg_dot;
-                            float dL_dG = co.w * dL_dalpha;
-                            float gdx = G * dx, gdy = G * dy;
-                            float dG_ddelx = -gdx * co.x - gdy * co.y;
-                            float dG_ddely = -gdy * co.z - gdx * co.y;
-                            g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                            g_my = dL_dG * dG_ddely * ddely_dy;
-                            g_a = -0.5f * gdx * dx * dL_dG;
-                            g_b = -gdx * dy * dL_dG;
-                            g_c = -0.5f * gdy * dy * dL_dG;
-                            g_o = G * dL_dalpha;
+                            m_w = co.w * dL_dalpha * G;           // dL/dG * G
+                            m_x = m_w * dx; m_y = m_w * dy;
+                            m_xx = m_x * dx; m_xy = m_x * dy; m_yy = m_y * dy;
                         }
                     }
                 }
                 if (__ballot(active) == 0ull) continue;         // wave-uniform
-                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-                g_a = wave_sum_to_lane63(g_a);   g_b = wave_sum_to_lane63(g_b);   g_c = wave_sum_to_lane63(g_c);
-                g_o = wave_sum_to_lane63(g_o);
-                g_r = wave_sum_to_lane63(g_r);   g_g = wave_sum_to_lane63(g_g);   g_bl = wave_sum_to_lane63(g_bl);
-                if (lane == 63) {
-                    float* a = s_acc[j];
-                    atomicAdd(a + 0, g_mx); atomicAdd(a + 1, g_my);
-                    atomicAdd(a + 2, g_a);  atomicAdd(a + 3, g_b);  atomicAdd(a + 4, g_c);
-                    atomicAdd(a + 5, g_o);
-                    atomicAdd(a + 6, g_r);  atomicAdd(a + 7, g_g);  atomicAdd(a + 8, g_bl);
-                    atomicOr(&s_touched[j >> 5], 1u << (j & 31));
+                m_w = quad_sum(m_w);   m_x = quad_sum(m_x);   m_y = quad_sum(m_y);
+                m_xx = quad_sum(m_xx); m_xy = quad_sum(m_xy); m_yy = quad_sum(m_yy);
+                m_r = quad_sum(m_r);   m_g = quad_sum(m_g);   m_b = quad_sum(m_b);
+                if ((lane & 3) == 3) {
+                    float* col = &slab[parked * 9][lane >> 2];
+                    col[0 * kSlabStride] = m_w;  col[1 * kSlabStride] = m_x;  col[2 * kSlabStride] = m_y;
+                    col[3 * kSlabStride] = m_xx; col[4 * kSlabStride] = m_xy; col[5 * kSlabStride] = m_yy;
+                    col[6 * kSlabStride] = m_r;  col[7 * kSlabStride] = m_g;  col[8 * kSlabStride] = m_b;
                 }
+                if (lane == 0) s_slot[wave][parked] = j;
+                if (++parked == kSlabG) { drain(kSlabG); parked = 0; }
             }
         }
+        if (parked) drain(parked);
         __syncthreads();
-        // flush: 16 lanes per staged Gaussian, one whole 64-byte row per atomic request
+        // flush: 16 lanes per staged Gaussian turn the raw sums into gradients; one 64-byte row per request
         const int comp = tid & 15;
 #pragma unroll 4
         for (int it = 0; it < kBlock / 16; ++it) {
             const int e = it * 16 + (tid >> 4);
-            if (e < n && ((s_touched[e >> 5] >> (e & 31)) & 1u) && comp < 9)
-                atomicAdd(&grad_rows[(size_t)s_id[e] * kRow + comp], s_acc[e][comp]);
+            if (e >= n || comp >= 9) continue;
+            const float* a = s_acc[e];
+            const float sw = a[0];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) any |= (a[k] != 0.0f);
+            if (!any) continue;                               // entry never evaluated by any quadrant
+            const float4 co = s_co[e];
+            float v;
+            switch (comp) {
+                case 0: v = -0.5f * (float)f.W * (co.x * a[1] + co.y * a[2]); break;   // dL/dmean2D.x (NDC-scaled)
+                case 1: v = -0.5f * (float)f.H * (co.z * a[2] + co.y * a[1]); break;   // dL/dmean2D.y
+                case 2: v = -0.5f * a[3]; break;                                       // dL/dA
+                case 3: v = -a[4]; break;                                              // dL/dB
+                case 4: v = -0.5f * a[5]; break;                                       // dL/dC
+                case 5: v = sw / co.w; break;                                          // dL/dopacity = sum G dL/dalpha
+                default: v = a[comp]; break;                                           // 6,7,8: rgb
+            }
+            atomicAdd(&grad_rows[(size_t)s_id[e] * kRow + comp], v);
         }
     }
 }
