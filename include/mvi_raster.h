@@ -106,11 +106,12 @@ int mvi_raster_mark_visible(int32_t P, const float* means3D, const float* viewma
 typedef struct mvi_raster_views {
     const float* depths;          /* [P] */
     const float* means2D;         /* [P,2] pixel centres */
-    const float* cov3D;           /* [P,6] */
+    const float* cov3D_a;         /* [P,4] xx, xy, xz, yy */
+    const float* cov3D_b;         /* [P,2] yz, zz */
     const float* conic_opacity;   /* [P,4] */
-    const float* rgb;             /* [P,3] */
+    const float* rgbd;            /* [P,4] r, g, b, depth */
     const uint32_t* tiles_touched;/* [P] */
-    const uint8_t* clamped;       /* [P,3] */
+    const uint8_t* clamped;       /* [P] bit c = colour channel c clamped at 0 */
     const uint32_t* tile_ids_sorted; /* [D] high word of the sort key; the full key of pair i is
                                       * tile_ids_sorted[i] << 32 | bits(depths[point_list[i]]) */
     const uint32_t* point_list;   /* [D] Gaussian index per sorted pair */

@@ -24,7 +24,7 @@ class RasterSettings(C.Structure):
 class RasterViews(C.Structure):
     """struct mvi_raster_views"""
     _fields_ = [(n, C.c_void_p) for n in (
-        "depths", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "clamped",
+        "depths", "means2D", "cov3D_a", "cov3D_b", "conic_opacity", "rgbd", "tiles_touched", "clamped",
         "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")]
 
 

@@ -218,8 +218,9 @@ int mvi_raster_get_views(int32_t P, int64_t D, int32_t W, int32_t H, const void*
     memset(out, 0, sizeof(*out));
     if (geom) {
         mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
-        out->depths = g.depths; out->means2D = reinterpret_cast<const float*>(g.xy); out->cov3D = g.cov3D;
-        out->conic_opacity = reinterpret_cast<const float*>(g.conic_opacity); out->rgb = g.rgb;
+        out->depths = g.depths; out->means2D = reinterpret_cast<const float*>(g.xy);
+        out->cov3D_a = reinterpret_cast<const float*>(g.cov_a); out->cov3D_b = reinterpret_cast<const float*>(g.cov_b);
+        out->conic_opacity = reinterpret_cast<const float*>(g.conic_opacity); out->rgbd = reinterpret_cast<const float*>(g.rgbd);
         out->tiles_touched = g.tiles_touched; out->clamped = g.clamped;
     }
     if (binning) {

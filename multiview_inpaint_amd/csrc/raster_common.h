@@ -38,11 +38,12 @@ struct Frame {
 struct GeomView {
     float* depths;            // [P]
     float2* xy;               // [P]
-    float* cov3D;             // [6P]
+    float4* cov_a;            // [P] cov3D xx, xy, xz, yy   (16-byte and 8-byte records: every lane's
+    float2* cov_b;            // [P] cov3D yz, zz           store/load is one whole aligned access)
     float4* conic_opacity;    // [P]
-    float* rgb;               // [3P]
+    float4* rgbd;             // [P] r, g, b, view-space depth (one gather per staged list entry)
     uint32_t* tiles_touched;  // [P]
-    uint8_t* clamped;         // [3P]
+    uint8_t* clamped;         // [P] bit c set = colour channel c was clamped at 0
     uint32_t* block_sums;     // [nblk]   tiles touched per 256-Gaussian block
     uint32_t* block_offsets;  // [nblk+1] exclusive scan of block_sums; [nblk] = D
     // depth sort of the Gaussians (binning level 1): ping-pong (depth bits, index) pairs
@@ -84,11 +85,12 @@ inline GeomView carve_geom(void* base, int P) {
     auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
     g.depths = (float*)take(4 * n);
     g.xy = (float2*)take(8 * n);
-    g.cov3D = (float*)take(24 * n);
+    g.cov_a = (float4*)take(16 * n);
+    g.cov_b = (float2*)take(8 * n);
     g.conic_opacity = (float4*)take(16 * n);
-    g.rgb = (float*)take(12 * n);
+    g.rgbd = (float4*)take(16 * n);
     g.tiles_touched = (uint32_t*)take(4 * n);
-    g.clamped = (uint8_t*)take(3 * n);
+    g.clamped = (uint8_t*)take(n);
     g.block_sums = (uint32_t*)take(4 * (size_t)nblk);
     g.block_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
     g.nsortP = (int)((n + kSortTile - 1) / kSortTile);

@@ -4,9 +4,48 @@
 // EWA cov2D, conic, 3-sigma radius, tile rectangle, SH colour (gs-simp/utils/sh_utils.py:57-112).
 // One thread per Gaussian, 256-thread blocks; each block also emits the sum of tiles touched so
 // the binning stage only has to scan ceil(P/256) block sums.
+//
+// HBM access: the caller's AoS arrays with a record that is not a power of two (shs [P,M,3] = 192 B
+// per Gaussian at degree 3, means3D/scales [P,3], the gradient outputs of the same shapes) are moved
+// between HBM and the block through LDS with fully coalesced 16-byte (or 4-byte) lane accesses — a
+// block's 256 records are one contiguous span — and each thread then reads / writes its own record
+// from LDS with an odd row stride (conflict-free). Per-lane strided global accesses of those arrays
+// cost 2.4x the bytes on reads and 3.3x on writes (measured: FETCH_SIZE / WRITE_SIZE).
 #include "raster_common.h"
 
 namespace mvi {
+
+// Copies the block's `n_rec` records of `rec` floats each from `src` (contiguous) into LDS rows of
+// `stride` floats. All threads of the block must call it; caller synchronises afterwards.
+__device__ __forceinline__ void stage_in(const float* __restrict__ src, float* lds, int n_rec, int rec, int stride) {
+    const int total = n_rec * rec;
+    if ((rec & 3) == 0) {
+        const int rv = rec >> 2;                           // float4 per record: a vector never straddles records
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int v = threadIdx.x; v < (total >> 2); v += kBlock) {
+            float4 x = s4[v];
+            float* d = lds + (v / rv) * stride + (v % rv) * 4;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += kBlock) lds[(e / rec) * stride + (e % rec)] = src[e];
+    }
+}
+// Inverse: LDS rows -> contiguous global span.
+__device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* lds, int n_rec, int rec, int stride) {
+    const int total = n_rec * rec;
+    if ((rec & 3) == 0) {
+        const int rv = rec >> 2;
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int v = threadIdx.x; v < (total >> 2); v += kBlock) {
+            const float* s_ = lds + (v / rv) * stride + (v % rv) * 4;
+            d4[v] = make_float4(s_[0], s_[1], s_[2], s_[3]);
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += kBlock) dst[e] = lds[(e / rec) * stride + (e % rec)];
+    }
+}
+__host__ __device__ inline int sh_stride(int M) { return 3 * M + 1 - ((3 * M) & 1); }   // odd row stride
 
 __device__ constexpr float SH_C0 = 0.28209479177387814f;
 __device__ constexpr float SH_C1 = 0.4886025119029199f;
@@ -99,10 +138,20 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii) {
 #pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)] SH rows, then [256][3] x 2
     __shared__ uint32_t s_sum;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * kBlock + tid;
+    const int blk0 = blockIdx.x * kBlock;
+    const int i = blk0 + tid;
+    const int n_rec = min(kBlock, f.P - blk0);
+    const int shs_w = shs ? sh_stride(f.M) : 0;
+    float* s_sh = s_dyn;
+    float* s_mean = s_dyn + (size_t)kBlock * shs_w;        // [256][3]
+    float* s_scale = s_mean + 3 * kBlock;                  // [256][3]
     if (tid == 0) s_sum = 0;
+    if (shs) stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+    stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
+    if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
     __syncthreads();
     float V[16], PM[16];
 #pragma unroll
@@ -112,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     int rad_out = 0;
     if (i < f.P) {
         do {
-            float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+            float px = s_mean[3 * tid], py = s_mean[3 * tid + 1], pz = s_mean[3 * tid + 2];
             float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
             float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
             float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
@@ -126,13 +175,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
             float c6[6];
             if (cov3D_precomp) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+                for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
             } else {
                 float R[3][3], Mx[3][3];
-                const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * i);
+                const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
                 quat_to_rot(q.x, q.y, q.z, q.w, R);
-                float s[3] = {f.scale_modifier * scales[3 * i], f.scale_modifier * scales[3 * i + 1],
-                              f.scale_modifier * scales[3 * i + 2]};
+                float s[3] = {f.scale_modifier * s_scale[3 * tid], f.scale_modifier * s_scale[3 * tid + 1],
+                              f.scale_modifier * s_scale[3 * tid + 2]};
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -144,8 +193,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 c6[4] = dot3(Mx[1][0], Mx[1][1], Mx[1][2], Mx[2][0], Mx[2][1], Mx[2][2]);
                 c6[5] = dot3(Mx[2][0], Mx[2][1], Mx[2][2], Mx[2][0], Mx[2][1], Mx[2][2]);
             }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) g.cov3D[6 * (size_t)i + k] = c6[k];
+            g.cov_a[i] = make_float4(c6[0], c6[1], c6[2], c6[3]);
+            g.cov_b[i] = make_float2(c6[4], c6[5]);
 
             Ewa e;
             ewa_setup(f, V, vx, vy, vz, e);
@@ -164,12 +213,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
             tile_rect(pix_x, pix_y, rad, f.gx, f.gy, x0, y0, x1, y1);
             if ((x1 - x0) * (y1 - y0) == 0) break;
 
+            float r0, r1, r2;
+            uint32_t clamp_bits = 0;
             if (colors_precomp) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    g.rgb[3 * (size_t)i + ch] = colors_precomp[3 * (size_t)i + ch];
-                    g.clamped[3 * (size_t)i + ch] = 0;
-                }
+                r0 = colors_precomp[3 * (size_t)i]; r1 = colors_precomp[3 * (size_t)i + 1]; r2 = colors_precomp[3 * (size_t)i + 2];
             } else {
                 float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
                 float len = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
@@ -177,21 +224,19 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 float bs[16];
                 sh_basis(f.deg, dx, dy, dz, bs);
                 const int nb = (f.deg + 1) * (f.deg + 1);
-                const float* sh = shs + (size_t)i * f.M * 3;
-                float r0 = bs[0] * sh[0], r1 = bs[0] * sh[1], r2 = bs[0] * sh[2];
+                const float* sh = s_sh + (size_t)tid * shs_w;
+                r0 = bs[0] * sh[0]; r1 = bs[0] * sh[1]; r2 = bs[0] * sh[2];
                 for (int k = 1; k < nb; ++k) {
                     r0 = __builtin_fmaf(bs[k], sh[3 * k], r0);
                     r1 = __builtin_fmaf(bs[k], sh[3 * k + 1], r1);
                     r2 = __builtin_fmaf(bs[k], sh[3 * k + 2], r2);
                 }
                 r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-                g.clamped[3 * (size_t)i] = r0 < 0.0f;
-                g.clamped[3 * (size_t)i + 1] = r1 < 0.0f;
-                g.clamped[3 * (size_t)i + 2] = r2 < 0.0f;
-                g.rgb[3 * (size_t)i] = fmaxf(r0, 0.0f);
-                g.rgb[3 * (size_t)i + 1] = fmaxf(r1, 0.0f);
-                g.rgb[3 * (size_t)i + 2] = fmaxf(r2, 0.0f);
+                clamp_bits = (r0 < 0.0f ? 1u : 0u) | (r1 < 0.0f ? 2u : 0u) | (r2 < 0.0f ? 4u : 0u);
+                r0 = fmaxf(r0, 0.0f); r1 = fmaxf(r1, 0.0f); r2 = fmaxf(r2, 0.0f);
             }
+            g.clamped[i] = (uint8_t)clamp_bits;
+            g.rgbd[i] = make_float4(r0, r1, r2, vz);
             g.depths[i] = vz;
             g.xy[i] = make_float2(pix_x, pix_y);
             g.conic_opacity[i] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
@@ -213,7 +258,11 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               int32_t* radii, hipStream_t st) {
     if (f.P <= 0) return 0;
     int nblk = (f.P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nblk), dim3(kBlock), 0, st, f, means3D, shs,
+    size_t lds = sizeof(float) * ((size_t)kBlock * (shs ? sh_stride(f.M) : 0) + 6 * kBlock);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)preprocess_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MVI_EHIP;
+    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nblk), dim3(kBlock), lds, st, f, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
@@ -258,9 +307,24 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= f.P) return;
-    const bool live = radii[i] > 0;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)] + 5 x [256][3]
+    const int tid = threadIdx.x;
+    const int blk0 = blockIdx.x * kBlock;
+    const int i = blk0 + tid;
+    const int n_rec = min(kBlock, f.P - blk0);
+    const int shs_w = shs ? sh_stride(f.M) : 0;
+    float* s_sh = s_dyn;                                   // SH rows in, dL/dSH rows out (same thread, same row)
+    float* s_mean = s_dyn + (size_t)kBlock * shs_w;
+    float* s_scale = s_mean + 3 * kBlock;
+    float* s_dmean = s_scale + 3 * kBlock;
+    float* s_dm2d = s_dmean + 3 * kBlock;
+    float* s_dscale = s_dm2d + 3 * kBlock;
+    if (shs) stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+    stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
+    if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
+    __syncthreads();
+    const bool in_range = i < f.P;
+    const bool live = in_range && radii[i] > 0;
     float gr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
         const float4* row = reinterpret_cast<const float4*>(grad_rows + (size_t)i * kGradRow);
@@ -268,12 +332,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b4.x; gr[5] = b4.y; gr[6] = b4.z; gr[7] = b4.w;
         gr[8] = grad_rows[(size_t)i * kGradRow + 8];
     }
-    dL_dmeans2D[3 * (size_t)i] = gr[0];
-    dL_dmeans2D[3 * (size_t)i + 1] = gr[1];
-    dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
-    dL_dopacity[i] = gr[5];
-    if (dL_dcolors) {
-        dL_dcolors[3 * (size_t)i] = gr[6]; dL_dcolors[3 * (size_t)i + 1] = gr[7]; dL_dcolors[3 * (size_t)i + 2] = gr[8];
+    s_dm2d[3 * tid] = gr[0]; s_dm2d[3 * tid + 1] = gr[1]; s_dm2d[3 * tid + 2] = 0.0f;
+    if (in_range) {
+        dL_dopacity[i] = gr[5];
+        if (dL_dcolors) {
+            dL_dcolors[3 * (size_t)i] = gr[6]; dL_dcolors[3 * (size_t)i + 1] = gr[7]; dL_dcolors[3 * (size_t)i + 2] = gr[8];
+        }
     }
     float dm[3] = {0, 0, 0};
     float g6[6] = {0, 0, 0, 0, 0, 0};
@@ -282,13 +346,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         float V[16], PM[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { V[k] = f.view[k]; PM[k] = f.proj[k]; }
-        float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        float px = s_mean[3 * tid], py = s_mean[3 * tid + 1], pz = s_mean[3 * tid + 2];
         float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
         float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
         float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
-        float c6[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = g.cov3D[6 * (size_t)i + k];
+        const float4 ca = g.cov_a[i];
+        const float2 cb = g.cov_b[i];
+        float c6[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
         Ewa e;
         ewa_setup(f, V, vx, vy, vz, e);
         float a, b, c;
@@ -351,46 +415,45 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             float bs[16], bx[16], by[16], bz[16];
             sh_basis(f.deg, dx, dy, dz, bs);
             sh_basis_grad(f.deg, dx, dy, dz, bx, by, bz);
-            const float* sh = shs + (size_t)i * f.M * 3;
-            float* dsh = dL_dshs + (size_t)i * f.M * 3;
+            float* sh = s_sh + (size_t)tid * shs_w;        // this thread's row: read SH, then overwrite with dL/dSH
+            const uint32_t cl = g.clamped[i];
             float gcol[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                gcol[ch] = g.clamped[3 * (size_t)i + ch] ? 0.0f : gr[6 + ch];
+            for (int ch = 0; ch < 3; ++ch) gcol[ch] = ((cl >> ch) & 1u) ? 0.0f : gr[6 + ch];
             float ddx = 0, ddy = 0, ddz = 0;
             for (int k = 0; k < nb; ++k) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    dsh[3 * k + ch] = bs[k] * gcol[ch];
                     float w = sh[3 * k + ch] * gcol[ch];
+                    sh[3 * k + ch] = bs[k] * gcol[ch];
                     ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
                 }
             }
-            for (int k = nb; k < f.M; ++k) { dsh[3 * k] = 0; dsh[3 * k + 1] = 0; dsh[3 * k + 2] = 0; }
+            for (int k = 3 * nb; k < 3 * f.M; ++k) sh[k] = 0.0f;
             float dotp = dx * ddx + dy * ddy + dz * ddz;
             dm[0] += (ddx - dx * dotp) / len;
             dm[1] += (ddy - dy * dotp) / len;
             dm[2] += (ddz - dz * dotp) / len;
         }
     } else if (shs) {
-        float* dsh = dL_dshs + (size_t)i * f.M * 3;
+        float* dsh = s_sh + (size_t)tid * shs_w;
         for (int k = 0; k < 3 * f.M; ++k) dsh[k] = 0.0f;
     }
-    dL_dmeans3D[3 * (size_t)i] = dm[0];
-    dL_dmeans3D[3 * (size_t)i + 1] = dm[1];
-    dL_dmeans3D[3 * (size_t)i + 2] = dm[2];
+    s_dmean[3 * tid] = dm[0]; s_dmean[3 * tid + 1] = dm[1]; s_dmean[3 * tid + 2] = dm[2];
 
     if (cov3D_precomp) {
+        if (in_range) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = g6[k];
+            for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = g6[k];
+        }
     } else {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         if (live) {
-            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * i);
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
             float R[3][3];
             quat_to_rot(q.x, q.y, q.z, q.w, R);
-            float s[3] = {f.scale_modifier * scales[3 * i], f.scale_modifier * scales[3 * i + 1],
-                          f.scale_modifier * scales[3 * i + 2]};
+            float s[3] = {f.scale_modifier * s_scale[3 * tid], f.scale_modifier * s_scale[3 * tid + 1],
+                          f.scale_modifier * s_scale[3 * tid + 2]};
             float Gf[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
                               {0.5f * g6[1], g6[3], 0.5f * g6[4]},
                               {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
@@ -415,10 +478,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             dq[3] = 2.0f * (-2 * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2 * qz * dR[1][1] +
                             qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] = ds[k];
-        *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        s_dscale[3 * tid] = ds[0]; s_dscale[3 * tid + 1] = ds[1]; s_dscale[3 * tid + 2] = ds[2];
+        if (in_range) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
+    __syncthreads();
+    stage_out(dL_dmeans3D + (size_t)blk0 * 3, s_dmean, n_rec, 3, 3);
+    stage_out(dL_dmeans2D + (size_t)blk0 * 3, s_dm2d, n_rec, 3, 3);
+    if (!cov3D_precomp) stage_out(dL_dscales + (size_t)blk0 * 3, s_dscale, n_rec, 3, 3);
+    if (shs) stage_out(dL_dshs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
 }
 
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
@@ -428,7 +495,11 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
                                float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st) {
     if (f.P <= 0) return 0;
     int nblk = (f.P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), 0, st, f, means3D, shs, scales,
+    size_t lds = sizeof(float) * ((size_t)kBlock * (shs ? sh_stride(f.M) : 0) + 15 * kBlock);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)preprocess_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MVI_EHIP;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), lds, st, f, means3D, shs, scales,
                        rotations, cov3D_precomp, radii, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
                        dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales, dL_drots);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;

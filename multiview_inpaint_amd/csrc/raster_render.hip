@@ -33,9 +33,9 @@ __device__ __forceinline__ bool quad_overlap(float2 c, float2 ext, float qx0, fl
 
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float2* __restrict__ xy, const float* __restrict__ rgb, const float4* __restrict__ conic_opacity,
-    const float* __restrict__ depths, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_color, float* __restrict__ out_depth) {
+    const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_depth) {
     __shared__ float2 s_xy[kBlock];
     __shared__ float2 s_ext[kBlock];
     __shared__ float4 s_co[kBlock];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
             s_xy[tid] = xy[id];
             s_co[tid] = co;
             s_ext[tid] = StagedExt::compute(co);
-            s_cd[tid] = make_float4(rgb[3 * (size_t)id], rgb[3 * (size_t)id + 1], rgb[3 * (size_t)id + 2], depths[id]);
+            s_cd[tid] = rgbd[id];
         }
         __syncthreads();
         const int n = todo < kBlock ? todo : kBlock;
@@ -110,7 +110,7 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
     if (f.W <= 0 || f.H <= 0) return 0;
     const uint32_t* plist = b.vals[b.passes & 1];
     hipLaunchKernelGGL(render_forward_kernel, dim3(f.gx, f.gy), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
-                       g.rgb, g.conic_opacity, g.depths, im.final_T, im.n_contrib, out_color, out_depth);
+                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -142,7 +142,7 @@ __device__ __forceinline__ float quad_sum(float v) {   // every lane of a quad e
 
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float2* __restrict__ xy, const float* __restrict__ rgb, const float4* __restrict__ conic_opacity,
+    const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ grad_rows) {
     __shared__ uint32_t s_id[kBlock];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
             s_xy[tid] = xy[id];
             s_co[tid] = co;
             s_ext[tid] = StagedExt::compute(co);
-            s_rgb[tid] = make_float4(rgb[3 * (size_t)id], rgb[3 * (size_t)id + 1], rgb[3 * (size_t)id + 2], 0.f);
+            s_rgb[tid] = rgbd[id];
         }
 #pragma unroll
         for (int c = 0; c < 12; ++c) s_acc[tid][c] = 0.0f;
@@ -298,7 +298,7 @@ int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView 
     if (f.W <= 0 || f.H <= 0 || D <= 0) return 0;
     const uint32_t* plist = b.vals[b.passes & 1];
     hipLaunchKernelGGL(render_backward_kernel, dim3(f.gx, f.gy), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
-                       g.rgb, g.conic_opacity, im.final_T, im.n_contrib, dL_dpix, grad_rows);
+                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, dL_dpix, grad_rows);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

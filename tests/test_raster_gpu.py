@@ -82,12 +82,19 @@ def _check_forward(R, ro, cam, sc, bg, full=True):
     ranges = st.tensor("ranges", (tiles, 2), torch.int32).cpu().numpy().view(np.uint32)
     assert np.array_equal(ranges, f["ranges"])
     # ---- per-Gaussian floats: shared arithmetic contract -> bit-exact where visible
-    for name, shape, ref in (("depths", (P,), f["depths"]), ("means2D", (P, 2), f["xy"]), ("cov3D", (P, 6), f["cov3D"]),
-                             ("conic_opacity", (P, 4), f["conic_opacity"]), ("rgb", (P, 3), f["rgb"])):
-        got = st.tensor(name, shape, torch.float32).cpu().numpy()
-        assert np.array_equal(got[vis], ref[vis]), name
-    cl = st.tensor("clamped", (P, 3), torch.uint8).cpu().numpy()
-    assert np.array_equal(cl[vis], f["clamped"][vis])
+    cov = np.concatenate([st.tensor("cov3D_a", (P, 4), torch.float32).cpu().numpy(),
+                          st.tensor("cov3D_b", (P, 2), torch.float32).cpu().numpy()], 1)
+    rgbd = st.tensor("rgbd", (P, 4), torch.float32).cpu().numpy()
+    got = dict(depths=st.tensor("depths", (P,), torch.float32).cpu().numpy(),
+               means2D=st.tensor("means2D", (P, 2), torch.float32).cpu().numpy(), cov3D=cov,
+               conic_opacity=st.tensor("conic_opacity", (P, 4), torch.float32).cpu().numpy(), rgb=rgbd[:, :3])
+    for name, ref in (("depths", f["depths"]), ("means2D", f["xy"]), ("cov3D", f["cov3D"]),
+                      ("conic_opacity", f["conic_opacity"]), ("rgb", f["rgb"])):
+        assert np.array_equal(got[name][vis], ref[vis]), name
+    assert np.array_equal(rgbd[vis, 3], f["depths"][vis])
+    cl = st.tensor("clamped", (P,), torch.uint8).cpu().numpy()
+    want = (f["clamped"][:, 0] | (f["clamped"][:, 1] << 1) | (f["clamped"][:, 2] << 2)).astype(np.uint8)
+    assert np.array_equal(cl[vis], want[vis])
     # ---- image outputs: 1e-4 rel outside threshold flips
     frac, worst = _close_frac(color.cpu().numpy(), f["color"])
     assert frac <= FLIP_FRAC and worst < 2e-2, (frac, worst)
