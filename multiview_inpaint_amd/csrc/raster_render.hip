@@ -54,43 +54,63 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = kDepthSentinel;
     uint32_t last = 0;
 
+    // software pipeline: the gathers of batch r+1 are issued before batch r is composited
+    float2 n_xy = make_float2(0.f, 0.f);
+    float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = n_co;
+    auto fetch = [&](int r) {
+        const uint32_t q = r0 + (uint32_t)(r * kBlock + tid);
+        if (q < r1) {
+            const uint32_t id = point_list[q];
+            n_xy = xy[id]; n_co = conic_opacity[id]; n_cd = rgbd[id];
+        }
+    };
+    if (rounds > 0) fetch(0);
     for (int r = 0; r < rounds; ++r, todo -= kBlock) {
         if (__syncthreads_count(done) == kBlock) break;
-        int progress = r * kBlock + tid;
-        if (r0 + progress < r1) {
-            uint32_t id = point_list[r0 + progress];
-            float4 co = conic_opacity[id];
-            s_xy[tid] = xy[id];
-            s_co[tid] = co;
-            s_ext[tid] = StagedExt::compute(co);
-            s_cd[tid] = rgbd[id];
-        }
+        s_xy[tid] = n_xy;
+        s_co[tid] = n_co;
+        s_ext[tid] = StagedExt::compute(n_co);
+        s_cd[tid] = n_cd;
         __syncthreads();
+        if (r + 1 < rounds) fetch(r + 1);
         const int n = todo < kBlock ? todo : kBlock;
         for (int c = 0; c < n; c += 64) {
             if (__ballot(!done) == 0ull) break;
             const int e = c + lane;
             const bool keep = e < n && quad_overlap(s_xy[e], s_ext[e], (float)qx0, (float)qy0);
             unsigned long long mask = __ballot(keep);
-            while (mask) {
-                const int j = c + __builtin_ctzll(mask);        // wave-uniform
+            if (mask == 0ull) continue;
+            int j = c + __builtin_ctzll(mask);                  // wave-uniform
+            float2 p = s_xy[j];
+            float4 co = s_co[j];
+            while (true) {
                 mask &= mask - 1;
-                if (done) continue;
-                float2 p = s_xy[j];
-                float4 co = s_co[j];
-                float dx = p.x - pfx, dy = p.y - pfy;
-                float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power > 0.0f) continue;
-                float alpha = fminf(kAlphaMax, co.w * __expf(power));
-                if (alpha < kAlphaMin) continue;
-                float test_T = T * (1.0f - alpha);
-                if (test_T < kTEps) { done = true; continue; }
-                float4 cd = s_cd[j];
-                float w = alpha * T;
-                C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                if (T > 0.5f && test_T < 0.5f) Dp = cd.w;       // median depth of the w-depth fork
-                T = test_T;
-                last = (uint32_t)(r * kBlock + j + 1);           // 1-based position in the tile's list
+                const bool more = mask != 0ull;
+                const int jn = more ? c + __builtin_ctzll(mask) : j;
+                const float2 pn = s_xy[jn];                     // next entry's LDS reads overlap this entry's math
+                const float4 con = s_co[jn];
+                if (!done) {
+                    float dx = p.x - pfx, dy = p.y - pfy;
+                    float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    if (power <= 0.0f) {
+                        float alpha = fminf(kAlphaMax, co.w * __expf(power));
+                        if (alpha >= kAlphaMin) {
+                            float test_T = T * (1.0f - alpha);
+                            if (test_T < kTEps) {
+                                done = true;
+                            } else {
+                                float4 cd = s_cd[j];
+                                float w = alpha * T;
+                                C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
+                                if (T > 0.5f && test_T < 0.5f) Dp = cd.w;   // median depth of the w-depth fork
+                                T = test_T;
+                                last = (uint32_t)(r * kBlock + j + 1);       // 1-based position in the tile's list
+                            }
+                        }
+                    }
+                }
+                if (!more) break;
+                j = jn; p = pn; co = con;
             }
         }
     }
@@ -128,7 +148,7 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
 // Gaussian): MI355X float atomics run at the 64-B-request rate. Row layout of grad_rows [P][16]:
 //   0 mean2D.x  1 mean2D.y  2 conic A  3 conic B  4 conic C  5 opacity  6 r  7 g  8 b  9..15 unused
 constexpr int kRow = 16;
-constexpr int kSlabG = 7;          // Gaussians parked per wave before a row-sum pass (7 x 9 = 63 rows)
+constexpr int kSlabG = 3;          // Gaussians parked per wave before a row-sum pass (3 x 9 = 27 rows)
 constexpr int kSlabStride = 20;    // floats per slab row (16 used; 80-byte rows keep b128 reads conflict-free)
 
 template <int CTRL>
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     __shared__ float2 s_ext[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_rgb[kBlock];
-    __shared__ float s_acc[kBlock][12];                               // raw moment sums per staged entry
+    __shared__ float s_acc[kBlock][9];                                // raw moment sums per staged entry
     __shared__ __attribute__((aligned(16))) float s_slab[4][kSlabG * 9][kSlabStride];
     __shared__ int s_slot[4][8];
     __shared__ uint32_t s_blast[4];
@@ -190,23 +210,32 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
         }
     };
 
+    // software pipeline: the gathers of batch r+1 are issued before batch r is replayed
+    uint32_t n_id = 0;
+    float2 n_xy = make_float2(0.f, 0.f);
+    float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = n_co;
+    auto fetch = [&](int r) {
+        const int hi_ = total - r * kBlock;
+        if (tid < hi_) {                                        // staged slot tid <-> list position hi_-1-tid
+            n_id = point_list[r0 + (uint32_t)(hi_ - 1 - tid)];
+            n_xy = xy[n_id]; n_co = conic_opacity[n_id]; n_cd = rgbd[n_id];
+        }
+    };
+    if (rounds > 0) fetch(0);
     for (int r = 0; r < rounds; ++r) {
         // batch r holds list positions hi-1 ... lo (descending); staged slot s <-> position hi-1-s
         const int hi = total - r * kBlock;
         const int n = hi < kBlock ? hi : kBlock;
         __syncthreads();
-        if (tid < n) {
-            uint32_t id = point_list[r0 + (uint32_t)(hi - 1 - tid)];
-            float4 co = conic_opacity[id];
-            s_id[tid] = id;
-            s_xy[tid] = xy[id];
-            s_co[tid] = co;
-            s_ext[tid] = StagedExt::compute(co);
-            s_rgb[tid] = rgbd[id];
-        }
+        s_id[tid] = n_id;
+        s_xy[tid] = n_xy;
+        s_co[tid] = n_co;
+        s_ext[tid] = StagedExt::compute(n_co);
+        s_rgb[tid] = n_cd;
 #pragma unroll
-        for (int c = 0; c < 12; ++c) s_acc[tid][c] = 0.0f;
+        for (int c = 0; c < 9; ++c) s_acc[tid][c] = 0.0f;
         __syncthreads();
+        if (r + 1 < rounds) fetch(r + 1);
         int parked = 0;                                         // wave-uniform
         for (int c = 0; c < n; c += 64) {
             const int e = c + lane;
@@ -214,15 +243,22 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
             const bool keep = e < n && (uint32_t)(hi - 1 - e) < wave_last &&
                               quad_overlap(s_xy[e], s_ext[e], (float)qx0, (float)qy0);
             unsigned long long mask = __ballot(keep);
-            while (mask) {
-                const int j = c + __builtin_ctzll(mask);        // wave-uniform
+            if (mask == 0ull) continue;
+            int j = c + __builtin_ctzll(mask);                  // wave-uniform
+            float2 p = s_xy[j];
+            float4 co = s_co[j];
+            float4 col = s_rgb[j];
+            while (true) {
                 mask &= mask - 1;
+                const bool more = mask != 0ull;
+                const int jn = more ? c + __builtin_ctzll(mask) : j;
+                const float2 pn = s_xy[jn];                     // next entry's LDS reads overlap this entry's math
+                const float4 con = s_co[jn];
+                const float4 coln = s_rgb[jn];
                 const uint32_t pos = (uint32_t)(hi - 1 - j);
                 float m_w = 0.f, m_x = 0.f, m_y = 0.f, m_xx = 0.f, m_xy = 0.f, m_yy = 0.f, m_r = 0.f, m_g = 0.f, m_b = 0.f;
                 bool active = false;
                 if (pos < last) {
-                    float2 p = s_xy[j];
-                    float4 co = s_co[j];
                     float dx = p.x - pfx, dy = p.y - pfy;
                     float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                     if (power <= 0.0f) {
@@ -233,7 +269,6 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                             const float inv_1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1-alpha in [0.01, 1]
                             T = T * inv_1ma;
                             float dchannel = alpha * T;
-                            float4 col = s_rgb[j];
                             acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
                             acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
                             acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
@@ -249,18 +284,21 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                         }
                     }
                 }
-                if (__ballot(active) == 0ull) continue;         // wave-uniform
-                m_w = quad_sum(m_w);   m_x = quad_sum(m_x);   m_y = quad_sum(m_y);
-                m_xx = quad_sum(m_xx); m_xy = quad_sum(m_xy); m_yy = quad_sum(m_yy);
-                m_r = quad_sum(m_r);   m_g = quad_sum(m_g);   m_b = quad_sum(m_b);
-                if ((lane & 3) == 3) {
-                    float* col = &slab[parked * 9][lane >> 2];
-                    col[0 * kSlabStride] = m_w;  col[1 * kSlabStride] = m_x;  col[2 * kSlabStride] = m_y;
-                    col[3 * kSlabStride] = m_xx; col[4 * kSlabStride] = m_xy; col[5 * kSlabStride] = m_yy;
-                    col[6 * kSlabStride] = m_r;  col[7 * kSlabStride] = m_g;  col[8 * kSlabStride] = m_b;
+                if (__ballot(active) != 0ull) {                 // wave-uniform
+                    m_w = quad_sum(m_w);   m_x = quad_sum(m_x);   m_y = quad_sum(m_y);
+                    m_xx = quad_sum(m_xx); m_xy = quad_sum(m_xy); m_yy = quad_sum(m_yy);
+                    m_r = quad_sum(m_r);   m_g = quad_sum(m_g);   m_b = quad_sum(m_b);
+                    if ((lane & 3) == 3) {
+                        float* colp = &slab[parked * 9][lane >> 2];
+                        colp[0 * kSlabStride] = m_w;  colp[1 * kSlabStride] = m_x;  colp[2 * kSlabStride] = m_y;
+                        colp[3 * kSlabStride] = m_xx; colp[4 * kSlabStride] = m_xy; colp[5 * kSlabStride] = m_yy;
+                        colp[6 * kSlabStride] = m_r;  colp[7 * kSlabStride] = m_g;  colp[8 * kSlabStride] = m_b;
+                    }
+                    if (lane == 0) s_slot[wave][parked] = j;
+                    if (++parked == kSlabG) { drain(kSlabG); parked = 0; }
                 }
-                if (lane == 0) s_slot[wave][parked] = j;
-                if (++parked == kSlabG) { drain(kSlabG); parked = 0; }
+                if (!more) break;
+                j = jn; p = pn; co = con; col = coln;
             }
         }
         if (parked) drain(parked);
