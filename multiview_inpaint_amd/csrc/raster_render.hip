@@ -89,25 +89,20 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
                 const int jn = more ? c + __builtin_ctzll(mask) : j;
                 const float2 pn = s_xy[jn];                     // next entry's LDS reads overlap this entry's math
                 const float4 con = s_co[jn];
-                if (!done) {
+                {   // branch-free body: every lane evaluates, selects commit (keeps EXEC untouched, no s_cbranch)
+                    const float4 cd = s_cd[j];
                     float dx = p.x - pfx, dy = p.y - pfy;
                     float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    if (power <= 0.0f) {
-                        float alpha = fminf(kAlphaMax, co.w * __expf(power));
-                        if (alpha >= kAlphaMin) {
-                            float test_T = T * (1.0f - alpha);
-                            if (test_T < kTEps) {
-                                done = true;
-                            } else {
-                                float4 cd = s_cd[j];
-                                float w = alpha * T;
-                                C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                                if (T > 0.5f && test_T < 0.5f) Dp = cd.w;   // median depth of the w-depth fork
-                                T = test_T;
-                                last = (uint32_t)(r * kBlock + j + 1);       // 1-based position in the tile's list
-                            }
-                        }
-                    }
+                    float alpha = fminf(kAlphaMax, co.w * __expf(power));
+                    float test_T = T * (1.0f - alpha);
+                    const bool valid = !done && power <= 0.0f && alpha >= kAlphaMin;
+                    const bool contrib = valid && !(test_T < kTEps);
+                    done = done || (valid && test_T < kTEps);
+                    float w = contrib ? alpha * T : 0.0f;
+                    C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
+                    Dp = (contrib && T > 0.5f && test_T < 0.5f) ? cd.w : Dp;   // median depth of the w-depth fork
+                    T = contrib ? test_T : T;
+                    last = contrib ? (uint32_t)(r * kBlock + j + 1) : last;    // 1-based position in the tile's list
                 }
                 if (!more) break;
                 j = jn; p = pn; co = con;
@@ -256,34 +251,28 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                 const float4 con = s_co[jn];
                 const float4 coln = s_rgb[jn];
                 const uint32_t pos = (uint32_t)(hi - 1 - j);
-                float m_w = 0.f, m_x = 0.f, m_y = 0.f, m_xx = 0.f, m_xy = 0.f, m_yy = 0.f, m_r = 0.f, m_g = 0.f, m_b = 0.f;
-                bool active = false;
-                if (pos < last) {
-                    float dx = p.x - pfx, dy = p.y - pfy;
-                    float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    if (power <= 0.0f) {
-                        float G = __expf(power);
-                        float alpha = fminf(kAlphaMax, co.w * G);
-                        if (alpha >= kAlphaMin) {
-                            active = true;
-                            const float inv_1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1-alpha in [0.01, 1]
-                            T = T * inv_1ma;
-                            float dchannel = alpha * T;
-                            acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
-                            acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
-                            acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
-                            lc0 = col.x; lc1 = col.y; lc2 = col.z;
-                            float dL_dalpha = (col.x - acc0) * dp0 + (col.y - acc1) * dp1 + (col.z - acc2) * dp2;
-                            m_r = dchannel * dp0; m_g = dchannel * dp1; m_b = dchannel * dp2;
-                            dL_dalpha *= T;
-                            last_alpha = alpha;
-                            dL_dalpha += (-T_final * inv_1ma) * bg_dot;
-                            m_w = co.w * dL_dalpha * G;           // dL/dG * G
-                            m_x = m_w * dx; m_y = m_w * dy;
-                            m_xx = m_x * dx; m_xy = m_x * dy; m_yy = m_y * dy;
-                        }
-                    }
-                }
+                // branch-free body: every lane evaluates, selects commit
+                float dx = p.x - pfx, dy = p.y - pfy;
+                float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                float G = __expf(fminf(power, 0.0f));
+                float alpha = fminf(kAlphaMax, co.w * G);
+                const bool active = pos < last && power <= 0.0f && alpha >= kAlphaMin;
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1-alpha in [0.01, 1]
+                const float Tn = T * inv_1ma;
+                const float a0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
+                const float a1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
+                const float a2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
+                float dL_dalpha = ((col.x - a0) * dp0 + (col.y - a1) * dp1 + (col.z - a2) * dp2) * Tn +
+                                  (-T_final * inv_1ma) * bg_dot;
+                const float dchannel = active ? alpha * Tn : 0.0f;
+                float m_r = dchannel * dp0, m_g = dchannel * dp1, m_b = dchannel * dp2;
+                float m_w = active ? co.w * dL_dalpha * G : 0.0f;             // dL/dG * G
+                float m_x = m_w * dx, m_y = m_w * dy;
+                float m_xx = m_x * dx, m_xy = m_x * dy, m_yy = m_y * dy;
+                T = active ? Tn : T;
+                acc0 = active ? a0 : acc0; acc1 = active ? a1 : acc1; acc2 = active ? a2 : acc2;
+                lc0 = active ? col.x : lc0; lc1 = active ? col.y : lc1; lc2 = active ? col.z : lc2;
+                last_alpha = active ? alpha : last_alpha;
                 if (__ballot(active) != 0ull) {                 // wave-uniform
                     m_w = quad_sum(m_w);   m_x = quad_sum(m_x);   m_y = quad_sum(m_y);
                     m_xx = quad_sum(m_xx); m_xy = quad_sum(m_xy); m_yy = quad_sum(m_yy);
