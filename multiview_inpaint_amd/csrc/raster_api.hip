@@ -9,6 +9,7 @@
 
 namespace mvi {
 int launch_scan_block_sums(GeomView g, int P, hipStream_t st);
+int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 }
 
 static thread_local char g_err[512] = "";
@@ -133,6 +134,8 @@ int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, 
     uint32_t total = 0;
     hipError_t e = hipMemcpyAsync(&total, g.block_offsets + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return hip_fail("copy num_rendered", e);
+    // binning level 1 does not depend on num_rendered: keep the device busy across the host read-back
+    if (mvi::launch_binning_level1(f, g, st)) return hip_fail("binning level 1", hipGetLastError());
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail("forward_geom sync", e);
     *num_rendered_host = (int64_t)total;

@@ -173,14 +173,18 @@ __global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restr
 
 // Stable scatter. Wave w of a block owns 512 consecutive pairs, item `it` of lane l is pair
 // w*512 + it*64 + l, so ranking items in `it` order inside a wave (64-bit __ballot peer masks) and
-// waves in order keeps the input order among equal digits.
+// waves in order keeps the input order among equal digits. The block's pairs are first put in
+// digit order in LDS, then written out by consecutive lanes: every digit's run leaves as one
+// contiguous, coalesced segment instead of 64 scattered dwords per wave-instruction.
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask, const uint32_t* __restrict__ block_hist,
     int nblk, const uint32_t* __restrict__ digit_tot) {
     __shared__ uint32_t s_wave_hist[4][256];
-    __shared__ uint32_t s_digit_base[256];
+    __shared__ uint32_t s_digit_base[256];     // global position of this block's first pair of digit d
+    __shared__ uint32_t s_local_start[256];    // position of digit d's run inside the block-sorted tile
     __shared__ uint32_t s_w4[4];
+    __shared__ uint32_t s_key[kSortTile], s_val[kSortTile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0;
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     }
     __syncthreads();
 
-    const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * (kSortItems * 64);
+    const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = tile0 + wave * (kSortItems * 64);
     uint32_t key[kSortItems], val[kSortItems], rank[kSortItems], dig[kSortItems];
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -227,22 +232,46 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
         rank[it] = prev + before;
     }
     __syncthreads();
-    {   // offset of each wave inside the block for every digit
-        uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid], c2 = s_wave_hist[2][tid];
+    {   // per digit: offset of each wave inside the block's run, and the run's start in the sorted tile
+        uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid], c2 = s_wave_hist[2][tid], c3 = s_wave_hist[3][tid];
+        uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
         __syncthreads();
+        if (lane == 63) s_w4[wave] = inc;
         s_wave_hist[0][tid] = 0;
         s_wave_hist[1][tid] = c0;
         s_wave_hist[2][tid] = c0 + c1;
         s_wave_hist[3][tid] = c0 + c1 + c2;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += s_w4[w];
+        s_local_start[tid] = wave_off + inc - tot;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
         if (dig[it] != 0xFFFFFFFFu) {
             uint32_t d = dig[it];
-            uint32_t dst = s_digit_base[d] + s_wave_hist[wave][d] + rank[it];
-            keys_out[dst] = key[it];
-            vals_out[dst] = val[it];
+            uint32_t lp = s_local_start[d] + s_wave_hist[wave][d] + rank[it];
+            s_key[lp] = key[it];
+            s_val[lp] = val[it];
+        }
+    }
+    __syncthreads();
+    const int count = (int)((D - tile0) < kSortTile ? (D - tile0) : kSortTile);
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+        int lp = it * kBlock + tid;
+        if (lp < count) {
+            uint32_t k = s_key[lp];
+            uint32_t d = (k >> shift) & mask;
+            uint32_t dst = s_digit_base[d] + ((uint32_t)lp - s_local_start[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_val[lp];
         }
     }
 }
@@ -277,14 +306,13 @@ static int radix_pass(uint32_t* const keys[2], uint32_t* const vals[2], int cur,
     return cur ^ 1;
 }
 
-// After this call the sorted pairs are in b.keys[b.passes & 1] (tile ids), b.vals[b.passes & 1].
-int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
-                   int64_t D, hipStream_t st) {
-    size_t tiles = (size_t)f.gx * f.gy;
-    if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
-    if (D <= 0 || f.P <= 0) return 0;
+// Level 1 + the scan of tiles touched in depth order. Needs nothing that depends on num_rendered, so
+// the forward enqueues it BEFORE the host reads num_rendered back: the device stays busy while the
+// host allocates the per-pair scratch.
+int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st) {
+    if (f.P <= 0) return 0;
     const int nblk = (f.P + kBlock - 1) / kBlock;
-    {   // level 1: Gaussians by depth (4 passes over P items; even count -> result back in buffer 0)
+    {   // Gaussians by depth (4 passes over P items; even count -> result back in buffer 0)
         StageTimer tm(kStSort, st);
         hipLaunchKernelGGL(depth_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.depths, g.tiles_touched,
                            g.dkeys[0], g.dvals[0]);
@@ -292,11 +320,23 @@ int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView
         for (int p = 0; p < 4; ++p)
             cur = radix_pass(g.dkeys, g.dvals, cur, f.P, 8 * p, 8, g.dhist, g.dtot, g.nsortP, st);
     }
-    {   // emission in depth order
+    StageTimer tm(kStDup, st);
+    hipLaunchKernelGGL(perm_block_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.dvals[0], g.tiles_touched,
+                       g.perm_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.perm_sums, g.perm_offsets, nblk);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+// Emission in depth order + level 2. After this call the sorted pairs are in b.keys[b.passes & 1]
+// (tile ids), b.vals[b.passes & 1].
+int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
+                   int64_t D, hipStream_t st) {
+    size_t tiles = (size_t)f.gx * f.gy;
+    if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
+    if (D <= 0 || f.P <= 0) return 0;
+    const int nblk = (f.P + kBlock - 1) / kBlock;
+    {
         StageTimer tm(kStDup, st);
-        hipLaunchKernelGGL(perm_block_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.dvals[0], g.tiles_touched,
-                           g.perm_sums);
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.perm_sums, g.perm_offsets, nblk);
         hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, g.dvals[0], radii, g.perm_offsets,
                            b.keys[0], b.vals[0]);
     }
