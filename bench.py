@@ -186,6 +186,11 @@ def main():
         total_bytes = sum(stage_bytes.values())
         ranges = st.tensor("ranges", (T, 2), torch.int32).long()
         lens = (ranges[:, 1] - ranges[:, 0]).float()
+        nc = st.tensor("n_contrib", (H, W), torch.int32).float()
+        ft = st.tensor("final_T", (H, W), torch.float32)
+        pad_h, pad_w = (-H) % 16, (-W) % 16
+        nct = torch.nn.functional.pad(nc, (0, pad_w, 0, pad_h)).reshape((H + pad_h) // 16, 16, (W + pad_w) // 16, 16)
+        tile_max = nct.amax(dim=(1, 3))
         out = {
             "metric": "Mpix/s fwd+bwd @1.5M Gauss 1080p",
             "value": round(world * Ppix / (dt / args.steps) / 1e6, 2),
@@ -198,6 +203,8 @@ def main():
                                    f"N={N} Gaussians, sh_degree {deg} (BASELINE.json configs[2] size, SURVEY.md §8d scene)",
                        "gaussians": N, "visible": V, "num_rendered_D": D, "tiles": T,
                        "tile_list_mean": round(float(lens.mean()), 1), "tile_list_max": int(lens.max()),
+                       "n_contrib_mean": round(float(nc.mean()), 1), "tile_max_contrib_mean": round(float(tile_max.mean()), 1),
+                       "pixels_saturated_frac": round(float((ft < 1e-3).float().mean()), 4),
                        "parallelism": f"views x{world}" + (" + RCCL all-reduce of the gradient bucket" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": stages[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -31,6 +31,11 @@ __device__ __forceinline__ bool quad_overlap(float2 c, float2 ext, float qx0, fl
            (c.y - ext.y <= qy0 + 7.0f);
 }
 
+// The CU's scalar unit issues one instruction per cycle for all four SIMDs, so the inner loop must
+// stay light on scalar work: the kept entries of a 64-entry chunk are compacted into a per-wave LDS
+// strip (lane-parallel copies at popcount positions) and walked by a plain counted loop, and a
+// pixel that has saturated is represented by T = 0 (its committed transmittance lives in T_out), so
+// the body needs no per-lane "done" mask and no divergent branch.
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
@@ -39,7 +44,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     __shared__ float2 s_xy[kBlock];
     __shared__ float2 s_ext[kBlock];
     __shared__ float4 s_co[kBlock];
-    __shared__ float4 s_cd[kBlock];   // r, g, b, depth
+    __shared__ float4 s_cd[kBlock];                 // r, g, b, depth
+    __shared__ float4 w_a[4][64], w_co[4][64], w_cd[4][64];   // per-wave compacted strip: (x, y, list position, -)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.y * f.gx + blockIdx.x;
     const int qx0 = blockIdx.x * kTile + 8 * (wave & 1), qy0 = blockIdx.y * kTile + 8 * (wave >> 1);
@@ -50,8 +56,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     int todo = (int)(r1 - r0);
     const int rounds = (todo + kBlock - 1) / kBlock;
 
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = kDepthSentinel;
+    float T = inside ? 1.0f : 0.0f;                 // 0 = this pixel takes no further contributions
+    float T_out = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = kDepthSentinel;
     uint32_t last = 0;
 
     // software pipeline: the gathers of batch r+1 are issued before batch r is composited
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     };
     if (rounds > 0) fetch(0);
     for (int r = 0; r < rounds; ++r, todo -= kBlock) {
-        if (__syncthreads_count(done) == kBlock) break;
+        if (__syncthreads_count(T <= 0.0f) == kBlock) break;
         s_xy[tid] = n_xy;
         s_co[tid] = n_co;
         s_ext[tid] = StagedExt::compute(n_co);
@@ -75,47 +81,48 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
         if (r + 1 < rounds) fetch(r + 1);
         const int n = todo < kBlock ? todo : kBlock;
         for (int c = 0; c < n; c += 64) {
-            if (__ballot(!done) == 0ull) break;
+            if (__ballot(T > 0.0f) == 0ull) break;
             const int e = c + lane;
             const bool keep = e < n && quad_overlap(s_xy[e], s_ext[e], (float)qx0, (float)qy0);
-            unsigned long long mask = __ballot(keep);
+            const unsigned long long mask = __ballot(keep);
             if (mask == 0ull) continue;
-            int j = c + __builtin_ctzll(mask);                  // wave-uniform
-            float2 p = s_xy[j];
-            float4 co = s_co[j];
-            while (true) {
-                mask &= mask - 1;
-                const bool more = mask != 0ull;
-                const int jn = more ? c + __builtin_ctzll(mask) : j;
-                const float2 pn = s_xy[jn];                     // next entry's LDS reads overlap this entry's math
-                const float4 con = s_co[jn];
-                {   // branch-free body: every lane evaluates, selects commit (keeps EXEC untouched, no s_cbranch)
-                    const float4 cd = s_cd[j];
-                    float dx = p.x - pfx, dy = p.y - pfy;
-                    float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    float alpha = fminf(kAlphaMax, co.w * __expf(power));
-                    float test_T = T * (1.0f - alpha);
-                    const bool valid = !done && power <= 0.0f && alpha >= kAlphaMin;
-                    const bool contrib = valid && !(test_T < kTEps);
-                    done = done || (valid && test_T < kTEps);
-                    float w = contrib ? alpha * T : 0.0f;
-                    C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                    Dp = (contrib && T > 0.5f && test_T < 0.5f) ? cd.w : Dp;   // median depth of the w-depth fork
-                    T = contrib ? test_T : T;
-                    last = contrib ? (uint32_t)(r * kBlock + j + 1) : last;    // 1-based position in the tile's list
-                }
-                if (!more) break;
-                j = jn; p = pn; co = con;
+            if (keep) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const float2 q = s_xy[e];
+                w_a[wave][pos] = make_float4(q.x, q.y, __uint_as_float((uint32_t)(r * kBlock + e + 1)), 0.f);
+                w_co[wave][pos] = s_co[e];
+                w_cd[wave][pos] = s_cd[e];
+            }
+            const int cnt = __popcll(mask);
+            float4 a = w_a[wave][0], co = w_co[wave][0], cd = w_cd[wave][0];
+            for (int k = 0; k < cnt; ++k) {
+                const int kn = k + 1 < 64 ? k + 1 : 63;
+                const float4 an = w_a[wave][kn], con = w_co[wave][kn], cdn = w_cd[wave][kn];   // next entry's reads overlap the math
+                float dx = a.x - pfx, dy = a.y - pfy;
+                float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                float alpha = fminf(kAlphaMax, co.w * __expf(power));
+                alpha = power <= 0.0f ? alpha : 0.0f;
+                const float test_T = T * (1.0f - alpha);                 // 0 for a saturated pixel
+                const bool valid = alpha >= kAlphaMin;
+                const bool contrib = valid && test_T >= kTEps;
+                const float w = contrib ? alpha * T : 0.0f;
+                C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
+                const float Tn = contrib ? test_T : T;
+                Dp = (T > 0.5f && Tn < 0.5f) ? cd.w : Dp;               // median depth of the w-depth fork
+                T_out = contrib ? test_T : T_out;
+                last = contrib ? __float_as_uint(a.z) : last;           // 1-based position in the tile's list
+                T = contrib ? test_T : (valid ? 0.0f : T);              // valid but below 1e-4: saturated from here on
+                a = an; co = con; cd = cdn;
             }
         }
     }
     if (inside) {
         size_t pix = (size_t)pyi * f.W + pxi, hw = (size_t)f.H * f.W;
-        final_T[pix] = T;
+        final_T[pix] = T_out;
         n_contrib[pix] = last;
-        out_color[pix] = C0 + T * f.bg[0];
-        out_color[hw + pix] = C1 + T * f.bg[1];
-        out_color[2 * hw + pix] = C2 + T * f.bg[2];
+        out_color[pix] = C0 + T_out * f.bg[0];
+        out_color[hw + pix] = C1 + T_out * f.bg[1];
+        out_color[2 * hw + pix] = C2 + T_out * f.bg[2];
         out_depth[pix] = Dp;
     }
 }
