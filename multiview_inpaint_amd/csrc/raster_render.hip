@@ -3,32 +3,39 @@
 // (forward: colour [3,H,W] + depth [1,H,W]) and loss.backward() (gs-simp/train.py:93).
 //
 // One 256-thread block per 16x16-pixel tile = 4 wave64, each wave an 8x8-pixel quadrant. The tile's
-// depth-sorted list is staged through LDS 256 entries at a time by the whole block; every staged
-// entry also gets the axis-aligned half-extents of its "active ellipse" {alpha >= 1/255}
-// (power >= -ln(255 o)  <=>  d^T conic d <= 2 ln(255 o); half-extents sqrt(2 ln(255 o) * cov_xx|yy)).
-// Each wave then tests 64 staged entries at a time against its own quadrant (one lane per entry),
-// takes the __ballot mask and walks only the set bits with scalar s_ff1: a Gaussian that cannot
-// reach alpha >= 1/255 anywhere in the quadrant is never evaluated. The test is conservative
-// (extents inflated by 0.1 % + 0.05 px), so results are identical to evaluating every entry.
+// depth-sorted list is staged through LDS 256 entries at a time by the whole block. Each wave then
+// tests 64 staged entries at a time against its own quadrant (one lane per entry): an entry is kept
+// iff its "active ellipse" {alpha >= 1/255} = {d^T conic d <= 2 ln(255 o)} can reach the quadrant
+// (exact minimum of the quadratic form over the box, quad_overlap). Only kept entries are evaluated
+// per pixel. The test is conservative (margin on 2 ln(255 o)), so results are identical to
+// evaluating every entry.
 #include "raster_common.h"
 
 namespace mvi {
 
-struct StagedExt {
-    // s_ext[e] = (hx, hy); negative hx = can never be active (opacity * 255 <= 1)
-    __device__ static float2 compute(float4 co) {
-        float t2 = 2.0f * __logf(255.0f * co.w);
-        if (!(t2 > 0.0f)) return make_float2(-1.0f, -1.0f);
-        float idet = 1.0f / (co.x * co.z - co.y * co.y);
-        float hx = sqrtf(t2 * co.z * idet), hy = sqrtf(t2 * co.x * idet);
-        return make_float2(hx * 1.001f + 0.05f, hy * 1.001f + 0.05f);
-    }
-};
+// Per staged entry: t2 = 2 ln(255 o) (+ margin), the largest Mahalanobis distance^2 d^T conic d at which
+// alpha = o exp(-d^T conic d / 2) still reaches 1/255; negative = can never be active.
+__device__ __forceinline__ float active_t2(float4 co) {
+    float t2 = 2.0f * __logf(255.0f * co.w);
+    return t2 > 0.0f ? t2 * 1.001f + 0.01f : -1.0f;
+}
 
-__device__ __forceinline__ bool quad_overlap(float2 c, float2 ext, float qx0, float qy0) {
-    // pixel centres of the quadrant span [qx0, qx0+7] x [qy0, qy0+7]
-    return ext.x >= 0.0f && (c.x + ext.x >= qx0) && (c.x - ext.x <= qx0 + 7.0f) && (c.y + ext.y >= qy0) &&
-           (c.y - ext.y <= qy0 + 7.0f);
+// Exact conservative test "can any point of the pixel quadrant [qx0,qx0+7] x [qy0,qy0+7] be active?":
+// the minimum of the convex form f(d) = A dx^2 + 2 B dx dy + C dy^2 over the box is 0 if the centre
+// is inside; otherwise it lies on one of the (at most two) box edges facing the centre, where the
+// 1-D minimiser is a clamped closed form. Continuous minimum <= minimum over pixel centres, and t2
+// carries a margin that dwarfs the rcp / rounding error, so no active pair is ever dropped.
+__device__ __forceinline__ bool quad_overlap(float2 c, float4 co, float t2, float qx0, float qy0) {
+    const float dxl = qx0 - c.x, dxr = dxl + 7.0f, dyl = qy0 - c.y, dyr = dyl + 7.0f;
+    const float px = fminf(fmaxf(0.0f, dxl), dxr), py = fminf(fmaxf(0.0f, dyl), dyr);   // box point nearest the centre, per axis
+    // edge x = px: dy* = clamp(-B px / C); edge y = py: dx* = clamp(-B py / A)
+    const float dy1 = fminf(fmaxf(-co.y * px * __builtin_amdgcn_rcpf(co.z), dyl), dyr);
+    const float dx2 = fminf(fmaxf(-co.y * py * __builtin_amdgcn_rcpf(co.x), dxl), dxr);
+    const float f1 = co.x * px * px + 2.0f * co.y * px * dy1 + co.z * dy1 * dy1;
+    const float f2 = co.x * dx2 * dx2 + 2.0f * co.y * dx2 * py + co.z * py * py;
+    // px == 0: only the y-facing edge matters (f2); py == 0: only f1; both 0: centre inside, f = 0
+    const float f = px == 0.0f ? (py == 0.0f ? 0.0f : f2) : (py == 0.0f ? f1 : fminf(f1, f2));
+    return f <= t2;
 }
 
 // The CU's scalar unit issues one instruction per cycle for all four SIMDs, so the inner loop must
@@ -42,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_depth) {
     __shared__ float2 s_xy[kBlock];
-    __shared__ float2 s_ext[kBlock];
+    __shared__ float s_t2[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_cd[kBlock];                 // r, g, b, depth
     __shared__ float4 w_a[4][64], w_co[4][64], w_cd[4][64];   // per-wave compacted strip: (x, y, list position, -)
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
         if (__syncthreads_count(T <= 0.0f) == kBlock) break;
         s_xy[tid] = n_xy;
         s_co[tid] = n_co;
-        s_ext[tid] = StagedExt::compute(n_co);
+        s_t2[tid] = active_t2(n_co);
         s_cd[tid] = n_cd;
         __syncthreads();
         if (r + 1 < rounds) fetch(r + 1);
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
         for (int c = 0; c < n; c += 64) {
             if (__ballot(T > 0.0f) == 0ull) break;
             const int e = c + lane;
-            const bool keep = e < n && quad_overlap(s_xy[e], s_ext[e], (float)qx0, (float)qy0);
+            const bool keep = e < n && quad_overlap(s_xy[e], s_co[e], s_t2[e], (float)qx0, (float)qy0);
             const unsigned long long mask = __ballot(keep);
             if (mask == 0ull) continue;
             if (keep) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ dL_dpix, float* __restrict__ grad_rows) {
     __shared__ uint32_t s_id[kBlock];
     __shared__ float2 s_xy[kBlock];
-    __shared__ float2 s_ext[kBlock];
+    __shared__ float s_t2[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_rgb[kBlock];
     __shared__ float s_acc[kBlock][9];                                // raw moment sums per staged entry
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
         s_id[tid] = n_id;
         s_xy[tid] = n_xy;
         s_co[tid] = n_co;
-        s_ext[tid] = StagedExt::compute(n_co);
+        s_t2[tid] = active_t2(n_co);
         s_rgb[tid] = n_cd;
 #pragma unroll
         for (int c = 0; c < 9; ++c) s_acc[tid][c] = 0.0f;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
             const int e = c + lane;
             // position of staged slot e is hi-1-e; this wave composited positions < wave_last only
             const bool keep = e < n && (uint32_t)(hi - 1 - e) < wave_last &&
-                              quad_overlap(s_xy[e], s_ext[e], (float)qx0, (float)qy0);
+                              quad_overlap(s_xy[e], s_co[e], s_t2[e], (float)qx0, (float)qy0);
             unsigned long long mask = __ballot(keep);
             if (mask == 0ull) continue;
             int j = c + __builtin_ctzll(mask);                  // wave-uniform
