@@ -19,7 +19,8 @@
  *       viewmatrix/projmatrix [16] in Camera.world_view_transform / full_proj_transform memory
  *       order (gs-simp/scene/cameras.py:60-62), campos [3], bg [3];
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it. Only
- *     mvi_raster_forward_geom synchronises it (once, to return num_rendered to the host);
+ *     mvi_raster_forward_geom blocks the host (once, on an event behind the 4-byte read-back of
+ *     num_rendered; the device keeps running the depth sort queued behind it);
  *   - the library owns no memory: scratch comes from the caller (sizes from the *_bytes queries),
  *     and the caller keeps geom/binning/image alive from forward to backward (the reference's
  *     autograd Function keeps them in ctx);

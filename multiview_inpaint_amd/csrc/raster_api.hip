@@ -131,13 +131,23 @@ int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, 
         if (mvi::launch_scan_block_sums(g, P, st)) return hip_fail("scan_block_sums", hipGetLastError());
     }
     int nblk = (P + mvi::kBlock - 1) / mvi::kBlock;
-    uint32_t total = 0;
-    hipError_t e = hipMemcpyAsync(&total, g.block_offsets + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    // read num_rendered back through a pinned word + an event recorded right behind the copy, then
+    // queue binning level 1 (independent of num_rendered): the host wakes up as soon as the count is
+    // there and allocates / launches stage 2 while the device is still sorting
+    static thread_local uint32_t* pinned = nullptr;
+    static thread_local hipEvent_t ev = nullptr;
+    hipError_t e;
+    if (!pinned) {
+        if ((e = hipHostMalloc((void**)&pinned, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return hip_fail("hipHostMalloc", e);
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail("hipEventCreate", e);
+    }
+    e = hipMemcpyAsync(pinned, g.block_offsets + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return hip_fail("copy num_rendered", e);
-    // binning level 1 does not depend on num_rendered: keep the device busy across the host read-back
+    if ((e = hipEventRecord(ev, st)) != hipSuccess) return hip_fail("event record", e);
     if (mvi::launch_binning_level1(f, g, st)) return hip_fail("binning level 1", hipGetLastError());
-    e = hipStreamSynchronize(st);
+    e = hipEventSynchronize(ev);
     if (e != hipSuccess) return hip_fail("forward_geom sync", e);
+    const uint32_t total = *pinned;
     *num_rendered_host = (int64_t)total;
     return MVI_OK;
 }

@@ -107,7 +107,7 @@ def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs
     u8 = dict(dtype=torch.uint8, device=dev)
     st.geom = torch.empty(L.mvi_raster_geom_bytes(P), **u8)
     st.image = torch.empty(L.mvi_raster_image_bytes(W, H), **u8)
-    st.radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    st.radii = torch.empty(P, dtype=torch.int32, device=dev)     # every entry is written by the preprocess kernel
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
