@@ -182,6 +182,14 @@ def main():
                 avg_ms = ms[i] / args.steps                  # a stage may be bracketed more than once per step
                 stages[name] = dict(ms=round(avg_ms, 4), GBs=round(stage_bytes[name] / avg_ms / 1e6, 1))
         dom = max(stages, key=lambda k: stages[k]["ms"])
+        # HBM bytes per launch of the dominant stage from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+        # separate rocprofv3 --pmc runs, gfx950 correction applied: profiles/raster_traffic.json); null if absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "raster_traffic.json")) as fh:
+                traffic = json.load(fh)["per_step_bytes_by_stage"].get(dom)
+        except (OSError, KeyError, ValueError):
+            pass
         ms_step = dt / args.steps * 1e3
         total_bytes = sum(stage_bytes.values())
         ranges = st.tensor("ranges", (T, 2), torch.int32).long()
@@ -208,7 +216,7 @@ def main():
                        "parallelism": f"views x{world}" + (" + RCCL all-reduce of the gradient bucket" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": stages[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(stage_bytes[dom]),
                          "whole_step": {"algorithmic_bytes": int(total_bytes),
                                         "GBs": round(total_bytes / ms_step / 1e6, 1),
