@@ -17,6 +17,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# gfx950 has one unified VGPR/AGPR file: keep the MFMA accumulators of the attention kernel in VGPRs so
+# the softmax reads them in place (no v_accvgpr_read/write shuffling between the two MFMA products)
+EXTRA = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -34,7 +37,7 @@ def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime())):
         return obj, False
-    subprocess.check_call([HIPCC, *FLAGS, "-c", src, "-o", obj])
+    subprocess.check_call([HIPCC, *FLAGS, *EXTRA.get(os.path.basename(src), []), "-c", src, "-o", obj])
     return obj, True
 
 

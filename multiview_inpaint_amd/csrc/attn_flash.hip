@@ -57,14 +57,17 @@ template <> struct Mma<__half> {
 
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
+constexpr float kRescaleThreshold = 8.0f;   // log2 units: O and l are rescaled only when the row max grows by > 2^8
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ v, T* __restrict__ out, int H, int Sq,
                                                          int Sk, float scale_log2e, int q_blocks, int total_blocks) {
     using M = Mma<T>;
     using frag = typename M::frag;
-    __shared__ __attribute__((aligned(16))) uint16_t s_k[kFK * kKStride];
-    __shared__ __attribute__((aligned(16))) uint16_t s_vt[kFD * kVStride];
+    // two K / V^T tile buffers: the next tile is written while the current one is read (one barrier per tile)
+    __shared__ __attribute__((aligned(16))) uint16_t s_k[2][kFK * kKStride];
+    __shared__ __attribute__((aligned(16))) uint16_t s_vt[2][kFD * kVStride];
 
     // XCD-aware block order: the 8 XCDs get contiguous runs of blocks, so the q-blocks that share one
     // (batch, head)'s K/V stream hit the same L2 (speed only; any placement is correct)
@@ -94,6 +97,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    // m is the reference exponent (scaled log2 units) the accumulators are expressed in; it trails the
+    // true row max by at most kRescaleThreshold, so p = exp2(s c - m) <= 2^8 and nothing overflows
     float m = -INFINITY, l = 0.f;
 
     // staging: thread -> (K row kr, 16-element segment ks) and (V key pair vp, 8-element segment vs)
@@ -113,27 +118,31 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
         rv0 = r0 < Sk ? *reinterpret_cast<const u32x4*>(pv) : z;
         rv1 = r0 + 1 < Sk ? *reinterpret_cast<const u32x4*>(pv + hd) : z;
     };
-    auto store_tile = [&]() {
-        *reinterpret_cast<u32x4*>(&s_k[kr * kKStride + 16 * ks]) = rk0;
-        *reinterpret_cast<u32x4*>(&s_k[kr * kKStride + 16 * ks + 8]) = rk1;
+    auto store_tile = [&](int buf) {
+        uint16_t* sk = s_k[buf];
+        uint16_t* sv = s_vt[buf];
+        *reinterpret_cast<u32x4*>(&sk[kr * kKStride + 16 * ks]) = rk0;
+        *reinterpret_cast<u32x4*>(&sk[kr * kKStride + 16 * ks + 8]) = rk1;
         // transpose: (V[key0][d], V[key0+1][d]) -> one dword at V^T[d][key0]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t a = rv0[i], c = rv1[i];
             uint32_t lo = (a & 0xFFFFu) | (c << 16), hi = (a >> 16) | (c & 0xFFFF0000u);
-            *reinterpret_cast<uint32_t*>(&s_vt[(8 * vs + 2 * i) * kVStride + 2 * vp]) = lo;
-            *reinterpret_cast<uint32_t*>(&s_vt[(8 * vs + 2 * i + 1) * kVStride + 2 * vp]) = hi;
+            *reinterpret_cast<uint32_t*>(&sv[(8 * vs + 2 * i) * kVStride + 2 * vp]) = lo;
+            *reinterpret_cast<uint32_t*>(&sv[(8 * vs + 2 * i + 1) * kVStride + 2 * vp]) = hi;
         }
     };
 
     const int n_tiles = (Sk + kFK - 1) / kFK;
     load_tile(0);
+    store_tile(0);
+    __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
-        __syncthreads();                                   // every wave is done reading the previous tile
-        store_tile();
-        __syncthreads();
+        const int buf = t & 1;
         if (t + 1 < n_tiles) load_tile((t + 1) * kFK);      // in flight during this tile's MFMAs
         const int k0 = t * kFK;
+        const uint16_t* sk = s_k[buf];
+        const uint16_t* sv = s_vt[buf];
 
         // ---- S^T = K Q^T
         f32x16 st[2];
@@ -143,38 +152,42 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
             for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                u32x4 raw = *reinterpret_cast<const u32x4*>(&s_k[(kb * 32 + qcol) * kKStride + 16 * s + 8 * hh]);
+                u32x4 raw = *reinterpret_cast<const u32x4*>(&sk[(kb * 32 + qcol) * kKStride + 16 * s + 8 * hh]);
                 st[kb] = M::mfma(as_frag<frag>(raw), qf[s], st[kb]);
             }
         }
-        // st[kb][r] is key k0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hh for query qrow
-        float rmax = -INFINITY;
-        const bool tail = k0 + kFK > Sk;
+        // st[kb][r] is key k0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hh for query qrow (raw, unscaled scores)
+        if (k0 + kFK > Sk) {                                  // tail tile only (block-uniform)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = st[kb][r] * scale_log2e;
-                if (tail && (k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) s = -INFINITY;
-                st[kb][r] = s;
-                rmax = fmaxf(rmax, s);
-            }
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
-        const float m_new = fmaxf(m, rmax);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                for (int r = 0; r < 16; ++r)
+                    if ((k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) st[kb][r] = -INFINITY;
+        }
+        float rmax = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) rmax = fmaxf(rmax, fmaxf(st[0][r], st[1][r]));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32)) * scale_log2e;   // scale > 0: max commutes with it
+        // deferred rescale: keep the old reference exponent unless the row max outgrew it by 2^8
+        const bool grow = rmax > m + kRescaleThreshold;        // always true on the first tile (m = -inf)
+        if (__ballot(grow) != 0ull) {                          // wave-uniform: skipped on almost every later tile
+            const float m_new = grow ? rmax : m;
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            m = m_new;
+        }
         float rsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], scale_log2e, -m));
                 st[kb][r] = p;
                 rsum += p;
             }
-        l = l * alpha + rsum;
-        m = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        l += rsum;
 
         // ---- O^T += V^T P^T ; P fragment of key-step (kb, s2) = registers 8 s2 .. 8 s2 + 7 of st[kb]
 #pragma unroll
@@ -188,13 +201,15 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
                 const int koff = 32 * kb + 16 * s2 + 4 * hh;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const uint16_t* row = &s_vt[(32 * db + qcol) * kVStride + koff];
+                    const uint16_t* row = &sv[(32 * db + qcol) * kVStride + koff];
                     u32x2 a0 = *reinterpret_cast<const u32x2*>(row);
                     u32x2 a1 = *reinterpret_cast<const u32x2*>(row + 8);
                     u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
                     o[db] = M::mfma(as_frag<frag>(av), pf, o[db]);
                 }
             }
+        if (t + 1 < n_tiles) store_tile(buf ^ 1);               // other buffer: nobody reads it during this tile
+        __syncthreads();
     }
     l += __shfl_xor(l, 32);
     if (qrow < Sq) {
