@@ -19,7 +19,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 # gfx950 has one unified VGPR/AGPR file: keep the MFMA accumulators of the attention kernel in VGPRs so
 # the softmax reads them in place (no v_accvgpr_read/write shuffling between the two MFMA products)
-EXTRA = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# -fno-honor-nans: scores are finite or -inf (masked tail), never NaN; lets fmaxf become v_max3_f32 without the
+# canonicalising v_max x,x the IEEE lowering inserts in front of every MFMA output
+EXTRA = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def sources():

@@ -28,6 +28,9 @@ namespace mvi {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -41,17 +44,19 @@ template <typename T> struct Mma;
 template <> struct Mma<__hip_bfloat16> {
     using frag = bf16x8;
     __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    __device__ static uint32_t pack2(float lo, float hi) {
-        __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-        return (uint32_t) * reinterpret_cast<uint16_t*>(&a) | ((uint32_t) * reinterpret_cast<uint16_t*>(&b) << 16);
+    __device__ static uint32_t pack2(float lo, float hi) {     // one v_cvt_pk_bf16_f32 (RNE)
+        f32x2 f = {lo, hi};
+        bf16x2 r = __builtin_convertvector(f, bf16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
     }
 };
 template <> struct Mma<__half> {
     using frag = f16x8;
     __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     __device__ static uint32_t pack2(float lo, float hi) {
-        __half2 h = __floats2half2_rn(lo, hi);
-        return *reinterpret_cast<uint32_t*>(&h);
+        f32x2 f = {lo, hi};
+        f16x2 r = __builtin_convertvector(f, f16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
     }
 };
 
@@ -146,15 +151,18 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
 
         // ---- S^T = K Q^T
         f32x16 st[2];
+        u32x4 kf[2][4];                                       // all eight K fragments in flight before the first MFMA
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                kf[kb][s] = *reinterpret_cast<const u32x4*>(&sk[(kb * 32 + qcol) * kKStride + 16 * s + 8 * hh]);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                u32x4 raw = *reinterpret_cast<const u32x4*>(&sk[(kb * 32 + qcol) * kKStride + 16 * s + 8 * hh]);
-                st[kb] = M::mfma(as_frag<frag>(raw), qf[s], st[kb]);
-            }
+            for (int s = 0; s < 4; ++s) st[kb] = M::mfma(as_frag<frag>(kf[kb][s]), qf[s], st[kb]);
         }
         // st[kb][r] is key k0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hh for query qrow (raw, unscaled scores)
         if (k0 + kFK > Sk) {                                  // tail tile only (block-uniform)
