@@ -36,6 +36,15 @@ int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float*
                        int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
                        int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same GroupNorm for the temporal layers: statistics over (C/groups, T, spatial) of a tensor stored
+ * [(videos*T), C, spatial] — i.e. GroupNorm of "b c t h w" (svd_inpaint1/sgm/modules/diffusionmodules/
+ * video_model.py:71-75, openaimodel.py:257-261 with dims=3) computed on the "(b t) c h w" layout the
+ * spatial layers produce, without the permute copies. Workspace: mvi_groupnorm_workspace_bytes(videos*T, ...). */
+int mvi_groupnorm_silu_temporal(const void* x, void* y, const float* weight, const float* bias,
+                                int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups,
+                                float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 /* out = softmax(q k^T * scale) v per (batch, head). Token-major layout, as the Linear projections
  * produce it: q/out [B, Sq, H, D], k/v [B, Sk, H, D], contiguous. No mask (none is used on the
  * denoise path). dtype selects the I/O type; fp32 I/O computes in fp32 (validation mode, 1e-4
@@ -44,6 +53,20 @@ int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float*
 int mvi_attention_forward(const void* q, const void* k, const void* v, void* out, int32_t B,
                           int32_t H, int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype,
                           void* stream);
+
+/* Self-attention over the FRAME axis of x laid out [(Bo*T), S, H, D] (token-major, frames outermost within
+ * a video — the layout the spatial layers leave behind), one softmax problem per (video, spatial token,
+ * head): rows are the T frames, strided by S*H*D. Replaces the reference's regrouping
+ * "(b t) s c -> (b s) t c" + attention + inverse regrouping
+ * (svd_inpaint1/sgm/modules/video_attention.py:115, :136-140) without moving any token. q, k, v, out
+ * share the layout. fp32 math for every dtype. */
+int mvi_attention_temporal(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                           int32_t S, int32_t H, int32_t D, float scale, int32_t dtype, void* stream);
+
+/* GEGLU gate of the transformer feed-forwards: out[r, j] = h[r, j] * gelu(h[r, inner + j]) (exact erf GELU),
+ * h [rows, 2*inner] -> out [rows, inner], contiguous. Replaces `x, gate = proj(x).chunk(2, -1); x * F.gelu(gate)`
+ * (svd_inpaint1/sgm/modules/attention.py:87-95). inner must be a multiple of 4 (fp32) / 8 (bf16, f16). */
+int mvi_geglu(const void* h, void* out, int64_t rows, int32_t inner, int32_t dtype, void* stream);
 
 /* Which kernel mvi_attention_forward would pick: 0 = rowtile fp32-math, 1 = MFMA flash. */
 int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);

@@ -8,8 +8,14 @@ def bind(L):
     L.mvi_groupnorm_workspace_bytes.argtypes = [i64, i32, i64, i32]
     L.mvi_groupnorm_silu.restype = C.c_int
     L.mvi_groupnorm_silu.argtypes = [vp, vp, vp, vp, i64, i32, i64, i32, f32, i32, i32, vp, sz, vp]
+    L.mvi_groupnorm_silu_temporal.restype = C.c_int
+    L.mvi_groupnorm_silu_temporal.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i32, f32, i32, i32, vp, sz, vp]
     L.mvi_attention_forward.restype = C.c_int
     L.mvi_attention_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.mvi_attention_temporal.restype = C.c_int
+    L.mvi_attention_temporal.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.mvi_geglu.restype = C.c_int
+    L.mvi_geglu.argtypes = [vp, vp, i64, i32, i32, vp]
     L.mvi_attention_kernel_kind.restype = C.c_int
     L.mvi_attention_kernel_kind.argtypes = [i32, i32, i32, i32]
     L.mvi_unet_last_error.restype = C.c_char_p

@@ -251,7 +251,7 @@ template int attn_flash_launch<__half>(const void*, const void*, const void*, vo
 // rowtile kernel (attn_rowtile.hip)
 template <typename T>
 int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
-                        float scale, hipStream_t st);
+                        float scale, hipStream_t st, int temporal_inner);
 int unet_fail(int code, const char* msg);
 
 }  // namespace mvi
@@ -275,11 +275,30 @@ extern "C" int mvi_attention_forward(const void* q, const void* k, const void* v
     } else {
         if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "attention: head dim must be 16, 32 or 64");
         switch (dtype) {
-            case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, Sq, Sk, D, scale, st); break;
-            case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, D, scale, st); break;
-            case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, Sq, Sk, D, scale, st); break;
+            case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0); break;
+            case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0); break;
+            case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0); break;
             default: return mvi::unet_fail(MVI_EINVAL, "attention: unknown dtype");
         }
     }
     return rc ? mvi::unet_fail(rc, "attention: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_attention_temporal(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                                      int32_t S, int32_t H, int32_t D, float scale, int32_t dtype, void* stream) {
+    if (Bo < 0 || T <= 0 || S <= 0 || H <= 0 || D <= 0) return mvi::unet_fail(MVI_EINVAL, "temporal attention: bad shape");
+    if (Bo == 0) return MVI_OK;
+    if (!q || !k || !v || !out) return mvi::unet_fail(MVI_EINVAL, "temporal attention: NULL pointer");
+    if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "temporal attention: head dim must be 16, 32 or 64");
+    if ((int64_t)Bo * S > 0x7FFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "temporal attention: too many problems");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Bo * S;
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, T, T, D, scale, st, S); break;
+        case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, T, T, D, scale, st, S); break;
+        case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, T, T, D, scale, st, S); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "temporal attention: unknown dtype");
+    }
+    return rc ? mvi::unet_fail(rc, "temporal attention: kernel launch failed") : MVI_OK;
 }

@@ -35,11 +35,21 @@ constexpr int kRtKeys = 32;      // keys per LDS tile
 constexpr int kRtWaves = 4;      // waves (= independent problems) per block
 
 // DV = D / 16 : number of 4-channel vectors a lane owns (D in {16, 32, 64, 128})
+// Addressing: batch index b = bo * inner + bi. Row r of (b, head h) starts at element
+//   bo * outer_stride + bi * inner_stride + r * row_stride + h * D        (separately for q/out and k/v).
+// Standard token-major [B, S, H, D]: inner = 1, outer_stride = S*H*D, row_stride = H*D.
+// Temporal attention over x [(bo T), S, H, D] without regrouping tokens: one problem per (bo, s):
+//   inner = S, inner_stride = H*D, outer_stride = T*S*H*D, row_stride = S*H*D, rows = frames.
+struct RtLayout {
+    int inner;
+    int64_t q_outer, q_inner, q_row, k_outer, k_inner, k_row;
+};
+
 template <typename T, int DV>
 __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                      const T* __restrict__ v, T* __restrict__ out,
                                                                      int B, int H, int Sq, int Sk, float scale,
-                                                                     int64_t n_problems, int q_tiles) {
+                                                                     int64_t n_problems, int q_tiles, RtLayout L) {
     constexpr int D = DV * 16;
     __shared__ float s_k[kRtWaves][kRtKeys][D];
     __shared__ float s_v[kRtWaves][kRtKeys][D];
@@ -52,7 +62,9 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
     const int64_t b = bh / H;
     const int row = qt * 16 + (lane >> 2), p = lane & 3;
     const bool row_ok = row < Sq;
-    const int64_t hd = (int64_t)H * D;
+    const int64_t bo = b / L.inner, bi = b % L.inner;
+    const int64_t qbase = bo * L.q_outer + bi * L.q_inner + (int64_t)h * D;
+    const int64_t kbase = bo * L.k_outer + bi * L.k_inner + (int64_t)h * D;
 
     float qr[DV][4], acc[DV][4];
 #pragma unroll
@@ -60,7 +72,7 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             acc[i][c] = 0.f;
-            qr[i][c] = row_ok ? to_f<T>(q[(b * Sq + row) * hd + (int64_t)h * D + 16 * i + 4 * p + c]) * scale : 0.f;
+            qr[i][c] = row_ok ? to_f<T>(q[qbase + row * L.q_row + 16 * i + 4 * p + c]) * scale : 0.f;
         }
     float m = -INFINITY, l = 0.f;
 
@@ -69,8 +81,8 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
         // stage K and V rows of this head: lane l copies 4-vectors l, l+64, ... of the nk x D tile
         for (int e = lane; e < nk * (D / 4); e += 64) {
             int kr = e / (D / 4), dv = e % (D / 4);
-            const T* kp = k + ((b * Sk + k0 + kr) * hd + (int64_t)h * D + 4 * dv);
-            const T* vp = v + ((b * Sk + k0 + kr) * hd + (int64_t)h * D + 4 * dv);
+            const T* kp = k + (kbase + (int64_t)(k0 + kr) * L.k_row + 4 * dv);
+            const T* vp = v + (kbase + (int64_t)(k0 + kr) * L.k_row + 4 * dv);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 s_k[wave][kr][4 * dv + c] = to_f<T>(kp[c]);
@@ -126,13 +138,28 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
         for (int i = 0; i < DV; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                out[(b * Sq + row) * hd + (int64_t)h * D + 16 * i + 4 * p + c] = from_f<T>(acc[i][c] * inv);
+                out[qbase + row * L.q_row + 16 * i + 4 * p + c] = from_f<T>(acc[i][c] * inv);
     }
 }
 
 template <typename T>
 int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
-                        float scale, hipStream_t st) {
+                        float scale, hipStream_t st, int temporal_inner) {
+    RtLayout L;
+    const int64_t hd = (int64_t)H * D;
+    if (temporal_inner > 0) {   // B = outer * temporal_inner problems; rows are frames strided by inner * H*D
+        L.inner = temporal_inner;
+        L.q_inner = L.k_inner = hd;
+        L.q_row = L.k_row = (int64_t)temporal_inner * hd;
+        L.q_outer = (int64_t)Sq * temporal_inner * hd;
+        L.k_outer = (int64_t)Sk * temporal_inner * hd;
+    } else {
+        L.inner = 1;
+        L.q_inner = L.k_inner = 0;
+        L.q_row = L.k_row = hd;
+        L.q_outer = (int64_t)Sq * hd;
+        L.k_outer = (int64_t)Sk * hd;
+    }
     const int q_tiles = (Sq + 15) / 16;
     const int64_t n = (int64_t)B * H * q_tiles;
     const int64_t blocks = (n + kRtWaves - 1) / kRtWaves;
@@ -140,7 +167,7 @@ int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, 
     dim3 grid((unsigned)blocks), blk(64 * kRtWaves);
 #define MVI_RT(DVV)                                                                                              \
     hipLaunchKernelGGL((attn_rowtile_kernel<T, DVV>), grid, blk, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, \
-                       B, H, Sq, Sk, scale, n, q_tiles)
+                       B, H, Sq, Sk, scale, n, q_tiles, L)
     switch (D) {
         case 16: MVI_RT(1); break;
         case 32: MVI_RT(2); break;
@@ -151,8 +178,8 @@ int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, 
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
-template int attn_rowtile_launch<float>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
-template int attn_rowtile_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
-template int attn_rowtile_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
+template int attn_rowtile_launch<float>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int);
+template int attn_rowtile_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int);
+template int attn_rowtile_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int);
 
 }  // namespace mvi

@@ -79,15 +79,32 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 
 // chunk = kGnBlock * kGnVecPerThread * kVec elements of one group (vector path needs E % kVec == 0
 // and a 16-B aligned base, checked on the host; otherwise VEC = false walks scalars)
+// A group is `slices` pieces of E contiguous elements each, piece s of group (n, g) starting at
+// ((n * slices + s) * C + g * Cg) * S. slices == 1 is the ordinary [N, C, S] GroupNorm; slices == T is
+// the temporal GroupNorm over "b c t h w" evaluated directly on the "(b t) c h w" tensor, no permute.
+// grid.x = slices * cps (chunks per slice), grid.y = N * G.
+struct GnGeom {
+    int64_t E;        // elements per slice = Cg * S
+    int64_t S;        // spatial positions per channel in a slice
+    int64_t slice_stride;   // C * S
+    int cps, slices, Cg, G;
+};
+__device__ __forceinline__ int64_t gn_slice_base(const GnGeom& q, int64_t g, int slice) {
+    const int64_t n = g / q.G, gi = g % q.G;
+    return (n * q.slices + slice) * q.slice_stride + gi * q.E;
+}
+
 template <typename T, bool VEC>
-__global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part,
-                                                            int64_t E, int chunks) {
+__global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, GnGeom q) {
     __shared__ float s_red[4];
     constexpr int KV = Io<T>::kVec;
     constexpr int CH = kGnBlock * kGnVecPerThread * KV;
     const int64_t g = blockIdx.y;
-    const int64_t e0 = (int64_t)blockIdx.x * CH;
-    const T* base = x + g * E;
+    const int slice = blockIdx.x / q.cps, chunk = blockIdx.x % q.cps;
+    const int64_t E = q.E;
+    const int chunks = q.cps * q.slices;
+    const int64_t e0 = (int64_t)chunk * CH;
+    const T* base = x + gn_slice_base(q, g, slice);
     float v[kGnVecPerThread * KV];
     int cnt = 0;
     float sum = 0.f;
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict_
     }
     m2 = block_sum(m2, s_red);
     if (threadIdx.x == 0) {
-        float* p = part + (g * chunks + blockIdx.x) * 3;
+        float* p = part + (g * chunks + blockIdx.x) * 3;   // blockIdx.x = slice * cps + chunk
         p[0] = (float)n_chunk; p[1] = mean; p[2] = m2;
     }
 }
@@ -135,12 +152,14 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ weight,
                                                             const float* __restrict__ bias,
-                                                            const float* __restrict__ part, int64_t E, int chunks,
-                                                            int64_t S, int Cg, int G, float eps, int silu) {
+                                                            const float* __restrict__ part, GnGeom q, float eps, int silu) {
     __shared__ float s_stat[2];
     constexpr int KV = Io<T>::kVec;
     constexpr int CH = kGnBlock * kGnVecPerThread * KV;
     const int64_t g = blockIdx.y;
+    const int slice = blockIdx.x / q.cps, chunk = blockIdx.x % q.cps;
+    const int64_t E = q.E, S = q.S;
+    const int chunks = q.cps * q.slices, Cg = q.Cg, G = q.G;
     if (threadIdx.x < 64) {
         // merge the group's partials: lanes take them round-robin, then a butterfly of Chan merges
         float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -168,9 +187,10 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
     __syncthreads();
     const float mean = s_stat[0], rstd = s_stat[1];
     const int c0 = (int)(g % G) * Cg;
-    const int64_t e0 = (int64_t)blockIdx.x * CH;
-    const T* xb = x + g * E;
-    T* yb = y + g * E;
+    const int64_t e0 = (int64_t)chunk * CH;
+    const int64_t sb = gn_slice_base(q, g, slice);
+    const T* xb = x + sb;
+    T* yb = y + sb;
 #pragma unroll
     for (int i = 0; i < kGnVecPerThread; ++i) {
         int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
@@ -199,23 +219,23 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
 }
 
 template <typename T>
-static int gn_launch(const void* x, void* y, const float* w, const float* b, int64_t N, int C, int64_t S, int G,
-                     float eps, int silu, float* part, hipStream_t st) {
+static int gn_launch(const void* x, void* y, const float* w, const float* b, int64_t N, int slices, int C, int64_t S,
+                     int G, float eps, int silu, float* part, hipStream_t st) {
     constexpr int KV = Io<T>::kVec;
     constexpr int CH = kGnBlock * kGnVecPerThread * KV;
-    const int Cg = C / G;
-    const int64_t E = (int64_t)Cg * S;
-    const int chunks = (int)((E + CH - 1) / CH);
+    GnGeom q;
+    q.Cg = C / G; q.G = G; q.S = S; q.slices = slices;
+    q.E = (int64_t)q.Cg * S;
+    q.slice_stride = (int64_t)C * S;
+    q.cps = (int)((q.E + CH - 1) / CH);
     const bool vec = (S % KV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
-    dim3 grid(chunks, (unsigned)(N * G));
+    dim3 grid((unsigned)(q.cps * slices), (unsigned)(N * G));
     if (vec) {
-        hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, E, chunks);
-        hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, E,
-                           chunks, S, Cg, G, eps, silu);
+        hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, q);
+        hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, q, eps, silu);
     } else {
-        hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, E, chunks);
-        hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, E,
-                           chunks, S, Cg, G, eps, silu);
+        hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, q);
+        hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, q, eps, silu);
     }
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
@@ -237,29 +257,42 @@ static int chunks_for(int64_t E, int dtype) {
 extern "C" size_t mvi_groupnorm_workspace_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups) {
     if (N <= 0 || C <= 0 || groups <= 0 || spatial <= 0) return 0;
     int64_t E = (int64_t)(C / groups) * spatial;
-    // sized for the dtype with the fewest elements per chunk (fp32)
+    // sized for the dtype with the fewest elements per chunk (fp32); N counts every (video, frame) row, so the
+    // same size covers the temporal form (N/T groups x T slices)
     return (size_t)(N * groups) * chunks_for(E, MVI_DT_F32) * 3 * sizeof(float);
 }
 
-extern "C" int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float* bias, int64_t N,
-                                  int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
-                                  int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
-    if (N < 0 || C <= 0 || groups <= 0 || spatial < 0 || C % groups != 0)
+static int gn_dispatch(const void* x, void* y, const float* weight, const float* bias, int64_t Nv, int32_t T, int32_t C,
+                       int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (Nv < 0 || T <= 0 || C <= 0 || groups <= 0 || spatial < 0 || C % groups != 0)
         return mvi::unet_fail(MVI_EINVAL, "groupnorm: C must be a positive multiple of groups");
-    if (N == 0 || spatial == 0) return MVI_OK;
+    if (Nv == 0 || spatial == 0) return MVI_OK;
     if (!x || !y || !weight || !bias || !workspace) return mvi::unet_fail(MVI_EINVAL, "groupnorm: NULL pointer");
-    if (N * groups > 0x7FFFFFFFll || N * groups > 65535ll * 65535ll) return mvi::unet_fail(MVI_EINVAL, "groupnorm: N*groups too large");
-    if (N * groups > 65535) return mvi::unet_fail(MVI_EINVAL, "groupnorm: N*groups exceeds grid.y (65535)");
-    if (workspace_bytes < mvi_groupnorm_workspace_bytes(N, C, spatial, groups))
+    if (Nv * groups > 65535) return mvi::unet_fail(MVI_EINVAL, "groupnorm: N*groups exceeds grid.y (65535)");
+    if (workspace_bytes < mvi_groupnorm_workspace_bytes(Nv * T, C, spatial, groups))
         return mvi::unet_fail(MVI_ENOMEM, "groupnorm: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
     int rc;
     switch (dtype) {
-        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, N, C, spatial, groups, eps, fuse_silu, part, st); break;
-        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, N, C, spatial, groups, eps, fuse_silu, part, st); break;
-        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, N, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
         default: return mvi::unet_fail(MVI_EINVAL, "groupnorm: unknown dtype");
     }
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float* bias, int64_t N,
+                                  int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                  int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return gn_dispatch(x, y, weight, bias, N, 1, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_groupnorm_silu_temporal(const void* x, void* y, const float* weight, const float* bias,
+                                           int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups,
+                                           float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    return gn_dispatch(x, y, weight, bias, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
 }

@@ -51,11 +51,17 @@ def inputs(device, T=14, h=72, w=128, seed=0, cfg_doubled=True):
     return r(B, 4, h, w), cond, torch.zeros(B // T if not cfg_doubled else B // (2 * T), T, device=device)
 
 
-def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True):
+def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, weights="bf16"):
+    """weights="bf16": parameters stored in bf16, no autocast (nothing is re-cast per step; GroupNorm
+    statistics, softmax and LayerNorm still accumulate in fp32 inside their kernels).
+    weights="fp32": fp32 parameters under torch.autocast(bf16), the reference's mixed-precision recipe
+    (it uses fp16 autocast, models/csvd.py:27-31)."""
     from . import hip_ops
     from .schedule import EDMDiscretization
-    eng = build(device, with_control=with_control)
+    eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)
     x, cond, ind = inputs(device, T, h, w)
+    if weights == "bf16":
+        cond = {k: v.bfloat16() for k, v in cond.items()}      # conditioning is computed once per sample
     if not with_control:
         cond.pop("control_hint")
     sig = EDMDiscretization(sigma_max=700.0)(25, device=device)
@@ -63,7 +69,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True):
 
     def step(i):
         s = sig[i % 25].expand(x.shape[0])
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=(weights != "bf16")):
             return eng.denoise(x, s, cond, **kw)
     for i in range(warmup):
         step(i)
@@ -77,7 +83,9 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True):
     prof = hip_ops.profile_summary()
     hip_ops.PROFILE = None
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
-               controlnet=with_control, dtype="bf16 autocast (fp32 weights, fp32 GroupNorm statistics/softmax)",
+               controlnet=with_control,
+               dtype=("bf16 weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights == "bf16"
+                      else "bf16 autocast over fp32 weights, fp32 GroupNorm statistics / softmax"),
                finite=bool(torch.isfinite(out).all()))
     ops = {}
     for kind, (calls, ms, work) in prof.items():

@@ -75,6 +75,13 @@ class SVDInpaintEngine(nn.Module):
             context = context * cond["crossattn_scale"]
         y = cond.get("vector")
         hint = cond.get("control_hint")
+        if not torch.is_autocast_enabled():
+            # parameters stored in reduced precision (no autocast): the sampler state stays fp32, the
+            # network sees its own dtype; timesteps stay fp32 for the sinusoidal embedding
+            wd = self.model.diffusion_model.time_embed[0].weight.dtype
+            cast = lambda t: t.to(wd) if torch.is_tensor(t) and t.is_floating_point() else t
+            xin, context, y = cast(xin), cast(context), cast(y)
+            hint = [cast(h) for h in hint] if isinstance(hint, list) else cast(hint)
         if "palette" in cond:
             hint = [hint, cond["palette"]]
         controls = None

@@ -79,6 +79,25 @@ def group_norm_silu(x, num_groups, weight, bias, eps, silu):
     return y
 
 
+def group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu):
+    """x [(b T), C, *spatial] contiguous; statistics per (video, group) over all T frames."""
+    L = _lib.lib()
+    if x.dtype not in _DT:
+        raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
+    xc = x if x.is_contiguous() else x.contiguous()
+    BT, Cc = xc.shape[0], xc.shape[1]
+    S = xc.numel() // max(BT * Cc, 1)
+    y = torch.empty_like(xc)
+    w = weight.detach().float().contiguous()
+    b = bias.detach().float().contiguous()
+    ws = _workspace(xc.device, L.mvi_groupnorm_workspace_bytes(BT, Cc, S, num_groups))
+    with torch.cuda.device(xc.device), _Timed("groupnorm", 2.0 * xc.numel() * xc.element_size(), xc.device):
+        _check(L.mvi_groupnorm_silu_temporal(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(), BT // T, int(T), Cc, S,
+                                             num_groups, float(eps), int(bool(silu)), _DT[x.dtype], ws.data_ptr(),
+                                             ws.numel(), _stream(xc.device)), "group_norm (temporal)")
+    return y
+
+
 def attention(q, k, v, heads):
     """q [B,Sq,H*D], k/v [B,Sk,H*D] -> [B,Sq,H*D]; scale = D**-0.5 (sgm/modules/attention.py:271)."""
     L = _lib.lib()
@@ -93,6 +112,34 @@ def attention(q, k, v, heads):
     with torch.cuda.device(q.device), _Timed(kind, 4.0 * B * heads * Sq * Sk * D, q.device):
         _check(L.mvi_attention_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, Sq, Sk, D,
                                        float(D) ** -0.5, _DT[q.dtype], _stream(q.device)), "attention")
+    return out
+
+
+def attention_temporal(q, k, v, heads, T):
+    """q/k/v [(bo*T), S, H*D] -> same; softmax over the T frames of each (video, token, head)."""
+    L = _lib.lib()
+    if q.dtype not in _DT or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError(f"attention_temporal: q/k/v must share a dtype in {list(_DT)}")
+    BT, S, HD = q.shape
+    D = HD // heads
+    q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device), _Timed("attention_temporal", 4.0 * (BT // T) * S * heads * T * T * D, q.device):
+        _check(L.mvi_attention_temporal(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), BT // T, T, S, heads, D,
+                                        float(D) ** -0.5, _DT[q.dtype], _stream(q.device)), "attention_temporal")
+    return out
+
+
+def geglu(h):
+    L = _lib.lib()
+    if h.dtype not in _DT:
+        raise TypeError(f"geglu: unsupported dtype {h.dtype}")
+    hc = h if h.is_contiguous() else h.contiguous()
+    inner = hc.shape[-1] // 2
+    rows = hc.numel() // (2 * inner)
+    out = torch.empty(*hc.shape[:-1], inner, dtype=h.dtype, device=h.device)
+    with torch.cuda.device(h.device), _Timed("geglu", 3.0 * rows * inner * h.element_size(), h.device):
+        _check(L.mvi_geglu(hc.data_ptr(), out.data_ptr(), rows, inner, _DT[h.dtype], _stream(h.device)), "geglu")
     return out
 
 

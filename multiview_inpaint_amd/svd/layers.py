@@ -119,8 +119,8 @@ class AlphaBlender(nn.Module):
         a = self.get_alpha(image_only_indicator)
         if a.size(0) != x_spatial.size(0):
             a = torch.cat([a] * 2)
-        a = a.to(x_spatial.dtype)
-        return a * x_spatial + (1.0 - a) * x_temporal
+        # alpha * spatial + (1 - alpha) * temporal as ONE pass: temporal + alpha * (spatial - temporal)
+        return torch.lerp(x_temporal, x_spatial, a.to(x_spatial.dtype))
 
 
 class Upsample(nn.Module):
@@ -261,6 +261,24 @@ class ResBlock(TimestepBlock):
         return self.skip_connection(x) + h
 
 
+def temporal_conv3_frames(x, conv: nn.Conv3d, T: int):
+    """Conv3d with kernel (3,1,1), padding (1,0,0) applied along the frame axis of x [(b T), Ci, H, W]
+    without leaving that layout: y_t = W[..., 0] x_{t-1} + W[..., 1] x_t + W[..., 2] x_{t+1} is ONE 1x1
+    convolution over the three neighbouring frames stacked on the channel axis (K = 3 Ci GEMM), instead
+    of permuting to b c t h w and running an im2col 3-D convolution."""
+    bt, ci, h, w = x.shape
+    b = bt // T
+    xv = x.reshape(b, T, ci, h, w)
+    xc = x.new_empty(b, T, 3 * ci, h, w)
+    xc[:, 1:, :ci] = xv[:, :-1]
+    xc[:, 0, :ci] = 0
+    xc[:, :, ci:2 * ci] = xv
+    xc[:, :-1, 2 * ci:] = xv[:, 1:]
+    xc[:, -1, 2 * ci:] = 0
+    wt = conv.weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(conv.out_channels, 3 * ci, 1, 1)   # tap-major channels
+    return F.conv2d(xc.reshape(bt, 3 * ci, h, w), wt, conv.bias)
+
+
 class VideoResBlock(ResBlock):
     """Spatial ResBlock on (b t) c h w, then a temporal ResBlock (Conv3d kernel (3,1,1)) on
     b c t h w, blended by AlphaBlender (video_model.py:12-81)."""
@@ -280,10 +298,39 @@ class VideoResBlock(ResBlock):
         self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy,
                                        rearrange_pattern="b t -> b 1 t 1 1")
 
+    def _frames_path_ok(self):
+        ts = self.time_stack
+        conv = ts.in_layers[2]
+        return (isinstance(conv, nn.Conv3d) and tuple(conv.kernel_size) == (3, 1, 1) and tuple(conv.padding) == (1, 0, 0)
+                and tuple(conv.stride) == (1, 1, 1) and not ts.updown and not ts.use_scale_shift_norm and not ts.skip_t_emb
+                and isinstance(ts.skip_connection, nn.Identity))
+
+    def _time_stack_frames(self, x, emb, T):
+        """The temporal ResBlock (video_model.py:41-54, openaimodel.py:328-354 with dims=3 and
+        exchange_temb_dims) evaluated on x [(b T), c, h, w]: temporal GroupNorm+SiLU with strided
+        statistics, (3,1,1) convolutions as channel-stacked 1x1 convolutions, per-frame embedding bias."""
+        ts = self.time_stack
+        g0, g1 = ts.in_layers[0], ts.out_layers[0]
+        h = ops.group_norm_frames(x, T, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True)
+        h = temporal_conv3_frames(h, ts.in_layers[2], T)
+        e = ts.emb_layers(emb).type(h.dtype)                       # [(b T), c]: already per frame
+        h = h + e[:, :, None, None]
+        h = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True)
+        h = temporal_conv3_frames(ts.out_layers[2](h), ts.out_layers[3], T)
+        return x + h
+
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):
         x = super().forward(x, emb)
         t = int(num_video_frames)
         bt, c, h, w = x.shape
+        if self._frames_path_ok():
+            xt = self._time_stack_frames(x, emb, t)
+            a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)
+            if a.ndim == 5:
+                if a.size(0) != bt // t:
+                    a = torch.cat([a] * 2)                                 # CFG-doubled batch (util.py:365-367)
+                a = a.transpose(1, 2).reshape(bt, 1, 1, 1)
+            return torch.lerp(xt, x, a.to(x.dtype))
         xs = x.reshape(bt // t, t, c, h, w).transpose(1, 2)          # b c t h w (view)
         xt = self.time_stack(xs, emb.reshape(bt // t, t, *emb.shape[1:]))
         out = self.time_mixer(x_spatial=xs, x_temporal=xt, image_only_indicator=image_only_indicator)

@@ -24,8 +24,23 @@ def group_norm(x, num_groups, weight, bias, eps, silu=False):
     if x.is_cuda and not _needs_autograd(x, weight, bias):
         from . import hip_ops
         return hip_ops.group_norm_silu(x, num_groups, weight, bias, eps, silu)
-    y = F.group_norm(x.float(), num_groups, weight, bias, eps).type(x.dtype)
+    y = F.group_norm(x.float(), num_groups, weight.float(), bias.float(), eps).type(x.dtype)
     return F.silu(y) if silu else y
+
+
+def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False):
+    """GroupNorm of the temporal layers — statistics over (C/G, T, H, W) per video — evaluated on the
+    frame-major tensor x [(b T), C, H, W] the spatial layers produce (the reference permutes to
+    b c t h w first: video_model.py:71-75). Output has x's layout and dtype."""
+    if x.is_cuda and not _needs_autograd(x, weight, bias):
+        from . import hip_ops
+        return hip_ops.group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu)
+    bt, c = x.shape[:2]
+    x5 = x.reshape(bt // T, T, c, *x.shape[2:]).transpose(1, 2)               # b c t h w
+    y = F.group_norm(x5.float(), num_groups, weight.float(), bias.float(), eps).type(x.dtype)
+    if silu:
+        y = F.silu(y)
+    return y.transpose(1, 2).reshape(x.shape)
 
 
 def attention(q, k, v, heads):
@@ -39,3 +54,30 @@ def attention(q, k, v, heads):
     qh, kh, vh = (t.reshape(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
     o = F.scaled_dot_product_attention(qh, kh, vh)
     return o.transpose(1, 2).reshape(B, Sq, HD)
+
+
+def attention_temporal(q, k, v, heads, T):
+    """Self-attention over the frame axis without regrouping tokens: q/k/v [(bo*T), S, H*D] ->
+    same shape; one softmax per (video, spatial token, head) over its T frames. Equals
+    `(b t) s c -> (b s) t c`, attention, and the inverse regrouping of the reference
+    (sgm/modules/video_attention.py:115, :136-140)."""
+    BT, S, HD = q.shape
+    if q.is_cuda and not _needs_autograd(q, k, v):
+        from . import hip_ops
+        return hip_ops.attention_temporal(q, k, v, heads, T)
+    bo = BT // T
+
+    def regroup(t):
+        return t.reshape(bo, T, S, HD).transpose(1, 2).reshape(bo * S, T, HD)
+    o = attention(regroup(q), regroup(k), regroup(v), heads)
+    return o.reshape(bo, S, T, HD).transpose(1, 2).reshape(BT, S, HD)
+
+
+def geglu(h):
+    """h [..., 2*inner] -> h[..., :inner] * gelu(h[..., inner:]) (sgm/modules/attention.py:93-95)."""
+    inner = h.shape[-1] // 2
+    if h.is_cuda and not _needs_autograd(h) and inner % 8 == 0:
+        from . import hip_ops
+        return hip_ops.geglu(h)
+    a, gate = h.chunk(2, dim=-1)
+    return a * F.gelu(gate)

@@ -27,8 +27,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        a, gate = self.proj(x).chunk(2, dim=-1)
-        return a * F.gelu(gate)
+        return ops.geglu(self.proj(x))
 
 
 class FeedForward(nn.Module):
@@ -79,6 +78,15 @@ class CrossAttention(nn.Module):
         if n_extra:
             out = out[:, n_extra:]
         return self.to_out(out)
+
+
+    def forward_temporal(self, x, T):
+        """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back."""
+        return self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
+
+    def single_token(self, ctx):
+        """Cross-attention to ONE context token: the projected value row (see forward)."""
+        return self.to_out(self.to_v(ctx))
 
 
 # the xformers-backed class of the reference; same maths, same parameters
@@ -209,6 +217,30 @@ class VideoTransformerBlock(nn.Module):
     def forward(self, x, context=None, timesteps=None):
         return maybe_checkpoint(lambda a, c: self._forward(a, c, timesteps), self.checkpoint, x, context)
 
+    def forward_in_place_layout(self, x, frame_context, timesteps):
+        """Same block on x [(b t), s, c] WITHOUT regrouping tokens to (b s) t c: LayerNorm, the
+        feed-forwards and the projections are per-token, the frame self-attention reads its T rows
+        with a stride (ops.attention_temporal), and the cross-attention sees one context token per
+        video (`frame_context` [b, 1, ctx_dim], the first frame's token: video_attention.py:250-254),
+        so its result is one row per video broadcast over frames and positions."""
+        assert not self.disable_self_attn and not self.switch_temporal_ca_to_sa
+        T = int(self.timesteps or timesteps)
+        if self.ff_in:
+            skip = x
+            x = self.ff_in(self.norm_in(x))
+            if self.is_res:
+                x = x + skip
+        x = self.attn1.forward_temporal(self.norm1(x), T) + x
+        if self.attn2 is not None:
+            # norm2(x) does not influence a single-token cross-attention (softmax over one key == 1)
+            row = self.attn2.single_token(frame_context)                 # [b, 1, c]
+            x = x + row.repeat_interleave(T, dim=0)                       # [(b t), 1, c] broadcast over s
+        skip = x
+        x = self.ff(self.norm3(x))
+        if self.is_res:
+            x = x + skip
+        return x
+
     def _forward(self, x, context=None, timesteps=None):
         assert self.timesteps or timesteps
         assert not (self.timesteps and timesteps) or self.timesteps == timesteps
@@ -264,7 +296,13 @@ class SpatialVideoTransformer(SpatialTransformer):
     def forward(self, x, context=None, time_context=None, timesteps=None, image_only_indicator=None):
         _, _, h, w = x.shape
         T = int(timesteps)
-        if self.use_spatial_context:
+        # SVD configuration (use_spatial_context, one CLIP token): the temporal blocks run on the
+        # spatial token layout, no "(b t) s c <-> (b s) t c" copies (4 full-tensor moves per block)
+        in_place = (self.use_spatial_context and context is not None and context.ndim == 3 and context.shape[1] == 1
+                    and all(not m.disable_self_attn and not m.switch_temporal_ca_to_sa for m in self.time_stack))
+        if in_place:
+            frame_context = context[::T]                                       # [b, 1, ctx_dim]
+        elif self.use_spatial_context:
             assert context.ndim == 3, f"n dims of spatial context should be 3 but are {context.ndim}"
             time_context = context[::T].repeat_interleave(h * w, dim=0)        # first frame's context per pixel
         elif time_context is not None:
@@ -277,6 +315,7 @@ class SpatialVideoTransformer(SpatialTransformer):
         emb = self.time_pos_embed(pe.to(self.time_pos_embed[0].weight.dtype))[:, None, :]
         for blk, mix in zip(self.transformer_blocks, self.time_stack):
             t = blk(t, context=context)
-            t = self.time_mixer(x_spatial=t, x_temporal=mix(t + emb, context=time_context, timesteps=T),
-                                image_only_indicator=image_only_indicator)
+            tt = mix.forward_in_place_layout(t + emb, frame_context, T) if in_place else \
+                mix(t + emb, context=time_context, timesteps=T)
+            t = self.time_mixer(x_spatial=t, x_temporal=tt, image_only_indicator=image_only_indicator)
         return self._tokens_out(t, x)

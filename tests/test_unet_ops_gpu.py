@@ -163,3 +163,39 @@ def test_small_unet_bf16_autocast_error_is_reported(G):
     e = rel(y.float(), torch.tensor(G["unet_out"]))
     print(f"bf16-autocast small-UNet relative error vs fp32 reference: {e:.3e}")
     assert e < 8e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1.0 / 128)])
+@pytest.mark.parametrize("bo,T,S,Hh,D", [(2, 14, 37, 5, 64), (1, 25, 8, 2, 16), (3, 3, 128, 2, 32)])
+def test_attention_temporal_matches_regrouped_attention(ops, dtype, tol, bo, T, S, Hh, D):
+    """Strided frame attention == regroup '(b t) s c -> (b s) t c', attend, regroup back (video_attention.py:115-140)."""
+    g = torch.Generator().manual_seed(T * 100 + S)
+    q, k, v = (torch.randn(bo * T, S, Hh * D, generator=g).to(dtype) for _ in range(3))
+    out = ops.attention_temporal(q.cuda(), k.cuda(), v.cuda(), Hh, T)
+    rg = lambda t: t.reshape(bo, T, S, Hh * D).transpose(1, 2).reshape(bo * S, T, Hh * D)
+    ref = _attn_ref(rg(q), rg(k), rg(v), Hh).reshape(bo, S, T, Hh * D).transpose(1, 2).reshape(bo * T, S, Hh * D)
+    assert out.dtype == dtype and rel(out, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.0 / 128)])
+@pytest.mark.parametrize("b,T,C,H,W", [(2, 14, 320, 9, 16), (1, 3, 64, 5, 7), (2, 14, 320, 72, 128), (3, 5, 96, 8, 8)])
+def test_groupnorm_frames_matches_5d_groupnorm(ops, dtype, tol, b, T, C, H, W):
+    """Temporal GroupNorm on the (b t) c h w layout == GroupNorm of the permuted b c t h w tensor."""
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(b * T, C, H, W, generator=g) * 1.7 + 0.3).to(dtype)
+    w, bb = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    x5 = x.double().reshape(b, T, C, H, W).transpose(1, 2)
+    ref = F.silu(F.group_norm(x5, 32, w.double(), bb.double(), 1e-5)).transpose(1, 2).reshape(b * T, C, H, W)
+    y = ops.group_norm_silu_frames(x.cuda(), T, 32, w.cuda(), bb.cuda(), 1e-5, True)
+    assert y.dtype == dtype and y.shape == x.shape and rel(y, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_geglu(ops, dtype, tol):
+    g = torch.Generator().manual_seed(3)
+    for shape in [(7, 33, 2 * 1280), (2, 5, 2 * 128), (28 * 576, 2 * 2560)]:
+        h = (torch.randn(shape, generator=g) * 2).to(dtype)
+        a, gate = h.double().chunk(2, -1)
+        ref = a * F.gelu(gate)
+        out = ops.geglu(h.cuda())
+        assert out.dtype == dtype and out.shape == ref.shape and rel(out, ref) < tol
