@@ -45,6 +45,17 @@ int mvi_groupnorm_silu_temporal(const void* x, void* y, const float* weight, con
                                 float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
+/* General form. chan_bias (nullable): fp32 [(videos*T), C] added to x before the statistics — the timestep-
+ * embedding bias a ResBlock adds in front of its second norm (openaimodel.py:341-352), fused so the sum is never
+ * written. stack3 != 0 (requires the temporal layout; y must not alias x): y is [(videos*T), 3C, spatial] and
+ * receives the normalised frame t at channel block 1 of row t, block 0 of row t+1 and block 2 of row t-1, with
+ * zero frames at the sequence ends — exactly the input a kernel-(3,1,1) temporal convolution needs when it is
+ * evaluated as one 1x1 convolution over 3C channels. T = 1 gives the plain [N, C, spatial] norm. */
+int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                          int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups, float eps,
+                          int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* out = softmax(q k^T * scale) v per (batch, head). Token-major layout, as the Linear projections
  * produce it: q/out [B, Sq, H, D], k/v [B, Sk, H, D], contiguous. No mask (none is used on the
  * denoise path). dtype selects the I/O type; fp32 I/O computes in fp32 (validation mode, 1e-4

@@ -88,6 +88,11 @@ struct GnGeom {
     int64_t S;        // spatial positions per channel in a slice
     int64_t slice_stride;   // C * S
     int cps, slices, Cg, G;
+    const float* chan_bias;   // optional [rows, C] added to x before the statistics (row = n * slices + slice):
+                              // the timestep-embedding bias of ResBlock (openaimodel.py:341-352) fused into the norm
+    int stack3;               // temporal form only: write y three times into [(videos T), 3C, S] — at channel
+                              // offset C of its own frame, offset 0 of the next frame and offset 2C of the previous
+                              // one (zeros at the sequence ends): the input of the (3,1,1) convolution as a 1x1
 };
 __device__ __forceinline__ int64_t gn_slice_base(const GnGeom& q, int64_t g, int slice) {
     const int64_t n = g / q.G, gi = g % q.G;
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict_
     const int chunks = q.cps * q.slices;
     const int64_t e0 = (int64_t)chunk * CH;
     const T* base = x + gn_slice_base(q, g, slice);
+    const float* cb = q.chan_bias ? q.chan_bias + ((g / q.G) * q.slices + slice) * (int64_t)(q.Cg * q.G) + (g % q.G) * q.Cg : nullptr;
     float v[kGnVecPerThread * KV];
     int cnt = 0;
     float sum = 0.f;
@@ -112,8 +118,15 @@ __global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict_
     for (int i = 0; i < kGnVecPerThread; ++i) {
         int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
         if (VEC) {
-            if (e < E) { Io<T>::load(base + e, v + i * KV); cnt += KV; }
-            else {
+            if (e < E) {
+                Io<T>::load(base + e, v + i * KV);
+                cnt += KV;
+                if (cb) {
+                    const float add = cb[e / q.S];
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) v[i * KV + k] += add;
+                }
+            } else {
 #pragma unroll
                 for (int k = 0; k < KV; ++k) v[i * KV + k] = 0.f;
             }
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict_
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
                 bool ok = e + k < E;
-                v[i * KV + k] = ok ? Io<T>::ld1(base + e + k) : 0.f;
+                v[i * KV + k] = ok ? Io<T>::ld1(base + e + k) + (cb ? cb[(e + k) / q.S] : 0.f) : 0.f;
                 cnt += ok;
             }
         }
@@ -187,10 +200,26 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
     __syncthreads();
     const float mean = s_stat[0], rstd = s_stat[1];
     const int c0 = (int)(g % G) * Cg;
+    const int C = Cg * G;
     const int64_t e0 = (int64_t)chunk * CH;
     const int64_t sb = gn_slice_base(q, g, slice);
+    const int64_t row = (g / G) * q.slices + slice;       // first-dimension index of x
     const T* xb = x + sb;
+    const float* cb = q.chan_bias ? q.chan_bias + row * C : nullptr;
+    // output addressing: plain = same as x; stack3 = rows of 3C channels
     T* yb = y + sb;
+    T *y_self = nullptr, *y_next = nullptr, *y_prev = nullptr, *y_zero = nullptr;
+    if (q.stack3) {
+        const int64_t rs = 3 * (int64_t)C * S;            // row stride of the stacked tensor
+        const int64_t co = (int64_t)c0 * S;               // this group's channel offset inside a C-block
+        y_self = y + row * rs + (int64_t)C * S + co;                                  // tap 1 of frame t
+        y_next = slice + 1 < q.slices ? y + (row + 1) * rs + co : nullptr;            // tap 0 of frame t+1
+        y_prev = slice > 0 ? y + (row - 1) * rs + 2 * (int64_t)C * S + co : nullptr;  // tap 2 of frame t-1
+        // the ends of the sequence see a zero frame: frame 0's tap 0 and frame T-1's tap 2 (written by this block
+        // when it owns frame 0 / frame T-1; a one-frame video needs both, handled by the second pointer below)
+        y_zero = slice == 0 ? y + row * rs + co : nullptr;
+    }
+    T* y_zero2 = (q.stack3 && slice == q.slices - 1) ? y + row * (3 * (int64_t)C * S) + 2 * (int64_t)C * S + (int64_t)c0 * S : nullptr;
 #pragma unroll
     for (int i = 0; i < kGnVecPerThread; ++i) {
         int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
@@ -198,29 +227,53 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
         float v[KV];
         if (VEC) {
             Io<T>::load(xb + e, v);
-            int c = c0 + (int)(e / S);                    // S % KV == 0 on this path: one channel per vector
-            float w = weight[c] * rstd, b = bias[c] - mean * w;
+            const int cl = (int)(e / S);                  // S % KV == 0 on this path: one channel per vector
+            const int c = c0 + cl;
+            const float add = cb ? cb[c] : 0.f;
+            float w = weight[c] * rstd, b = bias[c] + (add - mean) * w;
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
                 float t = v[k] * w + b;
                 v[k] = silu ? t / (1.0f + __expf(-t)) : t;
             }
-            Io<T>::store(yb + e, v);
+            if (!q.stack3) {
+                Io<T>::store(yb + e, v);
+            } else {
+                Io<T>::store(y_self + e, v);
+                if (y_next) Io<T>::store(y_next + e, v);
+                if (y_prev) Io<T>::store(y_prev + e, v);
+                if (y_zero || y_zero2) {
+                    float z[KV];
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) z[k] = 0.f;
+                    if (y_zero) Io<T>::store(y_zero + e, z);
+                    if (y_zero2) Io<T>::store(y_zero2 + e, z);
+                }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
                 if (e + k >= E) break;
                 int c = c0 + (int)((e + k) / S);
-                float t = (Io<T>::ld1(xb + e + k) - mean) * rstd * weight[c] + bias[c];
-                Io<T>::st1(yb + e + k, silu ? t / (1.0f + __expf(-t)) : t);
+                float t = (Io<T>::ld1(xb + e + k) + (cb ? cb[c] : 0.f) - mean) * rstd * weight[c] + bias[c];
+                t = silu ? t / (1.0f + __expf(-t)) : t;
+                if (!q.stack3) {
+                    Io<T>::st1(yb + e + k, t);
+                } else {
+                    Io<T>::st1(y_self + e + k, t);
+                    if (y_next) Io<T>::st1(y_next + e + k, t);
+                    if (y_prev) Io<T>::st1(y_prev + e + k, t);
+                    if (y_zero) Io<T>::st1(y_zero + e + k, 0.f);
+                    if (y_zero2) Io<T>::st1(y_zero2 + e + k, 0.f);
+                }
             }
         }
     }
 }
 
 template <typename T>
-static int gn_launch(const void* x, void* y, const float* w, const float* b, int64_t N, int slices, int C, int64_t S,
-                     int G, float eps, int silu, float* part, hipStream_t st) {
+static int gn_launch(const void* x, void* y, const float* w, const float* b, const float* chan_bias, int stack3, int64_t N,
+                     int slices, int C, int64_t S, int G, float eps, int silu, float* part, hipStream_t st) {
     constexpr int KV = Io<T>::kVec;
     constexpr int CH = kGnBlock * kGnVecPerThread * KV;
     GnGeom q;
@@ -228,6 +281,7 @@ static int gn_launch(const void* x, void* y, const float* w, const float* b, int
     q.E = (int64_t)q.Cg * S;
     q.slice_stride = (int64_t)C * S;
     q.cps = (int)((q.E + CH - 1) / CH);
+    q.chan_bias = chan_bias; q.stack3 = stack3;
     const bool vec = (S % KV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
     dim3 grid((unsigned)(q.cps * slices), (unsigned)(N * G));
     if (vec) {
@@ -262,7 +316,8 @@ extern "C" size_t mvi_groupnorm_workspace_bytes(int64_t N, int32_t C, int64_t sp
     return (size_t)(N * groups) * chunks_for(E, MVI_DT_F32) * 3 * sizeof(float);
 }
 
-static int gn_dispatch(const void* x, void* y, const float* weight, const float* bias, int64_t Nv, int32_t T, int32_t C,
+static int gn_dispatch(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int stack3,
+                       int64_t Nv, int32_t T, int32_t C,
                        int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
                        size_t workspace_bytes, void* stream) {
     if (Nv < 0 || T <= 0 || C <= 0 || groups <= 0 || spatial < 0 || C % groups != 0)
@@ -276,9 +331,9 @@ static int gn_dispatch(const void* x, void* y, const float* weight, const float*
     float* part = (float*)workspace;
     int rc;
     switch (dtype) {
-        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
-        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
-        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
         default: return mvi::unet_fail(MVI_EINVAL, "groupnorm: unknown dtype");
     }
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm: kernel launch failed") : MVI_OK;
@@ -287,12 +342,20 @@ static int gn_dispatch(const void* x, void* y, const float* weight, const float*
 extern "C" int mvi_groupnorm_silu(const void* x, void* y, const float* weight, const float* bias, int64_t N,
                                   int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
                                   int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
-    return gn_dispatch(x, y, weight, bias, N, 1, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
+    return gn_dispatch(x, y, weight, bias, nullptr, 0, N, 1, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mvi_groupnorm_silu_temporal(const void* x, void* y, const float* weight, const float* bias,
                                            int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups,
                                            float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
                                            size_t workspace_bytes, void* stream) {
-    return gn_dispatch(x, y, weight, bias, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
+    return gn_dispatch(x, y, weight, bias, nullptr, 0, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                     int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups, float eps,
+                                     int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (stack3 && x == y) return mvi::unet_fail(MVI_EINVAL, "groupnorm: stack3 output cannot alias the input");
+    return gn_dispatch(x, y, weight, bias, chan_bias, stack3 ? 1 : 0, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
 }

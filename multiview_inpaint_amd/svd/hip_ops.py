@@ -61,41 +61,37 @@ def _workspace(dev, nbytes):
     return w
 
 
-def group_norm_silu(x, num_groups, weight, bias, eps, silu):
+def _gn(x, T, num_groups, weight, bias, eps, silu, chan_bias, stack3):
     L = _lib.lib()
     if x.dtype not in _DT:
         raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
     xc = x if x.is_contiguous() else x.contiguous()
     N, Cc = xc.shape[0], xc.shape[1]
     S = xc.numel() // max(N * Cc, 1)
-    y = torch.empty_like(xc)
+    y = torch.empty((N, 3 * Cc, *xc.shape[2:]) if stack3 else xc.shape, dtype=x.dtype, device=x.device)
     w = weight.detach().float().contiguous()
     b = bias.detach().float().contiguous()
+    cb = None
+    if chan_bias is not None:
+        cb = chan_bias.detach().float().contiguous()
+        if cb.shape != (N, Cc):
+            raise ValueError(f"group_norm: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
     ws = _workspace(xc.device, L.mvi_groupnorm_workspace_bytes(N, Cc, S, num_groups))
-    with torch.cuda.device(xc.device), _Timed("groupnorm", 2.0 * xc.numel() * xc.element_size(), xc.device):
-        _check(L.mvi_groupnorm_silu(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc, S, num_groups,
-                                    float(eps), int(bool(silu)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
-                                    _stream(xc.device)), "group_norm")
+    with torch.cuda.device(xc.device), _Timed("groupnorm", (2.0 + 2.0 * bool(stack3)) * xc.numel() * xc.element_size(), xc.device):
+        _check(L.mvi_groupnorm_silu_ex(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                       None if cb is None else cb.data_ptr(), N // T, int(T), Cc, S, num_groups, float(eps),
+                                       int(bool(silu)), int(bool(stack3)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
+                                       _stream(xc.device)), "group_norm")
     return y
 
 
-def group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu):
+def group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=None):
+    return _gn(x, 1, num_groups, weight, bias, eps, silu, chan_bias, False)
+
+
+def group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu, chan_bias=None, stack3=False):
     """x [(b T), C, *spatial] contiguous; statistics per (video, group) over all T frames."""
-    L = _lib.lib()
-    if x.dtype not in _DT:
-        raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
-    xc = x if x.is_contiguous() else x.contiguous()
-    BT, Cc = xc.shape[0], xc.shape[1]
-    S = xc.numel() // max(BT * Cc, 1)
-    y = torch.empty_like(xc)
-    w = weight.detach().float().contiguous()
-    b = bias.detach().float().contiguous()
-    ws = _workspace(xc.device, L.mvi_groupnorm_workspace_bytes(BT, Cc, S, num_groups))
-    with torch.cuda.device(xc.device), _Timed("groupnorm", 2.0 * xc.numel() * xc.element_size(), xc.device):
-        _check(L.mvi_groupnorm_silu_temporal(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(), BT // T, int(T), Cc, S,
-                                             num_groups, float(eps), int(bool(silu)), _DT[x.dtype], ws.data_ptr(),
-                                             ws.numel(), _stream(xc.device)), "group_norm (temporal)")
-    return y
+    return _gn(x, int(T), num_groups, weight, bias, eps, silu, chan_bias, stack3)
 
 
 def attention(q, k, v, heads):

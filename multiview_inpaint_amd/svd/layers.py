@@ -61,8 +61,8 @@ def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
 class GroupNorm32(nn.GroupNorm):
     """GroupNorm computed in fp32 and cast back (util.py:274-276); HIP kernel on the GPU."""
 
-    def forward(self, x, silu: bool = False):
-        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, silu=silu)
+    def forward(self, x, silu: bool = False, chan_bias=None):
+        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, silu=silu, chan_bias=chan_bias)
 
 
 def normalization(channels):
@@ -253,30 +253,24 @@ class ResBlock(TimestepBlock):
             scale, shift = e.chunk(2, dim=1)
             h = self.out_layers[0](h) * (1 + scale) + shift
             h = self.out_layers[3](self.out_layers[2](F.silu(h)))
+        elif self.exchange_temb_dims:
+            h = norm_act(self.out_layers, h + e.transpose(1, 2))       # b t c ... -> b c t ...
+            h = self.out_layers[3](self.out_layers[2](h))
         else:
-            if self.exchange_temb_dims:
-                e = e.transpose(1, 2)                       # b t c ... -> b c t ...
-            h = norm_act(self.out_layers, h + e)
+            # h + emb is never materialised: the per-(sample, channel) bias is added inside the norm kernel
+            h = self.out_layers[0](h, silu=True, chan_bias=e.reshape(e.shape[0], e.shape[1]))
             h = self.out_layers[3](self.out_layers[2](h))
         return self.skip_connection(x) + h
 
 
-def temporal_conv3_frames(x, conv: nn.Conv3d, T: int):
-    """Conv3d with kernel (3,1,1), padding (1,0,0) applied along the frame axis of x [(b T), Ci, H, W]
-    without leaving that layout: y_t = W[..., 0] x_{t-1} + W[..., 1] x_t + W[..., 2] x_{t+1} is ONE 1x1
-    convolution over the three neighbouring frames stacked on the channel axis (K = 3 Ci GEMM), instead
-    of permuting to b c t h w and running an im2col 3-D convolution."""
-    bt, ci, h, w = x.shape
-    b = bt // T
-    xv = x.reshape(b, T, ci, h, w)
-    xc = x.new_empty(b, T, 3 * ci, h, w)
-    xc[:, 1:, :ci] = xv[:, :-1]
-    xc[:, 0, :ci] = 0
-    xc[:, :, ci:2 * ci] = xv
-    xc[:, :-1, 2 * ci:] = xv[:, 1:]
-    xc[:, -1, 2 * ci:] = 0
-    wt = conv.weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(conv.out_channels, 3 * ci, 1, 1)   # tap-major channels
-    return F.conv2d(xc.reshape(bt, 3 * ci, h, w), wt, conv.bias)
+def temporal_conv3_stacked(x3, conv: nn.Conv3d):
+    """Conv3d with kernel (3,1,1), padding (1,0,0) along the frame axis, given its input already stacked
+    as x3 [(b T), 3 Ci, H, W] = (frame t-1 | frame t | frame t+1) (ops.group_norm_frames(stack3=True)):
+    y_t = W[..., 0] x_{t-1} + W[..., 1] x_t + W[..., 2] x_{t+1} is ONE 1x1 convolution with K = 3 Ci,
+    instead of permuting to b c t h w and running an im2col 3-D convolution."""
+    ci3 = x3.shape[1]
+    wt = conv.weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(conv.out_channels, ci3, 1, 1)   # tap-major channels
+    return F.conv2d(x3, wt, conv.bias)
 
 
 class VideoResBlock(ResBlock):
@@ -311,12 +305,11 @@ class VideoResBlock(ResBlock):
         statistics, (3,1,1) convolutions as channel-stacked 1x1 convolutions, per-frame embedding bias."""
         ts = self.time_stack
         g0, g1 = ts.in_layers[0], ts.out_layers[0]
-        h = ops.group_norm_frames(x, T, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True)
-        h = temporal_conv3_frames(h, ts.in_layers[2], T)
-        e = ts.emb_layers(emb).type(h.dtype)                       # [(b T), c]: already per frame
-        h = h + e[:, :, None, None]
-        h = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True)
-        h = temporal_conv3_frames(ts.out_layers[2](h), ts.out_layers[3], T)
+        h3 = ops.group_norm_frames(x, T, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, stack3=True)
+        h = temporal_conv3_stacked(h3, ts.in_layers[2])
+        e = ts.emb_layers(emb)                                     # [(b T), c]: already per frame, fused into the norm
+        h3 = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, stack3=True)
+        h = temporal_conv3_stacked(ts.out_layers[2](h3), ts.out_layers[3])
         return x + h
 
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):

@@ -19,28 +19,49 @@ def _needs_autograd(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def group_norm(x, num_groups, weight, bias, eps, silu=False):
-    """GroupNorm over (C/G, *spatial) with fp32 statistics, optional fused SiLU; output dtype = x.dtype."""
-    if x.is_cuda and not _needs_autograd(x, weight, bias):
+def _stack3(y, T):
+    """[(b T), C, ...] -> [(b T), 3C, ...]: frame t-1 | frame t | frame t+1 on the channel axis (zeros at the ends)."""
+    bt, c = y.shape[:2]
+    yv = y.reshape(bt // T, T, c, *y.shape[2:])
+    out = y.new_zeros(bt // T, T, 3 * c, *y.shape[2:])
+    out[:, 1:, :c] = yv[:, :-1]
+    out[:, :, c:2 * c] = yv
+    out[:, :-1, 2 * c:] = yv[:, 1:]
+    return out.reshape(bt, 3 * c, *y.shape[2:])
+
+
+def group_norm(x, num_groups, weight, bias, eps, silu=False, chan_bias=None):
+    """GroupNorm over (C/G, *spatial) with fp32 statistics, optional fused SiLU; output dtype = x.dtype.
+    chan_bias [N, C] (optional) is added to x first (the ResBlock's timestep-embedding bias)."""
+    if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
-        return hip_ops.group_norm_silu(x, num_groups, weight, bias, eps, silu)
-    y = F.group_norm(x.float(), num_groups, weight.float(), bias.float(), eps).type(x.dtype)
+        return hip_ops.group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+    xf = x.float()
+    if chan_bias is not None:
+        xf = xf + chan_bias.float().reshape(*chan_bias.shape, *([1] * (x.ndim - 2)))
+    y = F.group_norm(xf, num_groups, weight.float(), bias.float(), eps).type(x.dtype)
     return F.silu(y) if silu else y
 
 
-def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False):
+def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False, chan_bias=None, stack3=False):
     """GroupNorm of the temporal layers — statistics over (C/G, T, H, W) per video — evaluated on the
     frame-major tensor x [(b T), C, H, W] the spatial layers produce (the reference permutes to
-    b c t h w first: video_model.py:71-75). Output has x's layout and dtype."""
-    if x.is_cuda and not _needs_autograd(x, weight, bias):
+    b c t h w first: video_model.py:71-75). chan_bias [(b T), C] is added first; stack3 returns the
+    result as [(b T), 3C, H, W] = (previous | own | next frame), the input of a (3,1,1) temporal
+    convolution evaluated as one 1x1 convolution."""
+    if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
-        return hip_ops.group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu)
+        return hip_ops.group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, stack3=stack3)
     bt, c = x.shape[:2]
-    x5 = x.reshape(bt // T, T, c, *x.shape[2:]).transpose(1, 2)               # b c t h w
-    y = F.group_norm(x5.float(), num_groups, weight.float(), bias.float(), eps).type(x.dtype)
+    xf = x.float()
+    if chan_bias is not None:
+        xf = xf + chan_bias.float().reshape(bt, c, *([1] * (x.ndim - 2)))
+    x5 = xf.reshape(bt // T, T, c, *x.shape[2:]).transpose(1, 2)              # b c t h w
+    y = F.group_norm(x5, num_groups, weight.float(), bias.float(), eps).type(x.dtype)
     if silu:
         y = F.silu(y)
-    return y.transpose(1, 2).reshape(x.shape)
+    y = y.transpose(1, 2).reshape(x.shape)
+    return _stack3(y, T) if stack3 else y
 
 
 def attention(q, k, v, heads):

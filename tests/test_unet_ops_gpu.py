@@ -199,3 +199,22 @@ def test_geglu(ops, dtype, tol):
         ref = a * F.gelu(gate)
         out = ops.geglu(h.cuda())
         assert out.dtype == dtype and out.shape == ref.shape and rel(out, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.0 / 128)])
+@pytest.mark.parametrize("b,T,C,H,W", [(2, 14, 320, 9, 16), (1, 1, 64, 5, 8), (2, 3, 96, 8, 8), (1, 2, 64, 3, 5)])
+def test_groupnorm_frames_fused_bias_and_stacked_output(ops, dtype, tol, b, T, C, H, W):
+    """chan_bias is added before the statistics; stack3 lays (t-1 | t | t+1) on the channel axis with zero ends."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(C + T)
+    x = (torch.randn(b * T, C, H, W, generator=g) * 1.3).to(dtype)
+    w, bb, cb = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(b * T, C, generator=g)
+    ref = dev_ops.group_norm_frames(x.double().cpu(), T, 32, w.double(), bb.double(), 1e-5, silu=True, chan_bias=cb.double(), stack3=True)
+    y = ops.group_norm_silu_frames(x.cuda(), T, 32, w.cuda(), bb.cuda(), 1e-5, True, chan_bias=cb.cuda(), stack3=True)
+    assert y.shape == (b * T, 3 * C, H, W) and rel(y, ref) < tol
+    yv = y.reshape(b, T, 3, C, H, W)
+    assert (yv[:, 0, 0] == 0).all() and (yv[:, -1, 2] == 0).all()
+    # plain layout with the bias only
+    ref2 = dev_ops.group_norm(x.double().cpu(), 32, w.double(), bb.double(), 1e-5, silu=False, chan_bias=cb.double())
+    y2 = ops.group_norm_silu(x.cuda(), 32, w.cuda(), bb.cuda(), 1e-5, False, chan_bias=cb.cuda())
+    assert rel(y2, ref2) < tol

@@ -28,14 +28,15 @@ step_ms = (int(rows[-1]["End_Timestamp"]) - int(rows[fl[-46]]["Start_Timestamp"]
 last = [r for r in rows if int(r["Start_Timestamp"]) >= int(rows[fl[-23]]["Start_Timestamp"]) - 30_000_000]
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in last:
-    k = r["Kernel_Name"].split("(")[0][:100]
+    k = r["Kernel_Name"]
+    k = (k[:60] + " ... " + k[k.find("native::", 80):k.find("native::", 80) + 120]) if "elementwise_kernel" in k or k.startswith("void at::native::") else k.split("(")[0][:100]
     agg[k][0] += 1
     agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 tot = sum(v[1] for v in agg.values())
 with open("$OUT/steady_step_kernels.txt", "w") as fo:
     print(f"steady-state step: {len(last)} kernels, {tot:.1f} ms of kernel time (window ~ last step)", file=fo)
     for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-        print(f"{k:102s} {n:5d} {ms:9.2f} ms {100 * ms / tot:5.1f}%", file=fo)
+        print(f"{k:190s} {n:5d} {ms:9.2f} ms {100 * ms / tot:5.1f}%", file=fo)
 print(open("$OUT/steady_step_kernels.txt").read())
 PY
 rm -rf $OUT/trace
