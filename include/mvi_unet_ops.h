@@ -79,6 +79,12 @@ int mvi_attention_temporal(const void* q, const void* k, const void* v, void* ou
  * (svd_inpaint1/sgm/modules/attention.py:87-95). inner must be a multiple of 4 (fp32) / 8 (bf16, f16). */
 int mvi_geglu(const void* h, void* out, int64_t rows, int32_t inner, int32_t dtype, void* stream);
 
+/* out[n, c, p] = h[n, c, p] + bias[c] + x[n, c, p] over [N, C, spatial] activations in one pass; x and bias are
+ * optional (NULL). Folds a convolution's bias (PyTorch-ROCm adds it in a separate kernel) and the ResBlock skip
+ * add `self.skip_connection(x) + h` (svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:354). out may alias h. */
+int mvi_bias_residual_add(const void* h, const void* x, const float* bias, void* out, int64_t N, int32_t C,
+                          int64_t spatial, int32_t dtype, void* stream);
+
 /* Which kernel mvi_attention_forward would pick: 0 = rowtile fp32-math, 1 = MFMA flash. */
 int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);
 

@@ -18,6 +18,8 @@ def bind(L):
     L.mvi_attention_temporal.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.mvi_geglu.restype = C.c_int
     L.mvi_geglu.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.mvi_bias_residual_add.restype = C.c_int
+    L.mvi_bias_residual_add.argtypes = [vp, vp, vp, vp, i64, i32, i64, i32, vp]
     L.mvi_attention_kernel_kind.restype = C.c_int
     L.mvi_attention_kernel_kind.argtypes = [i32, i32, i32, i32]
     L.mvi_unet_last_error.restype = C.c_char_p

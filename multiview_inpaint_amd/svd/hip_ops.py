@@ -139,5 +139,25 @@ def geglu(h):
     return out
 
 
+def bias_residual_add(h, bias, x):
+    L = _lib.lib()
+    if h.dtype not in _DT:
+        raise TypeError(f"bias_residual_add: unsupported dtype {h.dtype}")
+    hc = h if h.is_contiguous() else h.contiguous()
+    xc = None
+    if x is not None:
+        if x.shape != h.shape or x.dtype != h.dtype:
+            raise ValueError("bias_residual_add: x must match h in shape and dtype")
+        xc = x if x.is_contiguous() else x.contiguous()
+    N, Cc = hc.shape[0], hc.shape[1]
+    S = hc.numel() // max(N * Cc, 1)
+    b = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty_like(hc)
+    with torch.cuda.device(h.device), _Timed("bias_residual", (2.0 + (x is not None)) * hc.numel() * hc.element_size(), h.device):
+        _check(L.mvi_bias_residual_add(hc.data_ptr(), None if xc is None else xc.data_ptr(), None if b is None else b.data_ptr(),
+                                       out.data_ptr(), N, Cc, S, _DT[h.dtype], _stream(h.device)), "bias_residual_add")
+    return out
+
+
 def attention_kernel_kind(Sq, Sk, D, dtype):
     return int(_lib.lib().mvi_attention_kernel_kind(Sq, Sk, D, _DT[dtype]))

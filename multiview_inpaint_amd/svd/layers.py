@@ -69,6 +69,12 @@ def normalization(channels):
     return GroupNorm32(32, channels)
 
 
+def conv_no_bias(conv, x, bias=None):
+    """The convolution with its bias withheld (or replaced): the caller folds the bias into the next fused op,
+    because PyTorch-ROCm otherwise adds it in a separate broadcast pass over the whole activation."""
+    return conv._conv_forward(x, conv.weight, bias)
+
+
 def norm_act(seq: nn.Sequential, x):
     """Runs a `[GroupNorm32, SiLU, ...]` prefix as ONE fused op; returns the activated tensor."""
     return seq[0](x, silu=True)
@@ -240,6 +246,8 @@ class ResBlock(TimestepBlock):
         return maybe_checkpoint(self._forward, self.use_checkpoint, x, emb)
 
     def _forward(self, x, emb):
+        if not (self.updown or self.use_scale_shift_norm or self.skip_t_emb or self.exchange_temb_dims):
+            return self._forward_fused(x, emb)
         h = norm_act(self.in_layers, x)
         if self.updown:
             h, x = self.h_upd(h), self.x_upd(x)
@@ -263,14 +271,36 @@ class ResBlock(TimestepBlock):
         return self.skip_connection(x) + h
 
 
-def temporal_conv3_stacked(x3, conv: nn.Conv3d):
+def temporal_conv3_stacked(x3, conv: nn.Conv3d, with_bias=True):
     """Conv3d with kernel (3,1,1), padding (1,0,0) along the frame axis, given its input already stacked
     as x3 [(b T), 3 Ci, H, W] = (frame t-1 | frame t | frame t+1) (ops.group_norm_frames(stack3=True)):
     y_t = W[..., 0] x_{t-1} + W[..., 1] x_t + W[..., 2] x_{t+1} is ONE 1x1 convolution with K = 3 Ci,
     instead of permuting to b c t h w and running an im2col 3-D convolution."""
     ci3 = x3.shape[1]
     wt = conv.weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(conv.out_channels, ci3, 1, 1)   # tap-major channels
-    return F.conv2d(x3, wt, conv.bias)
+    return F.conv2d(x3, wt, conv.bias if with_bias else None)
+
+
+def _resblock_forward_fused(self, x, emb):
+    """The common ResBlock configuration (no up/down-sampling, additive embedding) with every bias and
+    broadcast add folded into a neighbouring kernel: conv1's bias rides with the embedding bias inside the
+    second GroupNorm, conv2's bias is added together with the skip tensor in one pass."""
+    conv1, conv2 = self.in_layers[2], self.out_layers[3]
+    h = conv_no_bias(conv1, norm_act(self.in_layers, x))
+    e = self.emb_layers(emb)
+    e = e.reshape(e.shape[0], e.shape[1]).float()
+    if conv1.bias is not None:
+        e = e + conv1.bias.float()
+    h = self.out_layers[0](h, silu=True, chan_bias=e)
+    h = conv_no_bias(conv2, self.out_layers[2](h))
+    if isinstance(self.skip_connection, nn.Identity):
+        return ops.bias_residual_add(h, conv2.bias, x)
+    sk = self.skip_connection
+    sb = sk.bias if conv2.bias is None else (conv2.bias if sk.bias is None else sk.bias + conv2.bias)
+    return h + conv_no_bias(sk, x, sb)
+
+
+ResBlock._forward_fused = _resblock_forward_fused
 
 
 class VideoResBlock(ResBlock):
@@ -305,12 +335,15 @@ class VideoResBlock(ResBlock):
         statistics, (3,1,1) convolutions as channel-stacked 1x1 convolutions, per-frame embedding bias."""
         ts = self.time_stack
         g0, g1 = ts.in_layers[0], ts.out_layers[0]
+        c1, c2 = ts.in_layers[2], ts.out_layers[3]
         h3 = ops.group_norm_frames(x, T, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, stack3=True)
-        h = temporal_conv3_stacked(h3, ts.in_layers[2])
-        e = ts.emb_layers(emb)                                     # [(b T), c]: already per frame, fused into the norm
+        h = temporal_conv3_stacked(h3, c1, with_bias=False)
+        e = ts.emb_layers(emb).float()                             # [(b T), c]: already per frame, fused into the norm
+        if c1.bias is not None:
+            e = e + c1.bias.float()
         h3 = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, stack3=True)
-        h = temporal_conv3_stacked(ts.out_layers[2](h3), ts.out_layers[3])
-        return x + h
+        h = temporal_conv3_stacked(ts.out_layers[2](h3), c2, with_bias=False)
+        return ops.bias_residual_add(h, c2.bias, x)
 
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):
         x = super().forward(x, emb)

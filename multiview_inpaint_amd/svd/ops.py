@@ -102,3 +102,16 @@ def geglu(h):
         return hip_ops.geglu(h)
     a, gate = h.chunk(2, dim=-1)
     return a * F.gelu(gate)
+
+
+def bias_residual_add(h, bias=None, x=None):
+    """h [N, C, *spatial] + bias[c] + x in one pass (conv bias and ResBlock skip add, openaimodel.py:354)."""
+    if h.is_cuda and not _needs_autograd(h, bias, x):
+        from . import hip_ops
+        return hip_ops.bias_residual_add(h, bias, x)
+    out = h
+    if bias is not None:
+        out = out + bias.to(h.dtype).reshape(1, -1, *([1] * (h.ndim - 2)))
+    if x is not None:
+        out = out + x
+    return out

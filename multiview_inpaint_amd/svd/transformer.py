@@ -158,7 +158,7 @@ class SpatialTransformer(nn.Module):
         h = self.norm(x)
         if not self.use_linear:
             h = self.proj_in(h)
-        h = h.flatten(2).transpose(1, 2)                     # b c h w -> b (h w) c
+        h = h.flatten(2).transpose(1, 2).contiguous()        # b c h w -> b (h w) c (contiguous: Linear fuses its bias)
         return self.proj_in(h) if self.use_linear else h
 
     def _tokens_out(self, t, x_in):

@@ -218,3 +218,17 @@ def test_groupnorm_frames_fused_bias_and_stacked_output(ops, dtype, tol, b, T, C
     ref2 = dev_ops.group_norm(x.double().cpu(), 32, w.double(), bb.double(), 1e-5, silu=False, chan_bias=cb.double())
     y2 = ops.group_norm_silu(x.cuda(), 32, w.cuda(), bb.cuda(), 1e-5, False, chan_bias=cb.cuda())
     assert rel(y2, ref2) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_bias_residual_add(ops, dtype, tol):
+    g = torch.Generator().manual_seed(11)
+    for shape in [(4, 64, 24, 16), (3, 96, 5, 7), (2, 320, 14, 9, 16)]:
+        h = torch.randn(shape, generator=g).to(dtype)
+        x = torch.randn(shape, generator=g).to(dtype)
+        b = torch.randn(shape[1], generator=g)
+        view = (1, -1) + (1,) * (len(shape) - 2)
+        for xx, bb in ((x, b), (None, b), (x, None)):
+            ref = h.double() + (0 if bb is None else bb.double().view(view)) + (0 if xx is None else xx.double())
+            out = ops.bias_residual_add(h.cuda(), None if bb is None else bb.cuda(), None if xx is None else xx.cuda())
+            assert out.dtype == dtype and rel(out, ref) < tol
