@@ -119,9 +119,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("MVI_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path with a 1-rank group
+    if world > 1 or force_dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            td.init_process_group("nccl", device_id=dev)
 
     W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
     M = (deg + 1) ** 2
@@ -141,12 +147,12 @@ def main():
     def step():
         color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
         R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, **kw)
-        if world > 1:
+        if world > 1 or force_dist:
             bucket.all_reduce()
         return st, radii
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +169,7 @@ def main():
     ms = (C.c_float * 8)()
     calls = (C.c_int32 * 8)()
     _lib.check(L.mvi_raster_timing_read(ms, calls), "timing_read")
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
@@ -236,7 +242,7 @@ def main():
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
             out["svd"] = svd
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         td.destroy_process_group()
 
 

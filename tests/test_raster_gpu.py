@@ -264,3 +264,28 @@ def test_full_size_properties_1p5M_1080p(R):
         err = (gb[k] - 2 * ga[k]).abs().max() / (gb[k].abs().max() + 1e-12)
         assert err < 1e-4, (k, float(err))
         assert (ga[k][radii == 0] == 0).all()
+
+
+def test_partial_sh_degree_scale_modifier_and_background_gradient(R, ro):
+    """sh_degree below the stored coefficient count (the reference raises the active degree during training,
+    gs-simp/scene/gaussian_model.py:119-121), scale_modifier != 1 and a non-zero background: forward + backward."""
+    cam, sc, bg = small_scene(8, N=1200, W=144, H=96, deg=3, log_scale=np.log(0.05))
+    sc = dict(sc, sh_degree=1)                             # 16 coefficients stored, degree 1 active
+    t = _to_dev(sc)
+    p = oracle_params(ro, cam, sc, bg, scale_modifier=0.7)
+    rs = _settings(R, cam, bg, 1, scale_modifier=0.7)
+    kw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    f = ro.forward(p, sc["means3D"], sc["opacities"], **kw)
+    g_img = np.random.default_rng(8).normal(size=(3, 96, 144)).astype(np.float32)
+    b = ro.backward(p, f, g_img, sc["means3D"], **kw)
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                  rotations=t["rotations"])
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
+                             rotations=t["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), f["radii"])
+    frac, worst = _close_frac(color.cpu().numpy(), f["color"])
+    assert frac <= FLIP_FRAC, (frac, worst)
+    assert (g["shs"][:, 4:] == 0).all()                   # inactive coefficients get exactly zero gradient
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
+        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
