@@ -14,11 +14,11 @@
 //                                S^T accumulators, converted in place: MFMA C/D layout == next B layout
 //                                up to the fixed key permutation the V^T fragment read follows)
 // K tile rows are padded to 72 elements (b128 reads conflict-free), V is stored transposed with a
-// row of 68 elements (b64 reads conflict-free). Global loads of tile t+1 are issued before the
-// MFMAs of tile t and written to LDS after them.
+// row of 68 elements (b64 reads conflict-free).
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../../include/mvi_raster.h"
 #include "../../include/mvi_unet_ops.h"
@@ -64,18 +64,25 @@ template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *re
 
 constexpr float kRescaleThreshold = 8.0f;   // log2 units: O and l are rescaled only when the row max grows by > 2^8
 
+// Software pipeline: one wave keeps BOTH pipes busy. While the VALU runs the softmax of tile t (scores
+// computed in the previous iteration), the matrix pipe runs S^T = K Q^T of tile t+1; the PV MFMAs of
+// tile t follow as their P fragments come out of the converts (the compiler's own schedule of that
+// single basic block spaces the 16 MFMAs ~8 VALU issues apart; sched_group_barrier hints made it worse).
+// Costs a second score accumulator; 163 VGPRs, pinned to 3 waves/SIMD. The issue port, not the matrix
+// pipe, bounds the loop at D = 64: 32 exp (8 cyc) + 32 fma + 32 add + 16 max3 + 16 cvt + 16 MFMA issue
+// slots ~ 900 cycles per wave-tile against 512 matrix-pipe cycles. LDS holds K_{t+1} / K_{t+2} and V_t / V_{t+1}: two buffers each, one
+// barrier per tile (K_{t+2} overwrites K_t, whose last reader finished before the previous barrier;
+// V_{t+1} overwrites V_{t-1} likewise).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                         const T* __restrict__ v, T* __restrict__ out, int H, int Sq,
-                                                         int Sk, float scale_log2e, int q_blocks, int total_blocks) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                   const T* __restrict__ v, T* __restrict__ out, int H,
+                                                                   int Sq, int Sk, float scale_log2e, int q_blocks,
+                                                                   int total_blocks) {
     using M = Mma<T>;
     using frag = typename M::frag;
-    // two K / V^T tile buffers: the next tile is written while the current one is read (one barrier per tile)
     __shared__ __attribute__((aligned(16))) uint16_t s_k[2][kFK * kKStride];
     __shared__ __attribute__((aligned(16))) uint16_t s_vt[2][kFD * kVStride];
 
-    // XCD-aware block order: the 8 XCDs get contiguous runs of blocks, so the q-blocks that share one
-    // (batch, head)'s K/V stream hit the same L2 (speed only; any placement is correct)
     int bid = blockIdx.x;
     if ((total_blocks & 7) == 0) bid = (bid & 7) * (total_blocks >> 3) + (bid >> 3);
     const int qb = bid % q_blocks;
@@ -89,7 +96,6 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
     const int q0 = qb * kFQ + wave * 32;
     const int qrow = q0 + qcol;
 
-    // Q fragments (B operand of S^T = K Q^T): element j of step s is Q[qrow][16 s + 8 hh + j]
     frag qf[4];
     {
         const T* qp = q + ((b * Sq + (qrow < Sq ? qrow : 0)) * hd + (int64_t)h * kFD + 8 * hh);
@@ -102,33 +108,33 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    // m is the reference exponent (scaled log2 units) the accumulators are expressed in; it trails the
-    // true row max by at most kRescaleThreshold, so p = exp2(s c - m) <= 2^8 and nothing overflows
     float m = -INFINITY, l = 0.f;
 
-    // staging: thread -> (K row kr, 16-element segment ks) and (V key pair vp, 8-element segment vs)
     const int kr = tid >> 2, ks = tid & 3;
     const int vp = tid >> 3, vs = tid & 7;
     const T* kbase = k + (b * Sk * hd + (int64_t)h * kFD);
     const T* vbase = v + (b * Sk * hd + (int64_t)h * kFD);
     u32x4 rk0, rk1, rv0, rv1;
-    auto load_tile = [&](int k0) {
-        const u32x4 z = {0, 0, 0, 0};
+    const u32x4 z4 = {0, 0, 0, 0};
+    auto load_k = [&](int k0) {
         int r = k0 + kr;
         const T* p = kbase + (int64_t)r * hd + 16 * ks;
-        rk0 = r < Sk ? *reinterpret_cast<const u32x4*>(p) : z;
-        rk1 = r < Sk ? *reinterpret_cast<const u32x4*>(p + 8) : z;
+        rk0 = r < Sk ? *reinterpret_cast<const u32x4*>(p) : z4;
+        rk1 = r < Sk ? *reinterpret_cast<const u32x4*>(p + 8) : z4;
+    };
+    auto load_v = [&](int k0) {
         int r0 = k0 + 2 * vp;
         const T* pv = vbase + (int64_t)r0 * hd + 8 * vs;
-        rv0 = r0 < Sk ? *reinterpret_cast<const u32x4*>(pv) : z;
-        rv1 = r0 + 1 < Sk ? *reinterpret_cast<const u32x4*>(pv + hd) : z;
+        rv0 = r0 < Sk ? *reinterpret_cast<const u32x4*>(pv) : z4;
+        rv1 = r0 + 1 < Sk ? *reinterpret_cast<const u32x4*>(pv + hd) : z4;
     };
-    auto store_tile = [&](int buf) {
+    auto store_k = [&](int buf) {
         uint16_t* sk = s_k[buf];
-        uint16_t* sv = s_vt[buf];
         *reinterpret_cast<u32x4*>(&sk[kr * kKStride + 16 * ks]) = rk0;
         *reinterpret_cast<u32x4*>(&sk[kr * kKStride + 16 * ks + 8]) = rk1;
-        // transpose: (V[key0][d], V[key0+1][d]) -> one dword at V^T[d][key0]
+    };
+    auto store_v = [&](int buf) {
+        uint16_t* sv = s_vt[buf];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t a = rv0[i], c = rv1[i];
@@ -137,21 +143,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
             *reinterpret_cast<uint32_t*>(&sv[(8 * vs + 2 * i + 1) * kVStride + 2 * vp]) = hi;
         }
     };
-
-    const int n_tiles = (Sk + kFK - 1) / kFK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) load_tile((t + 1) * kFK);      // in flight during this tile's MFMAs
-        const int k0 = t * kFK;
-        const uint16_t* sk = s_k[buf];
-        const uint16_t* sv = s_vt[buf];
-
-        // ---- S^T = K Q^T
-        f32x16 st[2];
-        u32x4 kf[2][4];                                       // all eight K fragments in flight before the first MFMA
+    auto qk = [&](const uint16_t* sk, f32x16* st) {
+        u32x4 kf[2][4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -164,8 +157,24 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
 #pragma unroll
             for (int s = 0; s < 4; ++s) st[kb] = M::mfma(as_frag<frag>(kf[kb][s]), qf[s], st[kb]);
         }
-        // st[kb][r] is key k0 + 32 kb + (r & 3) + 8 (r >> 2) + 4 hh for query qrow (raw, unscaled scores)
-        if (k0 + kFK > Sk) {                                  // tail tile only (block-uniform)
+    };
+
+    const int n_tiles = (Sk + kFK - 1) / kFK;
+    // prologue: K_0, V_0 -> buffers 0; K_1 -> buffer 1; scores of tile 0
+    load_k(0); load_v(0);
+    store_k(0); store_v(0);
+    if (n_tiles > 1) { load_k(kFK); store_k(1); }
+    __syncthreads();
+    f32x16 st[2], sn[2];
+    qk(s_k[0], st);
+
+    auto tile = [&](int t, auto has_next_c) {
+        constexpr bool kHasNext = decltype(has_next_c)::value;
+        const int k0 = t * kFK;
+        if (t + 2 < n_tiles) load_k((t + 2) * kFK);             // lands while this tile is processed
+        if (kHasNext) load_v((t + 1) * kFK);
+        // ---- row max of tile t, reference exponent (VALU only; rarely rescales)
+        if (!kHasNext && k0 + kFK > Sk) {                       // only the last tile can be ragged
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -175,10 +184,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
         float rmax = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) rmax = fmaxf(rmax, fmaxf(st[0][r], st[1][r]));
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 32)) * scale_log2e;   // scale > 0: max commutes with it
-        // deferred rescale: keep the old reference exponent unless the row max outgrew it by 2^8
-        const bool grow = rmax > m + kRescaleThreshold;        // always true on the first tile (m = -inf)
-        if (__ballot(grow) != 0ull) {                          // wave-uniform: skipped on almost every later tile
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32)) * scale_log2e;
+        const bool grow = rmax > m + kRescaleThreshold;
+        if (__ballot(grow) != 0ull) {
             const float m_new = grow ? rmax : m;
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             l *= alpha;
@@ -186,25 +194,23 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
             m = m_new;
         }
+        // ---- one scheduling region: QK^T of tile t+1 (matrix pipe) under exp/convert of tile t (VALU),
+        //      then PV of tile t as its P fragments become available
+        if (kHasNext) qk(s_k[(t + 1) & 1], sn);
+        const uint16_t* sv = s_vt[t & 1];
         float rsum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], scale_log2e, -m));
-                st[kb][r] = p;
-                rsum += p;
-            }
-        l += rsum;
-
-        // ---- O^T += V^T P^T ; P fragment of key-step (kb, s2) = registers 8 s2 .. 8 s2 + 7 of st[kb]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4 pr;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pr[i] = M::pack2(st[kb][8 * s2 + 2 * i], st[kb][8 * s2 + 2 * i + 1]);
+                for (int i = 0; i < 4; ++i) {
+                    float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][8 * s2 + 2 * i], scale_log2e, -m));
+                    float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][8 * s2 + 2 * i + 1], scale_log2e, -m));
+                    rsum += p0 + p1;
+                    pr[i] = M::pack2(p0, p1);
+                }
                 const frag pf = as_frag<frag>(pr);
                 const int koff = 32 * kb + 16 * s2 + 4 * hh;
 #pragma unroll
@@ -216,14 +222,21 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T* __restrict__ q
                     o[db] = M::mfma(as_frag<frag>(av), pf, o[db]);
                 }
             }
-        if (t + 1 < n_tiles) store_tile(buf ^ 1);               // other buffer: nobody reads it during this tile
-        __syncthreads();
-    }
+        l += rsum;
+        if (t + 2 < n_tiles) store_k(t & 1);                     // K_t is dead: its scores exist since the last iteration
+        if (kHasNext) store_v((t + 1) & 1);                      // V_{t-1} is dead
+        if (kHasNext) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[0][i] = sn[0][i]; st[1][i] = sn[1][i]; }
+        }
+    };
+    for (int t = 0; t + 1 < n_tiles; ++t) tile(t, std::true_type{});
+    tile(n_tiles - 1, std::false_type{});
     l += __shfl_xor(l, 32);
     if (qrow < Sq) {
         const float inv = 1.0f / l;
         T* op = out + ((b * Sq + qrow) * hd + (int64_t)h * kFD);
-        // o[db][r] is channel 32 db + (r & 3) + 8 (r >> 2) + 4 hh: four consecutive channels per 8-byte store
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
