@@ -85,6 +85,34 @@ int mvi_geglu(const void* h, void* out, int64_t rows, int32_t inner, int32_t dty
 int mvi_bias_residual_add(const void* h, const void* x, const float* bias, void* out, int64_t N, int32_t C,
                           int64_t spatial, int32_t dtype, void* stream);
 
+/* ---- token-row kernels of the transformer blocks: t [R, C] token-major, contiguous ------------------------------
+ * Residual add(s) + the NEXT LayerNorm in one pass (svd_inpaint1/sgm/modules/attention.py:544-572 `x = attn(norm(x)) + x`
+ * chains; video_attention.py:110-141):
+ *     s_pre = x + h                       (h optional: NULL -> s_pre = x)
+ *     s     = s_pre + row[r / row_div]    (row optional, [ceil(R / row_div), C], same dtype: the single-token
+ *                                          cross-attention row per image / per video, or the frame-index embedding)
+ *     y     = LayerNorm(s) * weight + bias          (statistics fp32; weight / bias fp32 [C])
+ * s_pre and s are written when their pointers are non-NULL (s_pre needs h; s needs h or row). Each materialised
+ * intermediate is rounded to the storage type where the unfused graph would round it. h == row == NULL is a plain
+ * LayerNorm (nn.LayerNorm, attention.py:509-511). C must split into 2^k lanes x <= 8 16-byte vectors
+ * (mvi_layernorm_supported tells). */
+int mvi_add_layernorm(const void* x, const void* h, const void* row, int64_t row_div, const float* weight,
+                      const float* bias, void* s_pre, void* s, void* y, int64_t R, int32_t C, float eps, int32_t dtype,
+                      void* stream);
+int mvi_layernorm_supported(int32_t C, int32_t dtype);
+
+/* out = lerp(x + h, base, alpha[r / row_div]) = alpha * base + (1 - alpha) * (x + h): the temporal block's last residual
+ * add fused with AlphaBlender (svd_inpaint1/sgm/modules/diffusionmodules/util.py:312-372; video_attention.py:290-294).
+ * alpha: fp32 [ceil(R / row_div)]; h optional. PyTorch's two-sided lerp formula. */
+int mvi_add_lerp(const void* x, const void* h, const void* base, const float* alpha, int64_t row_div, void* out, int64_t R,
+                 int32_t C, int32_t dtype, void* stream);
+
+/* out[n, c, p] = tok[n, p, c] + x_in[n, c, p]: "b (h w) c -> b c h w" and the transformer's outer skip connection
+ * (svd_inpaint1/sgm/modules/attention.py:717-722, video_attention.py:298-301) in one pass through an LDS tile.
+ * C and spatial must be multiples of the 16-byte vector width (4 fp32 / 8 bf16, f16). */
+int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64_t N, int32_t C, int64_t spatial,
+                             int32_t dtype, void* stream);
+
 /* Which kernel mvi_attention_forward would pick: 0 = rowtile fp32-math, 1 = MFMA flash. */
 int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);
 

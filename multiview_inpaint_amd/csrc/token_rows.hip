@@ -1,0 +1,269 @@
+// Token-row kernels of the transformer blocks for gfx950 — all HBM-bound, one pass each.
+// The reference's blocks (svd_inpaint1/sgm/modules/attention.py:544-572, video_attention.py:110-141,
+// :278-296) interleave residual adds, broadcast adds (the single-token cross-attention row, the frame-index
+// embedding) and LayerNorms over the token-major activation t [R, C]; every one of those is a separate
+// full-tensor pass in PyTorch (and PyTorch-ROCm's LayerNorm reaches < 1 TB/s at C = 320). Here:
+//
+//   add_layernorm : s_pre = x + h,  s = s_pre + row[r / row_div],  y = LayerNorm(s) * w + b
+//                   (h, row, and the s_pre / s outputs are optional) — residual add(s) + the NEXT norm in one pass
+//   add_lerp      : out = lerp(x + h, base, alpha[r / row_div])     — last residual add + AlphaBlender
+//                   (diffusionmodules/util.py:312-372) in one pass
+//   tokens_to_planes_add : out[n, c, p] = tok[n, p, c] + x_in[n, c, p]  — "b (h w) c -> b c h w" + the
+//                   transformer's outer skip (attention.py:717-722) through an LDS tile, no strided traffic
+//
+// Row layout of add_layernorm: a row of C elements is covered by L = 2^k lanes x K 16-byte vectors, vector j of
+// lane i at element (j * L + i) * V (V = 8 bf16/f16 or 4 fp32) — adjacent lanes read adjacent 16 B. The whole row
+// lives in registers: mean, then the centred sum of squares (two passes over registers, fp32), reduced over the
+// L lanes with xor shuffles. Intermediates that the unfused graph would materialise (s_pre, s) are rounded to the
+// storage type exactly there, so the fused result equals the op-by-op result bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+#include "unet_io.h"
+
+namespace mvi {
+
+int unet_fail(int code, const char* msg);
+
+struct AddLnArgs {
+    const void *x, *h, *row;
+    const float *w, *b;
+    void *s_pre, *s, *y;
+    int64_t R, row_div;
+    int C, L, log2L;
+    float eps;
+};
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(AddLnArgs a) {
+    constexpr int V = Io<T>::kVec;
+    const int L = a.L;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.log2L;
+    const int li = threadIdx.x & (L - 1);
+    if (r >= a.R) return;                       // rows are L-lane aligned: an L-group exits together (L <= 64)
+    const int64_t base = r * a.C;
+    const T* x = (const T*)a.x + base;
+    const T* h = a.h ? (const T*)a.h + base : nullptr;
+    const T* row = a.row ? (const T*)a.row + (r / a.row_div) * a.C : nullptr;
+    float v[K][V];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int e = (j * L + li) * V;
+        Io<T>::load(x + e, v[j]);
+        if (h) {
+            float t[V];
+            Io<T>::load(h + e, t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[j][k] = round_to<T>(v[j][k] + t[k]);
+        }
+        if (a.s_pre) Io<T>::store((T*)a.s_pre + base + e, v[j]);
+        if (row) {
+            float t[V];
+            Io<T>::load(row + e, t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[j][k] = round_to<T>(v[j][k] + t[k]);
+        }
+        if (a.s) Io<T>::store((T*)a.s + base + e, v[j]);
+#pragma unroll
+        for (int k = 0; k < V; ++k) sum += v[j][k];
+    }
+    for (int o = 1; o < L; o <<= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)a.C;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float d = v[j][k] - mean; m2 += d * d; }
+    for (int o = 1; o < L; o <<= 1) m2 += __shfl_xor(m2, o);
+    const float rstd = rsqrtf(m2 / (float)a.C + a.eps);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int e = (j * L + li) * V;
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = (v[j][k] - mean) * rstd * a.w[e + k] + a.b[e + k];
+        Io<T>::store((T*)a.y + base + e, o);
+    }
+}
+
+template <typename T>
+static int add_layernorm_launch(AddLnArgs a, hipStream_t st) {
+    constexpr int V = Io<T>::kVec;
+    if (a.C % V != 0) return MVI_EINVAL;
+    const int vecs = a.C / V;
+    int L = 1, log2L = 0;
+    while (L <= 64 && (vecs % L != 0 || vecs / L > 8)) { L <<= 1; ++log2L; }
+    if (L > 64) return MVI_EINVAL;
+    a.L = L; a.log2L = log2L;
+    const int K = vecs / L;
+    const int64_t threads = a.R * L;
+    const int64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+#define MVI_LN(KK) case KK: hipLaunchKernelGGL((add_layernorm_kernel<T, KK>), dim3((unsigned)blocks), dim3(256), 0, st, a); break
+    switch (K) {
+        MVI_LN(1); MVI_LN(2); MVI_LN(3); MVI_LN(4); MVI_LN(5); MVI_LN(6); MVI_LN(7); MVI_LN(8);
+        default: return MVI_EINVAL;
+    }
+#undef MVI_LN
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+// out = lerp(t, base, alpha) with t = x + h, in the two-sided form PyTorch's lerp uses
+// (weight < 0.5 ? start + w (end - start) : end - (end - start)(1 - w))
+template <typename T>
+__global__ __launch_bounds__(256) void add_lerp_kernel(const T* __restrict__ x, const T* __restrict__ h,
+                                                       const T* __restrict__ base, const float* __restrict__ alpha,
+                                                       T* __restrict__ out, int64_t n_vec, int vec_per_row, int64_t row_div) {
+    constexpr int V = Io<T>::kVec;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_vec) return;
+    const int64_t r = i / vec_per_row;
+    const float w = alpha[r / row_div];
+    float a[V], b[V], c[V];
+    Io<T>::load(x + i * V, a);
+    Io<T>::load(base + i * V, c);
+    if (h) {
+        Io<T>::load(h + i * V, b);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] = round_to<T>(a[k] + b[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float d = c[k] - a[k];
+        a[k] = w < 0.5f ? a[k] + w * d : c[k] - d * (1.0f - w);
+    }
+    Io<T>::store(out + i * V, a);
+}
+
+// out[n, c, p] = tok[n, p, c] + x_in[n, c, p]; 64 x 64 (p x c) tiles through LDS
+constexpr int kTpTile = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __restrict__ tok, const T* __restrict__ x_in,
+                                                                   T* __restrict__ out, int C, int64_t S, int p_tiles,
+                                                                   int c_tiles) {
+    constexpr int V = Io<T>::kVec;
+    constexpr int VPR = kTpTile / V;            // 16-B vectors per tile row
+    __shared__ float s_t[kTpTile][kTpTile + 1];
+    int bid = blockIdx.x;
+    const int pt = bid % p_tiles; bid /= p_tiles;
+    const int ct = bid % c_tiles;
+    const int64_t n = bid / c_tiles;
+    const int64_t p0 = (int64_t)pt * kTpTile;
+    const int c0 = ct * kTpTile;
+    // read tok[n, p0 + pr, c0 + 8 cv ..]: rows of the token-major tile
+    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
+        const int pr = i / VPR, cv = i % VPR;
+        if (p0 + pr < S && c0 + cv * V < C) {
+            float t[V];
+            Io<T>::load(tok + ((n * S + p0 + pr) * C + c0 + cv * V), t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s_t[pr][cv * V + k] = t[k];
+        }
+    }
+    __syncthreads();
+    // write out[n, c0 + cr, p0 + 8 pv ..]
+    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
+        const int cr = i / VPR, pv = i % VPR;
+        if (c0 + cr < C && p0 + pv * V < S) {
+            const int64_t o = (n * C + c0 + cr) * S + p0 + pv * V;
+            float t[V], xi[V];
+            Io<T>::load(x_in + o, xi);
+#pragma unroll
+            for (int k = 0; k < V; ++k) t[k] = s_t[pv * V + k][cr] + xi[k];
+            Io<T>::store(out + o, t);
+        }
+    }
+}
+
+}  // namespace mvi
+
+using namespace mvi;
+
+extern "C" int mvi_add_layernorm(const void* x, const void* h, const void* row, int64_t row_div, const float* weight,
+                                 const float* bias, void* s_pre, void* s, void* y, int64_t R, int32_t C, float eps,
+                                 int32_t dtype, void* stream) {
+    if (R < 0 || C <= 0) return unet_fail(MVI_EINVAL, "add_layernorm: bad shape");
+    if (R == 0) return MVI_OK;
+    if (!x || !weight || !bias || !y) return unet_fail(MVI_EINVAL, "add_layernorm: NULL pointer");
+    if (row && row_div <= 0) return unet_fail(MVI_EINVAL, "add_layernorm: row_div must be positive");
+    if (s_pre && !h) return unet_fail(MVI_EINVAL, "add_layernorm: s_pre requested without h");
+    if (s && !h && !row) return unet_fail(MVI_EINVAL, "add_layernorm: s requested without h or row");
+    AddLnArgs a{x, h, row, weight, bias, s_pre, s, y, R, row ? row_div : 1, C, 0, 0, eps};
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = add_layernorm_launch<float>(a, (hipStream_t)stream); break;
+        case MVI_DT_BF16: rc = add_layernorm_launch<__hip_bfloat16>(a, (hipStream_t)stream); break;
+        case MVI_DT_F16: rc = add_layernorm_launch<__half>(a, (hipStream_t)stream); break;
+        default: return unet_fail(MVI_EINVAL, "add_layernorm: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "add_layernorm: C must split into 2^k lanes x <= 8 16-byte vectors");
+    return rc ? unet_fail(MVI_EHIP, "add_layernorm: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_layernorm_supported(int32_t C, int32_t dtype) {
+    const int V = dtype == MVI_DT_F32 ? 4 : 8;
+    if (C <= 0 || C % V) return 0;
+    const int vecs = C / V;
+    for (int L = 1; L <= 64; L <<= 1)
+        if (vecs % L == 0 && vecs / L <= 8) return 1;
+    return 0;
+}
+
+template <typename T>
+static int add_lerp_launch(const void* x, const void* h, const void* base, const float* alpha, int64_t row_div, void* out,
+                           int64_t R, int C, hipStream_t st) {
+    constexpr int V = Io<T>::kVec;
+    if (C % V) return MVI_EINVAL;
+    const int64_t n_vec = R * (C / V);
+    const int64_t blocks = (n_vec + 255) / 256;
+    if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+    hipLaunchKernelGGL((add_lerp_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)h,
+                       (const T*)base, alpha, (T*)out, n_vec, C / V, row_div);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+extern "C" int mvi_add_lerp(const void* x, const void* h, const void* base, const float* alpha, int64_t row_div, void* out,
+                            int64_t R, int32_t C, int32_t dtype, void* stream) {
+    if (R < 0 || C <= 0 || row_div <= 0) return unet_fail(MVI_EINVAL, "add_lerp: bad shape");
+    if (R == 0) return MVI_OK;
+    if (!x || !base || !alpha || !out) return unet_fail(MVI_EINVAL, "add_lerp: NULL pointer");
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = add_lerp_launch<float>(x, h, base, alpha, row_div, out, R, C, (hipStream_t)stream); break;
+        case MVI_DT_BF16: rc = add_lerp_launch<__hip_bfloat16>(x, h, base, alpha, row_div, out, R, C, (hipStream_t)stream); break;
+        case MVI_DT_F16: rc = add_lerp_launch<__half>(x, h, base, alpha, row_div, out, R, C, (hipStream_t)stream); break;
+        default: return unet_fail(MVI_EINVAL, "add_lerp: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "add_lerp: C must be a multiple of the 16-byte vector width");
+    return rc ? unet_fail(MVI_EHIP, "add_lerp: kernel launch failed") : MVI_OK;
+}
+
+template <typename T>
+static int tokens_to_planes_launch(const void* tok, const void* x_in, void* out, int64_t N, int C, int64_t S, hipStream_t st) {
+    constexpr int V = Io<T>::kVec;
+    if (C % V || S % V) return MVI_EINVAL;
+    const int p_tiles = (int)((S + kTpTile - 1) / kTpTile), c_tiles = (C + kTpTile - 1) / kTpTile;
+    const int64_t blocks = N * p_tiles * c_tiles;
+    if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+    hipLaunchKernelGGL((tokens_to_planes_add_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)tok,
+                       (const T*)x_in, (T*)out, C, S, p_tiles, c_tiles);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+extern "C" int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64_t N, int32_t C, int64_t spatial,
+                                        int32_t dtype, void* stream) {
+    if (N < 0 || C <= 0 || spatial < 0) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: bad shape");
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!tok || !x_in || !out) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: NULL pointer");
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = tokens_to_planes_launch<float>(tok, x_in, out, N, C, spatial, (hipStream_t)stream); break;
+        case MVI_DT_BF16: rc = tokens_to_planes_launch<__hip_bfloat16>(tok, x_in, out, N, C, spatial, (hipStream_t)stream); break;
+        case MVI_DT_F16: rc = tokens_to_planes_launch<__half>(tok, x_in, out, N, C, spatial, (hipStream_t)stream); break;
+        default: return unet_fail(MVI_EINVAL, "tokens_to_planes_add: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: C and spatial must be multiples of the 16-byte vector width");
+    return rc ? unet_fail(MVI_EHIP, "tokens_to_planes_add: kernel launch failed") : MVI_OK;
+}

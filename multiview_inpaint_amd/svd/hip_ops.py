@@ -61,6 +61,25 @@ def _workspace(dev, nbytes):
     return w
 
 
+_f32_cache = {}
+
+
+def _f32(p):
+    """fp32 contiguous copy of a (small) parameter, cached per (storage, version): the kernels take their affine
+    parameters in fp32, the bf16-weights model stores them in bf16, and converting on every call costs a launch."""
+    if p.dtype == torch.float32 and p.is_contiguous():
+        return p.detach()
+    key = (p.data_ptr(), p._version, p.dtype, tuple(p.shape), p.device)
+    hit = _f32_cache.get(id(p))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    t = p.detach().float().contiguous()
+    if len(_f32_cache) > 8192:
+        _f32_cache.clear()
+    _f32_cache[id(p)] = (key, t)
+    return t
+
+
 def _gn(x, T, num_groups, weight, bias, eps, silu, chan_bias, stack3):
     L = _lib.lib()
     if x.dtype not in _DT:
@@ -69,8 +88,7 @@ def _gn(x, T, num_groups, weight, bias, eps, silu, chan_bias, stack3):
     N, Cc = xc.shape[0], xc.shape[1]
     S = xc.numel() // max(N * Cc, 1)
     y = torch.empty((N, 3 * Cc, *xc.shape[2:]) if stack3 else xc.shape, dtype=x.dtype, device=x.device)
-    w = weight.detach().float().contiguous()
-    b = bias.detach().float().contiguous()
+    w, b = _f32(weight), _f32(bias)
     cb = None
     if chan_bias is not None:
         cb = chan_bias.detach().float().contiguous()
@@ -151,11 +169,95 @@ def bias_residual_add(h, bias, x):
         xc = x if x.is_contiguous() else x.contiguous()
     N, Cc = hc.shape[0], hc.shape[1]
     S = hc.numel() // max(N * Cc, 1)
-    b = None if bias is None else bias.detach().float().contiguous()
+    b = None if bias is None else _f32(bias)
     out = torch.empty_like(hc)
     with torch.cuda.device(h.device), _Timed("bias_residual", (2.0 + (x is not None)) * hc.numel() * hc.element_size(), h.device):
         _check(L.mvi_bias_residual_add(hc.data_ptr(), None if xc is None else xc.data_ptr(), None if b is None else b.data_ptr(),
                                        out.data_ptr(), N, Cc, S, _DT[h.dtype], _stream(h.device)), "bias_residual_add")
+    return out
+
+
+def layernorm_supported(C_, dtype):
+    return dtype in _DT and bool(_lib.lib().mvi_layernorm_supported(int(C_), _DT[dtype]))
+
+
+def add_layer_norm(x, weight, bias, eps, h=None, row=None, ret_pre=False):
+    """x [..., C] contiguous; returns (y, s, s_pre): s_pre = x + h, s = s_pre + row (broadcast over equal runs of
+    rows), y = LayerNorm(s). s is None when neither h nor row is given; s_pre only when ret_pre and h."""
+    L = _lib.lib()
+    if x.dtype not in _DT:
+        raise TypeError(f"add_layer_norm: unsupported dtype {x.dtype}")
+    Cc = x.shape[-1]
+    xc = x if x.is_contiguous() else x.contiguous()
+    R = xc.numel() // Cc
+    hc = rc = None
+    row_div = 1
+    if h is not None:
+        if h.shape != x.shape or h.dtype != x.dtype:
+            raise ValueError("add_layer_norm: h must match x in shape and dtype")
+        hc = h if h.is_contiguous() else h.contiguous()
+    if row is not None:
+        if row.dtype != x.dtype or row.shape[-1] != Cc:
+            raise ValueError("add_layer_norm: row must be [G, C] / [G, 1, C] of x's dtype")
+        rc = row.reshape(-1, Cc)
+        rc = rc if rc.is_contiguous() else rc.contiguous()
+        G = rc.shape[0]
+        if G == 0 or R % G:
+            raise ValueError(f"add_layer_norm: {R} rows do not split into {G} equal runs")
+        row_div = R // G
+    y = torch.empty_like(xc)
+    s = torch.empty_like(xc) if (hc is not None or rc is not None) else None
+    s_pre = torch.empty_like(xc) if (ret_pre and hc is not None and rc is not None) else None
+    n_io = 2 + (hc is not None) + (s is not None) + (s_pre is not None)
+    with torch.cuda.device(x.device), _Timed("add_layernorm", float(n_io) * xc.numel() * xc.element_size(), x.device):
+        _check(L.mvi_add_layernorm(xc.data_ptr(), None if hc is None else hc.data_ptr(), None if rc is None else rc.data_ptr(),
+                                   row_div, _f32(weight).data_ptr(), _f32(bias).data_ptr(),
+                                   None if s_pre is None else s_pre.data_ptr(), None if s is None else s.data_ptr(),
+                                   y.data_ptr(), R, Cc, float(eps), _DT[x.dtype], _stream(x.device)), "add_layer_norm")
+    if ret_pre and s_pre is None:                  # no separate buffer needed: s_pre coincides with x or with s
+        s_pre = xc if hc is None else s
+    return y, s, s_pre
+
+
+def add_lerp(x, h, base, alpha):
+    """lerp(x + h, base, alpha) with alpha [G] fp32 broadcast over equal runs of the rows of x [..., C]."""
+    L = _lib.lib()
+    if x.dtype not in _DT or base.dtype != x.dtype or base.shape != x.shape:
+        raise TypeError("add_lerp: x and base must share shape and a supported dtype")
+    Cc = x.shape[-1]
+    xc = x if x.is_contiguous() else x.contiguous()
+    bc = base if base.is_contiguous() else base.contiguous()
+    hc = None
+    if h is not None:
+        if h.shape != x.shape or h.dtype != x.dtype:
+            raise ValueError("add_lerp: h must match x in shape and dtype")
+        hc = h if h.is_contiguous() else h.contiguous()
+    R = xc.numel() // Cc
+    al = alpha.detach().reshape(-1).float().contiguous()
+    G = al.numel()
+    if G == 0 or R % G:
+        raise ValueError(f"add_lerp: {R} rows do not split into {G} equal runs")
+    out = torch.empty_like(xc)
+    with torch.cuda.device(x.device), _Timed("add_lerp", (3.0 + (hc is not None)) * xc.numel() * xc.element_size(), x.device):
+        _check(L.mvi_add_lerp(xc.data_ptr(), None if hc is None else hc.data_ptr(), bc.data_ptr(), al.data_ptr(), R // G,
+                              out.data_ptr(), R, Cc, _DT[x.dtype], _stream(x.device)), "add_lerp")
+    return out
+
+
+def tokens_to_planes_add(tok, x_in):
+    """tok [N, S, C] + x_in [N, C, *spatial] -> [N, C, *spatial]."""
+    L = _lib.lib()
+    if tok.dtype not in _DT or x_in.dtype != tok.dtype:
+        raise TypeError("tokens_to_planes_add: tok and x_in must share a supported dtype")
+    N, S, Cc = tok.shape
+    if x_in.shape[0] != N or x_in.shape[1] != Cc or x_in.numel() != tok.numel():
+        raise ValueError(f"tokens_to_planes_add: tok {tuple(tok.shape)} does not match x_in {tuple(x_in.shape)}")
+    tc = tok if tok.is_contiguous() else tok.contiguous()
+    xc = x_in if x_in.is_contiguous() else x_in.contiguous()
+    out = torch.empty_like(xc)
+    with torch.cuda.device(tok.device), _Timed("tokens_to_planes_add", 3.0 * tc.numel() * tc.element_size(), tok.device):
+        _check(L.mvi_tokens_to_planes_add(tc.data_ptr(), xc.data_ptr(), out.data_ptr(), N, Cc, S, _DT[tok.dtype],
+                                          _stream(tok.device)), "tokens_to_planes_add")
     return out
 
 

@@ -115,3 +115,44 @@ def bias_residual_add(h, bias=None, x=None):
     if x is not None:
         out = out + x
     return out
+
+
+def add_layer_norm(x, norm, h=None, row=None, ret_pre=False):
+    """Residual add(s) fused with the next LayerNorm: s_pre = x + h, s = s_pre + row, y = norm(s) for token-major
+    x [B, S, C]; `row` [G, 1, C] (G divides B*S) is broadcast over equal runs of rows — the single-token
+    cross-attention row or the frame-index embedding. Returns (y, s, s_pre); s is x when h and row are None,
+    s_pre is returned only with ret_pre (and is s when row is None). `norm` is the nn.LayerNorm."""
+    C_ = x.shape[-1]
+    if x.is_cuda and not _needs_autograd(x, h, row, norm.weight, norm.bias):
+        from . import hip_ops
+        if norm.elementwise_affine and hip_ops.layernorm_supported(C_, x.dtype):
+            y, s, s_pre = hip_ops.add_layer_norm(x, norm.weight, norm.bias, norm.eps, h=h, row=row, ret_pre=ret_pre)
+            return y, (x if s is None else s), s_pre
+    s_pre = x if h is None else x + h
+    s = s_pre
+    if row is not None:
+        G = row.reshape(-1, C_).shape[0]
+        rows = x.numel() // C_
+        s = (s_pre.reshape(G, rows // G, C_) + row.reshape(G, 1, C_)).reshape(x.shape)
+    return norm(s), s, (s_pre if ret_pre else None)
+
+
+def add_lerp(x, h, base, alpha):
+    """lerp(x + h, base, alpha): alpha * base + (1 - alpha) * (x + h) with alpha [G] broadcast over equal runs of
+    the rows of x [B, S, C] (AlphaBlender after the temporal block's last residual add)."""
+    if x.is_cuda and not _needs_autograd(x, h, base, alpha) and x.shape[-1] % 8 == 0:
+        from . import hip_ops
+        return hip_ops.add_lerp(x, h, base, alpha)
+    t = x if h is None else x + h
+    C_ = x.shape[-1]
+    G = alpha.numel()
+    a = alpha.reshape(G, 1, 1).to(x.dtype)
+    return torch.lerp(t.reshape(G, -1, C_), base.reshape(G, -1, C_), a).reshape(x.shape)
+
+
+def tokens_to_planes_add(tok, x_in):
+    """tok [B, (h w), C] -> [B, C, h, w] plus x_in, one pass (SpatialTransformer's exit)."""
+    if tok.is_cuda and not _needs_autograd(tok, x_in) and tok.shape[-1] % 8 == 0 and tok.shape[1] % 8 == 0:
+        from . import hip_ops
+        return hip_ops.tokens_to_planes_add(tok, x_in)
+    return tok.transpose(1, 2).reshape(x_in.shape) + x_in

@@ -116,11 +116,29 @@ class BasicTransformerBlock(nn.Module):
         return self._forward(x, context, additional_tokens, n_times_crossframe_attn_in_self)
 
     def _forward(self, x, context=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
-        x = self.attn1(self.norm1(x), context=context if self.disable_self_attn else None,
-                       additional_tokens=additional_tokens,
-                       n_times_crossframe_attn_in_self=0 if self.disable_self_attn else n_times_crossframe_attn_in_self) + x
-        x = self.attn2(self.norm2(x), context=context, additional_tokens=additional_tokens) + x
-        return self.ff(self.norm3(x)) + x
+        if additional_tokens is not None or n_times_crossframe_attn_in_self:
+            x = self.attn1(self.norm1(x), context=context if self.disable_self_attn else None,
+                           additional_tokens=additional_tokens,
+                           n_times_crossframe_attn_in_self=0 if self.disable_self_attn else n_times_crossframe_attn_in_self) + x
+            x = self.attn2(self.norm2(x), context=context, additional_tokens=additional_tokens) + x
+            return self.ff(self.norm3(x)) + x
+        h, skip = self.forward_deferred(x, context)
+        return h + skip
+
+    def forward_deferred(self, x, context=None):
+        """The block with its last residual add left to the caller: returns (h, skip), block output = h + skip.
+        Every inner residual add is fused with the LayerNorm that follows it (ops.add_layer_norm). With a
+        single context token the cross-attention output is one row per image (CrossAttention.forward), norm2
+        cannot influence it and is not evaluated, and both inner adds collapse into one pass."""
+        n1, _, _ = ops.add_layer_norm(x, self.norm1)
+        a = self.attn1(n1, context=context if self.disable_self_attn else None)
+        ctx = x if context is None else context
+        if context is not None and ctx.shape[1] == 1:
+            n3, x, _ = ops.add_layer_norm(x, self.norm3, h=a, row=self.attn2.single_token(ctx))
+        else:
+            n2, x, _ = ops.add_layer_norm(x, self.norm2, h=a)
+            n3, x, _ = ops.add_layer_norm(x, self.norm3, h=self.attn2(n2, context=context))
+        return self.ff(n3), x
 
 
 def Normalize(in_channels):
@@ -164,11 +182,9 @@ class SpatialTransformer(nn.Module):
     def _tokens_out(self, t, x_in):
         b, c, h, w = x_in.shape
         if self.use_linear:
-            t = self.proj_out(t)
+            return ops.tokens_to_planes_add(self.proj_out(t), x_in)   # b (h w) c -> b c h w, + x_in, one pass
         t = t.transpose(1, 2).reshape(b, -1, h, w)
-        if not self.use_linear:
-            t = self.proj_out(t)
-        return t + x_in
+        return self.proj_out(t) + x_in
 
     def forward(self, x, context=None):
         ctxs = context if isinstance(context, list) else [context]
@@ -217,29 +233,33 @@ class VideoTransformerBlock(nn.Module):
     def forward(self, x, context=None, timesteps=None):
         return maybe_checkpoint(lambda a, c: self._forward(a, c, timesteps), self.checkpoint, x, context)
 
-    def forward_in_place_layout(self, x, frame_context, timesteps):
-        """Same block on x [(b t), s, c] WITHOUT regrouping tokens to (b s) t c: LayerNorm, the
-        feed-forwards and the projections are per-token, the frame self-attention reads its T rows
-        with a stride (ops.attention_temporal), and the cross-attention sees one context token per
-        video (`frame_context` [b, 1, ctx_dim], the first frame's token: video_attention.py:250-254),
-        so its result is one row per video broadcast over frames and positions."""
+    def forward_in_place_layout(self, h, skip, emb, frame_context, timesteps):
+        """Same block on tokens [(b t), s, c] WITHOUT regrouping to (b s) t c: LayerNorm, the feed-forwards
+        and the projections are per-token, the frame self-attention reads its T rows with a stride
+        (ops.attention_temporal), and the cross-attention sees one context token per video (`frame_context`
+        [b, 1, ctx_dim], the first frame's token: video_attention.py:250-254), so its result is one row per
+        video broadcast over frames and positions (norm2 cannot influence it and is not evaluated).
+
+        Input: the spatial block's output still split as h + skip (BasicTransformerBlock.forward_deferred) and
+        the frame-index embedding `emb` [(b t), 1, c]. Returns (x_spatial, f, x): x_spatial = h + skip, the
+        block output is f + x (x None when the block is not residual) — left un-added for the blend.
+        Every residual / broadcast add rides on the LayerNorm that follows it."""
         assert not self.disable_self_attn and not self.switch_temporal_ca_to_sa
         T = int(self.timesteps or timesteps)
         if self.ff_in:
-            skip = x
-            x = self.ff_in(self.norm_in(x))
+            ni, x, x_spatial = ops.add_layer_norm(skip, self.norm_in, h=h, row=emb, ret_pre=True)
+            fi = self.ff_in(ni)
             if self.is_res:
-                x = x + skip
-        x = self.attn1.forward_temporal(self.norm1(x), T) + x
-        if self.attn2 is not None:
-            # norm2(x) does not influence a single-token cross-attention (softmax over one key == 1)
-            row = self.attn2.single_token(frame_context)                 # [b, 1, c]
-            x = x + row.repeat_interleave(T, dim=0)                       # [(b t), 1, c] broadcast over s
-        skip = x
-        x = self.ff(self.norm3(x))
-        if self.is_res:
-            x = x + skip
-        return x
+                n1, x, _ = ops.add_layer_norm(x, self.norm1, h=fi)
+            else:
+                x = fi
+                n1, _, _ = ops.add_layer_norm(x, self.norm1)
+        else:
+            n1, x, x_spatial = ops.add_layer_norm(skip, self.norm1, h=h, row=emb, ret_pre=True)
+        a = self.attn1.forward_temporal(n1, T)
+        row = self.attn2.single_token(frame_context) if self.attn2 is not None else None     # [b, 1, c]
+        n3, x, _ = ops.add_layer_norm(x, self.norm3, h=a, row=row)
+        return x_spatial, self.ff(n3), (x if self.is_res else None)
 
     def _forward(self, x, context=None, timesteps=None):
         assert self.timesteps or timesteps
@@ -313,9 +333,20 @@ class SpatialVideoTransformer(SpatialTransformer):
         frame_idx = torch.arange(T, device=x.device).repeat(x.shape[0] // T)
         pe = timestep_embedding(frame_idx, self.in_channels, repeat_only=False, max_period=self.max_time_embed_period)
         emb = self.time_pos_embed(pe.to(self.time_pos_embed[0].weight.dtype))[:, None, :]
+        alpha = None
         for blk, mix in zip(self.transformer_blocks, self.time_stack):
-            t = blk(t, context=context)
-            tt = mix.forward_in_place_layout(t + emb, frame_context, T) if in_place else \
-                mix(t + emb, context=time_context, timesteps=T)
-            t = self.time_mixer(x_spatial=t, x_temporal=tt, image_only_indicator=image_only_indicator)
+            if in_place:
+                h_sp, skip = blk.forward_deferred(t, context)
+                x_spatial, f, x_t = mix.forward_in_place_layout(h_sp, skip, emb, frame_context, T)
+                if alpha is None:
+                    alpha = self.time_mixer.get_alpha(image_only_indicator)
+                    if alpha.numel() > 1 and alpha.size(0) != t.size(0):
+                        alpha = torch.cat([alpha] * 2)                      # the reference's CFG patch (util.py:365-367)
+                    alpha = alpha.reshape(-1).to(t.dtype)
+                # alpha * spatial + (1 - alpha) * (f + x_t), with the temporal block's last residual add inside
+                t = ops.add_lerp(f if x_t is None else x_t, None if x_t is None else f, x_spatial, alpha)
+            else:
+                t = blk(t, context=context)
+                tt = mix(t + emb, context=time_context, timesteps=T)
+                t = self.time_mixer(x_spatial=t, x_temporal=tt, image_only_indicator=image_only_indicator)
         return self._tokens_out(t, x)

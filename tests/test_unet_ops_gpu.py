@@ -232,3 +232,74 @@ def test_bias_residual_add(ops, dtype, tol):
             ref = h.double() + (0 if bb is None else bb.double().view(view)) + (0 if xx is None else xx.double())
             out = ops.bias_residual_add(h.cuda(), None if bb is None else bb.cuda(), None if xx is None else xx.cuda())
             assert out.dtype == dtype and rel(out, ref) < tol
+
+
+LN_CASES = [(2, 36, 320), (3, 16, 640), (2, 8, 1280), (4, 6, 32), (2, 5, 64), (2, 7, 48), (1, 3, 24), (28, 2304, 640)]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("B,S,C", LN_CASES)
+@pytest.mark.parametrize("mode", ["plain", "h", "row", "h+row"])
+def test_add_layernorm(ops, dtype, tol, B, S, C, mode):
+    """s_pre / s are bit-exact against the op-by-op PyTorch graph (same roundings to the storage type); the
+    LayerNorm output is compared with an fp64 LayerNorm of that same s."""
+    if dtype == torch.float32 and C % 4 or dtype != torch.float32 and C % 8:
+        pytest.skip("C not a multiple of the 16-byte vector")
+    if not ops.layernorm_supported(C, dtype):
+        pytest.skip("row split unsupported")
+    g = torch.Generator().manual_seed(B * 1000 + S * 10 + C)
+    x = (torch.randn(B, S, C, generator=g) * 1.5 + 0.3).to(dtype).cuda()
+    h = (torch.randn(B, S, C, generator=g)).to(dtype).cuda() if "h" in mode else None
+    row = (torch.randn(B, 1, C, generator=g)).to(dtype).cuda() if "row" in mode else None
+    w, b = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    y, s, s_pre = ops.add_layer_norm(x, w, b, 1e-5, h=h, row=row, ret_pre=True)
+    ref_pre = x if h is None else x + h
+    ref_s = ref_pre if row is None else ref_pre + row
+    assert torch.equal(s_pre, ref_pre)
+    if s is None:
+        assert mode == "plain"
+    else:
+        assert torch.equal(s, ref_s)
+    ref_y = F.layer_norm(ref_s.double(), (C,), w.double(), b.double(), 1e-5)
+    assert y.dtype == dtype and rel(y, ref_y) < tol
+
+
+def test_add_layernorm_row_runs_and_errors(ops):
+    """row broadcast over runs longer than one batch entry (the per-video cross-attention row) and the error paths."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 10, 64, generator=g).bfloat16().cuda()            # 6 = 2 videos x 3 frames
+    row = torch.randn(2, 1, 64, generator=g).bfloat16().cuda()
+    w, b = torch.ones(64).cuda(), torch.zeros(64).cuda()
+    y, s, _ = ops.add_layer_norm(x, w, b, 1e-5, row=row)
+    assert torch.equal(s, x + row.repeat_interleave(3, dim=0))
+    with pytest.raises(ValueError):
+        ops.add_layer_norm(x, w, b, 1e-5, row=row[:, :, :32])
+    with pytest.raises(ValueError):
+        ops.add_layer_norm(x, w, b, 1e-5, row=torch.zeros(7, 1, 64, device="cuda", dtype=torch.bfloat16))
+    with pytest.raises(Exception):
+        ops.add_layer_norm(torch.zeros(2, 3, 20, device="cuda", dtype=torch.bfloat16), torch.ones(20).cuda(), torch.zeros(20).cuda(), 1e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("with_h", [False, True])
+def test_add_lerp(ops, dtype, tol, with_h):
+    g = torch.Generator().manual_seed(9)
+    B, S, C = 6, 37, 320
+    x, h, base = ((torch.randn(B, S, C, generator=g)).to(dtype).cuda() for _ in range(3))
+    alpha = torch.tensor([0.62, 1.0, 0.3, 0.0, 0.5, 0.999]).to(dtype).cuda()
+    out = ops.add_lerp(x, h if with_h else None, base, alpha)
+    t = x + h if with_h else x
+    ref = torch.lerp(t, base, alpha.reshape(B, 1, 1))
+    assert out.dtype == dtype and rel(out, ref) < tol
+    assert torch.equal(out[1], base[1]) and torch.equal(out[3], t[3])          # alpha = 1 / 0 are exact
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 320, 9, 16), (3, 64, 8, 8), (1, 640, 5, 8), (2, 1280, 3, 8), (2, 72, 4, 6)])
+def test_tokens_to_planes_add(ops, dtype, N, C, H, W):
+    g = torch.Generator().manual_seed(N + C + H)
+    tok = torch.randn(N, H * W, C, generator=g).to(dtype).cuda()
+    x_in = torch.randn(N, C, H, W, generator=g).to(dtype).cuda()
+    out = ops.tokens_to_planes_add(tok, x_in)
+    ref = tok.transpose(1, 2).reshape(N, C, H, W) + x_in
+    assert out.shape == x_in.shape and torch.equal(out, ref)
