@@ -56,6 +56,14 @@ int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight, const flo
                           int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* The same norm (x [N, C, spatial], optional chan_bias, optional SiLU) with TOKEN-MAJOR output y [N, spatial, C]:
+ * "b c h w -> b (h w) c" (svd_inpaint1/sgm/modules/attention.py:700-707) fused into the apply pass, for consumers that
+ * contract over channels (proj_in Linear; a channels-last convolution). C and spatial must be multiples of the 16-byte
+ * vector width; y must not alias x. */
+int mvi_groupnorm_silu_tokens(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                              int64_t N, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                              int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out = softmax(q k^T * scale) v per (batch, head). Token-major layout, as the Linear projections
  * produce it: q/out [B, Sq, H, D], k/v [B, Sk, H, D], contiguous. No mask (none is used on the
  * denoise path). dtype selects the I/O type; fp32 I/O computes in fp32 (validation mode, 1e-4

@@ -225,9 +225,77 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
     }
 }
 
+// Token-major output: y[n, s, c] = act(GroupNorm(x)[n, c, s]) — "b c h w -> b (h w) c" fused into the apply pass, for the
+// consumers that contract over channels (the transformer's proj_in Linear, attention.py:700-707; the channels-last
+// 3x3 convolution of ResBlock). One block = a 64 (channels) x 64 (positions) tile through LDS; the tile's channels
+// merge their groups' partials themselves (a handful per group), so no extra finalise launch exists.
+constexpr int kGnTok = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_tokens_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                              const float* __restrict__ weight,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ part, GnGeom q, float eps, int silu,
+                                                              int s_tiles, int c_tiles) {
+    constexpr int V = Io<T>::kVec;
+    constexpr int VPR = kGnTok / V;
+    __shared__ float s_t[kGnTok][kGnTok + 1];
+    __shared__ float s_sc[kGnTok], s_sh[kGnTok];
+    int bid = blockIdx.x;
+    const int stile = bid % s_tiles; bid /= s_tiles;
+    const int ctile = bid % c_tiles;
+    const int64_t n = bid / c_tiles;
+    const int C = q.Cg * q.G;
+    const int c0 = ctile * kGnTok;
+    const int64_t s0 = (int64_t)stile * kGnTok, S = q.S;
+    if (threadIdx.x < kGnTok) {
+        const int c = c0 + threadIdx.x;
+        if (c < C) {
+            const int64_t g = n * q.G + c / q.Cg;
+            float cnt = 0.f, mean = 0.f, m2 = 0.f;
+            for (int k = 0; k < q.cps; ++k) {
+                const float* p = part + (g * q.cps + k) * 3;
+                const float nb = p[0], mb = p[1], m2b = p[2];
+                const float nt = cnt + nb, d = mb - mean;
+                mean += d * (nb / nt);
+                m2 += m2b + d * d * (cnt * nb / nt);
+                cnt = nt;
+            }
+            const float rstd = rsqrtf(m2 / cnt + eps);
+            const float add = q.chan_bias ? q.chan_bias[n * C + c] : 0.f;
+            const float w = weight[c] * rstd;
+            s_sc[threadIdx.x] = w;
+            s_sh[threadIdx.x] = bias[c] + (add - mean) * w;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGnTok * VPR; i += 256) {
+        const int cr = i / VPR, sv = i % VPR;
+        if (c0 + cr < C && s0 + sv * V < S) {
+            float v[V];
+            Io<T>::load(x + ((n * C + c0 + cr) * S + s0 + sv * V), v);
+            const float w = s_sc[cr], b = s_sh[cr];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float t = v[k] * w + b;
+                s_t[cr][sv * V + k] = silu ? t / (1.0f + __expf(-t)) : t;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGnTok * VPR; i += 256) {
+        const int sr = i / VPR, cv = i % VPR;
+        if (s0 + sr < S && c0 + cv * V < C) {
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = s_t[cv * V + k][sr];
+            Io<T>::store(y + ((n * S + s0 + sr) * C + c0 + cv * V), o);
+        }
+    }
+}
+
 template <typename T>
 static int gn_launch(const void* x, void* y, const float* w, const float* b, const float* chan_bias, int stack3, int64_t N,
-                     int slices, int C, int64_t S, int G, float eps, int silu, float* part, hipStream_t st) {
+                     int slices, int C, int64_t S, int G, float eps, int silu, float* part, hipStream_t st, int tokens = 0) {
     constexpr int KV = Io<T>::kVec;
     constexpr int CH = kGnBlock * kGnVecPerThread * KV;
     GnGeom q;
@@ -238,6 +306,16 @@ static int gn_launch(const void* x, void* y, const float* w, const float* b, con
     q.chan_bias = chan_bias; q.stack3 = stack3;
     const bool vec = (S % KV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
     dim3 grid((unsigned)(q.cps * slices), (unsigned)(N * G));
+    if (tokens) {
+        if (!vec || C % KV != 0 || slices != 1 || stack3) return MVI_EINVAL;
+        const int s_tiles = (int)((S + kGnTok - 1) / kGnTok), c_tiles = (C + kGnTok - 1) / kGnTok;
+        const int64_t blocks = N * s_tiles * c_tiles;
+        if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+        hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, q);
+        hipLaunchKernelGGL((gn_apply_tokens_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)y, w, b, part,
+                           q, eps, silu, s_tiles, c_tiles);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
     if (vec) {
         hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, q);
         hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, q, eps, silu);
@@ -273,7 +351,7 @@ extern "C" size_t mvi_groupnorm_workspace_bytes(int64_t N, int32_t C, int64_t sp
 static int gn_dispatch(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int stack3,
                        int64_t Nv, int32_t T, int32_t C,
                        int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, void* stream, int tokens = 0) {
     if (Nv < 0 || T <= 0 || C <= 0 || groups <= 0 || spatial < 0 || C % groups != 0)
         return mvi::unet_fail(MVI_EINVAL, "groupnorm: C must be a positive multiple of groups");
     if (Nv == 0 || spatial == 0) return MVI_OK;
@@ -285,11 +363,13 @@ static int gn_dispatch(const void* x, void* y, const float* weight, const float*
     float* part = (float*)workspace;
     int rc;
     switch (dtype) {
-        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
-        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
-        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st); break;
+        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens); break;
+        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens); break;
+        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens); break;
         default: return mvi::unet_fail(MVI_EINVAL, "groupnorm: unknown dtype");
     }
+    if (rc == MVI_EINVAL)
+        return mvi::unet_fail(MVI_EINVAL, "groupnorm (token-major output): C and spatial must be multiples of the 16-byte vector, 16-B aligned");
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm: kernel launch failed") : MVI_OK;
 }
 
@@ -312,4 +392,11 @@ extern "C" int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight
                                      size_t workspace_bytes, void* stream) {
     if (stack3 && x == y) return mvi::unet_fail(MVI_EINVAL, "groupnorm: stack3 output cannot alias the input");
     return gn_dispatch(x, y, weight, bias, chan_bias, stack3 ? 1 : 0, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_groupnorm_silu_tokens(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                         int64_t N, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                         int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (x == y) return mvi::unet_fail(MVI_EINVAL, "groupnorm: token-major output cannot alias the input");
+    return gn_dispatch(x, y, weight, bias, chan_bias, 0, N, 1, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream, 1);
 }

@@ -58,6 +58,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     (it uses fp16 autocast, models/csvd.py:27-31)."""
     from . import hip_ops
     from .schedule import EDMDiscretization
+    torch.backends.cudnn.benchmark = True       # let MIOpen time its convolution solvers during warm-up (+10 % on 3x3 convs)
     eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)
     x, cond, ind = inputs(device, T, h, w)
     if weights == "bf16":

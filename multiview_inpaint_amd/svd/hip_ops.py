@@ -107,6 +107,29 @@ def group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=None):
     return _gn(x, 1, num_groups, weight, bias, eps, silu, chan_bias, False)
 
 
+def group_norm_silu_tokens(x, num_groups, weight, bias, eps, silu, chan_bias=None):
+    """GroupNorm(+SiLU) of x [N, C, *spatial] returned token-major [N, prod(spatial), C]."""
+    L = _lib.lib()
+    if x.dtype not in _DT:
+        raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
+    xc = x if x.is_contiguous() else x.contiguous()
+    N, Cc = xc.shape[0], xc.shape[1]
+    S = xc.numel() // max(N * Cc, 1)
+    y = torch.empty((N, S, Cc), dtype=x.dtype, device=x.device)
+    cb = None
+    if chan_bias is not None:
+        cb = chan_bias.detach().float().contiguous()
+        if cb.shape != (N, Cc):
+            raise ValueError(f"group_norm: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
+    ws = _workspace(xc.device, L.mvi_groupnorm_workspace_bytes(N, Cc, S, num_groups))
+    with torch.cuda.device(xc.device), _Timed("groupnorm_tokens", 2.0 * xc.numel() * xc.element_size(), xc.device):
+        _check(L.mvi_groupnorm_silu_tokens(xc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
+                                           None if cb is None else cb.data_ptr(), N, Cc, S, num_groups, float(eps),
+                                           int(bool(silu)), _DT[x.dtype], ws.data_ptr(), ws.numel(), _stream(xc.device)),
+               "group_norm_tokens")
+    return y
+
+
 def group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu, chan_bias=None, stack3=False):
     """x [(b T), C, *spatial] contiguous; statistics per (video, group) over all T frames."""
     return _gn(x, int(T), num_groups, weight, bias, eps, silu, chan_bias, stack3)

@@ -64,6 +64,10 @@ class GroupNorm32(nn.GroupNorm):
     def forward(self, x, silu: bool = False, chan_bias=None):
         return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, silu=silu, chan_bias=chan_bias)
 
+    def forward_tokens(self, x, silu: bool = False, chan_bias=None):
+        """The same norm with token-major output [N, (h w), C]."""
+        return ops.group_norm_tokens(x, self.num_groups, self.weight, self.bias, self.eps, silu=silu, chan_bias=chan_bias)
+
 
 def normalization(channels):
     return GroupNorm32(32, channels)

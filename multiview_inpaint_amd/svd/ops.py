@@ -43,6 +43,16 @@ def group_norm(x, num_groups, weight, bias, eps, silu=False, chan_bias=None):
     return F.silu(y) if silu else y
 
 
+def group_norm_tokens(x, num_groups, weight, bias, eps, silu=False, chan_bias=None):
+    """group_norm(...) returned token-major: [N, C, *spatial] -> [N, prod(spatial), C] ("b c h w -> b (h w) c"
+    fused into the normalisation's write)."""
+    S = x[0, 0].numel()
+    if (x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias) and x.shape[1] % 8 == 0 and S % 8 == 0):
+        from . import hip_ops
+        return hip_ops.group_norm_silu_tokens(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+    return group_norm(x, num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
+
+
 def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False, chan_bias=None, stack3=False):
     """GroupNorm of the temporal layers — statistics over (C/G, T, H, W) per video — evaluated on the
     frame-major tensor x [(b T), C, H, W] the spatial layers produce (the reference permutes to

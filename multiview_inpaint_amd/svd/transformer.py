@@ -173,11 +173,10 @@ class SpatialTransformer(nn.Module):
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1))
 
     def _tokens_in(self, x):
-        h = self.norm(x)
-        if not self.use_linear:
-            h = self.proj_in(h)
-        h = h.flatten(2).transpose(1, 2).contiguous()        # b c h w -> b (h w) c (contiguous: Linear fuses its bias)
-        return self.proj_in(h) if self.use_linear else h
+        if self.use_linear:
+            return self.proj_in(self.norm.forward_tokens(x))  # the norm writes b (h w) c directly
+        h = self.proj_in(self.norm(x))
+        return h.flatten(2).transpose(1, 2).contiguous()      # b c h w -> b (h w) c
 
     def _tokens_out(self, t, x_in):
         b, c, h, w = x_in.shape

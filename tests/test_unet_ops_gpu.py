@@ -303,3 +303,21 @@ def test_tokens_to_planes_add(ops, dtype, N, C, H, W):
     out = ops.tokens_to_planes_add(tok, x_in)
     ref = tok.transpose(1, 2).reshape(N, C, H, W) + x_in
     assert out.shape == x_in.shape and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 320, 9, 16), (3, 64, 8, 8), (2, 1280, 3, 8), (2, 96, 4, 6), (28, 320, 72, 128)])
+@pytest.mark.parametrize("silu,with_bias", [(False, False), (True, True)])
+def test_groupnorm_token_major_output(ops, dtype, tol, N, C, H, W, silu, with_bias):
+    """GroupNorm(+chan_bias, +SiLU) written as [N, (h w), C] equals the NCHW result transposed."""
+    g = torch.Generator().manual_seed(N * 7 + C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.3 + 0.4).to(dtype)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    cb = torch.randn(N, C, generator=g) if with_bias else None
+    xf = x.double() + (cb.double()[:, :, None, None] if with_bias else 0.0)
+    ref = F.group_norm(xf, 32, w.double(), b.double(), 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.group_norm_silu_tokens(x.cuda(), 32, w.cuda(), b.cuda(), 1e-6, silu, chan_bias=None if cb is None else cb.cuda())
+    assert y.shape == (N, H * W, C) and y.dtype == dtype and y.is_contiguous()
+    assert rel(y, ref.flatten(2).transpose(1, 2)) < tol
