@@ -141,13 +141,20 @@ def main():
         projmatrix=torch.tensor(cam["projmatrix"], device=dev), sh_degree=deg,
         campos=torch.tensor(cam["campos"], device=dev), prefiltered=False)
     g_img = torch.randn(3, H, W, device=dev, generator=torch.Generator(dev).manual_seed(rank))
-    bucket = mdist.GradBucket(N, M, dev)
     kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    # exchange step: one flat all-reduce, or — when it moves fewer bytes (W < 2M) — the SH gradient in
+    # factored form (all-gather of 3 floats per view and Gaussian + local rebuild) and an all-reduce of the other 11
+    mode = os.environ.get("MVI_BENCH_EXCHANGE", "auto")
+    distributed = world > 1 or force_dist
+    factored = distributed and (mode == "factored" or (mode == "auto" and mdist.FactoredGradExchange.pays(M, world)))
+    bucket = mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev)
 
     def step():
         color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
-        R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, **kw)
-        if world > 1 or force_dist:
+        R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, sh_grad="factor" if factored else "dense", **kw)
+        if factored:
+            bucket.exchange(t["means3D"], rs.campos)
+        elif distributed:
             bucket.all_reduce()
         return st, radii
 
@@ -219,7 +226,9 @@ def main():
                        "tile_list_mean": round(float(lens.mean()), 1), "tile_list_max": int(lens.max()),
                        "n_contrib_mean": round(float(nc.mean()), 1), "tile_max_contrib_mean": round(float(tile_max.mean()), 1),
                        "pixels_saturated_frac": round(float((ft < 1e-3).float().mean()), 4),
-                       "parallelism": f"views x{world}" + (" + RCCL all-reduce of the gradient bucket" if world > 1 else "")},
+                       "parallelism": f"views x{world}" + ((" + RCCL all-gather of SH colour factors + all-reduce of 11 floats/Gaussian"
+                                                            if factored else " + RCCL all-reduce of the gradient bucket")
+                                                           if distributed else "")},
             "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": stages[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -241,9 +250,11 @@ def main():
             if not args.no_cpu_baseline:
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
             out["svd"] = svd
-        print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         td.destroy_process_group()
+    if rank == 0:
+        C.CDLL(None).fflush(None)            # RCCL's banner sits in the C stdio buffer: flush it first so that the
+        print(json.dumps(out), flush=True)   # JSON line is the LAST line of stdout
 
 
 if __name__ == "__main__":

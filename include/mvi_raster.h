@@ -87,6 +87,9 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t n
  * gs-simp/scene/gaussian_model.py:482-484), dL_dopacity [P], and
  * dL_dshs [P,M,3] | dL_dcolors [P,3], dL_dscales [P,3] + dL_drotations [P,4] | dL_dcov3D [P,6]
  * (pass NULL for the member of each pair that was not a forward input).
+ * With shs as the forward input, dL_dcolors is an OPTIONAL extra output: the colour factor of the rank-1 SH
+ * gradient, dL/dSH[k][c] = Y_k(dir) * dL_dcolors[c] (clamped channels zeroed); dL_dshs may then be NULL and the
+ * dense gradient is rebuilt — summed over views — by mvi_raster_sh_backward_views (view-parallel training).
  * grad_rows_scratch: [P,16] fp32 scratch (64-byte accumulation row per Gaussian). */
 int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t num_rendered,
                         const float* means3D, const float* shs, const float* colors_precomp,
@@ -96,6 +99,15 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
                         float* dL_dmeans2D, float* dL_dopacity, float* dL_dshs, float* dL_dcolors,
                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                         float* grad_rows_scratch, void* stream);
+
+/* View-parallel training (no counterpart in the reference, which is single-GPU: gs-simp/train.sh:1):
+ * dL_dshs[g,k,c] = sum over views v of Y_k(normalize(means3D[g] - campos[v])) * dL_dcolors[v,g,c] for k < (deg+1)^2,
+ * zero for the inactive coefficients. View v's camera centre is campos + v * campos_stride (3 floats), its colour
+ * factors dL_dcolors + v * colors_view_stride ([P,3]; strides in floats, so both can live in one all-gathered
+ * buffer) — 12 B per Gaussian and view on the wire instead of 12*M B in an all-reduce. dL_dshs [P,M,3] overwritten. */
+int mvi_raster_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t n_views, const float* means3D,
+                                 const float* campos, int64_t campos_stride, const float* dL_dcolors,
+                                 int64_t colors_view_stride, float* dL_dshs, void* stream);
 
 /* visible [P] uint8 = 1 where view-space z > 0.2 (the plug-in's markVisible; unused by the
  * reference but part of the plug-in surface). */

@@ -193,7 +193,8 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
     if (!means3D || !radii || !geom || !image || !dL_dout_color || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity ||
         !dL_dconic_scratch)
         return fail(MVI_EINVAL, "NULL required pointer in backward%s");
-    if (shs && !dL_dshs) return fail(MVI_EINVAL, "dL_dshs is NULL but shs was a forward input%s");
+    if (shs && !dL_dshs && !dL_dcolors)
+        return fail(MVI_EINVAL, "dL_dshs and dL_dcolors are both NULL but shs was a forward input%s");
     if (colors_precomp && !dL_dcolors) return fail(MVI_EINVAL, "dL_dcolors is NULL but colors_precomp was a forward input%s");
     if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
         return fail(MVI_EINVAL, "missing covariance gradient output%s");
@@ -212,9 +213,24 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
     }
     mvi::StageTimer tm(mvi::kStPreBwd, st);
     if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, grad_rows,
-                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, colors_precomp ? dL_dcolors : nullptr,
+                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors,
                                         dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, st))
         return hip_fail("preprocess_backward", hipGetLastError());
+    return MVI_OK;
+}
+
+int mvi_raster_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t n_views, const float* means3D,
+                                 const float* campos, int64_t campos_stride, const float* dL_dcolors,
+                                 int64_t colors_view_stride, float* dL_dshs, void* stream) {
+    if (P < 0 || M < 1 || M > 16 || sh_degree < 0 || (sh_degree + 1) * (sh_degree + 1) > M || n_views < 1)
+        return fail(MVI_EINVAL, "bad shape for sh_backward_views (need 1 <= (deg+1)^2 <= M <= 16, n_views >= 1)%s");
+    if (P == 0) return MVI_OK;
+    if (!means3D || !campos || !dL_dcolors || !dL_dshs) return fail(MVI_EINVAL, "NULL pointer in sh_backward_views%s");
+    if (campos_stride < 3 || colors_view_stride < 3 * (int64_t)P)
+        return fail(MVI_EINVAL, "sh_backward_views: campos_stride must be >= 3 and colors_view_stride >= 3 P%s");
+    if (mvi::launch_sh_backward_views(P, M, sh_degree, n_views, means3D, campos, campos_stride, dL_dcolors,
+                                      colors_view_stride, dL_dshs, (hipStream_t)stream))
+        return hip_fail("sh_backward_views", hipGetLastError());
     return MVI_OK;
 }
 

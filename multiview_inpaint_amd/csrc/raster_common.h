@@ -216,6 +216,8 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                            const float* dL_dpix, float* grad_rows, hipStream_t st);
 constexpr int kGradRow = 16;   // floats per Gaussian in the backward accumulation rows (64 B)
+int launch_sh_backward_views(int P, int M, int deg, int n_views, const float* means3D, const float* campos,
+                             int64_t campos_stride, const float* gcol, int64_t gcol_stride, float* dL_dshs, hipStream_t st);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st);
 
 }  // namespace mvi

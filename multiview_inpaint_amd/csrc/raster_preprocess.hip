@@ -336,7 +336,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     if (in_range) {
         dL_dopacity[i] = gr[5];
         if (dL_dcolors) {
-            dL_dcolors[3 * (size_t)i] = gr[6]; dL_dcolors[3 * (size_t)i + 1] = gr[7]; dL_dcolors[3 * (size_t)i + 2] = gr[8];
+            // colours-precomp input: the colour gradient itself. SH input: the colour factor of the rank-1 SH gradient
+            // dL/dSH[k][c] = Y_k(dir) * (clamped_c ? 0 : dL/dcolour_c) (mvi_raster_sh_backward_views rebuilds the rest)
+            const uint32_t cl = (shs && live) ? g.clamped[i] : 0u;
+            dL_dcolors[3 * (size_t)i] = (cl & 1u) ? 0.0f : gr[6];
+            dL_dcolors[3 * (size_t)i + 1] = (cl & 2u) ? 0.0f : gr[7];
+            dL_dcolors[3 * (size_t)i + 2] = (cl & 4u) ? 0.0f : gr[8];
         }
     }
     float dm[3] = {0, 0, 0};
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     stage_out(dL_dmeans3D + (size_t)blk0 * 3, s_dmean, n_rec, 3, 3);
     stage_out(dL_dmeans2D + (size_t)blk0 * 3, s_dm2d, n_rec, 3, 3);
     if (!cov3D_precomp) stage_out(dL_dscales + (size_t)blk0 * 3, s_dscale, n_rec, 3, 3);
-    if (shs) stage_out(dL_dshs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+    if (shs && dL_dshs) stage_out(dL_dshs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
 }
 
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
@@ -502,6 +507,61 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), lds, st, f, means3D, shs, scales,
                        rotations, cov3D_precomp, radii, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
                        dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales, dL_drots);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+// View-parallel training: the SH gradient of one view is rank-1 per Gaussian,
+// dL/dSH[k][c] = Y_k(dir_view) * gcol_view[c], so ranks exchange gcol (3 floats per Gaussian) instead of the
+// 3M-float gradient and every rank rebuilds the SUM over views here from the views' camera centres:
+// dL_dshs[g][k][c] = sum_v Y_k(normalize(mean_g - campos_v)) * gcol[v][g][c]   (k < (deg+1)^2, zero above).
+// One thread per Gaussian; rows leave through LDS like the single-view backward (coalesced AoS writes).
+__global__ __launch_bounds__(kBlock) void sh_backward_views_kernel(int P, int M, int deg, int n_views,
+                                                                    const float* __restrict__ means3D,
+                                                                    const float* __restrict__ campos,
+                                                                    int64_t campos_stride,
+                                                                    const float* __restrict__ gcol,
+                                                                    int64_t gcol_stride,
+                                                                    float* __restrict__ dL_dshs) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)]
+    const int tid = threadIdx.x;
+    const int blk0 = blockIdx.x * kBlock;
+    const int i = blk0 + tid;
+    const int n_rec = min(kBlock, P - blk0);
+    const int w = sh_stride(M);
+    const int nb = (deg + 1) * (deg + 1);
+    float acc[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    if (i < P) {
+        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        for (int v = 0; v < n_views; ++v) {
+            const float* gc = gcol + (size_t)v * gcol_stride + (size_t)i * 3;
+            const float* cp = campos + (size_t)v * campos_stride;
+            const float c0 = gc[0], c1 = gc[1], c2 = gc[2];
+            if (c0 == 0.0f && c1 == 0.0f && c2 == 0.0f) continue;          // not seen (or fully clamped) in this view
+            const float ox = px - cp[0], oy = py - cp[1], oz = pz - cp[2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float bs[16];
+            sh_basis(deg, ox / len, oy / len, oz / len, bs);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < nb) { acc[k][0] += bs[k] * c0; acc[k][1] += bs[k] * c1; acc[k][2] += bs[k] * c2; }
+        }
+    }
+    float* row = s_dyn + (size_t)tid * w;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < M) { row[3 * k] = acc[k][0]; row[3 * k + 1] = acc[k][1]; row[3 * k + 2] = acc[k][2]; }
+    __syncthreads();
+    stage_out(dL_dshs + (size_t)blk0 * M * 3, s_dyn, n_rec, 3 * M, w);
+}
+
+int launch_sh_backward_views(int P, int M, int deg, int n_views, const float* means3D, const float* campos,
+                             int64_t campos_stride, const float* gcol, int64_t gcol_stride, float* dL_dshs, hipStream_t st) {
+    if (P <= 0) return 0;
+    const size_t lds = sizeof(float) * (size_t)kBlock * sh_stride(M);
+    hipLaunchKernelGGL(sh_backward_views_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), lds, st, P, M, deg, n_views,
+                       means3D, campos, campos_stride, gcol, gcol_stride, dL_dshs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

@@ -126,9 +126,14 @@ def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs
 
 
 def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_color, means3D, shs=None,
-                       colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, out=None):
+                       colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, out=None, sh_grad="dense"):
     """Runs the HIP backward. Returns dict of gradients (None for inputs that were not given).
-    `out` may hold preallocated contiguous fp32 tensors (e.g. dist.GradBucket.views) to write into."""
+    `out` may hold preallocated contiguous fp32 tensors (e.g. dist.GradBucket.views) to write into.
+    sh_grad (SH input only): "dense" -> g["shs"] [P,M,3]; "factor" -> g["sh_color_factor"] [P,3] instead, the
+    colour factor of the rank-1 SH gradient (see sh_backward_views; view-parallel training exchanges this);
+    "both" -> both."""
+    if sh_grad not in ("dense", "factor", "both"):
+        raise ValueError(f"sh_grad must be 'dense', 'factor' or 'both', got {sh_grad!r}")
     L = _lib.lib()
     fr = _Frame(rs)
     dev = means3D.device
@@ -147,7 +152,10 @@ def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_
              shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
     dcolors = None
     if shs is not None:
-        g["shs"] = buf("shs", P, st.M, 3)
+        if sh_grad != "factor":
+            g["shs"] = buf("shs", P, st.M, 3)
+        if sh_grad != "dense":
+            dcolors = g["sh_color_factor"] = buf("sh_color_factor", P, 3)
     else:
         dcolors = g["colors_precomp"] = buf("colors_precomp", P, 3)
     if cov3D_precomp is not None:
@@ -165,6 +173,40 @@ def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_
             _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(scratch), stream),
             "rasterize backward")
     return g
+
+
+def sh_backward_views(means3D, campos, color_factors, M, sh_degree, out=None):
+    """Sum over views of the SH gradient rebuilt from per-view colour factors:
+    out[g,k,c] = sum_v Y_k(normalize(means3D[g] - campos[v])) * color_factors[v,g,c]  ->  [P,M,3].
+    campos [V,3] and color_factors [V,P,3] may be strided views of one (all-gathered) buffer as long as their
+    inner dimensions are contiguous."""
+    L = _lib.lib()
+    dev = means3D.device
+    P = means3D.shape[0]
+    V = color_factors.shape[0]
+    if campos.shape != (V, 3) or color_factors.shape != (V, P, 3):
+        raise ValueError(f"sh_backward_views: campos {tuple(campos.shape)} / color_factors {tuple(color_factors.shape)} "
+                         f"do not match V={V}, P={P}")
+    for t in (means3D, campos, color_factors):
+        if t.dtype != torch.float32 or t.device != dev:
+            raise RuntimeError("sh_backward_views: fp32 tensors on one device required")
+    if not means3D.is_contiguous():
+        means3D = means3D.contiguous()
+    if V > 1 and (campos.stride(1) != 1 or color_factors.stride(2) != 1 or color_factors.stride(1) != 3):
+        campos, color_factors = campos.contiguous(), color_factors.contiguous()
+    elif V == 1:
+        campos, color_factors = campos.contiguous(), color_factors.contiguous()
+    if out is None:
+        out = torch.empty(P, M, 3, dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (P, M, 3) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        raise RuntimeError(f"sh_backward_views: out must be a contiguous fp32 ({P}, {M}, 3) tensor on {dev}")
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_sh_backward_views(P, M, int(sh_degree), V, _ptr(means3D), _ptr(campos),
+                                                  campos.stride(0) if V > 1 else 3, _ptr(color_factors),
+                                                  color_factors.stride(0) if V > 1 else 3 * P, _ptr(out), stream),
+                   "sh_backward_views")
+    return out
 
 
 def _opt(t):

@@ -62,7 +62,30 @@ def _worker(rank, world, port, out_dir):
     want_d = sum(vis[r].float()[:, None] for r in range(world))
     want_m = torch.stack([torch.where(vis[r], rad[r].float(), torch.zeros(P)) for r in range(world)]).max(0).values
     assert torch.allclose(accum, want_a, atol=1e-6) and torch.equal(denom, want_d) and torch.equal(mx, want_m)
-    torch.save(dict(flat=bucket.flat, accum=accum), os.path.join(out_dir, f"r{rank}.pt"))
+    # 4. factored SH exchange == all-reduce of the dense gradients (SH part rebuilt from 3 floats per view)
+    for Mx, deg in ((16, 3), (16, 1), (4, 1)):
+        g4 = [torch.Generator().manual_seed(400 + 10 * Mx + r) for r in range(world)]
+        means = torch.randn(P, 3, generator=torch.Generator().manual_seed(7)) * 2 + torch.tensor([0.0, 0.0, 5.0])
+        cams = [torch.randn(3, generator=g4[r]) for r in range(world)]
+        fac = [torch.randn(P, 3, generator=g4[r]) * (torch.rand(P, 1, generator=g4[r]) > 0.3) for r in range(world)]
+        small = [{n: torch.randn(P, w, generator=g4[r]) for n, w in md.FactoredGradExchange.SMALL} for r in range(world)]
+        ex = md.FactoredGradExchange(P, Mx, deg, "cpu")
+        ex.views["sh_color_factor"].copy_(fac[rank])
+        for n, v in small[rank].items():
+            ex.views[n].copy_(v)
+        got = ex.exchange(means, cams[rank])
+        nb = (deg + 1) ** 2
+        dense = torch.zeros(P, Mx, 3)
+        for r in range(world):
+            d = means - cams[r]
+            Y = md._sh_basis_cpu(deg, d / d.norm(dim=-1, keepdim=True))           # [P, nb]
+            dense[:, :nb] += Y[:, :, None] * fac[r][:, None, :]
+        assert torch.allclose(got["shs"], dense, rtol=1e-5, atol=1e-6), (Mx, deg)
+        assert float(got["shs"][:, nb:].abs().max() if nb < Mx else 0.0) == 0.0
+        for n, _ in md.FactoredGradExchange.SMALL:
+            assert torch.allclose(got[n], sum(small[r][n] for r in range(world)), rtol=1e-5, atol=1e-6), n
+    assert md.FactoredGradExchange.pays(16, 8) and not md.FactoredGradExchange.pays(4, 8) and not md.FactoredGradExchange.pays(1, 2)
+    torch.save(dict(flat=bucket.flat, accum=accum, shs=got["shs"]), os.path.join(out_dir, f"r{rank}.pt"))
     td.destroy_process_group()
 
 
@@ -71,3 +94,18 @@ def test_view_parallel_exchange_world2(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     a, b = (torch.load(tmp_path / f"r{r}.pt") for r in range(world))
     assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["accum"], b["accum"])   # ranks agree bit for bit
+    assert torch.equal(a["shs"], b["shs"])
+
+
+def test_sh_basis_matches_reference_eval_sh_golden():
+    """dist._sh_basis_cpu against the imported reference's eval_sh (tests/golden/raster_partial.npz, generated by
+    tools/gen_golden_raster.py from gs-simp/utils/sh_utils.py:57-112): sum_k Y_k(d) sh[k] + 0.5, clamped at 0."""
+    import numpy as np
+    from multiview_inpaint_amd import dist as md
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster_partial.npz"))
+    dirs, sh = torch.tensor(G["sh_dirs"]), torch.tensor(G["sh_coeffs"])
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    for deg in range(4):
+        Y = md._sh_basis_cpu(deg, dirs)                                           # [64, nb]
+        rgb = torch.clamp_min(torch.einsum("pk,pkc->pc", Y, sh[:, :Y.shape[1]]) + 0.5, 0.0)
+        assert torch.allclose(rgb, torch.tensor(G[f"sh_rgb_deg{deg}"]), rtol=1e-5, atol=1e-6), deg

@@ -289,3 +289,54 @@ def test_partial_sh_degree_scale_modifier_and_background_gradient(R, ro):
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
         frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
         assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+
+
+@pytest.mark.parametrize("deg,store_deg", [(3, 3), (1, 3), (0, 0)])
+def test_factored_sh_gradient_and_multi_view_rebuild(R, deg, store_deg):
+    """View-parallel exchange form of the SH gradient: the colour factor of each view
+    (sh_grad="factor") plus mvi_raster_sh_backward_views reproduces the SUM of the views' dense SH gradients
+    (dense gradients are oracle-checked in test_backward_parity_small)."""
+    from multiview_inpaint_amd import synthetic as syn
+    rng = np.random.default_rng(11)
+    Rm, T0 = syn.random_rotation(rng), rng.normal(size=3)
+    cams = [syn.make_camera(160, 112, 50.0, Rm, T0), syn.make_camera(160, 112, 50.0, Rm, T0 + np.array([0.35, -0.2, 0.1]))]
+    sc = syn.make_scene(1500, cams[0], store_deg, 11, log_scale_mean=np.log(0.05), zmin=1.0, zmax=6.0)
+    bg = np.array([0.3, 0.1, 0.7], np.float32)
+    t = _to_dev(sc)
+    P, M = t["shs"].shape[0], t["shs"].shape[1]
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    dense, factors, campos = [], [], []
+    for v, cam in enumerate(cams):
+        rs = _settings(R, cam, bg, deg)
+        g_img = torch.tensor(np.random.default_rng(20 + v).normal(size=(3, cam["H"], cam["W"])).astype(np.float32), device="cuda")
+        _, radii, _, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+        assert int((radii > 0).sum()) > P // 3
+        gd = R.rasterize_backward(rs, st, g_img, t["means3D"], **kw)
+        gb = R.rasterize_backward(rs, st, g_img, t["means3D"], sh_grad="both", **kw)
+        gf = R.rasterize_backward(rs, st, g_img, t["means3D"], sh_grad="factor", **kw)
+        assert gf["shs"] is None and gf["sh_color_factor"].shape == (P, 3)
+        for k in ("means3D", "opacities", "scales", "rotations"):
+            frac, worst = _close_frac(gf[k].cpu().numpy(), gd[k].cpu().numpy())
+            assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)          # atomics: summation order only
+        frac, worst = _close_frac(gf["sh_color_factor"].cpu().numpy(), gb["sh_color_factor"].cpu().numpy())
+        assert frac <= 5e-4 and worst < 5e-2
+        # the degree-0 coefficient of the dense gradient is C0 * factor
+        frac, worst = _close_frac((gb["sh_color_factor"] * 0.28209479177387814).cpu().numpy(), gb["shs"][:, 0].cpu().numpy())
+        assert frac <= 1e-5 and worst < 1e-5
+        dense.append(gb["shs"])
+        factors.append(gb["sh_color_factor"])
+        campos.append(rs.campos)
+    both, cp = torch.stack(factors), torch.stack(campos)
+    for n_views in (1, 2):
+        out = R.sh_backward_views(t["means3D"], cp[:n_views], both[:n_views], M, deg)
+        want = sum(dense[:n_views])
+        frac, worst = _close_frac(out.cpu().numpy(), want.cpu().numpy(), rtol=1e-5)
+        assert out.shape == (P, M, 3) and frac == 0.0, (n_views, frac, worst)
+    # strided inputs, as they sit in the all-gathered buffer [W, 3P + 3]
+    packed = torch.zeros(2, 3 * P + 3, device="cuda")
+    packed[:, :3 * P] = both.reshape(2, -1)
+    packed[:, 3 * P:] = cp
+    out2 = R.sh_backward_views(t["means3D"], packed[:, 3 * P:], packed[:, :3 * P].view(2, P, 3), M, deg)
+    assert torch.equal(out2, R.sh_backward_views(t["means3D"], cp, both, M, deg))
+    with pytest.raises(ValueError):
+        R.sh_backward_views(t["means3D"], cp[:1], both, M, deg)

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from multiview_inpaint_amd.svd import bench_svd  # noqa: E402
 from multiview_inpaint_amd.svd.schedule import EDMDiscretization  # noqa: E402
 
+torch.backends.cudnn.benchmark = True
 dev = torch.device("cuda")
 eng = bench_svd.build(dev, dtype=torch.bfloat16)
 x, cond, ind = bench_svd.inputs(dev)
