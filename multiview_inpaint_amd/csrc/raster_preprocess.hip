@@ -20,12 +20,27 @@ namespace mvi {
 __device__ __forceinline__ void stage_in(const float* __restrict__ src, float* lds, int n_rec, int rec, int stride) {
     const int total = n_rec * rec;
     if ((rec & 3) == 0) {
+        // float4 per lane, kStageUnroll loads issued back to back before the first LDS write: with one load in
+        // flight per lane (the rolled loop waits vmcnt(0) every trip) these HBM-bound kernels sat at ~3 TB/s
+        constexpr int kStageUnroll = 6;
         const int rv = rec >> 2;                           // float4 per record: a vector never straddles records
+        const int nvec = total >> 2;
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        for (int v = threadIdx.x; v < (total >> 2); v += kBlock) {
-            float4 x = s4[v];
-            float* d = lds + (v / rv) * stride + (v % rv) * 4;
-            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += kBlock * kStageUnroll) {
+            float4 x[kStageUnroll];
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; ++u) {
+                const int v = v0 + u * kBlock;
+                if (v < nvec) x[u] = s4[v];
+            }
+#pragma unroll
+            for (int u = 0; u < kStageUnroll; ++u) {
+                const int v = v0 + u * kBlock;
+                if (v < nvec) {
+                    float* d = lds + (v / rv) * stride + (v % rv) * 4;
+                    d[0] = x[u].x; d[1] = x[u].y; d[2] = x[u].z; d[3] = x[u].w;
+                }
+            }
         }
     } else {
         for (int e = threadIdx.x; e < total; e += kBlock) lds[(e / rec) * stride + (e % rec)] = src[e];
@@ -152,6 +167,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     if (shs) stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
     if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
+    // per-lane operands requested before the barrier so they travel with the staged rows
+    float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+    float opac = 0.f;
+    if (i < f.P) {
+        if (!cov3D_precomp) q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+        opac = opacities[i];
+    }
     __syncthreads();
     float V[16], PM[16];
 #pragma unroll
@@ -178,7 +200,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
                 for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
             } else {
                 float R[3][3], Mx[3][3];
-                const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
                 quat_to_rot(q.x, q.y, q.z, q.w, R);
                 float s[3] = {f.scale_modifier * s_scale[3 * tid], f.scale_modifier * s_scale[3 * tid + 1],
                               f.scale_modifier * s_scale[3 * tid + 2]};
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
             g.rgbd[i] = make_float4(r0, r1, r2, vz);
             g.depths[i] = vz;
             g.xy[i] = make_float2(pix_x, pix_y);
-            g.conic_opacity[i] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
+            g.conic_opacity[i] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opac);
             rad_out = rad;
             touched = (uint32_t)((x1 - x0) * (y1 - y0));
         } while (false);
@@ -322,23 +343,31 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     if (shs) stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
     if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
-    __syncthreads();
+    // per-lane operands requested before the barrier so they travel with the staged rows
     const bool in_range = i < f.P;
     const bool live = in_range && radii[i] > 0;
     float gr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), qrot = make_float4(1.f, 0.f, 0.f, 0.f);
+    float2 cb = make_float2(0.f, 0.f);
+    uint32_t cl_bits = 0;
     if (live) {
         const float4* row = reinterpret_cast<const float4*>(grad_rows + (size_t)i * kGradRow);
         float4 a = row[0], b4 = row[1];
         gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b4.x; gr[5] = b4.y; gr[6] = b4.z; gr[7] = b4.w;
         gr[8] = grad_rows[(size_t)i * kGradRow + 8];
+        ca = g.cov_a[i];
+        cb = g.cov_b[i];
+        if (!cov3D_precomp) qrot = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+        if (shs) cl_bits = g.clamped[i];
     }
+    __syncthreads();
     s_dm2d[3 * tid] = gr[0]; s_dm2d[3 * tid + 1] = gr[1]; s_dm2d[3 * tid + 2] = 0.0f;
     if (in_range) {
         dL_dopacity[i] = gr[5];
         if (dL_dcolors) {
             // colours-precomp input: the colour gradient itself. SH input: the colour factor of the rank-1 SH gradient
             // dL/dSH[k][c] = Y_k(dir) * (clamped_c ? 0 : dL/dcolour_c) (mvi_raster_sh_backward_views rebuilds the rest)
-            const uint32_t cl = (shs && live) ? g.clamped[i] : 0u;
+            const uint32_t cl = cl_bits;
             dL_dcolors[3 * (size_t)i] = (cl & 1u) ? 0.0f : gr[6];
             dL_dcolors[3 * (size_t)i + 1] = (cl & 2u) ? 0.0f : gr[7];
             dL_dcolors[3 * (size_t)i + 2] = (cl & 4u) ? 0.0f : gr[8];
@@ -355,8 +384,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
         float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
         float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
-        const float4 ca = g.cov_a[i];
-        const float2 cb = g.cov_b[i];
         float c6[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
         Ewa e;
         ewa_setup(f, V, vx, vy, vz, e);
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             sh_basis(f.deg, dx, dy, dz, bs);
             sh_basis_grad(f.deg, dx, dy, dz, bx, by, bz);
             float* sh = s_sh + (size_t)tid * shs_w;        // this thread's row: read SH, then overwrite with dL/dSH
-            const uint32_t cl = g.clamped[i];
+            const uint32_t cl = cl_bits;
             float gcol[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) gcol[ch] = ((cl >> ch) & 1u) ? 0.0f : gr[6 + ch];
@@ -454,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     } else {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         if (live) {
-            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+            const float4 q = qrot;
             float R[3][3];
             quat_to_rot(q.x, q.y, q.z, q.w, R);
             float s[3] = {f.scale_modifier * s_scale[3 * tid], f.scale_modifier * s_scale[3 * tid + 1],
