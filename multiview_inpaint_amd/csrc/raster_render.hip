@@ -13,6 +13,10 @@
 
 namespace mvi {
 
+// ballot of a predicate that already lives in a lane mask: no 0/1 materialisation (__ballot(int) costs two VALU issues)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+
 // Per staged entry: t2 = 2 ln(255 o) (+ margin), the largest Mahalanobis distance^2 d^T conic d at which
 // alpha = o exp(-d^T conic d / 2) still reaches 1/255; negative = can never be active.
 __device__ __forceinline__ float active_t2(float4 co) {
@@ -88,10 +92,10 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
         if (r + 1 < rounds) fetch(r + 1);
         const int n = todo < kBlock ? todo : kBlock;
         for (int c = 0; c < n; c += 64) {
-            if (__ballot(T > 0.0f) == 0ull) break;
+            if (ballot64(T > 0.0f) == 0ull) break;
             const int e = c + lane;
             const bool keep = e < n && quad_overlap(s_xy[e], s_co[e], s_t2[e], (float)qx0, (float)qy0);
-            const unsigned long long mask = __ballot(keep);
+            const unsigned long long mask = ballot64(keep);
             if (mask == 0ull) continue;
             if (keep) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -169,6 +173,27 @@ __device__ __forceinline__ float quad_sum(float v) {   // every lane of a quad e
     return quad_add<0x4e>(quad_add<0xb1>(v));
 }
 
+// Quad totals of nine values in 18 instructions: v_add_f32_dpp reads the neighbour lane and adds in ONE instruction.
+// Written as asm because the compiler lowers update_dpp + add to v_mov_b32_dpp + v_add (two issues each; the kernel is
+// VALU-issue-bound, SQ_INSTS_VALU x 4 cycles ~ its whole duration). The leading s_nop covers the VALU-write -> DPP-read
+// hazard for whatever instruction precedes the block (the assembler does not pad inline asm); inside the block every
+// value is re-read nine instructions after it was written.
+#define MVI_DPP1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define MVI_DPP2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void quad_sum9(float& a, float& b, float& c, float& d, float& e, float& f, float& g, float& h,
+                                          float& i) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" MVI_DPP1 "v_add_f32_dpp %1, %1, %1" MVI_DPP1 "v_add_f32_dpp %2, %2, %2" MVI_DPP1
+        "v_add_f32_dpp %3, %3, %3" MVI_DPP1 "v_add_f32_dpp %4, %4, %4" MVI_DPP1 "v_add_f32_dpp %5, %5, %5" MVI_DPP1
+        "v_add_f32_dpp %6, %6, %6" MVI_DPP1 "v_add_f32_dpp %7, %7, %7" MVI_DPP1 "v_add_f32_dpp %8, %8, %8" MVI_DPP1
+        "v_add_f32_dpp %0, %0, %0" MVI_DPP2 "v_add_f32_dpp %1, %1, %1" MVI_DPP2 "v_add_f32_dpp %2, %2, %2" MVI_DPP2
+        "v_add_f32_dpp %3, %3, %3" MVI_DPP2 "v_add_f32_dpp %4, %4, %4" MVI_DPP2 "v_add_f32_dpp %5, %5, %5" MVI_DPP2
+        "v_add_f32_dpp %6, %6, %6" MVI_DPP2 "v_add_f32_dpp %7, %7, %7" MVI_DPP2 "v_add_f32_dpp %8, %8, %8" MVI_DPP2
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
+}
+#undef MVI_DPP1
+#undef MVI_DPP2
+
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
@@ -195,7 +220,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float T_final = inside ? final_T[pix] : 0.0f;
     float T = T_final;
     const uint32_t last = inside ? n_contrib[pix] : 0u;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    // The reference carries accum_rec[3] and last_color[3] and sums (c - accum_rec) . dL/dpixel over the channels; both
+    // recurrences are linear, so their dot products with dL/dpixel are carried instead (two scalars, not six)
+    float acc_dot = 0.f, lc_dot = 0.f, last_alpha = 0.f;
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
     if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
     const float bg_dot = f.bg[0] * dp0 + f.bg[1] * dp1 + f.bg[2] * dp2;
@@ -215,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
             float4 a = row[0], b = row[1], c = row[2], d = row[3];
             float sum = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) +
                         ((d.x + d.y) + (d.z + d.w));
-            atomicAdd(&s_acc[s_slot[wave][my_slot]][my_mom], sum);
+            atomicAdd(&s_acc[0][0] + (__mul24(s_slot[wave][my_slot], 9) + my_mom), sum);
         }
     };
 
@@ -251,57 +278,62 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
             // position of staged slot e is hi-1-e; this wave composited positions < wave_last only
             const bool keep = e < n && (uint32_t)(hi - 1 - e) < wave_last &&
                               quad_overlap(s_xy[e], s_co[e], s_t2[e], (float)qx0, (float)qy0);
-            unsigned long long mask = __ballot(keep);
+            unsigned long long mask = ballot64(keep);
             if (mask == 0ull) continue;
             int j = c + __builtin_ctzll(mask);                  // wave-uniform
-            float2 p = s_xy[j];
-            float4 co = s_co[j];
-            float4 col = s_rgb[j];
-            while (true) {
+            // One entry: evaluate all 64 pixels branch-free, commit where active, reduce, park. `nx_*` receive the NEXT
+            // entry's operands (LDS broadcast reads issued first, so they overlap this entry's math). Called with the
+            // two register sets swapping roles, so nothing is moved between iterations.
+            auto entry = [&](const int jc, const float2 p, const float4 co, const float4 col, float2& nx_p, float4& nx_co,
+                             float4& nx_col, int& jn) -> bool {
                 mask &= mask - 1;
                 const bool more = mask != 0ull;
-                const int jn = more ? c + __builtin_ctzll(mask) : j;
-                const float2 pn = s_xy[jn];                     // next entry's LDS reads overlap this entry's math
-                const float4 con = s_co[jn];
-                const float4 coln = s_rgb[jn];
-                const uint32_t pos = (uint32_t)(hi - 1 - j);
-                // branch-free body: every lane evaluates, selects commit
+                jn = more ? c + __builtin_ctzll(mask) : jc;
+                nx_p = s_xy[jn];
+                nx_co = s_co[jn];
+                nx_col = s_rgb[jn];
+                const uint32_t pos = (uint32_t)(hi - 1 - jc);
                 float dx = p.x - pfx, dy = p.y - pfy;
                 float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 float G = __expf(fminf(power, 0.0f));
                 float alpha = fminf(kAlphaMax, co.w * G);
                 const bool active = pos < last && power <= 0.0f && alpha >= kAlphaMin;
+                const unsigned long long any_active = ballot64(active);
                 const float inv_1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1-alpha in [0.01, 1]
                 const float Tn = T * inv_1ma;
-                const float a0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
-                const float a1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
-                const float a2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2;
-                float dL_dalpha = ((col.x - a0) * dp0 + (col.y - a1) * dp1 + (col.z - a2) * dp2) * Tn +
-                                  (-T_final * inv_1ma) * bg_dot;
+                const float c_dot = col.x * dp0 + col.y * dp1 + col.z * dp2;
+                const float a_dot = last_alpha * lc_dot + (1.0f - last_alpha) * acc_dot;
+                float dL_dalpha = (c_dot - a_dot) * Tn + (-T_final * inv_1ma) * bg_dot;
                 const float dchannel = active ? alpha * Tn : 0.0f;
                 float m_r = dchannel * dp0, m_g = dchannel * dp1, m_b = dchannel * dp2;
                 float m_w = active ? co.w * dL_dalpha * G : 0.0f;             // dL/dG * G
                 float m_x = m_w * dx, m_y = m_w * dy;
                 float m_xx = m_x * dx, m_xy = m_x * dy, m_yy = m_y * dy;
                 T = active ? Tn : T;
-                acc0 = active ? a0 : acc0; acc1 = active ? a1 : acc1; acc2 = active ? a2 : acc2;
-                lc0 = active ? col.x : lc0; lc1 = active ? col.y : lc1; lc2 = active ? col.z : lc2;
+                acc_dot = active ? a_dot : acc_dot;
+                lc_dot = active ? c_dot : lc_dot;
                 last_alpha = active ? alpha : last_alpha;
-                if (__ballot(active) != 0ull) {                 // wave-uniform
-                    m_w = quad_sum(m_w);   m_x = quad_sum(m_x);   m_y = quad_sum(m_y);
-                    m_xx = quad_sum(m_xx); m_xy = quad_sum(m_xy); m_yy = quad_sum(m_yy);
-                    m_r = quad_sum(m_r);   m_g = quad_sum(m_g);   m_b = quad_sum(m_b);
+                if (any_active != 0ull) {                       // wave-uniform
+                    quad_sum9(m_w, m_x, m_y, m_xx, m_xy, m_yy, m_r, m_g, m_b);
+                    const int pk = __builtin_amdgcn_readfirstlane(parked);   // scalar: the slab address is SGPR + lane part
                     if ((lane & 3) == 3) {
-                        float* colp = &slab[parked * 9][lane >> 2];
+                        float* colp = &slab[0][0] + (pk * (9 * kSlabStride) + (lane >> 2));
                         colp[0 * kSlabStride] = m_w;  colp[1 * kSlabStride] = m_x;  colp[2 * kSlabStride] = m_y;
                         colp[3 * kSlabStride] = m_xx; colp[4 * kSlabStride] = m_xy; colp[5 * kSlabStride] = m_yy;
                         colp[6 * kSlabStride] = m_r;  colp[7 * kSlabStride] = m_g;  colp[8 * kSlabStride] = m_b;
                     }
-                    if (lane == 0) s_slot[wave][parked] = j;
-                    if (++parked == kSlabG) { drain(kSlabG); parked = 0; }
+                    if (lane == 0) s_slot[wave][pk] = jc;
+                    parked = pk + 1;
+                    if (parked == kSlabG) { drain(kSlabG); parked = 0; }
                 }
-                if (!more) break;
-                j = jn; p = pn; co = con; col = coln;
+                return more;
+            };
+            float2 pA = s_xy[j], pB;
+            float4 coA = s_co[j], coB, colA = s_rgb[j], colB;
+            int jB = j;
+            while (true) {
+                if (!entry(j, pA, coA, colA, pB, coB, colB, jB)) break;
+                if (!entry(jB, pB, coB, colB, pA, coA, colA, j)) break;
             }
         }
         if (parked) drain(parked);
