@@ -226,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
     if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
     const float bg_dot = f.bg[0] * dp0 + f.bg[1] * dp1 + f.bg[2] * dp2;
+    const float bg_term = -T_final * bg_dot;                // dL/dalpha's background part is bg_term / (1 - alpha)
     // deepest list position composited by any pixel of this wave / of the block
     uint32_t wave_last = last;
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
@@ -295,18 +296,19 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                 const uint32_t pos = (uint32_t)(hi - 1 - jc);
                 float dx = p.x - pfx, dy = p.y - pfy;
                 float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                float G = __expf(fminf(power, 0.0f));
-                float alpha = fminf(kAlphaMax, co.w * G);
+                float G = __expf(power);                        // power > 0 (inf, NaN) is never active: selected away below
+                const float oG = co.w * G;
+                float alpha = fminf(kAlphaMax, oG);
                 const bool active = pos < last && power <= 0.0f && alpha >= kAlphaMin;
                 const unsigned long long any_active = ballot64(active);
                 const float inv_1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1-alpha in [0.01, 1]
                 const float Tn = T * inv_1ma;
                 const float c_dot = col.x * dp0 + col.y * dp1 + col.z * dp2;
                 const float a_dot = last_alpha * lc_dot + (1.0f - last_alpha) * acc_dot;
-                float dL_dalpha = (c_dot - a_dot) * Tn + (-T_final * inv_1ma) * bg_dot;
+                float dL_dalpha = (c_dot - a_dot) * Tn + bg_term * inv_1ma;
                 const float dchannel = active ? alpha * Tn : 0.0f;
                 float m_r = dchannel * dp0, m_g = dchannel * dp1, m_b = dchannel * dp2;
-                float m_w = active ? co.w * dL_dalpha * G : 0.0f;             // dL/dG * G
+                float m_w = active ? oG * dL_dalpha : 0.0f;                   // dL/dG * G
                 float m_x = m_w * dx, m_y = m_w * dy;
                 float m_xx = m_x * dx, m_xy = m_x * dy, m_yy = m_y * dy;
                 T = active ? Tn : T;
