@@ -1,0 +1,49 @@
+"""profiles/raster_traffic.json from the PMC passes of tools/profile_raster.sh.
+Usage: python tools/make_traffic_json.py gpurun_out/<tag> <tag>   (reads pmc_fetch.txt / pmc_write.txt)
+Correction (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
+a 128-B request as 64 B for 16-B/lane reads -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is."""
+import json
+import os
+import re
+import sys
+
+d, tag = sys.argv[1], sys.argv[2]
+STAGE = {"preprocess_forward_kernel": "preprocess_forward", "scan_block_sums_kernel": "scan_block_sums",
+         "depth_keys_kernel": "radix_sort", "radix_count_kernel": "radix_sort", "radix_scan_rows_kernel": "radix_sort",
+         "radix_scatter_kernel": "radix_sort", "perm_block_sums_kernel": "duplicate_keys", "emit_pairs_kernel": "duplicate_keys",
+         "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward",
+         "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
+STEPS = 6          # bench.py --steps 5 --warmup 1
+
+
+def parse(path):
+    out, k = {}, None
+    for line in open(path):
+        if line.startswith("mvi::"):
+            k = line.strip().split("::")[1]
+            out[k] = {}
+        else:
+            m = re.match(r"\s+(\S+)\s+([\d.]+)\s+\(n=(\d+)\)", line)
+            if m and k:
+                out[k][m.group(1)] = (float(m.group(2)), int(m.group(3)))
+    return out
+
+
+f, w = parse(os.path.join(d, "pmc_fetch.txt")), parse(os.path.join(d, "pmc_write.txt"))
+per_kernel, per_stage = {}, {}
+for k in sorted(f):
+    fv, n = f[k]["FETCH_SIZE"]
+    wv = w[k]["WRITE_SIZE"][0]
+    lps = n / STEPS
+    fb, wb = fv * 1024 * lps, wv * 1024 * lps
+    corr = int(2 * fb + wb)
+    per_kernel[k] = dict(launches_per_step=lps, FETCH_SIZE_bytes=int(fb), WRITE_SIZE_bytes=int(wb), hbm_bytes_corrected=corr)
+    per_stage[STAGE[k]] = per_stage.get(STAGE[k], 0) + corr
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum (separate passes), python3 bench.py --steps 5 "
+                 f"--warmup 1 --path raster --no-cpu-baseline, MI355X, round 1 (tools/profile_raster.sh {tag})",
+       "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane reads -> read bytes = 2 x FETCH_SIZE x 1024 "
+                     "(MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024 as is (includes the 64-B float-atomic requests)",
+       "per_step_bytes_by_stage": per_stage, "per_kernel": per_kernel,
+       "render_backward_atomic_requests_64B": w["render_backward_kernel"]["TCC_EA0_ATOMIC_sum"][0]}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "raster_traffic.json"), "w"), indent=1)
+print(json.dumps(per_stage, indent=1))
