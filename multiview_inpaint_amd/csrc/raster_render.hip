@@ -2,13 +2,13 @@
 // Replaces the plug-in's render stages behind gs-simp/gaussian_renderer/__init__.py:85-93
 // (forward: colour [3,H,W] + depth [1,H,W]) and loss.backward() (gs-simp/train.py:93).
 //
-// One 256-thread block per 16x16-pixel tile = 4 wave64, each wave an 8x8-pixel quadrant. The tile's
-// depth-sorted list is staged through LDS 256 entries at a time by the whole block. Each wave then
-// tests 64 staged entries at a time against its own quadrant (one lane per entry): an entry is kept
-// iff its "active ellipse" {alpha >= 1/255} = {d^T conic d <= 2 ln(255 o)} can reach the quadrant
-// (exact minimum of the quadratic form over the box, quad_overlap). Only kept entries are evaluated
-// per pixel. The test is conservative (margin on 2 ln(255 o)), so results are identical to
-// evaluating every entry.
+// One block per 16x16-pixel tile. Forward: 256 threads = 4 wave64, each wave an 8x8-pixel quadrant, one pixel per
+// lane. Backward: 128 threads = 2 wave64, each wave a 16x8 half tile, two pixels per lane on packed fp32 math.
+// The tile's depth-sorted list is staged through LDS one entry per thread and round by the whole block. Each wave
+// then tests 64 staged entries at a time against its own pixel box (one lane per entry): an entry is kept iff its
+// "active ellipse" {alpha >= 1/255} = {d^T conic d <= 2 ln(255 o)} can reach the box (exact minimum of the
+// quadratic form over the box, quad_overlap). Only kept entries are evaluated per pixel. The test is conservative
+// (margin on 2 ln(255 o)), so results are identical to evaluating every entry.
 #include "raster_common.h"
 
 namespace mvi {
@@ -29,8 +29,9 @@ __device__ __forceinline__ float active_t2(float4 co) {
 // is inside; otherwise it lies on one of the (at most two) box edges facing the centre, where the
 // 1-D minimiser is a clamped closed form. Continuous minimum <= minimum over pixel centres, and t2
 // carries a margin that dwarfs the rcp / rounding error, so no active pair is ever dropped.
-__device__ __forceinline__ bool quad_overlap(float2 c, float4 co, float t2, float qx0, float qy0) {
-    const float dxl = qx0 - c.x, dxr = dxl + 7.0f, dyl = qy0 - c.y, dyr = dyl + 7.0f;
+__device__ __forceinline__ bool quad_overlap(float2 c, float4 co, float t2, float qx0, float qy0, float bw = 7.0f,
+                                             float bh = 7.0f) {
+    const float dxl = qx0 - c.x, dxr = dxl + bw, dyl = qy0 - c.y, dyr = dyl + bh;
     const float px = fminf(fmaxf(0.0f, dxl), dxr), py = fminf(fmaxf(0.0f, dyl), dyr);   // box point nearest the centre, per axis
     // edge x = px: dy* = clamp(-B px / C); edge y = py: dx* = clamp(-B py / A)
     const float dy1 = fminf(fmaxf(-co.y * px * __builtin_amdgcn_rcpf(co.z), dyl), dyr);
@@ -148,30 +149,21 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
 }
 
 // ------------------------------------------------------------------------------------ backward
-// Back-to-front replay over the entries [0, max n_contrib of the tile) only. Each lane owns a pixel.
-// Per evaluated (quadrant, Gaussian) pair every lane produces 9 RAW moments
+// Back-to-front replay over the entries [0, max n_contrib of the tile) only.
+// Per evaluated (half tile, Gaussian) pair every pixel produces 9 RAW moments
 //     W = o G dL/dalpha,  W dx,  W dy,  W dx^2,  W dx dy,  W dy^2,  alpha T dL/dC_{r,g,b}
 // (the per-Gaussian factors — conic coefficients, 1/o, the 0.5 W / 0.5 H screen scale — are applied
-// once per (tile, Gaussian) after the sums). The 64-lane sums take two DPP steps inside each quad,
-// then the 16 quad partials of up to 7 Gaussians x 9 moments are parked in a per-wave LDS slab
-// (rows of 16, stride 20) and summed by ONE lane per row — 63 rows per wave64 — which adds the row
-// total into the block's per-entry accumulator. That replaces 6 cross-lane steps per value by 2
-// plus ~1/7 of a 16-element row sum. Once per 256-entry batch the block turns the raw sums into
-// gradients and flushes them with float atomics shaped as whole 64-byte rows (16 lanes per
-// Gaussian): MI355X float atomics run at the 64-B-request rate. Row layout of grad_rows [P][16]:
+// once per (tile, Gaussian) after the sums). A lane adds its two pixels, two DPP steps give quad totals,
+// then the 16 quad partials of up to kSlabG Gaussians x 9 moments are parked in a per-wave LDS slab
+// (rows of 16, stride 20) and summed by ONE lane per row, which adds the row total into the block's
+// per-entry accumulator. Once per staged batch the block turns the raw sums into gradients and flushes
+// them with float atomics shaped as whole 64-byte rows (16 lanes per Gaussian): MI355X float atomics
+// run at the 64-B-request rate. Row layout of grad_rows [P][16]:
 //   0 mean2D.x  1 mean2D.y  2 conic A  3 conic B  4 conic C  5 opacity  6 r  7 g  8 b  9..15 unused
 constexpr int kRow = 16;
 constexpr int kSlabG = 3;          // Gaussians parked per wave before a row-sum pass (3 x 9 = 27 rows)
 constexpr int kSlabStride = 20;    // floats per slab row (16 used; 80-byte rows keep b128 reads conflict-free)
 
-template <int CTRL>
-__device__ __forceinline__ float quad_add(float v) {
-    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-    return v + __int_as_float(t);
-}
-__device__ __forceinline__ float quad_sum(float v) {   // every lane of a quad ends with the quad total
-    return quad_add<0x4e>(quad_add<0xb1>(v));
-}
 
 // Quad totals of nine values in 18 instructions: v_add_f32_dpp reads the neighbour lane and adds in ONE instruction.
 // Written as asm because the compiler lowers update_dpp + add to v_mov_b32_dpp + v_add (two issues each; the kernel is
@@ -194,47 +186,64 @@ __device__ __forceinline__ void quad_sum9(float& a, float& b, float& c, float& d
 #undef MVI_DPP1
 #undef MVI_DPP2
 
-__global__ __launch_bounds__(kBlock) void render_backward_kernel(
+// ---- backward, two pixels per lane --------------------------------------------------------------------------------
+// Back-to-front replay of the tile's list (positions < max n_contrib of the tile only) with the same exact box
+// culling as the forward. Every pixel produces 9 raw moments per evaluated Gaussian (W, W dx, W dy, W dx^2, W dx dy,
+// W dy^2, alpha T dL/dC); quad totals by DPP, the 16 quad partials of up to kSlabG Gaussians are parked in a per-wave
+// LDS slab and summed by one lane per row; per (tile, Gaussian) the block converts raw sums into gradients once and
+// flushes them with float atomics shaped as whole 64-byte rows (grad_rows [P][16]).
+// The kernel sits at the fp32 VALU issue roof. With one pixel per lane it needed ~90 vector
+// instructions per (wave, Gaussian), ~33 of them (DPP quad sums, slab, drain) independent of how many pixels the wave
+// covers. Here a wave covers a 16x8 half tile, lane l owning the vertically adjacent pixels (x = l & 15, y = 2 (l >> 4) + {0, 1}):
+// the per-pixel math runs on packed fp32 (v_pk_mul/add/fma_f32: two pixels per instruction at full rate), the two
+// pixels are summed in the lane before the quad reduction, and the reduction/slab cost is paid once per 128 pixels.
+// Block = 128 threads = one tile; 128 list entries are staged per round. Decisions (alpha, active) use the same
+// operation order as the forward kernel (products rounded, one fma per sum), element-wise.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+constexpr int kB2 = 128;
+
+__global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_backward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, float* __restrict__ grad_rows) {
-    __shared__ uint32_t s_id[kBlock];
-    __shared__ float2 s_xy[kBlock];
-    __shared__ float s_t2[kBlock];
-    __shared__ float4 s_co[kBlock];
-    __shared__ float4 s_rgb[kBlock];
-    __shared__ float s_acc[kBlock][9];                                // raw moment sums per staged entry
-    __shared__ __attribute__((aligned(16))) float s_slab[4][kSlabG * 9][kSlabStride];
-    __shared__ int s_slot[4][8];
-    __shared__ uint32_t s_blast[4];
+#pragma clang fp contract(off)
+    __shared__ uint32_t s_id[kB2];
+    __shared__ float2 s_xy[kB2];
+    __shared__ float s_t2[kB2];
+    __shared__ float4 s_co[kB2];
+    __shared__ float4 s_rgb[kB2];
+    __shared__ float s_acc[kB2][9];                                   // raw moment sums per staged entry
+    __shared__ __attribute__((aligned(16))) float s_slab[2][kSlabG * 9][kSlabStride];
+    __shared__ int s_slot[2][8];
+    __shared__ uint32_t s_blast[2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.y * f.gx + blockIdx.x;
-    const int qx0 = blockIdx.x * kTile + 8 * (wave & 1), qy0 = blockIdx.y * kTile + 8 * (wave >> 1);
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < f.W && pyi < f.H;
-    const float pfx = (float)pxi, pfy = (float)pyi;
+    const int hx0 = blockIdx.x * kTile, hy0 = blockIdx.y * kTile + 8 * wave;          // this wave's 16 x 8 half tile
+    const int pxi = hx0 + (lane & 15), py0 = hy0 + 2 * (lane >> 4), py1 = py0 + 1;
+    const bool in0 = pxi < f.W && py0 < f.H, in1 = pxi < f.W && py1 < f.H;
+    const float pfx = (float)pxi;
+    const f2 pfy = {(float)py0, (float)py1};
     const uint32_t r0 = ranges[2 * tile];
-    const size_t pix = (size_t)pyi * f.W + pxi, hw = (size_t)f.H * f.W;
+    const size_t hw = (size_t)f.H * f.W, pix0 = (size_t)py0 * f.W + pxi, pix1 = pix0 + f.W;
 
-    const float T_final = inside ? final_T[pix] : 0.0f;
-    float T = T_final;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    // The reference carries accum_rec[3] and last_color[3] and sums (c - accum_rec) . dL/dpixel over the channels; both
-    // recurrences are linear, so their dot products with dL/dpixel are carried instead (two scalars, not six)
-    float acc_dot = 0.f, lc_dot = 0.f, last_alpha = 0.f;
-    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
-    if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
-    const float bg_dot = f.bg[0] * dp0 + f.bg[1] * dp1 + f.bg[2] * dp2;
-    const float bg_term = -T_final * bg_dot;                // dL/dalpha's background part is bg_term / (1 - alpha)
-    // deepest list position composited by any pixel of this wave / of the block
-    uint32_t wave_last = last;
+    const f2 T_final = {in0 ? final_T[pix0] : 0.0f, in1 ? final_T[pix1] : 0.0f};
+    f2 T = T_final;
+    const uint32_t last0 = in0 ? n_contrib[pix0] : 0u, last1 = in1 ? n_contrib[pix1] : 0u;
+    f2 acc_dot = {0.f, 0.f}, lc_dot = {0.f, 0.f}, last_alpha = {0.f, 0.f};
+    f2 dp0 = {0.f, 0.f}, dp1 = {0.f, 0.f}, dp2 = {0.f, 0.f};
+    if (in0) { dp0.x = dL_dpix[pix0]; dp1.x = dL_dpix[hw + pix0]; dp2.x = dL_dpix[2 * hw + pix0]; }
+    if (in1) { dp0.y = dL_dpix[pix1]; dp1.y = dL_dpix[hw + pix1]; dp2.y = dL_dpix[2 * hw + pix1]; }
+    const f2 bg_dot = f.bg[0] * dp0 + f.bg[1] * dp1 + f.bg[2] * dp2;
+    const f2 bg_term = -T_final * bg_dot;                   // dL/dalpha's background part is bg_term / (1 - alpha)
+    uint32_t wave_last = max(last0, last1);
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
     if (lane == 0) s_blast[wave] = wave_last;
     __syncthreads();
-    const int total = (int)max(max(s_blast[0], s_blast[1]), max(s_blast[2], s_blast[3]));
-    const int rounds = (total + kBlock - 1) / kBlock;
-    // row-sum pass: lane r < 9 * parked owns slab row r = slot * 9 + moment
+    const int total = (int)max(s_blast[0], s_blast[1]);
+    const int rounds = (total + kB2 - 1) / kB2;
     const int my_slot = (lane * 57) >> 9, my_mom = lane - 9 * my_slot;      // lane / 9, lane % 9 for lane < 64
     float (*slab)[kSlabStride] = s_slab[wave];
     auto drain = [&](int parked) {
@@ -247,12 +256,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
         }
     };
 
-    // software pipeline: the gathers of batch r+1 are issued before batch r is replayed
     uint32_t n_id = 0;
     float2 n_xy = make_float2(0.f, 0.f);
     float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = n_co;
     auto fetch = [&](int r) {
-        const int hi_ = total - r * kBlock;
+        const int hi_ = total - r * kB2;
         if (tid < hi_) {                                        // staged slot tid <-> list position hi_-1-tid
             n_id = point_list[r0 + (uint32_t)(hi_ - 1 - tid)];
             n_xy = xy[n_id]; n_co = conic_opacity[n_id]; n_cd = rgbd[n_id];
@@ -260,9 +268,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     };
     if (rounds > 0) fetch(0);
     for (int r = 0; r < rounds; ++r) {
-        // batch r holds list positions hi-1 ... lo (descending); staged slot s <-> position hi-1-s
-        const int hi = total - r * kBlock;
-        const int n = hi < kBlock ? hi : kBlock;
+        const int hi = total - r * kB2;
+        const int n = hi < kB2 ? hi : kB2;
         __syncthreads();
         s_id[tid] = n_id;
         s_xy[tid] = n_xy;
@@ -276,15 +283,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
         int parked = 0;                                         // wave-uniform
         for (int c = 0; c < n; c += 64) {
             const int e = c + lane;
-            // position of staged slot e is hi-1-e; this wave composited positions < wave_last only
             const bool keep = e < n && (uint32_t)(hi - 1 - e) < wave_last &&
-                              quad_overlap(s_xy[e], s_co[e], s_t2[e], (float)qx0, (float)qy0);
+                              quad_overlap(s_xy[e], s_co[e], s_t2[e], (float)hx0, (float)hy0, 15.0f, 7.0f);
             unsigned long long mask = ballot64(keep);
             if (mask == 0ull) continue;
             int j = c + __builtin_ctzll(mask);                  // wave-uniform
-            // One entry: evaluate all 64 pixels branch-free, commit where active, reduce, park. `nx_*` receive the NEXT
-            // entry's operands (LDS broadcast reads issued first, so they overlap this entry's math). Called with the
-            // two register sets swapping roles, so nothing is moved between iterations.
             auto entry = [&](const int jc, const float2 p, const float4 co, const float4 col, float2& nx_p, float4& nx_co,
                              float4& nx_col, int& jn) -> bool {
                 mask &= mask - 1;
@@ -294,30 +297,41 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                 nx_co = s_co[jn];
                 nx_col = s_rgb[jn];
                 const uint32_t pos = (uint32_t)(hi - 1 - jc);
-                float dx = p.x - pfx, dy = p.y - pfy;
-                float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                float G = __expf(power);                        // power > 0 (inf, NaN) is never active: selected away below
-                const float oG = co.w * G;
-                float alpha = fminf(kAlphaMax, oG);
-                const bool active = pos < last && power <= 0.0f && alpha >= kAlphaMin;
-                const unsigned long long any_active = ballot64(active);
-                const float inv_1ma = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1-alpha in [0.01, 1]
-                const float Tn = T * inv_1ma;
-                const float c_dot = col.x * dp0 + col.y * dp1 + col.z * dp2;
-                const float a_dot = last_alpha * lc_dot + (1.0f - last_alpha) * acc_dot;
-                float dL_dalpha = (c_dot - a_dot) * Tn + bg_term * inv_1ma;
-                const float dchannel = active ? alpha * Tn : 0.0f;
-                float m_r = dchannel * dp0, m_g = dchannel * dp1, m_b = dchannel * dp2;
-                float m_w = active ? oG * dL_dalpha : 0.0f;                   // dL/dG * G
-                float m_x = m_w * dx, m_y = m_w * dy;
-                float m_xx = m_x * dx, m_xy = m_x * dy, m_yy = m_y * dy;
-                T = active ? Tn : T;
-                acc_dot = active ? a_dot : acc_dot;
-                lc_dot = active ? c_dot : lc_dot;
-                last_alpha = active ? alpha : last_alpha;
+                const float dx = p.x - pfx;
+                const f2 dy = splat(p.y) - pfy;
+                // power = -0.5 (A dx^2 + C dy^2) - B dx dy with the forward's rounding: fma(dx, A dx, (C dy) dy), fma(., -0.5, -(B dx) dy)
+                const float ax = co.x * dx, bx = co.y * dx;
+                const f2 cyy = (co.z * dy) * dy;
+                const f2 sq = pk_fma(splat(dx), splat(ax), cyy);
+                const f2 bxy = bx * dy;
+                const f2 power = pk_fma(sq, splat(-0.5f), -bxy);
+                const f2 G = {__expf(power.x), __expf(power.y)};    // power > 0 (inf, NaN) is never active: selected away
+                const f2 oG = co.w * G;
+                const f2 alpha = __builtin_elementwise_min(splat(kAlphaMax), oG);
+                const bool act0 = pos < last0 && power.x <= 0.0f && alpha.x >= kAlphaMin;
+                const bool act1 = pos < last1 && power.y <= 0.0f && alpha.y >= kAlphaMin;
+                const unsigned long long any_active = ballot64(act0) | ballot64(act1);
+                const f2 om = splat(1.0f) - alpha;                   // in [0.01, 1]
+                const f2 inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const f2 Tn = T * inv;
+                const f2 c_dot = pk_fma(splat(col.z), dp2, pk_fma(splat(col.y), dp1, col.x * dp0));
+                const f2 a_dot = pk_fma(last_alpha, lc_dot, (splat(1.0f) - last_alpha) * acc_dot);
+                const f2 dL_dalpha = pk_fma(c_dot - a_dot, Tn, bg_term * inv);
+                f2 dch = alpha * Tn, mw = oG * dL_dalpha;
+                dch.x = act0 ? dch.x : 0.0f; dch.y = act1 ? dch.y : 0.0f;
+                mw.x = act0 ? mw.x : 0.0f;   mw.y = act1 ? mw.y : 0.0f;
+                T.x = act0 ? Tn.x : T.x;             T.y = act1 ? Tn.y : T.y;
+                acc_dot.x = act0 ? a_dot.x : acc_dot.x; acc_dot.y = act1 ? a_dot.y : acc_dot.y;
+                lc_dot.x = act0 ? c_dot.x : lc_dot.x;   lc_dot.y = act1 ? c_dot.y : lc_dot.y;
+                last_alpha.x = act0 ? alpha.x : last_alpha.x; last_alpha.y = act1 ? alpha.y : last_alpha.y;
                 if (any_active != 0ull) {                       // wave-uniform
+                    const f2 vr = dch * dp0, vg = dch * dp1, vb = dch * dp2;
+                    const f2 vx = mw * dx, vy = mw * dy;
+                    const f2 vxx = vx * dx, vxy = vx * dy, vyy = vy * dy;
+                    float m_w = mw.x + mw.y, m_x = vx.x + vx.y, m_y = vy.x + vy.y, m_xx = vxx.x + vxx.y,
+                          m_xy = vxy.x + vxy.y, m_yy = vyy.x + vyy.y, m_r = vr.x + vr.y, m_g = vg.x + vg.y, m_b = vb.x + vb.y;
                     quad_sum9(m_w, m_x, m_y, m_xx, m_xy, m_yy, m_r, m_g, m_b);
-                    const int pk = __builtin_amdgcn_readfirstlane(parked);   // scalar: the slab address is SGPR + lane part
+                    const int pk = __builtin_amdgcn_readfirstlane(parked);
                     if ((lane & 3) == 3) {
                         float* colp = &slab[0][0] + (pk * (9 * kSlabStride) + (lane >> 2));
                         colp[0 * kSlabStride] = m_w;  colp[1 * kSlabStride] = m_x;  colp[2 * kSlabStride] = m_y;
@@ -343,15 +357,15 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
         // flush: 16 lanes per staged Gaussian turn the raw sums into gradients; one 64-byte row per request
         const int comp = tid & 15;
 #pragma unroll 4
-        for (int it = 0; it < kBlock / 16; ++it) {
-            const int e = it * 16 + (tid >> 4);
+        for (int it = 0; it < kB2 / 8; ++it) {
+            const int e = it * 8 + (tid >> 4);
             if (e >= n || comp >= 9) continue;
             const float* a = s_acc[e];
             const float sw = a[0];
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 9; ++k) any |= (a[k] != 0.0f);
-            if (!any) continue;                               // entry never evaluated by any quadrant
+            if (!any) continue;                               // entry never evaluated by either half tile
             const float4 co = s_co[e];
             float v;
             switch (comp) {
@@ -372,7 +386,7 @@ int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView 
                            const float* dL_dpix, float* grad_rows, hipStream_t st) {
     if (f.W <= 0 || f.H <= 0 || D <= 0) return 0;
     const uint32_t* plist = b.vals[b.passes & 1];
-    hipLaunchKernelGGL(render_backward_kernel, dim3(f.gx, f.gy), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
+    hipLaunchKernelGGL(render_backward_kernel, dim3(f.gx, f.gy), dim3(kB2), 0, st, f, im.ranges, plist, g.xy,
                        g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, dL_dpix, grad_rows);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
