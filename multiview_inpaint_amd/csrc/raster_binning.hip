@@ -123,21 +123,31 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
 }
 
 // ---- stable 8-bit LSD radix pass over (u32 key, u32 value) pairs: count / scan / scatter -------
-__global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint32_t* __restrict__ keys, int64_t D, int shift,
-                                                             uint32_t mask, uint32_t* __restrict__ block_hist,
-                                                             int nblk) {
-    __shared__ uint32_t s_hist[256];
-    const int tid = threadIdx.x;
-    s_hist[tid] = 0;
+// One 1024-thread block = kCountTiles (4) consecutive sort tiles, one per 256-thread group. Row d of block_hist then
+// receives 4 consecutive counts as one 16-byte store instead of four 4-byte words at a stride of nblk words
+// (measured before: 23 MB written per launch for 3 MB of counts).
+__global__ __launch_bounds__(1024) void radix_count_kernel(const uint32_t* __restrict__ keys, int64_t D, int shift,
+                                                           uint32_t mask, uint32_t* __restrict__ block_hist,
+                                                           int nblk) {
+    __shared__ uint32_t s_hist[kCountTiles][256];
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
+    s_hist[grp][t] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = ((int64_t)blockIdx.x * kCountTiles + grp) * kSortTile;
+    uint32_t key[kSortItems];
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
-        int64_t idx = base + it * kBlock + tid;
-        if (idx < D) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
+        const int64_t idx = base + it * 256 + t;
+        key[it] = idx < D ? keys[idx] : 0xFFFFFFFFu;
     }
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it)
+        if (base + it * 256 + t < D) atomicAdd(&s_hist[grp][(key[it] >> shift) & mask], 1u);
     __syncthreads();
-    block_hist[(size_t)tid * nblk + blockIdx.x] = s_hist[tid];
+    if (tid < 256) {
+        uint4 v = make_uint4(s_hist[0][tid], s_hist[1][tid], s_hist[2][tid], s_hist[3][tid]);
+        *reinterpret_cast<uint4*>(block_hist + (size_t)tid * nblk + (size_t)blockIdx.x * kCountTiles) = v;
+    }
 }
 
 // block d turns row d of block_hist into exclusive offsets inside digit d; digit_tot[d] = row sum
@@ -299,7 +309,7 @@ int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
 static int radix_pass(uint32_t* const keys[2], uint32_t* const vals[2], int cur, int64_t n, int shift, int bits,
                       uint32_t* hist, uint32_t* tot, int nsort, hipStream_t st) {
     uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(radix_count_kernel, dim3(nsort), dim3(kBlock), 0, st, keys[cur], n, shift, mask, hist, nsort);
+    hipLaunchKernelGGL(radix_count_kernel, dim3(nsort / kCountTiles), dim3(1024), 0, st, keys[cur], n, shift, mask, hist, nsort);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, hist, nsort, tot);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nsort), dim3(kBlock), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
                        vals[cur ^ 1], n, shift, mask, hist, nsort, tot);

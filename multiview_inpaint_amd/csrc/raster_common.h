@@ -23,6 +23,11 @@ constexpr float kDepthSentinel = 15.0f;    // gs-simp/gen_seq.py:50
 
 constexpr int kSortTile = 2048;            // keys per block in one radix pass (256 threads x 8)
 constexpr int kSortItems = 8;
+constexpr int kCountTiles = 4;            // sort tiles per block of the count kernel: one 16-byte run per histogram row
+__host__ __device__ inline int sort_blocks(int64_t n) {     // radix-pass blocks, padded so the count kernel writes whole runs
+    int b = (int)((n + kSortTile - 1) / kSortTile);
+    return (b + kCountTiles - 1) / kCountTiles * kCountTiles;
+}
 
 // Per-call constants every kernel needs, passed by value (lives in SGPRs).
 struct Frame {
@@ -93,7 +98,7 @@ inline GeomView carve_geom(void* base, int P) {
     g.clamped = (uint8_t*)take(n);
     g.block_sums = (uint32_t*)take(4 * (size_t)nblk);
     g.block_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
-    g.nsortP = (int)((n + kSortTile - 1) / kSortTile);
+    g.nsortP = sort_blocks(n);
     for (int i = 0; i < 2; ++i) { g.dkeys[i] = (uint32_t*)take(4 * n); g.dvals[i] = (uint32_t*)take(4 * n); }
     g.dhist = (uint32_t*)take(4 * 256 * (size_t)g.nsortP);
     g.dtot = (uint32_t*)take(4 * 256);
@@ -126,7 +131,7 @@ inline BinningView carve_binning(void* base, int64_t D, int W, int H) {
     char* p = (char*)base;
     size_t o = 0;
     size_t n = (size_t)(D > 0 ? D : 1);
-    v.nsort = (int)((n + kSortTile - 1) / kSortTile);
+    v.nsort = sort_blocks(n);
     v.key_bits = tile_bits(W, H);
     v.passes = (v.key_bits + 7) / 8;
     auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
