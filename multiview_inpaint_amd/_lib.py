@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI HIP library (include/mvi_raster.h, include/mvi_unet_ops.h).
+"""ctypes binding of the C-ABI HIP library (include/mvi_raster.h, include/mvi_unet_ops.h, include/mvi_train_ops.h).
 
 There is NO fallback: if libmvi_hip.so is missing or does not export a declared symbol this
 module raises, and every op of the package fails with it."""
@@ -82,6 +82,7 @@ def lib():
     L.mvi_raster_stage_name.restype = C.c_char_p
     L.mvi_raster_stage_name.argtypes = [C.c_int]
     _bind_unet_ops(L)
+    _bind_train_ops(L)
     _lib = L
     return L
 
@@ -93,6 +94,16 @@ def _bind_unet_ops(L):
     except ImportError:
         return
     _unet_ops_bind.bind(L)
+
+
+def _bind_train_ops(L):
+    """include/mvi_train_ops.h"""
+    vp, i32, sz, f32 = C.c_void_p, C.c_int32, C.c_size_t, C.c_float
+    L.mvi_photometric_loss_workspace_bytes.restype = sz
+    L.mvi_photometric_loss_workspace_bytes.argtypes = [i32, i32]
+    L.mvi_photometric_loss.restype = C.c_int
+    L.mvi_photometric_loss.argtypes = [vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, sz, vp]
+    L.mvi_train_last_error.restype = C.c_char_p
 
 
 def check(rc, what):
