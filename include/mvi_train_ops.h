@@ -28,6 +28,37 @@ int mvi_photometric_loss(const float* image, const float* gt, const float* weigh
                          float lambda_dssim, float upstream, float* out3, float* dL_dimage, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* torch.optim.Adam (weight_decay 0, amsgrad off) over up to MVI_ADAM_MAX_GROUPS tensors in one launch — the optimizer
+ * of gs-simp/scene/gaussian_model.py:154-163 (six groups, per-group lr, eps 1e-15), stepped at gs-simp/train.py:126-128.
+ * `groups_host` is a HOST array (copied into the kernel arguments); every tensor pointer in it is a device pointer to
+ * n fp32 elements; param / exp_avg / exp_avg_sq are updated in place. `step` is the 1-based step count AFTER this
+ * update (state["step"] + 1). Same operation order as torch's _single_tensor_adam; betas and eps are doubles because
+ * torch derives 1 - beta and the bias corrections from Python floats before rounding to fp32. */
+#define MVI_ADAM_MAX_GROUPS 8
+typedef struct mvi_adam_group {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    float lr;
+} mvi_adam_group;
+int mvi_adam_step(const mvi_adam_group* groups_host, int32_t n_groups, double beta1, double beta2, double eps,
+                  int32_t step, void* stream);
+
+/* The activated views of the Gaussian parameters the renderer consumes, in one launch
+ * (gs-simp/scene/gaussian_model.py:95-115; setup_functions :44-59): scales [P,3] = exp(raw_scaling),
+ * rotations [P,4] = normalize(raw_rotation) (F.normalize, eps 1e-12), opacities [P,1] = sigmoid(raw_opacity),
+ * shs [P,M,3] = cat(features_dc [P,1,3], features_rest [P,M-1,3], dim 1); and their chain rule in one launch. */
+int mvi_gaussian_activations(int32_t P, int32_t M, const float* raw_scaling, const float* raw_rotation,
+                             const float* raw_opacity, const float* features_dc, const float* features_rest,
+                             float* scales, float* rotations, float* opacities, float* shs, void* stream);
+int mvi_gaussian_activations_backward(int32_t P, int32_t M, const float* raw_rotation, const float* scales,
+                                      const float* opacities, const float* dL_dscales, const float* dL_drotations,
+                                      const float* dL_dopacities, const float* dL_dshs, float* dL_draw_scaling,
+                                      float* dL_draw_rotation, float* dL_draw_opacity, float* dL_dfeatures_dc,
+                                      float* dL_dfeatures_rest, void* stream);
+
 const char* mvi_train_last_error(void);
 
 #ifdef __cplusplus

@@ -28,6 +28,12 @@ class RasterViews(C.Structure):
         "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")]
 
 
+class AdamGroup(C.Structure):
+    """struct mvi_adam_group (include/mvi_train_ops.h)"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float)]
+
+
 def declared_symbols():
     """Every function name declared in include/*.h."""
     names = []
@@ -104,6 +110,12 @@ def _bind_train_ops(L):
     L.mvi_photometric_loss.restype = C.c_int
     L.mvi_photometric_loss.argtypes = [vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, sz, vp]
     L.mvi_train_last_error.restype = C.c_char_p
+    L.mvi_adam_step.restype = C.c_int
+    L.mvi_adam_step.argtypes = [C.POINTER(AdamGroup), i32, C.c_double, C.c_double, C.c_double, i32, vp]
+    L.mvi_gaussian_activations.restype = C.c_int
+    L.mvi_gaussian_activations.argtypes = [i32, i32] + [vp] * 10
+    L.mvi_gaussian_activations_backward.restype = C.c_int
+    L.mvi_gaussian_activations_backward.argtypes = [i32, i32] + [vp] * 13
 
 
 def check(rc, what):

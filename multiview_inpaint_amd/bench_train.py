@@ -1,0 +1,88 @@
+"""One full 3DGS training iteration on the GPU (the region gs-simp/train.py times between iter_start and iter_end plus
+the optimizer step): parameter activations -> rasterize -> L1 + DSSIM loss -> backward -> Adam, N = 1.5 M Gaussians,
+1920x1080, sh_degree 3, synthetic scene. Two variants of everything AROUND the HIP rasterizer:
+  hip   : multiview_inpaint_amd.train_ops (fused activations, fused loss, fused Adam)
+  torch : the reference's own PyTorch-ROCm formulation (exp / normalize / sigmoid / cat, loss_utils-style SSIM with
+          five depthwise convs, torch.optim.Adam)
+Usage (GPU box): python -m multiview_inpaint_amd.bench_train [--steps 20]; bench.py reports the same numbers as
+"train_iteration"."""
+import argparse
+import json
+
+import torch
+import torch.nn.functional as F
+
+from . import raster as R, synthetic as syn, train_ops as T
+
+
+def torch_loss(img, gt, lam=0.2):
+    w1 = torch.tensor([pow(2.718281828459045, -(x - 5) ** 2 / 4.5) for x in range(11)], device=img.device)
+    w1 = w1 / w1.sum()
+    win = (w1[:, None] @ w1[None, :]).expand(3, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t[None], win, padding=5, groups=3)[0]
+    mu1, mu2 = conv(img), conv(gt)
+    s1, s2, s12 = conv(img * img) - mu1 * mu1, conv(gt * gt) - mu2 * mu2, conv(img * gt) - mu1 * mu2
+    smap = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+    return 0.8 * (img - gt).abs().mean() + 0.2 * (1 - smap.mean())
+
+
+def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
+    dev = torch.device("cuda")
+    cam = syn.make_camera(W, H, 50.0)
+    sc = syn.make_scene(N, cam, deg, seed=0)
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items() if k != "sh_degree"}
+    raw = dict(xyz=t["means3D"], f_dc=t["shs"][:, :1].contiguous(), f_rest=t["shs"][:, 1:].contiguous(),
+               opacity=torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)), scaling=torch.log(t["scales"]), rotation=t["rotations"])
+    prm = {k: torch.nn.Parameter(v.clone()) for k, v in raw.items()}
+    lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3)
+    groups = [{"params": [prm[k]], "lr": lrs[k], "name": k} for k in prm]
+    opt = (T.FusedAdam if variant == "hip" else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+    rs = R.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
+        scale_modifier=1.0, viewmatrix=torch.tensor(cam["viewmatrix"], device=dev),
+        projmatrix=torch.tensor(cam["projmatrix"], device=dev), sh_degree=deg, campos=torch.tensor(cam["campos"], device=dev),
+        prefiltered=False)
+    rast = R.GaussianRasterizer(rs)
+    gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(dev).manual_seed(1))
+
+    def step():
+        if variant == "hip":
+            scales, rots, opac, shs = T.activate_gaussians(prm["scaling"], prm["rotation"], prm["opacity"], prm["f_dc"], prm["f_rest"])
+        else:
+            scales, rots, opac = torch.exp(prm["scaling"]), F.normalize(prm["rotation"]), torch.sigmoid(prm["opacity"])
+            shs = torch.cat((prm["f_dc"], prm["f_rest"]), dim=1)
+        means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
+        image, radii, depth = rast(means3D=prm["xyz"], means2D=means2D, shs=shs, colors_precomp=None, opacities=opac,
+                                   scales=scales, rotations=rots, cov3D_precomp=None)
+        loss = T.fused_l1_dssim_loss(image, gt, 0.2) if variant == "hip" else torch_loss(image, gt)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        loss = step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    return dict(variant=variant, ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 1), loss=round(loss.item(), 5))
+
+
+def run_both(steps=20, warmup=3):
+    out = [run(v, steps, warmup) for v in ("hip", "torch")]
+    return {"workload": "full 3DGS training iteration (activations, rasterize, L1+DSSIM, backward, Adam), N=1.5M, 1920x1080, "
+                        "sh_degree 3; the HIP rasterizer in both variants, the ops around it fused HIP vs PyTorch-ROCm ops",
+            "results": out, "speedup_of_the_surrounding_ops": round(out[1]["ms_per_iteration"] / out[0]["ms_per_iteration"], 2)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    print(json.dumps(run_both(a.steps, a.warmup)))

@@ -100,3 +100,110 @@ def ssim(img1, img2, window_size=11, size_average=True):
     if window_size != 11 or not size_average:
         raise NotImplementedError("ssim: only window_size=11, size_average=True (the only form the training scripts use)")
     return _PhotometricLoss.apply(img1, img2, None, 1.0, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Adam
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps) — weight_decay 0, amsgrad off: the configuration of
+    gs-simp/scene/gaussian_model.py:163 — stepping every parameter tensor of all groups in ONE HIP launch.
+    State layout is torch.optim.Adam's (state[p] = {"step", "exp_avg", "exp_avg_sq"}), so the reference's
+    densification code, which edits optimizer.state directly (gaussian_model.py:335-404), and state_dict()
+    checkpoints (gaussian_model.py:61-93 capture/restore) work unchanged. Replace
+    `torch.optim.Adam(l, lr=0.0, eps=1e-15)` by `FusedAdam(l, lr=0.0, eps=1e-15)`."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        # tensors that share (betas, eps, step) go into one launch; the reference has one such set
+        buckets = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                    raise RuntimeError("FusedAdam: fp32 GPU parameters only; there is no CPU path")
+                if p.grad.is_sparse or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: dense contiguous parameters only")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                key = (group["betas"], group["eps"], int(st["step"]), p.device)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+                buckets.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"])))
+        for (betas, eps, step, dev), items in buckets.items():
+            for i in range(0, len(items), 8):
+                chunk = items[i:i + 8]
+                arr = (_lib.AdamGroup * len(chunk))()
+                for k, (p, g, m, v, lr) in enumerate(chunk):
+                    arr[k] = _lib.AdamGroup(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr)
+                with torch.cuda.device(dev):
+                    _check(L.mvi_adam_step(arr, len(chunk), float(betas[0]), float(betas[1]), float(eps), step,
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "adam_step")
+        return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parameter activations
+
+class _Activate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_scaling, raw_rotation, raw_opacity, features_dc, features_rest):
+        L = _lib.lib()
+        ts = [raw_scaling, raw_rotation, raw_opacity, features_dc, features_rest]
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in ts):
+            raise RuntimeError("activate_gaussians: fp32 GPU tensors only; there is no CPU path")
+        rs, rr, ro, fd, fr = (t.detach().contiguous() for t in ts)
+        P, M = rs.shape[0], 1 + fr.shape[1]
+        if rs.shape != (P, 3) or rr.shape != (P, 4) or ro.numel() != P or fd.shape != (P, 1, 3) or fr.shape != (P, M - 1, 3):
+            raise ValueError("activate_gaussians: expected [P,3], [P,4], [P,1], [P,1,3], [P,M-1,3]")
+        dev = rs.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        scales, rots, opac = torch.empty(P, 3, **f32), torch.empty(P, 4, **f32), torch.empty(P, 1, **f32)
+        shs = torch.empty(P, M, 3, **f32)
+        p = lambda t: None if t.numel() == 0 else C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            _check(L.mvi_gaussian_activations(P, M, p(rs), p(rr), p(ro), p(fd), p(fr), p(scales), p(rots), p(opac), p(shs),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gaussian_activations")
+        ctx.save_for_backward(rr, scales, opac)
+        ctx.M = M
+        return scales, rots, opac, shs
+
+    @staticmethod
+    def backward(ctx, d_scales, d_rots, d_opac, d_shs):
+        L = _lib.lib()
+        rr, scales, opac = ctx.saved_tensors
+        P, M, dev = rr.shape[0], ctx.M, rr.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda g, shape: torch.zeros(shape, **f32) if g is None else g.to(torch.float32).contiguous()
+        d_scales, d_rots, d_opac, d_shs = z(d_scales, (P, 3)), z(d_rots, (P, 4)), z(d_opac, (P, 1)), z(d_shs, (P, M, 3))
+        o_s, o_r, o_o = torch.empty(P, 3, **f32), torch.empty(P, 4, **f32), torch.empty(P, 1, **f32)
+        o_dc, o_rest = torch.empty(P, 1, 3, **f32), torch.empty(P, M - 1, 3, **f32)
+        p = lambda t: None if t.numel() == 0 else C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            _check(L.mvi_gaussian_activations_backward(P, M, p(rr), p(scales), p(opac), p(d_scales), p(d_rots), p(d_opac),
+                                                       p(d_shs), p(o_s), p(o_r), p(o_o), p(o_dc), p(o_rest),
+                                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "gaussian_activations_backward")
+        return o_s, o_r, o_o, o_dc, o_rest
+
+
+def activate_gaussians(raw_scaling, raw_rotation, raw_opacity, features_dc, features_rest):
+    """(get_scaling, get_rotation, get_opacity, get_features) of gs-simp/scene/gaussian_model.py:95-115 in one launch,
+    differentiable: returns scales [P,3], rotations [P,4], opacities [P,1], shs [P,M,3]."""
+    return _Activate.apply(raw_scaling, raw_rotation, raw_opacity, features_dc, features_rest)

@@ -68,7 +68,7 @@ def test_reference_named_functions_are_differentiable(T):
     img.grad = None
     fused = T.fused_l1_dssim_loss(img, gt, 0.2, mask=mask)
     (3.0 * fused).backward()
-    assert abs(float(loss) - float(G[f"{name}_loss"])) < 1e-5 and abs(float(fused) - float(loss)) < 1e-6
+    assert abs(loss.item() - float(G[f"{name}_loss"])) < 1e-5 and abs(fused.item() - loss.item()) < 1e-6
     g_ref = torch.tensor(G[f"{name}_grad"]).cuda()
     assert float((g_sep - g_ref).abs().max()) < 1e-4 * float(g_ref.abs().max())
     assert float((img.grad / 3.0 - g_ref).abs().max()) < 1e-4 * float(g_ref.abs().max())
@@ -114,3 +114,87 @@ def test_ragged_sizes_and_errors(T):
         T.photometric_loss_forward_backward(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))
     with pytest.raises(NotImplementedError):
         T.ssim(torch.zeros(3, 4, 4).cuda(), torch.zeros(3, 4, 4).cuda(), window_size=7)
+
+
+def test_fused_adam_matches_torch_adam(T):
+    """Six parameter groups as in gaussian_model.py:154-163 (per-group lr, eps 1e-15), 5 steps with changing lr:
+    parameters and both moments equal torch.optim.Adam's (the reference's optimizer), state layout included."""
+    torch.manual_seed(0)
+    P = 4099
+    shapes = dict(xyz=(P, 3), f_dc=(P, 1, 3), f_rest=(P, 15, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4))
+    lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3)
+    init = {k: torch.randn(s) for k, s in shapes.items()}
+    def make(opt_cls):
+        ps = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in init.items()}
+        return ps, opt_cls([{"params": [ps[k]], "lr": lrs[k], "name": k} for k in shapes], lr=0.0, eps=1e-15)
+    pa, oa = make(torch.optim.Adam)
+    pb, ob = make(T.FusedAdam)
+    for it in range(5):
+        g = torch.Generator().manual_seed(100 + it)
+        grads = {k: (torch.randn(s, generator=g) * (0.0 if (k == "opacity" and it == 2) else 1e-2)).cuda() for k, s in shapes.items()}
+        for ps, opt in ((pa, oa), (pb, ob)):
+            for grp in opt.param_groups:
+                if grp["name"] == "xyz":
+                    grp["lr"] = lrs["xyz"] * (0.9 ** it)              # update_learning_rate, gaussian_model.py:169-175
+            for k in shapes:
+                ps[k].grad = grads[k].clone()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    for k in shapes:
+        sa, sb = oa.state[pa[k]], ob.state[pb[k]]
+        assert set(sb.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sb["step"]) == 5.0
+        for a, b, what in ((pa[k], pb[k], "param"), (sa["exp_avg"], sb["exp_avg"], "exp_avg"), (sa["exp_avg_sq"], sb["exp_avg_sq"], "exp_avg_sq")):
+            err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
+            assert err < 2e-6, (k, what, err)
+    # the state dict round-trips into torch.optim.Adam (checkpoint compatibility)
+    pc, oc = make(torch.optim.Adam)
+    oc.load_state_dict(ob.state_dict())
+    assert float(oc.state[pc["xyz"]]["step"]) == 5.0
+    with pytest.raises(RuntimeError):
+        cpu_p = torch.nn.Parameter(torch.zeros(4))
+        cpu_p.grad = torch.zeros(4)
+        T.FusedAdam([cpu_p]).step()
+
+
+def test_adam_ragged_sizes_and_many_tensors(T):
+    torch.manual_seed(1)
+    sizes = [1, 3, 5, 1023, 1024, 1025, 4097, 7, 2, 100003]           # 10 tensors -> two launches; unaligned tails
+    pa = [torch.nn.Parameter(torch.randn(n).cuda()) for n in sizes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = torch.optim.Adam(pa, lr=1e-2), T.FusedAdam(pb, lr=1e-2)
+    for it in range(3):
+        for a, b in zip(pa, pb):
+            a.grad = torch.randn_like(a)
+            b.grad = a.grad.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) < 2e-6 * float(a.abs().max() + 1.0)
+
+
+def test_activate_gaussians_forward_backward(T):
+    torch.manual_seed(2)
+    P, M = 3001, 16
+    raw = dict(s=torch.randn(P, 3) - 4.0, r=torch.randn(P, 4), o=torch.randn(P, 1) * 2, dc=torch.randn(P, 1, 3), rest=torch.randn(P, M - 1, 3) * 0.2)
+    raw["r"][5] = 0.0                                                     # degenerate quaternion: F.normalize's eps clamp
+    def run(fn):
+        t = {k: v.clone().cuda().requires_grad_(True) for k, v in raw.items()}
+        outs = fn(t["s"], t["r"], t["o"], t["dc"], t["rest"])
+        g = torch.Generator(device="cuda").manual_seed(3)
+        cot = [torch.randn(o.shape, device="cuda", generator=g) for o in outs]
+        torch.autograd.backward(outs, cot)
+        return outs, {k: v.grad for k, v in t.items()}
+    ref = lambda s, r, o, dc, rest: (torch.exp(s), F.normalize(r), torch.sigmoid(o), torch.cat((dc, rest), dim=1))   # gaussian_model.py:44-59, :95-115
+    o_ref, g_ref = run(ref)
+    o_hip, g_hip = run(T.activate_gaussians)
+    for a, b in zip(o_ref, o_hip):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    for k in raw:
+        a, b = g_ref[k], g_hip[k]
+        ok = torch.ones(P, dtype=torch.bool, device="cuda")
+        if k == "r":
+            ok[5] = False                                              # 0/eps: both finite, direction arbitrary
+        assert float((a[ok] - b[ok]).abs().max()) <= 1e-5 * float(a[ok].abs().max()), k
+    assert torch.equal(o_hip[3][:, :1], raw["dc"].cuda()) and torch.equal(o_hip[3][:, 1:], raw["rest"].cuda())
+    # degree 0: no features_rest
+    s, r, o, shs = T.activate_gaussians(raw["s"].cuda(), raw["r"].cuda(), raw["o"].cuda(), raw["dc"].cuda(), torch.zeros(P, 0, 3).cuda())
+    assert shs.shape == (P, 1, 3) and torch.equal(shs, raw["dc"].cuda())
