@@ -240,9 +240,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and args.path == "both":
+            # SURVEY.md §8f rows either side of the rasterizer: one full training iteration, fused HIP ops vs PyTorch ops
+            t = bucket = st = g_img = None
+            torch.cuda.empty_cache()
+            from multiview_inpaint_amd import bench_train
+            out["train_iteration"] = bench_train.run_both(steps=10, warmup=2)
         if world == 1 and args.path in ("both", "svd"):
             # second half of the BASELINE.json metric: SVD 14-frame 576x1024 denoise steps/s
-            del t, bucket, st, g_img
+            t = bucket = st = g_img = None
             torch.cuda.empty_cache()
             from multiview_inpaint_amd.svd import bench_svd
             svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=1)
