@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kAdamBlock) void adam_step_kernel(AdamTable t, floa
 
 // ---- activations -----------------------------------------------------------------------------------------------
 // One thread per Gaussian for the small attributes; the SH concat is a flat float copy done by all threads.
+template <int ROW>                       // ROW = 3 M floats per Gaussian (0 = run-time value): constant divisions
 __global__ __launch_bounds__(256) void gaussian_activations_kernel(int P, int M, const float* __restrict__ raw_scale,
                                                                    const float* __restrict__ raw_rot,
                                                                    const float* __restrict__ raw_opacity,
@@ -89,15 +90,16 @@ __global__ __launch_bounds__(256) void gaussian_activations_kernel(int P, int M,
         opac[i] = 1.0f / (1.0f + expf(-raw_opacity[i]));
     }
     // shs[g][0][:] = f_dc[g][0][:], shs[g][1..M-1][:] = f_rest[g][:][:]: consecutive lanes write consecutive floats
-    const int row = 3 * M;
-    const int64_t total = (int64_t)P * row;
-    for (int64_t e = i; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t g = e / row;
-        const int k = (int)(e - g * row);
+    // (32-bit index math: P * 3M < 2^31 is checked on the host)
+    const uint32_t row = ROW ? ROW : 3u * (uint32_t)M;
+    const uint32_t total = (uint32_t)P * row, stride = gridDim.x * 256u;
+    for (uint32_t e = (uint32_t)i; e < total; e += stride) {
+        const uint32_t g = e / row, k = e - g * row;
         shs[e] = k < 3 ? f_dc[3 * g + k] : f_rest[g * (row - 3) + (k - 3)];
     }
 }
 
+template <int ROW>
 __global__ __launch_bounds__(256) void gaussian_activations_backward_kernel(
     int P, int M, const float* __restrict__ raw_rot, const float* __restrict__ scales, const float* __restrict__ opac,
     const float* __restrict__ d_scales, const float* __restrict__ d_rots, const float* __restrict__ d_opac,
@@ -123,11 +125,10 @@ __global__ __launch_bounds__(256) void gaussian_activations_backward_kernel(
         const float s = opac[i];
         d_raw_opacity[i] = d_opac[i] * s * (1.0f - s);
     }
-    const int row = 3 * M;
-    const int64_t total = (int64_t)P * row;
-    for (int64_t e = i; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t g = e / row;
-        const int k = (int)(e - g * row);
+    const uint32_t row = ROW ? ROW : 3u * (uint32_t)M;
+    const uint32_t total = (uint32_t)P * row, stride = gridDim.x * 256u;
+    for (uint32_t e = (uint32_t)i; e < total; e += stride) {
+        const uint32_t g = e / row, k = e - g * row;
         const float v = d_shs[e];
         if (k < 3) d_f_dc[3 * g + k] = v; else d_f_rest[g * (row - 3) + (k - 3)] = v;
     }
@@ -175,9 +176,19 @@ extern "C" int mvi_gaussian_activations(int32_t P, int32_t M, const float* raw_s
     if (!raw_scaling || !raw_rotation || !raw_opacity || !features_dc || (M > 1 && !features_rest) || !scales || !rotations ||
         !opacities || !shs)
         return train_fail(MVI_EINVAL, "gaussian_activations: NULL pointer");
-    const int blocks = (P + 255) / 256;
-    hipLaunchKernelGGL(gaussian_activations_kernel, dim3(blocks * 4 > 0 ? blocks * 4 : 1), dim3(256), 0, (hipStream_t)stream, P,
-                       M, raw_scaling, raw_rotation, raw_opacity, features_dc, features_rest, scales, rotations, opacities, shs);
+    if ((int64_t)P * 3 * M >= 0x7FFFFFFFll) return train_fail(MVI_EINVAL, "gaussian_activations: P * 3M must fit 31 bits");
+    const dim3 grid((unsigned)((P + 255) / 256) * 4), blk(256);
+#define MVI_ACT(R)                                                                                                      \
+    hipLaunchKernelGGL((gaussian_activations_kernel<R>), grid, blk, 0, (hipStream_t)stream, P, M, raw_scaling, raw_rotation, \
+                       raw_opacity, features_dc, features_rest, scales, rotations, opacities, shs)
+    switch (M) {
+        case 1: MVI_ACT(3); break;
+        case 4: MVI_ACT(12); break;
+        case 9: MVI_ACT(27); break;
+        case 16: MVI_ACT(48); break;
+        default: MVI_ACT(0); break;
+    }
+#undef MVI_ACT
     return hipGetLastError() == hipSuccess ? MVI_OK : train_fail(MVI_EHIP, "gaussian_activations: kernel launch failed");
 }
 
@@ -192,9 +203,19 @@ extern "C" int mvi_gaussian_activations_backward(int32_t P, int32_t M, const flo
     if (!raw_rotation || !scales || !opacities || !dL_dscales || !dL_drotations || !dL_dopacities || !dL_dshs ||
         !dL_draw_scaling || !dL_draw_rotation || !dL_draw_opacity || !dL_dfeatures_dc || (M > 1 && !dL_dfeatures_rest))
         return train_fail(MVI_EINVAL, "gaussian_activations_backward: NULL pointer");
-    const int blocks = (P + 255) / 256;
-    hipLaunchKernelGGL(gaussian_activations_backward_kernel, dim3(blocks * 4), dim3(256), 0, (hipStream_t)stream, P, M,
-                       raw_rotation, scales, opacities, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_draw_scaling,
-                       dL_draw_rotation, dL_draw_opacity, dL_dfeatures_dc, dL_dfeatures_rest);
+    if ((int64_t)P * 3 * M >= 0x7FFFFFFFll) return train_fail(MVI_EINVAL, "gaussian_activations_backward: P * 3M must fit 31 bits");
+    const dim3 grid((unsigned)((P + 255) / 256) * 4), blk(256);
+#define MVI_ACTB(R)                                                                                                          \
+    hipLaunchKernelGGL((gaussian_activations_backward_kernel<R>), grid, blk, 0, (hipStream_t)stream, P, M, raw_rotation, scales, \
+                       opacities, dL_dscales, dL_drotations, dL_dopacities, dL_dshs, dL_draw_scaling, dL_draw_rotation,           \
+                       dL_draw_opacity, dL_dfeatures_dc, dL_dfeatures_rest)
+    switch (M) {
+        case 1: MVI_ACTB(3); break;
+        case 4: MVI_ACTB(12); break;
+        case 9: MVI_ACTB(27); break;
+        case 16: MVI_ACTB(48); break;
+        default: MVI_ACTB(0); break;
+    }
+#undef MVI_ACTB
     return hipGetLastError() == hipSuccess ? MVI_OK : train_fail(MVI_EHIP, "gaussian_activations_backward: kernel launch failed");
 }
