@@ -43,6 +43,32 @@ __device__ __forceinline__ bool quad_overlap(float2 c, float4 co, float t2, floa
     return f <= t2;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+constexpr int kB2 = 128;                // threads per tile in the backward kernel: 2 wave64, two pixels per lane
+
+// power = -0.5 (A dx^2 + C dy^2) - B dx dy for the lane's two pixels (same x, adjacent y), ONE rounding recipe shared by
+// the forward and the backward kernel so the backward replays the forward's alpha / threshold decisions exactly:
+// products rounded, fma(dx, A dx, (C dy) dy), then fma(., -0.5, -(B dx) dy).
+__device__ __forceinline__ f2 gauss_power(float4 co, float dx, f2 dy) {
+#pragma clang fp contract(off)
+    const float ax = co.x * dx, bx = co.y * dx;
+    const f2 cyy = (co.z * dy) * dy;
+    const f2 sq = pk_fma(splat(dx), splat(ax), cyy);
+    const f2 bxy = bx * dy;
+    return pk_fma(sq, splat(-0.5f), -bxy);
+}
+
+__device__ __forceinline__ float gauss_power1(float4 co, float dx, float dy) {     // the same recipe, one pixel
+#pragma clang fp contract(off)
+    const float ax = co.x * dx, bx = co.y * dx;
+    const float cyy = (co.z * dy) * dy;
+    const float sq = __builtin_fmaf(dx, ax, cyy);
+    const float bxy = bx * dy;
+    return __builtin_fmaf(sq, -0.5f, -bxy);
+}
+
 // The CU's scalar unit issues one instruction per cycle for all four SIMDs, so the inner loop must
 // stay light on scalar work: the kept entries of a 64-entry chunk are compacted into a per-wave LDS
 // strip (lane-parallel copies at popcount positions) and walked by a plain counted loop, and a
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
                 const int kn = k + 1 < 64 ? k + 1 : 63;
                 const float4 an = w_a[wave][kn], con = w_co[wave][kn], cdn = w_cd[wave][kn];   // next entry's reads overlap the math
                 float dx = a.x - pfx, dy = a.y - pfy;
-                float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                float power = gauss_power1(co, dx, dy);
                 float alpha = fminf(kAlphaMax, co.w * __expf(power));
                 alpha = power <= 0.0f ? alpha : 0.0f;
                 const float test_T = T * (1.0f - alpha);                 // 0 for a saturated pixel
@@ -199,11 +225,6 @@ __device__ __forceinline__ void quad_sum9(float& a, float& b, float& c, float& d
 // pixels are summed in the lane before the quad reduction, and the reduction/slab cost is paid once per 128 pixels.
 // Block = 128 threads = one tile; 128 list entries are staged per round. Decisions (alpha, active) use the same
 // operation order as the forward kernel (products rounded, one fma per sum), element-wise.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
-constexpr int kB2 = 128;
-
 __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_backward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
@@ -299,12 +320,7 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const uint32_t pos = (uint32_t)(hi - 1 - jc);
                 const float dx = p.x - pfx;
                 const f2 dy = splat(p.y) - pfy;
-                // power = -0.5 (A dx^2 + C dy^2) - B dx dy with the forward's rounding: fma(dx, A dx, (C dy) dy), fma(., -0.5, -(B dx) dy)
-                const float ax = co.x * dx, bx = co.y * dx;
-                const f2 cyy = (co.z * dy) * dy;
-                const f2 sq = pk_fma(splat(dx), splat(ax), cyy);
-                const f2 bxy = bx * dy;
-                const f2 power = pk_fma(sq, splat(-0.5f), -bxy);
+                const f2 power = gauss_power(co, dx, dy);          // the forward's rounding recipe
                 const f2 G = {__expf(power.x), __expf(power.y)};    // power > 0 (inf, NaN) is never active: selected away
                 const f2 oG = co.w * G;
                 const f2 alpha = __builtin_elementwise_min(splat(kAlphaMax), oG);
