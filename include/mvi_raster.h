@@ -100,6 +100,24 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                         float* grad_rows_scratch, void* stream);
 
+/* Raw-parameter forms ("fused activation + pack pre-pass"): the same two calls fed with the
+ * GaussianModel's UN-activated parameters exactly as it stores them (gs-simp/scene/gaussian_model.py:95-115, :44-59):
+ * xyz [P,3], features_dc [P,1,3], features_rest [P,M-1,3], raw_opacity [P,1], raw_scaling [P,3], raw_rotation [P,4].
+ * sigmoid / exp / F.normalize (eps 1e-12) and the SH concatenation happen inside the preprocess kernels, and the
+ * backward applies their chain rule, so exp / normalize / sigmoid / cat and their autograd nodes — 5 + ~12 PyTorch
+ * kernels, the cat alone moving 2 x 192 B per Gaussian each way — disappear. mvi_raster_forward_render is shared.
+ * Gradients are with respect to the raw parameters; dL_dmeans2D as in mvi_raster_backward. */
+int mvi_raster_forward_geom_raw(const mvi_raster_settings* s, int32_t P, int32_t M, const float* xyz,
+                                const float* features_dc, const float* features_rest, const float* raw_opacity,
+                                const float* raw_scaling, const float* raw_rotation, void* geom, size_t geom_bytes,
+                                int32_t* radii, int64_t* num_rendered_host, void* stream);
+int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t num_rendered, const float* xyz,
+                            const float* features_dc, const float* features_rest, const float* raw_opacity,
+                            const float* raw_scaling, const float* raw_rotation, const int32_t* radii, const void* geom,
+                            const void* binning, const void* image, const float* dL_dout_color, float* dL_dxyz,
+                            float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+                            float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch, void* stream);
+
 /* View-parallel training (no counterpart in the reference, which is single-GPU: gs-simp/train.sh:1):
  * dL_dshs[g,k,c] = sum over views v of Y_k(normalize(means3D[g] - campos[v])) * dL_dcolors[v,g,c] for k < (deg+1)^2,
  * zero for the inactive coefficients. View v's camera centre is campos + v * campos_stride (3 floats), its colour

@@ -99,6 +99,12 @@ size_t mvi_raster_geom_bytes(int32_t P) { return mvi::carve_geom(nullptr, P).byt
 size_t mvi_raster_image_bytes(int32_t W, int32_t H) { return mvi::carve_image(nullptr, W, H).bytes; }
 size_t mvi_raster_binning_bytes(int64_t D, int32_t W, int32_t H) { return mvi::carve_binning(nullptr, D, W, H).bytes; }
 
+static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_t P, int32_t M, const float* means3D,
+                             const float* shs, const float* colors_precomp, const float* opacities,
+                             const float* scales, const float* rotations, const float* cov3D_precomp,
+                             void* geom, size_t geom_bytes, int32_t* radii, int64_t* num_rendered_host,
+                             void* stream);
+
 int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D,
                             const float* shs, const float* colors_precomp, const float* opacities,
                             const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -106,6 +112,29 @@ int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, 
                             void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, M, f)) return rc;
+    return forward_geom_impl(s, f, P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, geom,
+                             geom_bytes, radii, num_rendered_host, stream);
+}
+
+int mvi_raster_forward_geom_raw(const mvi_raster_settings* s, int32_t P, int32_t M, const float* xyz,
+                                const float* features_dc, const float* features_rest, const float* raw_opacity,
+                                const float* raw_scaling, const float* raw_rotation, void* geom, size_t geom_bytes,
+                                int32_t* radii, int64_t* num_rendered_host, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, M, f)) return rc;
+    if (P > 0 && (!features_dc || (M > 1 && !features_rest) || !raw_scaling || !raw_rotation))
+        return fail(MVI_EINVAL, "NULL raw parameter pointer%s");
+    f.raw = 1;
+    f.shs_rest = features_rest;
+    return forward_geom_impl(s, f, P, M, xyz, features_dc, nullptr, raw_opacity, raw_scaling, raw_rotation, nullptr, geom,
+                             geom_bytes, radii, num_rendered_host, stream);
+}
+
+static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_t P, int32_t M, const float* means3D,
+                             const float* shs, const float* colors_precomp, const float* opacities,
+                             const float* scales, const float* rotations, const float* cov3D_precomp,
+                             void* geom, size_t geom_bytes, int32_t* radii, int64_t* num_rendered_host,
+                             void* stream) {
     if (!num_rendered_host) return fail(MVI_EINVAL, "num_rendered_host is NULL%s");
     *num_rendered_host = 0;
     if (P == 0) return MVI_OK;
@@ -176,6 +205,13 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D
     return MVI_OK;
 }
 
+static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const int32_t* radii, const void* geom, const void* binning,
+                         const void* image, const float* dL_dout_color, float* dL_dmeans3D, float* dL_dmeans2D,
+                         float* dL_dopacity, float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations,
+                         float* dL_dcov3D, float* dL_dconic_scratch, void* stream, mvi::RawBackwardExtra rawx);
+
 int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t D, const float* means3D,
                         const float* shs, const float* colors_precomp, const float* scales,
                         const float* rotations, const float* cov3D_precomp, const int32_t* radii,
@@ -185,6 +221,37 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
                         float* dL_drotations, float* dL_dcov3D, float* dL_dconic_scratch, void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, M, f)) return rc;
+    return backward_impl(f, P, D, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, radii, geom, binning, image,
+                         dL_dout_color, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dshs, dL_dcolors, dL_dscales, dL_drotations,
+                         dL_dcov3D, dL_dconic_scratch, stream, mvi::RawBackwardExtra());
+}
+
+int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t D, const float* xyz,
+                            const float* features_dc, const float* features_rest, const float* raw_opacity,
+                            const float* raw_scaling, const float* raw_rotation, const int32_t* radii, const void* geom,
+                            const void* binning, const void* image, const float* dL_dout_color, float* dL_dxyz,
+                            float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+                            float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, M, f)) return rc;
+    if (P > 0 && (!features_dc || (M > 1 && (!features_rest || !dL_dfeatures_rest)) || !raw_opacity || !dL_dfeatures_dc))
+        return fail(MVI_EINVAL, "NULL raw parameter / gradient pointer%s");
+    f.raw = 1;
+    f.shs_rest = features_rest;
+    mvi::RawBackwardExtra rawx;
+    rawx.raw_opacity = raw_opacity;
+    rawx.dL_dshs_rest = dL_dfeatures_rest;
+    return backward_impl(f, P, D, xyz, features_dc, nullptr, raw_scaling, raw_rotation, nullptr, radii, geom, binning, image,
+                         dL_dout_color, dL_dxyz, dL_dmeans2D, dL_draw_opacity, dL_dfeatures_dc, nullptr, dL_draw_scaling,
+                         dL_draw_rotation, nullptr, grad_rows_scratch, stream, rawx);
+}
+
+static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const int32_t* radii, const void* geom, const void* binning,
+                         const void* image, const float* dL_dout_color, float* dL_dmeans3D, float* dL_dmeans2D,
+                         float* dL_dopacity, float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations,
+                         float* dL_dcov3D, float* dL_dconic_scratch, void* stream, mvi::RawBackwardExtra rawx) {
     if (P == 0) return MVI_OK;
     if ((shs == nullptr) == (colors_precomp == nullptr))
         return fail(MVI_EINVAL, "Please provide excatly one of either SHs or precomputed colors!%s");
@@ -214,7 +281,7 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
     mvi::StageTimer tm(mvi::kStPreBwd, st);
     if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, grad_rows,
                                         dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors,
-                                        dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, st))
+                                        dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, st, rawx))
         return hip_fail("preprocess_backward", hipGetLastError());
     return MVI_OK;
 }

@@ -37,6 +37,10 @@ struct Frame {
     const float* proj;   // [16] device
     const float* campos; // [3]  device
     const float* bg;     // [3]  device
+    // raw-parameter mode (mvi_raster_*_raw): `shs` is features_dc [P,1,3], shs_rest is features_rest [P,M-1,3], and
+    // opacities / scales / rotations are the un-activated parameters (sigmoid / exp / normalize happen in the kernels)
+    const float* shs_rest = nullptr;
+    int raw = 0;
 };
 
 // ---- scratch layouts (all offsets 256-B aligned) ---------------------------------------------
@@ -209,11 +213,14 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               const float* colors_precomp, const float* opacities, const float* scales,
                               const float* rotations, const float* cov3D_precomp, GeomView g,
                               int32_t* radii, hipStream_t st);
+// raw mode only: raw_opacity [P] (chain rule of the sigmoid), dL_dshs_rest [P,M-1,3]
+struct RawBackwardExtra { const float* raw_opacity = nullptr; float* dL_dshs_rest = nullptr; };
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
                                const float* scales, const float* rotations, const float* cov3D_precomp,
                                const int32_t* radii, GeomView g, const float* grad_rows, float* dL_dmeans3D,
                                float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors, float* dL_dshs,
-                               float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st);
+                               float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st,
+                               RawBackwardExtra raw = RawBackwardExtra());
 int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
                    int64_t D, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,

@@ -60,6 +60,50 @@ __device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* 
         for (int e = threadIdx.x; e < total; e += kBlock) dst[e] = lds[(e / rec) * stride + (e % rec)];
     }
 }
+// The same for records whose length is not a multiple of 4 floats (features_rest: 3 (M - 1) = 45 / 24 / 9): float4
+// loads over the contiguous span, every component placed by (record, offset) — the record index comes from one fp32
+// multiply (exact for spans < 2^22 floats), not from an integer division. `lds` points at column 0 of the target.
+__device__ __forceinline__ void stage_in_split(const float* __restrict__ src, float* lds, int n_rec, int rec, int stride) {
+    const int total = n_rec * rec, nvec = total >> 2;
+    const float inv = 1.0f / (float)rec;
+    auto put = [&](int e, float v) {
+        const int r = (int)(((float)e + 0.5f) * inv);
+        lds[r * stride + (e - r * rec)] = v;
+    };
+    constexpr int kU = 6;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += kBlock * kU) {
+        float4 x[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int v = v0 + u * kBlock; if (v < nvec) x[u] = s4[v]; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int v = v0 + u * kBlock;
+            if (v < nvec) { put(4 * v, x[u].x); put(4 * v + 1, x[u].y); put(4 * v + 2, x[u].z); put(4 * v + 3, x[u].w); }
+        }
+    }
+    for (int e = 4 * nvec + threadIdx.x; e < total; e += kBlock) put(e, src[e]);
+}
+__device__ __forceinline__ void stage_out_split(float* __restrict__ dst, const float* lds, int n_rec, int rec, int stride) {
+    const int total = n_rec * rec, nvec = total >> 2;
+    const float inv = 1.0f / (float)rec;
+    auto get = [&](int e) {
+        const int r = (int)(((float)e + 0.5f) * inv);
+        return lds[r * stride + (e - r * rec)];
+    };
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int v = threadIdx.x; v < nvec; v += kBlock) d4[v] = make_float4(get(4 * v), get(4 * v + 1), get(4 * v + 2), get(4 * v + 3));
+    for (int e = 4 * nvec + threadIdx.x; e < total; e += kBlock) dst[e] = get(e);
+}
+// SH rows of a block into / out of LDS rows of `stride` floats: one [P,M,3] array, or (raw mode) features_dc [P,1,3] +
+// features_rest [P,M-1,3] landing in the same rows, so the rest of the kernel does not care
+__device__ __forceinline__ void stage_sh_in(const Frame& f, const float* shs, float* s_sh, int blk0, int n_rec, int stride) {
+    if (!f.raw) { stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, stride); return; }
+    stage_in(shs + (size_t)blk0 * 3, s_sh, n_rec, 3, stride);
+    if (f.M > 1) stage_in_split(f.shs_rest + (size_t)blk0 * (3 * f.M - 3), s_sh + 3, n_rec, 3 * f.M - 3, stride);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 __host__ __device__ inline int sh_stride(int M) { return 3 * M + 1 - ((3 * M) & 1); }   // odd row stride
 
 __device__ constexpr float SH_C0 = 0.28209479177387814f;
@@ -164,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     float* s_mean = s_dyn + (size_t)kBlock * shs_w;        // [256][3]
     float* s_scale = s_mean + 3 * kBlock;                  // [256][3]
     if (tid == 0) s_sum = 0;
-    if (shs) stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+    if (shs) stage_sh_in(f, shs, s_sh, blk0, n_rec, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
     if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
     // per-lane operands requested before the barrier so they travel with the staged rows
@@ -173,6 +217,11 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
     if (i < f.P) {
         if (!cov3D_precomp) q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
         opac = opacities[i];
+        if (f.raw) {                                        // gaussian_model.py:44-59: sigmoid, F.normalize (eps 1e-12)
+            const float nq = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            q = make_float4(q.x / nq, q.y / nq, q.z / nq, q.w / nq);
+            opac = sigmoidf_(opac);
+        }
     }
     __syncthreads();
     float V[16], PM[16];
@@ -201,8 +250,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
             } else {
                 float R[3][3], Mx[3][3];
                 quat_to_rot(q.x, q.y, q.z, q.w, R);
-                float s[3] = {f.scale_modifier * s_scale[3 * tid], f.scale_modifier * s_scale[3 * tid + 1],
-                              f.scale_modifier * s_scale[3 * tid + 2]};
+                float sa[3] = {s_scale[3 * tid], s_scale[3 * tid + 1], s_scale[3 * tid + 2]};
+                if (f.raw) { sa[0] = expf(sa[0]); sa[1] = expf(sa[1]); sa[2] = expf(sa[2]); }
+                float s[3] = {f.scale_modifier * sa[0], f.scale_modifier * sa[1], f.scale_modifier * sa[2]};
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii, GeomView g,
     const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)] + 5 x [256][3]
     const int tid = threadIdx.x;
     const int blk0 = blockIdx.x * kBlock;
@@ -340,11 +390,12 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float* s_dmean = s_scale + 3 * kBlock;
     float* s_dm2d = s_dmean + 3 * kBlock;
     float* s_dscale = s_dm2d + 3 * kBlock;
-    if (shs) stage_in(shs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+    if (shs) stage_sh_in(f, shs, s_sh, blk0, n_rec, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
     if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
     // per-lane operands requested before the barrier so they travel with the staged rows
     const bool in_range = i < f.P;
+    const float raw_o = (f.raw && in_range) ? rawx.raw_opacity[i] : 0.0f;
     const bool live = in_range && radii[i] > 0;
     float gr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), qrot = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -363,7 +414,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     __syncthreads();
     s_dm2d[3 * tid] = gr[0]; s_dm2d[3 * tid + 1] = gr[1]; s_dm2d[3 * tid + 2] = 0.0f;
     if (in_range) {
-        dL_dopacity[i] = gr[5];
+        float go = gr[5];
+        if (f.raw) { const float o = sigmoidf_(raw_o); go *= o * (1.0f - o); }    // d sigmoid
+        dL_dopacity[i] = go;
         if (dL_dcolors) {
             // colours-precomp input: the colour gradient itself. SH input: the colour factor of the rank-1 SH gradient
             // dL/dSH[k][c] = Y_k(dir) * (clamped_c ? 0 : dL/dcolour_c) (mvi_raster_sh_backward_views rebuilds the rest)
@@ -481,11 +534,17 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     } else {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         if (live) {
-            const float4 q = qrot;
+            float4 q = qrot;
+            float nq = 1.0f;
+            if (f.raw) {
+                nq = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+                q = make_float4(q.x / nq, q.y / nq, q.z / nq, q.w / nq);
+            }
             float R[3][3];
             quat_to_rot(q.x, q.y, q.z, q.w, R);
-            float s[3] = {f.scale_modifier * s_scale[3 * tid], f.scale_modifier * s_scale[3 * tid + 1],
-                          f.scale_modifier * s_scale[3 * tid + 2]};
+            float sa[3] = {s_scale[3 * tid], s_scale[3 * tid + 1], s_scale[3 * tid + 2]};
+            if (f.raw) { sa[0] = expf(sa[0]); sa[1] = expf(sa[1]); sa[2] = expf(sa[2]); }
+            float s[3] = {f.scale_modifier * sa[0], f.scale_modifier * sa[1], f.scale_modifier * sa[2]};
             float Gf[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
                               {0.5f * g6[1], g6[3], 0.5f * g6[4]},
                               {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
@@ -509,6 +568,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                             qr * dR[2][0] + qz * dR[2][1] - 2 * qy * dR[2][2]);
             dq[3] = 2.0f * (-2 * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2 * qz * dR[1][1] +
                             qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+            if (f.raw) {                                   // chain rule of exp and of y = q / |q|: (g - y (y . g)) / |q|
+                ds[0] *= sa[0]; ds[1] *= sa[1]; ds[2] *= sa[2];
+                const float dot = q.x * dq[0] + q.y * dq[1] + q.z * dq[2] + q.w * dq[3];
+                const float inq = 1.0f / nq;
+                dq[0] = (dq[0] - q.x * dot) * inq; dq[1] = (dq[1] - q.y * dot) * inq;
+                dq[2] = (dq[2] - q.z * dot) * inq; dq[3] = (dq[3] - q.w * dot) * inq;
+            }
         }
         s_dscale[3 * tid] = ds[0]; s_dscale[3 * tid + 1] = ds[1]; s_dscale[3 * tid + 2] = ds[2];
         if (in_range) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
@@ -517,14 +583,21 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     stage_out(dL_dmeans3D + (size_t)blk0 * 3, s_dmean, n_rec, 3, 3);
     stage_out(dL_dmeans2D + (size_t)blk0 * 3, s_dm2d, n_rec, 3, 3);
     if (!cov3D_precomp) stage_out(dL_dscales + (size_t)blk0 * 3, s_dscale, n_rec, 3, 3);
-    if (shs && dL_dshs) stage_out(dL_dshs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+    if (shs && dL_dshs) {
+        if (!f.raw) {
+            stage_out(dL_dshs + (size_t)blk0 * f.M * 3, s_sh, n_rec, 3 * f.M, shs_w);
+        } else {                                           // dL/dfeatures_dc [P,1,3] and dL/dfeatures_rest [P,M-1,3]
+            stage_out(dL_dshs + (size_t)blk0 * 3, s_sh, n_rec, 3, shs_w);
+            if (f.M > 1) stage_out_split(rawx.dL_dshs_rest + (size_t)blk0 * (3 * f.M - 3), s_sh + 3, n_rec, 3 * f.M - 3, shs_w);
+        }
+    }
 }
 
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
                                const float* scales, const float* rotations, const float* cov3D_precomp,
                                const int32_t* radii, GeomView g, const float* grad_rows, float* dL_dmeans3D,
                                float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors, float* dL_dshs,
-                               float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st) {
+                               float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st, RawBackwardExtra rawx) {
     if (f.P <= 0) return 0;
     int nblk = (f.P + kBlock - 1) / kBlock;
     size_t lds = sizeof(float) * ((size_t)kBlock * (shs ? sh_stride(f.M) : 0) + 15 * kBlock);
@@ -533,7 +606,7 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
         return MVI_EHIP;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), lds, st, f, means3D, shs, scales,
                        rotations, cov3D_precomp, radii, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
-                       dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales, dL_drots);
+                       dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales, dL_drots, rawx);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

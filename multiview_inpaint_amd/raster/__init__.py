@@ -209,6 +209,86 @@ def sh_backward_views(means3D, campos, color_factors, M, sh_degree, out=None):
     return out
 
 
+def rasterize_forward_raw(rs: GaussianRasterizationSettings, xyz, features_dc, features_rest, raw_opacity, raw_scaling,
+                          raw_rotation):
+    """HIP forward fed with the GaussianModel's un-activated parameters (gaussian_model.py:95-115 happens in the
+    kernels). Returns (color, radii, depth, RasterState) like rasterize_forward."""
+    L = _lib.lib()
+    fr = _Frame(rs)
+    dev = xyz.device
+    if dev.type != "cuda":
+        raise RuntimeError("xyz must be on the GPU; the rasterizer has no CPU path")
+    P, M = int(xyz.shape[0]), 1 + int(features_rest.shape[1])
+    if features_dc.shape != (P, 1, 3) or features_rest.shape != (P, M - 1, 3) or raw_opacity.numel() != P or \
+            raw_scaling.shape != (P, 3) or raw_rotation.shape != (P, 4):
+        raise ValueError("rasterize_forward_raw: expected [P,3], [P,1,3], [P,M-1,3], [P,1], [P,3], [P,4]")
+    H, W = int(rs.image_height), int(rs.image_width)
+    st = RasterState()
+    st.P, st.M, st.W, st.H = P, M, W, H
+    u8 = dict(dtype=torch.uint8, device=dev)
+    st.geom = torch.empty(L.mvi_raster_geom_bytes(P), **u8)
+    st.image = torch.empty(L.mvi_raster_image_bytes(W, H), **u8)
+    st.radii = torch.empty(P, dtype=torch.int32, device=dev)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    D = C.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_forward_geom_raw(C.byref(fr.c), P, M, _ptr(xyz), _ptr(features_dc), _ptr(features_rest),
+                                                 _ptr(raw_opacity), _ptr(raw_scaling), _ptr(raw_rotation), _ptr(st.geom),
+                                                 st.geom.numel(), _ptr(st.radii), C.byref(D), stream),
+                   "rasterize forward raw (geom)")
+        st.D = int(D.value)
+        st.binning = torch.empty(L.mvi_raster_binning_bytes(st.D, W, H) if st.D else 0, **u8)
+        _lib.check(L.mvi_raster_forward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), st.geom.numel(),
+                                               _ptr(st.binning), st.binning.numel(), _ptr(st.image), st.image.numel(),
+                                               _ptr(color), _ptr(depth), stream), "rasterize forward (render)")
+    return color, st.radii, depth, st
+
+
+def rasterize_backward_raw(rs: GaussianRasterizationSettings, st: RasterState, grad_color, xyz, features_dc, features_rest,
+                           raw_opacity, raw_scaling, raw_rotation):
+    """HIP backward with respect to the raw parameters. Returns dict(xyz, means2D, features_dc, features_rest,
+    opacity, scaling, rotation)."""
+    L = _lib.lib()
+    fr = _Frame(rs)
+    dev, P, M = xyz.device, st.P, st.M
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = dict(xyz=torch.empty(P, 3, **f32), means2D=torch.empty(P, 3, **f32), opacity=torch.empty(P, 1, **f32),
+             features_dc=torch.empty(P, 1, 3, **f32), features_rest=torch.empty(P, M - 1, 3, **f32),
+             scaling=torch.empty(P, 3, **f32), rotation=torch.empty(P, 4, **f32))
+    scratch = torch.empty(P, 16, **f32)
+    grad_color = grad_color.to(torch.float32).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_backward_raw(
+            C.byref(fr.c), P, M, st.D, _ptr(xyz), _ptr(features_dc), _ptr(features_rest), _ptr(raw_opacity), _ptr(raw_scaling),
+            _ptr(raw_rotation), _ptr(st.radii), _ptr(st.geom), _ptr(st.binning), _ptr(st.image), _ptr(grad_color),
+            _ptr(g["xyz"]), _ptr(g["means2D"]), _ptr(g["opacity"]), _ptr(g["features_dc"]), _ptr(g["features_rest"]),
+            _ptr(g["scaling"]), _ptr(g["rotation"]), _ptr(scratch), stream), "rasterize backward raw")
+    return g
+
+
+class _RasterizeRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, raw_opacity, raw_scaling, raw_rotation, rs):
+        a = [t.detach().to(torch.float32).contiguous() for t in (xyz, features_dc, features_rest, raw_opacity, raw_scaling,
+                                                                  raw_rotation)]
+        color, radii, depth, st = rasterize_forward_raw(rs, *a)
+        ctx.rs, ctx.st, ctx.a = rs, st, a
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _gr, _gd):
+        st = ctx.st
+        if st.P == 0:
+            return tuple(torch.zeros_like(t) for t in (ctx.a[0], ctx.a[0], *ctx.a[1:])) + (None,)
+        g = rasterize_backward_raw(ctx.rs, st, grad_color, *ctx.a)
+        return (g["xyz"], g["means2D"], g["features_dc"], g["features_rest"], g["opacity"].view_as(ctx.a[3]), g["scaling"],
+                g["rotation"], None)
+
+
 def _opt(t):
     """None or empty -> None; otherwise contiguous fp32."""
     if t is None or t.numel() == 0:
@@ -259,6 +339,13 @@ class GaussianRasterizer(torch.nn.Module):
             _lib.check(L.mvi_raster_mark_visible(p.shape[0], _ptr(p), _ptr(fr.keep[1]), _ptr(fr.keep[2]), _ptr(out), stream),
                        "mark_visible")
         return out.bool()
+
+    def forward_raw(self, xyz, means2D, features_dc, features_rest, raw_opacity, raw_scaling, raw_rotation):
+        """The same render fed with the GaussianModel's parameter tensors as stored (_xyz, _features_dc, _features_rest,
+        _opacity, _scaling, _rotation): the activations of gaussian_model.py:95-115 and their chain rule run inside the
+        preprocess kernels. Returns (color, radii, depth); gradients flow to the raw parameters and to means2D."""
+        return _RasterizeRaw.apply(xyz, means2D, features_dc, features_rest, raw_opacity, raw_scaling, raw_rotation,
+                                   self.raster_settings)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):

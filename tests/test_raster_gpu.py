@@ -340,3 +340,42 @@ def test_factored_sh_gradient_and_multi_view_rebuild(R, deg, store_deg):
     assert torch.equal(out2, R.sh_backward_views(t["means3D"], cp, both, M, deg))
     with pytest.raises(ValueError):
         R.sh_backward_views(t["means3D"], cp[:1], both, M, deg)
+
+
+@pytest.mark.parametrize("deg,store_deg", [(3, 3), (1, 2), (0, 0)])
+def test_raw_parameter_path_equals_activations_plus_standard_path(R, deg, store_deg):
+    """forward_raw (sigmoid / exp / normalize / SH concat inside the preprocess kernels, chain rule in the backward)
+    against train_ops.activate_gaussians + the standard path: same integer outputs bit for bit (both use the same
+    device expressions for the activations), images and raw-parameter gradients to summation order."""
+    from multiview_inpaint_amd import train_ops as T
+    cam, sc, bg = small_scene(21, N=1500, W=160, H=112, deg=store_deg, log_scale=np.log(0.05))
+    t = _to_dev(sc)
+    P, M = t["shs"].shape[0], t["shs"].shape[1]
+    raw = dict(xyz=t["means3D"], dc=t["shs"][:, :1].contiguous(), rest=t["shs"][:, 1:].contiguous(),
+               o=torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)), s=torch.log(t["scales"]),
+               q=t["rotations"] * (0.5 + torch.rand(P, 1, device="cuda", generator=torch.Generator("cuda").manual_seed(1))))
+    rs = _settings(R, cam, bg, deg)
+    g_img = torch.tensor(np.random.default_rng(5).normal(size=(3, cam["H"], cam["W"])).astype(np.float32), device="cuda")
+    rast = R.GaussianRasterizer(rs)
+
+    def run(raw_mode):
+        p = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        m2d = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        if raw_mode:
+            color, radii, depth = rast.forward_raw(p["xyz"], m2d, p["dc"], p["rest"], p["o"], p["s"], p["q"])
+        else:
+            scales, rots, opac, shs = T.activate_gaussians(p["s"], p["q"], p["o"], p["dc"], p["rest"])
+            color, radii, depth = rast(means3D=p["xyz"], means2D=m2d, shs=shs, opacities=opac, scales=scales, rotations=rots)
+        (color * g_img).sum().backward()
+        return color.detach(), radii, depth, {**{k: v.grad for k, v in p.items()}, "m2d": m2d.grad}
+
+    c0, r0, d0, g0 = run(False)
+    c1, r1, d1, g1 = run(True)
+    assert torch.equal(r0, r1) and int((r0 > 0).sum()) > P // 3
+    assert torch.equal(c0, c1) and torch.equal(d0, d1)                 # forward has no atomics: identical
+    for k in g0:
+        assert g1[k] is not None and g1[k].shape == g0[k].shape, k
+        if g0[k].numel() == 0:
+            continue                                                   # degree 0: features_rest is [P,0,3]
+        frac, worst = _close_frac(g1[k].cpu().numpy(), g0[k].cpu().numpy())
+        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
