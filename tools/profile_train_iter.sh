@@ -9,7 +9,7 @@ cat > /tmp/bt.py <<PY
 import sys, json
 sys.path.insert(0, "$R")
 from multiview_inpaint_amd import bench_train
-print(json.dumps(bench_train.run("hip", 10, 2)))
+print(json.dumps(bench_train.run("hip_raw", 10, 2)))
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /tmp/bt.py > $OUT/run.log 2>&1
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
