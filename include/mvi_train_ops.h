@@ -59,6 +59,12 @@ int mvi_gaussian_activations_backward(int32_t P, int32_t M, const float* raw_rot
                                       float* dL_draw_rotation, float* dL_draw_opacity, float* dL_dfeatures_dc,
                                       float* dL_dfeatures_rest, void* stream);
 
+/* simple_knn._C.distCUDA2 (gs-simp/scene/gaussian_model.py:20, :134, :546, :623; third-party plug-in, absent from the
+ * reference tree): mean_dist2[i] = mean of the squared distances from points[i] to its 3 nearest OTHER points
+ * (exact; FLT_MAX terms when fewer than 3 exist). points [N,3] fp32, mean_dist2 [N]. Initialisation / densification
+ * only — exact tiled brute force, O(N^2). */
+int mvi_knn3_mean_dist2(const float* points, int32_t N, float* mean_dist2, void* stream);
+
 const char* mvi_train_last_error(void);
 
 #ifdef __cplusplus

@@ -114,6 +114,8 @@ def _bind_train_ops(L):
     L.mvi_photometric_loss.restype = C.c_int
     L.mvi_photometric_loss.argtypes = [vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, sz, vp]
     L.mvi_train_last_error.restype = C.c_char_p
+    L.mvi_knn3_mean_dist2.restype = C.c_int
+    L.mvi_knn3_mean_dist2.argtypes = [vp, i32, vp, vp]
     L.mvi_adam_step.restype = C.c_int
     L.mvi_adam_step.argtypes = [C.POINTER(AdamGroup), i32, C.c_double, C.c_double, C.c_double, i32, vp]
     L.mvi_gaussian_activations.restype = C.c_int

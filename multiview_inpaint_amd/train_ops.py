@@ -207,3 +207,22 @@ def activate_gaussians(raw_scaling, raw_rotation, raw_opacity, features_dc, feat
     """(get_scaling, get_rotation, get_opacity, get_features) of gs-simp/scene/gaussian_model.py:95-115 in one launch,
     differentiable: returns scales [P,3], rotations [P,4], opacities [P,1], shs [P,M,3]."""
     return _Activate.apply(raw_scaling, raw_rotation, raw_opacity, features_dc, features_rest)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# simple_knn
+
+def distCUDA2(points):
+    """simple_knn._C.distCUDA2: [N,3] fp32 GPU tensor -> [N] mean squared distance to the 3 nearest other points
+    (gs-simp/scene/gaussian_model.py:134, :546, :623). Same name and signature as the plug-in."""
+    if not points.is_cuda:
+        raise RuntimeError(f"distCUDA2: points must be on the GPU (got {points.device}); there is no CPU path")
+    if points.ndim != 2 or points.shape[1] != 3:
+        raise ValueError(f"distCUDA2: points must be [N,3] (got {tuple(points.shape)})")
+    p = points.detach().to(torch.float32).contiguous()
+    out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        _check(_lib.lib().mvi_knn3_mean_dist2(C.c_void_p(p.data_ptr()) if p.numel() else None, p.shape[0],
+                                              C.c_void_p(out.data_ptr()) if p.numel() else None,
+                                              C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)), "distCUDA2")
+    return out

@@ -58,3 +58,17 @@ def photometric_loss(image, gt, lambda_dssim=0.2, weight=None, need_grad=True):
         gx = (1 - lambda_dssim) * np.sign(x - y) / n - lambda_dssim * g / n
         out["grad"] = gx * wmap
     return out
+
+
+def knn3_mean_dist2(points):
+    """distCUDA2 of simple_knn (call sites gs-simp/scene/gaussian_model.py:134, :546, :623; the package itself is a
+    third-party CUDA plug-in absent from the tree — PARITY UNPINNED beyond its published behaviour): mean of the squared
+    distances to the 3 nearest other points, exact, by brute force in fp64 chunks."""
+    p = np.asarray(points, np.float64)
+    n = p.shape[0]
+    out = np.empty(n)
+    for a in range(0, n, 512):
+        d = ((p[a:a + 512, None, :] - p[None, :, :]) ** 2).sum(-1)
+        d[np.arange(d.shape[0]), np.arange(a, a + d.shape[0])] = np.inf
+        out[a:a + 512] = np.sort(d, axis=1)[:, :3].mean(1)
+    return out

@@ -85,7 +85,7 @@ def test_full_size_against_torch_restatement_and_properties(T):
         ref = _torch_loss(x, gt, 0.2, wt)
         ref.backward()
         out3, grad = T.photometric_loss_forward_backward(img, gt, 0.2, wt)
-        assert abs(float(out3[0]) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        assert abs(out3[0].item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
         assert float((grad - x.grad).abs().max()) < 1e-4 * float(x.grad.abs().max())
         if wt is not None:
             assert float(grad[:, mask[0] > 0].abs().max()) == 0.0       # masked pixels receive no gradient
@@ -106,7 +106,7 @@ def test_ragged_sizes_and_errors(T):
         ref = _torch_loss(x, gt, 0.2)
         ref.backward()
         out3, grad = T.photometric_loss_forward_backward(img, gt, 0.2)
-        assert abs(float(out3[0]) - float(ref)) < 1e-5
+        assert abs(out3[0].item() - ref.item()) < 1e-5
         assert float((grad - x.grad).abs().max()) < 1e-4 * float(x.grad.abs().max())
     with pytest.raises(ValueError):
         T.photometric_loss_forward_backward(torch.zeros(3, 4, 4).cuda(), torch.zeros(3, 4, 5).cuda())
@@ -198,3 +198,29 @@ def test_activate_gaussians_forward_backward(T):
     # degree 0: no features_rest
     s, r, o, shs = T.activate_gaussians(raw["s"].cuda(), raw["r"].cuda(), raw["o"].cuda(), raw["dc"].cuda(), torch.zeros(P, 0, 3).cuda())
     assert shs.shape == (P, 1, 3) and torch.equal(shs, raw["dc"].cuda())
+
+
+@pytest.mark.parametrize("N", [4, 255, 256, 257, 5000])
+def test_distcuda2_matches_exact_3nn(T, N):
+    import loss_oracle as lo
+    rng = np.random.default_rng(N)
+    pts = (rng.normal(size=(N, 3)) * np.array([3.0, 1.0, 0.3])).astype(np.float32)
+    if N >= 256:
+        pts[10] = pts[200]                                             # a duplicated point: distance 0 counts
+    got = T.distCUDA2(torch.tensor(pts).cuda()).cpu().numpy()
+    want = lo.knn3_mean_dist2(pts)
+    assert got.shape == (N,) and np.abs(got - want).max() <= 2e-6 * want.max() + 1e-12
+    # the drop-in package exports the plug-in's symbol
+    sys.path.insert(0, os.path.join(ROOT, "multiview_inpaint_amd", "dropin"))
+    from simple_knn._C import distCUDA2
+    assert torch.equal(distCUDA2(torch.tensor(pts).cuda()).cpu(), torch.tensor(got))
+
+
+def test_distcuda2_edge_cases(T):
+    assert T.distCUDA2(torch.zeros(0, 3).cuda()).shape == (0,)
+    d = T.distCUDA2(torch.tensor([[0.0, 0, 0], [1.0, 0, 0]]).cuda())     # fewer than 3 neighbours: FLT_MAX terms, like the plug-in
+    assert bool((d > 1e37).all())
+    with pytest.raises(ValueError):
+        T.distCUDA2(torch.zeros(5, 2).cuda())
+    with pytest.raises(RuntimeError):
+        T.distCUDA2(torch.zeros(5, 3))
