@@ -121,6 +121,12 @@ int mvi_add_lerp(const void* x, const void* h, const void* base, const float* al
 int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64_t N, int32_t C, int64_t spatial,
                              int32_t dtype, void* stream);
 
+/* x[r, :] = softmax(scale * x[r, :]) in place, x [rows, cols] contiguous, scale > 0, fp32 statistics. The scaled
+ * softmax between the two library GEMMs of the first-stage autoencoder's single-head attention with D = C = 512
+ * (svd_inpaint1/sgm/modules/diffusionmodules/model.py:180-195, scaled_dot_product_attention with one head): the
+ * score matrix of a frame chunk is held in HBM. One read and one write per score for cols <= 12288. */
+int mvi_softmax_rows(void* x, int64_t rows, int32_t cols, float scale, int32_t dtype, void* stream);
+
 /* Which kernel mvi_attention_forward would pick: 0 = rowtile fp32-math, 1 = MFMA flash. */
 int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);
 

@@ -30,6 +30,8 @@ def bind(L):
     L.mvi_add_lerp.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, vp]
     L.mvi_tokens_to_planes_add.restype = C.c_int
     L.mvi_tokens_to_planes_add.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp]
+    L.mvi_softmax_rows.restype = C.c_int
+    L.mvi_softmax_rows.argtypes = [vp, i64, i32, f32, i32, vp]
     L.mvi_attention_kernel_kind.restype = C.c_int
     L.mvi_attention_kernel_kind.argtypes = [i32, i32, i32, i32]
     L.mvi_unet_last_error.restype = C.c_char_p

@@ -152,6 +152,38 @@ def attention(q, k, v, heads):
     return out
 
 
+def softmax_rows_(x, scale):
+    """x [..., cols] contiguous: softmax(scale * x) over the last axis, in place."""
+    L = _lib.lib()
+    if x.dtype not in _DT or not x.is_contiguous():
+        raise TypeError("softmax_rows_: contiguous fp32/bf16/f16 tensor expected")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    with torch.cuda.device(x.device), _Timed("softmax_rows", 2.0 * x.numel() * x.element_size(), x.device):
+        _check(L.mvi_softmax_rows(x.data_ptr(), rows, cols, float(scale), _DT[x.dtype], _stream(x.device)), "softmax_rows")
+    return x
+
+
+_WIDE_SCORE_BYTES = 8 << 30        # scores held at once (of 288 GB)
+
+
+def attention_wide(q, k, v):
+    """Single-head attention with a wide head (D = C, e.g. 512 in the first-stage autoencoder's mid block): q [B,Sq,D],
+    k/v [B,Sk,D] -> [B,Sq,D], scale D**-0.5. The D-deep contractions are library GEMMs (like the convolutions and
+    Linear layers); the scores of a chunk of frames stay in HBM and are normalised in place by the HIP softmax."""
+    B, Sq, D = q.shape
+    Sk = k.shape[1]
+    out = torch.empty_like(q)
+    per = Sq * Sk * q.element_size()
+    step = max(1, min(B, _WIDE_SCORE_BYTES // max(per, 1)))
+    kt = k.transpose(1, 2)
+    for b0 in range(0, B, step):
+        s = torch.bmm(q[b0:b0 + step], kt[b0:b0 + step])
+        softmax_rows_(s, float(D) ** -0.5)
+        torch.bmm(s, v[b0:b0 + step], out=out[b0:b0 + step])
+    return out
+
+
 def attention_temporal(q, k, v, heads, T):
     """q/k/v [(bo*T), S, H*D] -> same; softmax over the T frames of each (video, token, head)."""
     L = _lib.lib()

@@ -87,6 +87,17 @@ def attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, Sq, HD)
 
 
+def attention_wide(q, k, v):
+    """Single-head attention whose head is the whole channel axis (model.py:180-195: D = C = 512): q [B,Sq,D],
+    k/v [B,Sk,D] -> [B,Sq,D]."""
+    if q.is_cuda and not _needs_autograd(q, k, v):
+        from . import hip_ops
+        if q.shape[-1] <= 64 and q.shape[-1] in (16, 32, 64):
+            return hip_ops.attention(q, k, v, 1)
+        return hip_ops.attention_wide(q.contiguous(), k.contiguous(), v.contiguous())
+    return F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+
+
 def attention_temporal(q, k, v, heads, T):
     """Self-attention over the frame axis without regrouping tokens: q/k/v [(bo*T), S, H*D] ->
     same shape; one softmax per (video, spatial token, head) over its T frames. Equals

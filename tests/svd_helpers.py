@@ -46,3 +46,16 @@ def seeded_inputs(seed, T=T_FRAMES, hw=LATENT_HW, cfg=SMALL_UNET, cfg_doubled=Tr
         x=r(B, 4, h, w), concat=r(B, 4, h, w), crossattn=r(B, 1, cfg["context_dim"]), vector=r(B, cfg["adm_in_channels"]),
         control_hint=torch.rand(B, 7, 8 * h, 8 * w, generator=g), sigma=torch.exp(r(B) * 1.2),
         image_only_indicator=torch.zeros(1, T), num_video_frames=T)
+
+
+# ---- first-stage autoencoder: small config of configs/test/svd_f_est_ctrl_simp1.yaml:131-159
+SMALL_VAE = dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
+                 ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+VAE_T = 3
+VAE_HW = (32, 16)
+VAE_SAMPLE_SEED = 5
+
+
+def vae_inputs(seed, T=VAE_T, hw=VAE_HW):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(T, 3, *hw, generator=g) * 2 - 1

@@ -1,0 +1,135 @@
+"""GPU parity of the first-stage autoencoder on the HIP ops (through the C-ABI): the scaled row
+softmax and the wide single-head attention against fp64 PyTorch on the CPU, the small encoder / video decoder against
+the golden outputs of the imported reference (tests/golden/vae_small.npz), and the full-size mid-block attention
+shape through a size-independent property. fp32 I/O: 1e-4 relative (the reference runs the first stage in fp32:
+disable_first_stage_autocast, configs/test/svd_f_est_ctrl_simp1.yaml:6)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import svd_helpers as H
+
+pytestmark = pytest.mark.gpu
+DROPIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiview_inpaint_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from multiview_inpaint_amd.svd import hip_ops
+    return hip_ops
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "vae_small.npz"))
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 9216), (33, 77), (5, 13001), (3, 12288), (1, 1), (64, 2304), (2, 12292)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_softmax_rows(ops, rows, cols, dtype):
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 6).to(dtype)
+    x[0, cols // 2] = 60.0                                    # one dominant score
+    scale = 0.0442
+    want = torch.softmax(x.double() * scale, dim=-1)
+    got = ops.softmax_rows_(x.to(DEV).clone(), scale)
+    tol = {torch.float32: 2e-6, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dtype]
+    assert rel(got, want) < tol * 1.01 + 1e-7
+    if dtype == torch.float32:
+        assert float((got.double().sum(-1) - 1).abs().max()) < 1e-5
+
+
+def test_softmax_rows_rejects_bad_arguments(ops):
+    x = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(Exception):
+        ops.softmax_rows_(x, 0.0)
+    with pytest.raises(TypeError):
+        ops.softmax_rows_(x.t(), 1.0)
+    assert ops.softmax_rows_(torch.zeros(0, 8, device=DEV), 1.0).shape == (0, 8)
+
+
+@pytest.mark.parametrize("B,S,D", [(3, 200, 512), (2, 77, 96), (1, 1024, 128)])
+def test_attention_wide_fp32(ops, B, S, D):
+    g = torch.Generator().manual_seed(B * S + D)
+    q, k, v = (torch.randn(B, S, D, generator=g) for _ in range(3))
+    want = F.scaled_dot_product_attention(q.double()[:, None], k.double()[:, None], v.double()[:, None])[:, 0]
+    got = ops.attention_wide(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert rel(got, want) < 1e-4
+    # chunked over the batch: same values
+    saved = ops._WIDE_SCORE_BYTES
+    try:
+        ops._WIDE_SCORE_BYTES = S * S * 4
+        assert torch.equal(ops.attention_wide(q.to(DEV), k.to(DEV), v.to(DEV)), got)
+    finally:
+        ops._WIDE_SCORE_BYTES = saved
+
+
+def test_attention_wide_full_size_row_stochastic(ops):
+    """Mid-block shape of the 576x1024 decode (S = 72*128 = 9216, D = 512), one frame: with v = ones the output is 1
+    (softmax rows sum to one), and with v = k = one-hot keys the output is the attention matrix's column mass."""
+    S, D = 9216, 512
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(1, S, D, generator=g).to(DEV)
+    k = torch.randn(1, S, D, generator=g).to(DEV)
+    out = ops.attention_wide(q, k, torch.ones(1, S, D, device=DEV))
+    assert float((out - 1).abs().max()) < 1e-5
+    rows = torch.randint(0, S, (64,), generator=g)
+    v = torch.randn(1, S, D, generator=g).to(DEV)
+    got = ops.attention_wide(q, k, v)[0, rows.to(DEV)]
+    want = F.scaled_dot_product_attention(q[0, rows.to(DEV)].double()[None, None], k.double()[:, None], v.double()[:, None])[0, 0]
+    assert rel(got, want) < 1e-4
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from sgm.util import instantiate_from_config
+    import test_vae_cpu as C
+    eng = instantiate_from_config(C.FIRST_STAGE).eval()
+    eng.encoder.load_state_dict(H.seeded_state_dict(eng.encoder, 41), strict=True)
+    eng.decoder.load_state_dict(H.seeded_state_dict(eng.decoder, 42), strict=True)
+    return eng.to(DEV)
+
+
+def test_small_autoencoder_on_hip_ops_matches_the_reference_golden(G, engine, ops):
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            m, _ = engine.encode(H.vae_inputs(31).to(DEV), unregularized=True)
+            z = torch.tensor(G["z_sample"]).to(DEV)
+            y = engine.decode(z, timesteps=H.VAE_T)
+            y2 = engine.decode(torch.cat([z, z.flip(0)]), timesteps=H.VAE_T)
+            ys = engine.decode(z, timesteps=H.VAE_T, skip_video=True)
+        torch.cuda.synchronize()
+        kinds = set(k for k, *_ in ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+    assert rel(m, G["enc_moments"]) < 1e-4
+    assert rel(y, G["vdec_out_conv_only"]) < 1e-4
+    assert rel(y2, G["vdec_out2_conv_only"]) < 1e-4
+    assert rel(ys, G["vdec_out_skip_video"]) < 1e-4
+    # the HIP kernels are what ran
+    assert {"groupnorm", "bias_residual", "softmax_rows", "tokens_to_planes_add"} <= kinds, kinds
+
+
+def test_video_block_on_hip_ops(G):
+    from sgm.modules.autoencoding.temporal_ae import VideoBlock
+    vb = VideoBlock(64).eval()
+    vb.load_state_dict(H.seeded_state_dict(vb, 44), strict=True)
+    vb = vb.to(DEV)
+    xb = torch.randn(2 * H.VAE_T, 64, 8, 4, generator=torch.Generator().manual_seed(32)).to(DEV)
+    with torch.no_grad():
+        assert rel(vb(xb, timesteps=H.VAE_T), G["vblock_out"]) < 1e-4
+        assert rel(vb(xb, timesteps=H.VAE_T, skip_video=True), G["vblock_out_skip"]) < 1e-4
