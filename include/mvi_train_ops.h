@@ -65,6 +65,25 @@ int mvi_gaussian_activations_backward(int32_t P, int32_t M, const float* raw_rot
  * only — exact tiled brute force, O(N^2). */
 int mvi_knn3_mean_dist2(const float* points, int32_t N, float* mean_dist2, void* stream);
 
+/* Row compaction of many tensors by ONE keep-mask — prune_points / _prune_optimizer
+ * (gs-simp/scene/gaussian_model.py:351-382), where the reference runs `t[mask]` on 6 parameters, 12 Adam moments and 3
+ * per-Gaussian statistics one at a time. mvi_compact_plan scans keep_mask [P] (uint8, nonzero = keep) into the list of
+ * kept source rows inside `workspace` (mvi_compact_workspace_bytes(P), 256-byte aligned) and writes the kept count to
+ * n_keep_device (optional; the caller reads it back to size the outputs). mvi_compact_gather then copies, for every
+ * table entry, out[j, :] = in[src_row(j), :] for j < n_keep; rows are `width` 4-byte words (any 32-bit element type),
+ * 1 <= width <= 8192. Results equal boolean indexing bit for bit. `tensors_host` is a HOST array. */
+#define MVI_COMPACT_MAX_TENSORS 24
+typedef struct mvi_compact_tensor {
+    const void* in;   /* [P, width] */
+    void* out;        /* [n_keep, width] */
+    int32_t width;
+} mvi_compact_tensor;
+size_t mvi_compact_workspace_bytes(int32_t P);
+int mvi_compact_plan(const uint8_t* keep_mask, int32_t P, void* workspace, size_t workspace_bytes,
+                     uint32_t* n_keep_device, void* stream);
+int mvi_compact_gather(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P, uint32_t n_keep,
+                       const void* workspace, void* stream);
+
 const char* mvi_train_last_error(void);
 
 #ifdef __cplusplus

@@ -34,6 +34,11 @@ class AdamGroup(C.Structure):
                 ("n", C.c_int64), ("lr", C.c_float)]
 
 
+class CompactTensor(C.Structure):
+    """struct mvi_compact_tensor (include/mvi_train_ops.h)"""
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("width", C.c_int32)]
+
+
 def declared_symbols():
     """Every function name declared in include/*.h."""
     names = []
@@ -118,6 +123,12 @@ def _bind_train_ops(L):
     L.mvi_knn3_mean_dist2.argtypes = [vp, i32, vp, vp]
     L.mvi_adam_step.restype = C.c_int
     L.mvi_adam_step.argtypes = [C.POINTER(AdamGroup), i32, C.c_double, C.c_double, C.c_double, i32, vp]
+    L.mvi_compact_workspace_bytes.restype = sz
+    L.mvi_compact_workspace_bytes.argtypes = [i32]
+    L.mvi_compact_plan.restype = C.c_int
+    L.mvi_compact_plan.argtypes = [vp, i32, vp, sz, vp, vp]
+    L.mvi_compact_gather.restype = C.c_int
+    L.mvi_compact_gather.argtypes = [C.POINTER(CompactTensor), i32, i32, C.c_uint32, vp, vp]
     L.mvi_gaussian_activations.restype = C.c_int
     L.mvi_gaussian_activations.argtypes = [i32, i32] + [vp] * 10
     L.mvi_gaussian_activations_backward.restype = C.c_int

@@ -21,7 +21,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # the softmax reads them in place (no v_accvgpr_read/write shuffling between the two MFMA products)
 # -fno-honor-nans: scores are finite or -inf (masked tail), never NaN; lets fmaxf become v_max3_f32 without the
 # canonicalising v_max x,x the IEEE lowering inserts in front of every MFMA output
-EXTRA = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
+EXTRA = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"] + os.environ.get("MVI_ATTN_FLAGS", "").split()}
 
 
 def sources():

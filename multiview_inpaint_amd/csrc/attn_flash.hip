@@ -62,19 +62,25 @@ template <> struct Mma<__half> {
 
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
+#ifndef MVI_ATTN_WPE
+#define MVI_ATTN_WPE 3            // waves per SIMD the kernel is compiled for (register budget 512 / MVI_ATTN_WPE)
+#endif
+
 constexpr float kRescaleThreshold = 8.0f;   // log2 units: O and l are rescaled only when the row max grows by > 2^8
 
 // Software pipeline: one wave keeps BOTH pipes busy. While the VALU runs the softmax of tile t (scores
 // computed in the previous iteration), the matrix pipe runs S^T = K Q^T of tile t+1; the PV MFMAs of
 // tile t follow as their P fragments come out of the converts (the compiler's own schedule of that
 // single basic block spaces the 16 MFMAs ~8 VALU issues apart; sched_group_barrier hints made it worse).
+// Measured and rejected: a 2x unrolled loop whose two score accumulators swap roles (removes the 16 v_mov_b64 of the
+// loop latch) — 168 VGPRs + 43 spilled at 3 waves/SIMD: 597 TFLOP/s, 746 at 2 waves/SIMD, against 778 for this form.
 // Costs a second score accumulator; 163 VGPRs, pinned to 3 waves/SIMD. The issue port, not the matrix
 // pipe, bounds the loop at D = 64: 32 exp (8 cyc) + 32 fma + 32 add + 16 max3 + 16 cvt + 16 MFMA issue
 // slots ~ 900 cycles per wave-tile against 512 matrix-pipe cycles. LDS holds K_{t+1} / K_{t+2} and V_t / V_{t+1}: two buffers each, one
 // barrier per tile (K_{t+2} overwrites K_t, whose last reader finished before the previous barrier;
 // V_{t+1} overwrites V_{t-1} likewise).
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WPE, MVI_ATTN_WPE))) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                    const T* __restrict__ v, T* __restrict__ out, int H,
                                                                    int Sq, int Sk, float scale_log2e, int q_blocks,
                                                                    int total_blocks) {

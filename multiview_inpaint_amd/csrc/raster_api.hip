@@ -159,7 +159,7 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
         mvi::StageTimer tm(mvi::kStScan, st);
         if (mvi::launch_scan_block_sums(g, P, st)) return hip_fail("scan_block_sums", hipGetLastError());
     }
-    int nblk = (P + mvi::kBlock - 1) / mvi::kBlock;
+    int nblk = (P + mvi::kPB - 1) / mvi::kPB;
     // read num_rendered back through a pinned word + an event recorded right behind the copy, then
     // queue binning level 1 (independent of num_rendered): the host wakes up as soon as the count is
     // there and allocates / launches stage 2 while the device is still sorting

@@ -299,9 +299,28 @@ __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __r
     if (i == D - 1) ranges[2 * t + 1] = (uint32_t)D;
 }
 
+// The per-block sums of the preprocess kernel are only needed as their TOTAL (num_rendered; pair emission works from
+// the depth-ordered sums): one block adds them up with no barrier inside the loop and leaves the total where the
+// scan used to put it (offsets[n]).
+__global__ __launch_bounds__(1024) void total_block_sums_kernel(const uint32_t* __restrict__ sums,
+                                                                uint32_t* __restrict__ offsets, int n) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += sums[i];
+    acc = wave_sum_u32(acc);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_wave[w];
+        offsets[n] = t;
+    }
+}
+
 int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
-    int nblk = (P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_offsets, nblk);
+    int nblk = (P + kPB - 1) / kPB;
+    hipLaunchKernelGGL(total_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_offsets, nblk);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -353,9 +372,14 @@ int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView
     int cur = 0;
     {   // level 2: stable partition by tile id
         StageTimer tm(kStSort, st);
+        // the tile bits are split evenly over the passes (13 bits: 7 + 6, not 8 + 5): a block's 2048 pairs leave in
+        // runs of 2048 / 2^bits pairs per digit, and the first pass's 32-byte runs were the least coalesced stores
+        int shift = 0;
         for (int p = 0; p < b.passes; ++p) {
-            int bits = b.key_bits - 8 * p < 8 ? b.key_bits - 8 * p : 8;
-            cur = radix_pass(b.keys, b.vals, cur, D, 8 * p, bits, b.block_hist, b.digit_tot, b.nsort, st);
+            const int left = b.passes - p;
+            const int bits = (b.key_bits - shift + left - 1) / left;
+            cur = radix_pass(b.keys, b.vals, cur, D, shift, bits, b.block_hist, b.digit_tot, b.nsort, st);
+            shift += bits;
         }
     }
     int nrb = (int)((D + kBlock - 1) / kBlock);

@@ -12,6 +12,9 @@ namespace mvi {
 
 constexpr int kTile = MVI_TILE;            // 16x16 pixels per tile, one 256-thread block (4 wave64)
 constexpr int kBlock = 256;
+constexpr int kPB = 128;                    // threads (= Gaussians) per block of the per-Gaussian preprocess kernels: their LDS
+                                           // rows (192 B of SH per Gaussian) cap residency, and 5 blocks of 128 overlap their
+                                           // load / compute / store phases where 2 blocks of 256 could not
 constexpr float kNearZ = 0.2f;             // view-space z cull
 constexpr float kLowpass = 0.3f;           // cov2D diagonal dilation
 constexpr float kFrustumClamp = 1.3f;
@@ -53,8 +56,8 @@ struct GeomView {
     float4* rgbd;             // [P] r, g, b, view-space depth (one gather per staged list entry)
     uint32_t* tiles_touched;  // [P]
     uint8_t* clamped;         // [P] bit c set = colour channel c was clamped at 0
-    uint32_t* block_sums;     // [nblk]   tiles touched per 256-Gaussian block
-    uint32_t* block_offsets;  // [nblk+1] exclusive scan of block_sums; [nblk] = D
+    uint32_t* block_sums;     // [npre]   tiles touched per preprocess block (kPB Gaussians)
+    uint32_t* block_offsets;  // [npre+1] exclusive scan of block_sums; [npre] = D
     // depth sort of the Gaussians (binning level 1): ping-pong (depth bits, index) pairs
     uint32_t* dkeys[2];       // [P]
     uint32_t* dvals[2];       // [P]; after the 4 passes dvals[0] = Gaussian indices in depth order
@@ -100,8 +103,9 @@ inline GeomView carve_geom(void* base, int P) {
     g.rgbd = (float4*)take(16 * n);
     g.tiles_touched = (uint32_t*)take(4 * n);
     g.clamped = (uint8_t*)take(n);
-    g.block_sums = (uint32_t*)take(4 * (size_t)nblk);
-    g.block_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
+    const size_t npre = (n + kPB - 1) / kPB;
+    g.block_sums = (uint32_t*)take(4 * npre);
+    g.block_offsets = (uint32_t*)take(4 * (npre + 1));
     g.nsortP = sort_blocks(n);
     for (int i = 0; i < 2; ++i) { g.dkeys[i] = (uint32_t*)take(4 * n); g.dvals[i] = (uint32_t*)take(4 * n); }
     g.dhist = (uint32_t*)take(4 * 256 * (size_t)g.nsortP);

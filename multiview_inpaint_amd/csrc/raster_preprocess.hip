@@ -2,13 +2,13 @@
 // Replaces the plug-in's preprocess stages behind gs-simp/gaussian_renderer/__init__.py:85-93:
 // frustum cull, cov3D from scale/quaternion (gs-simp/utils/general_utils.py:66-112 conventions),
 // EWA cov2D, conic, 3-sigma radius, tile rectangle, SH colour (gs-simp/utils/sh_utils.py:57-112).
-// One thread per Gaussian, 256-thread blocks; each block also emits the sum of tiles touched so
-// the binning stage only has to scan ceil(P/256) block sums.
+// One thread per Gaussian, kPB-thread blocks; each block also emits the sum of tiles touched so
+// the binning stage only has to scan ceil(P/kPB) block sums.
 //
 // HBM access: the caller's AoS arrays with a record that is not a power of two (shs [P,M,3] = 192 B
 // per Gaussian at degree 3, means3D/scales [P,3], the gradient outputs of the same shapes) are moved
 // between HBM and the block through LDS with fully coalesced 16-byte (or 4-byte) lane accesses — a
-// block's 256 records are one contiguous span — and each thread then reads / writes its own record
+// block's kPB records are one contiguous span — and each thread then reads / writes its own record
 // from LDS with an odd row stride (conflict-free). Per-lane strided global accesses of those arrays
 // cost 2.4x the bytes on reads and 3.3x on writes (measured: FETCH_SIZE / WRITE_SIZE).
 #include "raster_common.h"
@@ -26,16 +26,16 @@ __device__ __forceinline__ void stage_in(const float* __restrict__ src, float* l
         const int rv = rec >> 2;                           // float4 per record: a vector never straddles records
         const int nvec = total >> 2;
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        for (int v0 = threadIdx.x; v0 < nvec; v0 += kBlock * kStageUnroll) {
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += kPB * kStageUnroll) {
             float4 x[kStageUnroll];
 #pragma unroll
             for (int u = 0; u < kStageUnroll; ++u) {
-                const int v = v0 + u * kBlock;
+                const int v = v0 + u * kPB;
                 if (v < nvec) x[u] = s4[v];
             }
 #pragma unroll
             for (int u = 0; u < kStageUnroll; ++u) {
-                const int v = v0 + u * kBlock;
+                const int v = v0 + u * kPB;
                 if (v < nvec) {
                     float* d = lds + (v / rv) * stride + (v % rv) * 4;
                     d[0] = x[u].x; d[1] = x[u].y; d[2] = x[u].z; d[3] = x[u].w;
@@ -43,7 +43,7 @@ __device__ __forceinline__ void stage_in(const float* __restrict__ src, float* l
             }
         }
     } else {
-        for (int e = threadIdx.x; e < total; e += kBlock) lds[(e / rec) * stride + (e % rec)] = src[e];
+        for (int e = threadIdx.x; e < total; e += kPB) lds[(e / rec) * stride + (e % rec)] = src[e];
     }
 }
 // Inverse: LDS rows -> contiguous global span.
@@ -52,12 +52,12 @@ __device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* 
     if ((rec & 3) == 0) {
         const int rv = rec >> 2;
         float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int v = threadIdx.x; v < (total >> 2); v += kBlock) {
+        for (int v = threadIdx.x; v < (total >> 2); v += kPB) {
             const float* s_ = lds + (v / rv) * stride + (v % rv) * 4;
             d4[v] = make_float4(s_[0], s_[1], s_[2], s_[3]);
         }
     } else {
-        for (int e = threadIdx.x; e < total; e += kBlock) dst[e] = lds[(e / rec) * stride + (e % rec)];
+        for (int e = threadIdx.x; e < total; e += kPB) dst[e] = lds[(e / rec) * stride + (e % rec)];
     }
 }
 // The same for records whose length is not a multiple of 4 floats (features_rest: 3 (M - 1) = 45 / 24 / 9): float4
@@ -72,17 +72,17 @@ __device__ __forceinline__ void stage_in_split(const float* __restrict__ src, fl
     };
     constexpr int kU = 6;
     const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int v0 = threadIdx.x; v0 < nvec; v0 += kBlock * kU) {
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += kPB * kU) {
         float4 x[kU];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) { const int v = v0 + u * kBlock; if (v < nvec) x[u] = s4[v]; }
+        for (int u = 0; u < kU; ++u) { const int v = v0 + u * kPB; if (v < nvec) x[u] = s4[v]; }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const int v = v0 + u * kBlock;
+            const int v = v0 + u * kPB;
             if (v < nvec) { put(4 * v, x[u].x); put(4 * v + 1, x[u].y); put(4 * v + 2, x[u].z); put(4 * v + 3, x[u].w); }
         }
     }
-    for (int e = 4 * nvec + threadIdx.x; e < total; e += kBlock) put(e, src[e]);
+    for (int e = 4 * nvec + threadIdx.x; e < total; e += kPB) put(e, src[e]);
 }
 __device__ __forceinline__ void stage_out_split(float* __restrict__ dst, const float* lds, int n_rec, int rec, int stride) {
     const int total = n_rec * rec, nvec = total >> 2;
@@ -92,8 +92,8 @@ __device__ __forceinline__ void stage_out_split(float* __restrict__ dst, const f
         return lds[r * stride + (e - r * rec)];
     };
     float4* d4 = reinterpret_cast<float4*>(dst);
-    for (int v = threadIdx.x; v < nvec; v += kBlock) d4[v] = make_float4(get(4 * v), get(4 * v + 1), get(4 * v + 2), get(4 * v + 3));
-    for (int e = 4 * nvec + threadIdx.x; e < total; e += kBlock) dst[e] = get(e);
+    for (int v = threadIdx.x; v < nvec; v += kPB) d4[v] = make_float4(get(4 * v), get(4 * v + 1), get(4 * v + 2), get(4 * v + 3));
+    for (int e = 4 * nvec + threadIdx.x; e < total; e += kPB) dst[e] = get(e);
 }
 // SH rows of a block into / out of LDS rows of `stride` floats: one [P,M,3] array, or (raw mode) features_dc [P,1,3] +
 // features_rest [P,M-1,3] landing in the same rows, so the rest of the kernel does not care
@@ -191,22 +191,22 @@ __device__ __forceinline__ void cov2d_from_cov3d(const Ewa& e, const float* c6, 
     c = dot3(t1[0], t1[1], t1[2], e.Tm[1][0], e.Tm[1][1], e.Tm[1][2]) + kLowpass;
 }
 
-__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(
+__global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
     Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii) {
 #pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)] SH rows, then [256][3] x 2
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [kPB][sh_stride(M)] SH rows, then [kPB][3] x 2
     __shared__ uint32_t s_sum;
     const int tid = threadIdx.x;
-    const int blk0 = blockIdx.x * kBlock;
+    const int blk0 = blockIdx.x * kPB;
     const int i = blk0 + tid;
-    const int n_rec = min(kBlock, f.P - blk0);
+    const int n_rec = min(kPB, f.P - blk0);
     const int shs_w = shs ? sh_stride(f.M) : 0;
     float* s_sh = s_dyn;
-    float* s_mean = s_dyn + (size_t)kBlock * shs_w;        // [256][3]
-    float* s_scale = s_mean + 3 * kBlock;                  // [256][3]
+    float* s_mean = s_dyn + (size_t)kPB * shs_w;        // [kPB][3]
+    float* s_scale = s_mean + 3 * kPB;                  // [kPB][3]
     if (tid == 0) s_sum = 0;
     if (shs) stage_sh_in(f, shs, s_sh, blk0, n_rec, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
@@ -328,12 +328,12 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               const float* rotations, const float* cov3D_precomp, GeomView g,
                               int32_t* radii, hipStream_t st) {
     if (f.P <= 0) return 0;
-    int nblk = (f.P + kBlock - 1) / kBlock;
-    size_t lds = sizeof(float) * ((size_t)kBlock * (shs ? sh_stride(f.M) : 0) + 6 * kBlock);
+    int nblk = (f.P + kPB - 1) / kPB;
+    size_t lds = sizeof(float) * ((size_t)kPB * (shs ? sh_stride(f.M) : 0) + 6 * kPB);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)preprocess_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MVI_EHIP;
-    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nblk), dim3(kBlock), lds, st, f, means3D, shs,
+    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nblk), dim3(kPB), lds, st, f, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
@@ -371,25 +371,25 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // One thread per Gaussian. Input: grad_rows [P][16] from render_backward (mean2D.xy NDC-scaled,
 // dL/dA, dL/dB, dL/dC of power = -0.5(A dx^2 + C dy^2) - B dx dy, dL/dopacity, dL/drgb).
 // Outputs are written for every Gaussian (zeros where radii == 0).
-__global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
+__global__ __launch_bounds__(kPB) void preprocess_backward_kernel(
     Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii, GeomView g,
     const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)] + 5 x [256][3]
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [kPB][sh_stride(M)] + 5 x [kPB][3]
     const int tid = threadIdx.x;
-    const int blk0 = blockIdx.x * kBlock;
+    const int blk0 = blockIdx.x * kPB;
     const int i = blk0 + tid;
-    const int n_rec = min(kBlock, f.P - blk0);
+    const int n_rec = min(kPB, f.P - blk0);
     const int shs_w = shs ? sh_stride(f.M) : 0;
     float* s_sh = s_dyn;                                   // SH rows in, dL/dSH rows out (same thread, same row)
-    float* s_mean = s_dyn + (size_t)kBlock * shs_w;
-    float* s_scale = s_mean + 3 * kBlock;
-    float* s_dmean = s_scale + 3 * kBlock;
-    float* s_dm2d = s_dmean + 3 * kBlock;
-    float* s_dscale = s_dm2d + 3 * kBlock;
+    float* s_mean = s_dyn + (size_t)kPB * shs_w;
+    float* s_scale = s_mean + 3 * kPB;
+    float* s_dmean = s_scale + 3 * kPB;
+    float* s_dm2d = s_dmean + 3 * kPB;
+    float* s_dscale = s_dm2d + 3 * kPB;
     if (shs) stage_sh_in(f, shs, s_sh, blk0, n_rec, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
     if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
@@ -599,12 +599,12 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
                                float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors, float* dL_dshs,
                                float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st, RawBackwardExtra rawx) {
     if (f.P <= 0) return 0;
-    int nblk = (f.P + kBlock - 1) / kBlock;
-    size_t lds = sizeof(float) * ((size_t)kBlock * (shs ? sh_stride(f.M) : 0) + 15 * kBlock);
+    int nblk = (f.P + kPB - 1) / kPB;
+    size_t lds = sizeof(float) * ((size_t)kPB * (shs ? sh_stride(f.M) : 0) + 15 * kPB);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)preprocess_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MVI_EHIP;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kBlock), lds, st, f, means3D, shs, scales,
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nblk), dim3(kPB), lds, st, f, means3D, shs, scales,
                        rotations, cov3D_precomp, radii, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
                        dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales, dL_drots, rawx);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
@@ -615,18 +615,18 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
 // 3M-float gradient and every rank rebuilds the SUM over views here from the views' camera centres:
 // dL_dshs[g][k][c] = sum_v Y_k(normalize(mean_g - campos_v)) * gcol[v][g][c]   (k < (deg+1)^2, zero above).
 // One thread per Gaussian; rows leave through LDS like the single-view backward (coalesced AoS writes).
-__global__ __launch_bounds__(kBlock) void sh_backward_views_kernel(int P, int M, int deg, int n_views,
+__global__ __launch_bounds__(kPB) void sh_backward_views_kernel(int P, int M, int deg, int n_views,
                                                                     const float* __restrict__ means3D,
                                                                     const float* __restrict__ campos,
                                                                     int64_t campos_stride,
                                                                     const float* __restrict__ gcol,
                                                                     int64_t gcol_stride,
                                                                     float* __restrict__ dL_dshs) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [256][sh_stride(M)]
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [kPB][sh_stride(M)]
     const int tid = threadIdx.x;
-    const int blk0 = blockIdx.x * kBlock;
+    const int blk0 = blockIdx.x * kPB;
     const int i = blk0 + tid;
-    const int n_rec = min(kBlock, P - blk0);
+    const int n_rec = min(kPB, P - blk0);
     const int w = sh_stride(M);
     const int nb = (deg + 1) * (deg + 1);
     float acc[16][3];
@@ -659,22 +659,22 @@ __global__ __launch_bounds__(kBlock) void sh_backward_views_kernel(int P, int M,
 int launch_sh_backward_views(int P, int M, int deg, int n_views, const float* means3D, const float* campos,
                              int64_t campos_stride, const float* gcol, int64_t gcol_stride, float* dL_dshs, hipStream_t st) {
     if (P <= 0) return 0;
-    const size_t lds = sizeof(float) * (size_t)kBlock * sh_stride(M);
-    hipLaunchKernelGGL(sh_backward_views_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), lds, st, P, M, deg, n_views,
+    const size_t lds = sizeof(float) * (size_t)kPB * sh_stride(M);
+    hipLaunchKernelGGL(sh_backward_views_kernel, dim3((P + kPB - 1) / kPB), dim3(kPB), lds, st, P, M, deg, n_views,
                        means3D, campos, campos_stride, gcol, gcol_stride, dL_dshs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
                                     uint8_t* __restrict__ visible) {
-    int i = blockIdx.x * kBlock + threadIdx.x;
+    int i = blockIdx.x * kPB + threadIdx.x;
     if (i >= P) return;
     float vz = affine3(view[2], view[6], view[10], view[14], means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
     visible[i] = vz > kNearZ;
 }
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, P, means3D, view, visible);
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kPB - 1) / kPB), dim3(kPB), 0, st, P, means3D, view, visible);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

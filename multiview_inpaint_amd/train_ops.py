@@ -226,3 +226,76 @@ def distCUDA2(points):
                                               C.c_void_p(out.data_ptr()) if p.numel() else None,
                                               C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)), "distCUDA2")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# prune_points / _prune_optimizer tensor surgery (SURVEY.md §8f-3)
+
+def compact_rows(keep_mask, tensors):
+    """[t[keep_mask] for t in tensors] for tensors sharing their first dimension P — the boolean indexing of
+    prune_points / _prune_optimizer (gs-simp/scene/gaussian_model.py:351-382) over the 6 parameters, 12 Adam moments and
+    3 statistics — with ONE scan of the mask and ONE gather launch (bit-identical results). 4-byte element types."""
+    tensors = list(tensors)
+    if not keep_mask.is_cuda:
+        raise RuntimeError("compact_rows: GPU tensors expected; there is no CPU path")
+    P = keep_mask.shape[0]
+    if keep_mask.ndim != 1 or any(t.shape[0] != P or t.device != keep_mask.device for t in tensors):
+        raise ValueError("compact_rows: mask [P] and tensors [P, ...] on one device expected")
+    if any(t.element_size() != 4 for t in tensors):
+        raise TypeError("compact_rows: 4-byte element types only")
+    L, dev = _lib.lib(), keep_mask.device
+    m = (keep_mask if keep_mask.dtype in (torch.bool, torch.uint8) else keep_mask != 0).contiguous()
+    srcs = [t.detach().contiguous() for t in tensors]
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        nbytes = L.mvi_compact_workspace_bytes(P)
+        ws = _workspace(dev, nbytes + 256)
+        cnt = ws[nbytes:nbytes + 4].view(torch.int32)         # the kept count lives behind the plan
+        _check(L.mvi_compact_plan(C.c_void_p(m.data_ptr()) if P else None, P, C.c_void_p(ws.data_ptr()), nbytes,
+                                  C.c_void_p(cnt.data_ptr()), st), "compact_plan")
+        n_keep = int(cnt.item())                                # the one host synchronisation: output sizes
+        outs = [t.new_empty((n_keep,) + tuple(t.shape[1:])) for t in srcs]
+        for i in range(0, len(srcs), 24):
+            chunk = [(s, o) for s, o in zip(srcs[i:i + 24], outs[i:i + 24]) if s[0:1].numel() > 0]
+            if not chunk or n_keep == 0:
+                continue
+            tab = (_lib.CompactTensor * len(chunk))()
+            for e, (s, o) in zip(tab, chunk):
+                e.in_, e.out, e.width = s.data_ptr(), o.data_ptr(), s[0].numel()
+            _check(L.mvi_compact_gather(tab, len(chunk), P, n_keep, C.c_void_p(ws.data_ptr()), st), "compact_gather")
+    return outs
+
+
+def prune_optimizer_state(optimizer, keep_mask, extra=()):
+    """_prune_optimizer + prune_points (gaussian_model.py:351-382) for a torch.optim.Adam / FusedAdam whose groups hold
+    one parameter each: parameters, exp_avg, exp_avg_sq and the `extra` per-Gaussian tensors are compacted together.
+    Returns ({group name: new nn.Parameter}, [compacted extras]); optimizer.state is re-keyed like the reference does."""
+    groups = [g for g in optimizer.param_groups]
+    flat, slots = [], []
+    for g in groups:
+        p = g["params"][0]
+        stt = optimizer.state.get(p, None)
+        flat.append(p.data)
+        slots.append((g, "param"))
+        if stt is not None and "exp_avg" in stt:
+            flat += [stt["exp_avg"], stt["exp_avg_sq"]]
+            slots += [(g, "exp_avg"), (g, "exp_avg_sq")]
+    outs = compact_rows(keep_mask, flat + list(extra))
+    new = {}
+    it = iter(outs)
+    by_group = {}
+    for (g, kind) in slots:
+        by_group.setdefault(id(g), {})[kind] = next(it)
+    for g in groups:
+        old = g["params"][0]
+        stt = optimizer.state.get(old, None)
+        r = by_group[id(g)]
+        if stt is not None:
+            if "exp_avg" in r:
+                stt["exp_avg"], stt["exp_avg_sq"] = r["exp_avg"], r["exp_avg_sq"]
+            del optimizer.state[old]
+        g["params"][0] = torch.nn.Parameter(r["param"].requires_grad_(True))
+        if stt is not None:
+            optimizer.state[g["params"][0]] = stt
+        new[g.get("name", len(new))] = g["params"][0]
+    return new, list(it)

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 G = np.load(os.path.join(ROOT, "tests", "golden", "loss_small.npz"))
@@ -224,3 +225,78 @@ def test_distcuda2_edge_cases(T):
         T.distCUDA2(torch.zeros(5, 2).cuda())
     with pytest.raises(RuntimeError):
         T.distCUDA2(torch.zeros(5, 3))
+
+
+# ---- prune_points / _prune_optimizer tensor surgery ------------------------------------------------
+
+@pytest.mark.parametrize("P,frac", [(1, 1.0), (1, 0.0), (1023, 0.5), (1025, 0.9), (70001, 0.37), (4096, 0.0), (4096, 1.0)])
+def test_compact_rows_equals_boolean_indexing(P, frac):
+    from multiview_inpaint_amd import train_ops as T
+    g = torch.Generator().manual_seed(P)
+    mask = (torch.rand(P, generator=g) < frac).to(DEV)
+    ts = [torch.randn(P, 3, generator=g), torch.randn(P, 1, 3, generator=g), torch.randn(P, 15, 3, generator=g),
+          torch.randn(P, 1, generator=g), torch.randn(P, 4, generator=g), torch.randn(P, generator=g),
+          torch.randint(0, 1 << 30, (P, 2), generator=g, dtype=torch.int32)]
+    ts = [t.to(DEV) for t in ts]
+    outs = T.compact_rows(mask, ts)
+    for t, o in zip(ts, outs):
+        assert o.dtype == t.dtype and torch.equal(o, t[mask])
+
+
+def test_compact_rows_many_tensors_and_bad_arguments():
+    from multiview_inpaint_amd import train_ops as T
+    P = 5000
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.rand(P, generator=g) < 0.6).to(DEV)
+    ts = [torch.randn(P, 1 + (i % 5), generator=g).to(DEV) for i in range(30)]       # more than one table
+    for t, o in zip(ts, T.compact_rows(mask, ts)):
+        assert torch.equal(o, t[mask])
+    with pytest.raises(TypeError):
+        T.compact_rows(mask, [torch.zeros(P, 2, dtype=torch.float64, device=DEV)])
+    with pytest.raises(ValueError):
+        T.compact_rows(mask, [torch.zeros(P + 1, 2, device=DEV)])
+    with pytest.raises(RuntimeError):
+        T.compact_rows(mask.cpu(), [])
+
+
+def test_prune_optimizer_state_matches_the_reference_recipe():
+    """gaussian_model.py:351-382 on torch.optim.Adam: after pruning, parameters, both moments and the statistics equal
+    the reference's per-tensor boolean indexing, and the optimizer keeps stepping."""
+    from multiview_inpaint_amd import train_ops as T
+    P = 3000
+    g = torch.Generator().manual_seed(5)
+    shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (15, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,)}
+
+    def make():
+        gg = torch.Generator().manual_seed(6)
+        ps = {k: torch.nn.Parameter(torch.randn(P, *s, generator=gg).to(DEV)) for k, s in shapes.items()}
+        opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": k} for k, p in ps.items()], lr=0.0, eps=1e-15)
+        for p in ps.values():
+            p.grad = torch.randn(p.shape, generator=gg).to(DEV)
+        opt.step()
+        return ps, opt
+    mask = (torch.rand(P, generator=g) < 0.7).to(DEV)
+    stats = [torch.randn(P, 1, generator=g).to(DEV), torch.randn(P, generator=g).to(DEV)]
+    ps_a, opt_a = make()
+    new, extras = T.prune_optimizer_state(opt_a, mask, extra=stats)
+    ps_b, opt_b = make()
+    for grp in opt_b.param_groups:                       # the reference's loop, verbatim semantics
+        stt = opt_b.state.get(grp["params"][0], None)
+        stt["exp_avg"], stt["exp_avg_sq"] = stt["exp_avg"][mask], stt["exp_avg_sq"][mask]
+        del opt_b.state[grp["params"][0]]
+        grp["params"][0] = torch.nn.Parameter(grp["params"][0][mask].requires_grad_(True))
+        opt_b.state[grp["params"][0]] = stt
+    for ga, gb in zip(opt_a.param_groups, opt_b.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert ga["name"] == gb["name"] and new[ga["name"]] is pa and pa.requires_grad
+        assert torch.equal(pa, pb)
+        assert torch.equal(opt_a.state[pa]["exp_avg"], opt_b.state[pb]["exp_avg"])
+        assert torch.equal(opt_a.state[pa]["exp_avg_sq"], opt_b.state[pb]["exp_avg_sq"])
+        assert opt_a.state[pa]["step"] == opt_b.state[pb]["step"]
+    assert torch.equal(extras[0], stats[0][mask]) and torch.equal(extras[1], stats[1][mask])
+    for ga, gb in zip(opt_a.param_groups, opt_b.param_groups):
+        ga["params"][0].grad = torch.ones_like(ga["params"][0])
+        gb["params"][0].grad = torch.ones_like(gb["params"][0])
+    opt_a.step(); opt_b.step()
+    for ga, gb in zip(opt_a.param_groups, opt_b.param_groups):
+        assert torch.equal(ga["params"][0], gb["params"][0])

@@ -68,11 +68,11 @@ def test_attention_wide_fp32(ops, B, S, D):
     want = F.scaled_dot_product_attention(q.double()[:, None], k.double()[:, None], v.double()[:, None])[:, 0]
     got = ops.attention_wide(q.to(DEV), k.to(DEV), v.to(DEV))
     assert rel(got, want) < 1e-4
-    # chunked over the batch: same values
+    # chunked over the batch (one frame's scores at a time): the same result up to the GEMM library's summation order
     saved = ops._WIDE_SCORE_BYTES
     try:
         ops._WIDE_SCORE_BYTES = S * S * 4
-        assert torch.equal(ops.attention_wide(q.to(DEV), k.to(DEV), v.to(DEV)), got)
+        assert rel(ops.attention_wide(q.to(DEV), k.to(DEV), v.to(DEV)), want) < 1e-4
     finally:
         ops._WIDE_SCORE_BYTES = saved
 

@@ -28,12 +28,13 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--encode", action="store_true")
+    ap.add_argument("--search", action="store_true", help="let MIOpen time its solvers in the warm-up (minutes in fp32)")
     a = ap.parse_args()
     from multiview_inpaint_amd.svd import hip_ops, vae
     import svd_helpers as H
     dev = "cuda:0"
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[a.dtype]
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = a.search
     eng = vae.AutoencodingEngine(encoder_config=vae.Encoder(**FULL),
                                  decoder_config=vae.VideoDecoder(**FULL, video_kernel_size=[3, 1, 1])).eval()
     eng.decoder.load_state_dict(H.seeded_state_dict(eng.decoder, 42))
@@ -46,8 +47,11 @@ def main():
 
     def run(fn, arg):
         with torch.no_grad():
-            y = fn(arg)                                           # warm-up: MIOpen solver search
+            print("warm-up ...", file=sys.stderr, flush=True)
+            t0 = time.perf_counter()
+            y = fn(arg)                                           # warm-up (MIOpen solver search with --search)
             torch.cuda.synchronize()
+            print(f"warm-up done in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
             hip_ops.PROFILE = []
             t0 = time.perf_counter()
             for _ in range(a.iters):
