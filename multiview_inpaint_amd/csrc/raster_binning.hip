@@ -3,7 +3,8 @@
 // gs-simp/gaussian_renderer/__init__.py:85-93 and produces the SAME sorted pair order (stable sort
 // of key = tile << 32 | depth bits, ties in Gaussian-index order) — but never materialises or moves
 // 64-bit keys:
-//   level 1  sort the P Gaussians by depth bits (32-bit keys, 4 stable 8-bit passes over P items);
+//   level 1  sort the P Gaussians by depth bits (32-bit keys written by the preprocess kernel, 4 stable 8-bit
+//            passes over P items);
 //   emit     walk the Gaussians in that order and write one (tile id, Gaussian index) pair per
 //            covered tile, coalesced per 256-Gaussian block;
 //   level 2  stable partition of the D pairs by tile id (ceil(log2 T / 8) = 2 passes).
@@ -43,16 +44,6 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
     if (tid == 0) offsets[n] = s_carry;
 }
 
-// ---- level 1 input: (depth bits | 0xFFFFFFFF for culled, index) -------------------------------
-__global__ __launch_bounds__(kBlock) void depth_keys_kernel(int P, const float* __restrict__ depths,
-                                                            const uint32_t* __restrict__ tiles_touched,
-                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P) return;
-    keys[i] = tiles_touched[i] ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;   // depth > 0.2: bits are monotonic
-    vals[i] = (uint32_t)i;
-}
-
 // tiles touched per 256 depth-ordered Gaussians
 __global__ __launch_bounds__(kBlock) void perm_block_sums_kernel(int P, const uint32_t* __restrict__ order,
                                                                  const uint32_t* __restrict__ tiles_touched,
@@ -72,7 +63,6 @@ __global__ __launch_bounds__(kBlock) void perm_block_sums_kernel(int P, const ui
 // ---- pair emission in depth order: block = 256 consecutive entries of `order`; the block's output
 // slots are written coalesced (slot j finds its Gaussian by binary search over the in-block scan)
 __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g, const uint32_t* __restrict__ order,
-                                                            const int32_t* __restrict__ radii,
                                                             const uint32_t* __restrict__ block_offsets,
                                                             uint32_t* __restrict__ tile_keys,
                                                             uint32_t* __restrict__ vals) {
@@ -83,15 +73,14 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = blockIdx.x * kBlock + tid;
     uint32_t t = 0, gi = 0;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    int x0 = 0, y0 = 0, x1 = 0;
     if (pos < f.P) {
         gi = order[pos];
-        const int rad = radii[gi];
-        if (rad > 0) {
-            float2 p = g.xy[gi];
-            tile_rect(p.x, p.y, rad, f.gx, f.gy, x0, y0, x1, y1);
-            t = (uint32_t)((x1 - x0) * (y1 - y0));
-        }
+        const uint2 rc = g.rect[gi];                          // the preprocess kernel's tile_rect result, one gather
+        x0 = (int)(rc.x & 0xFFFFu); y0 = (int)(rc.x >> 16);
+        const int w = (int)(rc.y & 0xFFFFu), h = (int)(rc.y >> 16);
+        x1 = x0 + w;
+        t = (uint32_t)(w * h);
     }
     s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0; s_gi[tid] = gi;
     uint32_t inc = t;
@@ -123,25 +112,31 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
 }
 
 // ---- stable 8-bit LSD radix pass over (u32 key, u32 value) pairs: count / scan / scatter -------
-// One 1024-thread block = kCountTiles (4) consecutive sort tiles, one per 256-thread group. Row d of block_hist then
-// receives 4 consecutive counts as one 16-byte store instead of four 4-byte words at a stride of nblk words
+// Sort tile = 512 * kW pairs (kW waves per scatter block). The P-sized level-1 passes use kW = 4 (2048-pair tiles: they
+// are short and need many blocks); the D-sized level-2 passes use kW = 8 (4096-pair tiles): a block's pairs leave in
+// runs of tile / 2^bits pairs per digit, and longer runs mean fewer partially written cache lines.
+// Count: one 1024-thread block = kCountTiles (4) consecutive sort tiles, one per 256-thread group. Row d of block_hist
+// then receives 4 consecutive counts as one 16-byte store instead of four 4-byte words at a stride of nblk words
 // (measured before: 23 MB written per launch for 3 MB of counts).
+template <int kW>
 __global__ __launch_bounds__(1024) void radix_count_kernel(const uint32_t* __restrict__ keys, int64_t D, int shift,
                                                            uint32_t mask, uint32_t* __restrict__ block_hist,
                                                            int nblk) {
+    constexpr int kItems = 2 * kW;                       // per thread of a 256-thread group
+    constexpr int kTileW = 512 * kW;
     __shared__ uint32_t s_hist[kCountTiles][256];
     const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
     s_hist[grp][t] = 0;
     __syncthreads();
-    const int64_t base = ((int64_t)blockIdx.x * kCountTiles + grp) * kSortTile;
-    uint32_t key[kSortItems];
+    const int64_t base = ((int64_t)blockIdx.x * kCountTiles + grp) * kTileW;
+    uint32_t key[kItems];
 #pragma unroll
-    for (int it = 0; it < kSortItems; ++it) {
+    for (int it = 0; it < kItems; ++it) {
         const int64_t idx = base + it * 256 + t;
         key[it] = idx < D ? keys[idx] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int it = 0; it < kSortItems; ++it)
+    for (int it = 0; it < kItems; ++it)
         if (base + it * 256 + t < D) atomicAdd(&s_hist[grp][(key[it] >> shift) & mask], 1u);
     __syncthreads();
     if (tid < 256) {
@@ -186,35 +181,42 @@ __global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restr
 // waves in order keeps the input order among equal digits. The block's pairs are first put in
 // digit order in LDS, then written out by consecutive lanes: every digit's run leaves as one
 // contiguous, coalesced segment instead of 64 scattered dwords per wave-instruction.
-__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+// The per-digit bookkeeping (256 digits) is done by the first 256 threads of the block.
+template <int kW>
+__global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask, const uint32_t* __restrict__ block_hist,
     int nblk, const uint32_t* __restrict__ digit_tot) {
-    __shared__ uint32_t s_wave_hist[4][256];
+    constexpr int kNT = 64 * kW, kTileW = 512 * kW;
+    __shared__ uint32_t s_wave_hist[kW][256];
     __shared__ uint32_t s_digit_base[256];     // global position of this block's first pair of digit d
     __shared__ uint32_t s_local_start[256];    // position of digit d's run inside the block-sorted tile
     __shared__ uint32_t s_w4[4];
-    __shared__ uint32_t s_key[kSortTile], s_val[kSortTile];
+    __shared__ uint32_t s_key[kTileW], s_val[kTileW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool digit_thread = tid < 256;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s_wave_hist[w][tid] = 0;
-    {   // exclusive scan of the 256 digit totals -> start of each digit in the output
-        uint32_t v = digit_tot[tid];
-        uint32_t inc = v;
+    for (int i = tid; i < kW * 256; i += kNT) (&s_wave_hist[0][0])[i] = 0;
+    uint32_t dv = 0, dinc = 0;
+    if (digit_thread) {   // exclusive scan of the 256 digit totals -> start of each digit in the output
+        dv = digit_tot[tid];
+        dinc = dv;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
+            uint32_t t = __shfl_up(dinc, o);
+            if (lane >= o) dinc += t;
         }
-        if (lane == 63) s_w4[wave] = inc;
-        __syncthreads();
+        if (lane == 63) s_w4[wave] = dinc;
+    }
+    __syncthreads();
+    if (digit_thread) {
         uint32_t wave_off = 0;
         for (int w = 0; w < wave; ++w) wave_off += s_w4[w];
-        s_digit_base[tid] = wave_off + inc - v + block_hist[(size_t)tid * nblk + blockIdx.x];
+        s_digit_base[tid] = wave_off + dinc - dv + block_hist[(size_t)tid * nblk + blockIdx.x];
     }
     __syncthreads();
 
-    const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
+    const int64_t tile0 = (int64_t)blockIdx.x * kTileW;
     const int64_t base = tile0 + wave * (kSortItems * 64);
     uint32_t key[kSortItems], val[kSortItems], rank[kSortItems], dig[kSortItems];
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
@@ -242,21 +244,27 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
         rank[it] = prev + before;
     }
     __syncthreads();
-    {   // per digit: offset of each wave inside the block's run, and the run's start in the sorted tile
-        uint32_t c0 = s_wave_hist[0][tid], c1 = s_wave_hist[1][tid], c2 = s_wave_hist[2][tid], c3 = s_wave_hist[3][tid];
-        uint32_t tot = c0 + c1 + c2 + c3, inc = tot;
+    // per digit: offset of each wave inside the block's run, and the run's start in the sorted tile
+    uint32_t tot = 0, inc = 0;
+    if (digit_thread) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kW; ++w) {
+            const uint32_t c = s_wave_hist[w][tid];
+            s_wave_hist[w][tid] = run;                    // same thread reads and rewrites column tid
+            run += c;
+        }
+        tot = run;
+        inc = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t t = __shfl_up(inc, o);
             if (lane >= o) inc += t;
         }
-        __syncthreads();
-        if (lane == 63) s_w4[wave] = inc;
-        s_wave_hist[0][tid] = 0;
-        s_wave_hist[1][tid] = c0;
-        s_wave_hist[2][tid] = c0 + c1;
-        s_wave_hist[3][tid] = c0 + c1 + c2;
-        __syncthreads();
+        if (lane == 63) s_w4[wave] = inc;                 // last read of s_w4 was two barriers ago
+    }
+    __syncthreads();
+    if (digit_thread) {
         uint32_t wave_off = 0;
         for (int w = 0; w < wave; ++w) wave_off += s_w4[w];
         s_local_start[tid] = wave_off + inc - tot;
@@ -272,10 +280,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
         }
     }
     __syncthreads();
-    const int count = (int)((D - tile0) < kSortTile ? (D - tile0) : kSortTile);
+    const int count = (int)((D - tile0) < kTileW ? (D - tile0) : kTileW);
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
-        int lp = it * kBlock + tid;
+        int lp = it * kNT + tid;
         if (lp < count) {
             uint32_t k = s_key[lp];
             uint32_t d = (k >> shift) & mask;
@@ -324,13 +332,15 @@ int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
-// one stable pass over n pairs; returns the index (0/1) of the buffer holding the result
+// one stable pass over n pairs in tiles of 512 * kW; nsort = sort_blocks(n, kW); returns the index (0/1) of the buffer
+// holding the result
+template <int kW>
 static int radix_pass(uint32_t* const keys[2], uint32_t* const vals[2], int cur, int64_t n, int shift, int bits,
                       uint32_t* hist, uint32_t* tot, int nsort, hipStream_t st) {
     uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(radix_count_kernel, dim3(nsort / kCountTiles), dim3(1024), 0, st, keys[cur], n, shift, mask, hist, nsort);
+    hipLaunchKernelGGL((radix_count_kernel<kW>), dim3(nsort / kCountTiles), dim3(1024), 0, st, keys[cur], n, shift, mask, hist, nsort);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, hist, nsort, tot);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nsort), dim3(kBlock), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
+    hipLaunchKernelGGL((radix_scatter_kernel<kW>), dim3(nsort), dim3(64 * kW), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
                        vals[cur ^ 1], n, shift, mask, hist, nsort, tot);
     return cur ^ 1;
 }
@@ -343,11 +353,10 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st) {
     const int nblk = (f.P + kBlock - 1) / kBlock;
     {   // Gaussians by depth (4 passes over P items; even count -> result back in buffer 0)
         StageTimer tm(kStSort, st);
-        hipLaunchKernelGGL(depth_keys_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.depths, g.tiles_touched,
-                           g.dkeys[0], g.dvals[0]);
+        // the keys (depth bits, 0xFFFFFFFF for culled) and indices were written by the preprocess kernel
         int cur = 0;
         for (int p = 0; p < 4; ++p)
-            cur = radix_pass(g.dkeys, g.dvals, cur, f.P, 8 * p, 8, g.dhist, g.dtot, g.nsortP, st);
+            cur = radix_pass<kSortWavesP>(g.dkeys, g.dvals, cur, f.P, 8 * p, 8, g.dhist, g.dtot, g.nsortP, st);
     }
     StageTimer tm(kStDup, st);
     hipLaunchKernelGGL(perm_block_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.dvals[0], g.tiles_touched,
@@ -366,19 +375,19 @@ int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView
     const int nblk = (f.P + kBlock - 1) / kBlock;
     {
         StageTimer tm(kStDup, st);
-        hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, g.dvals[0], radii, g.perm_offsets,
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, g.dvals[0], g.perm_offsets,
                            b.keys[0], b.vals[0]);
     }
     int cur = 0;
     {   // level 2: stable partition by tile id
         StageTimer tm(kStSort, st);
-        // the tile bits are split evenly over the passes (13 bits: 7 + 6, not 8 + 5): a block's 2048 pairs leave in
-        // runs of 2048 / 2^bits pairs per digit, and the first pass's 32-byte runs were the least coalesced stores
+        // the tile bits are split evenly over the passes (13 bits: 7 + 6, not 8 + 5): a block's 4096 pairs leave in
+        // runs of 4096 / 2^bits pairs per digit, and the first pass's 32-byte runs were the least coalesced stores
         int shift = 0;
         for (int p = 0; p < b.passes; ++p) {
             const int left = b.passes - p;
             const int bits = (b.key_bits - shift + left - 1) / left;
-            cur = radix_pass(b.keys, b.vals, cur, D, shift, bits, b.block_hist, b.digit_tot, b.nsort, st);
+            cur = radix_pass<kSortWavesD>(b.keys, b.vals, cur, D, shift, bits, b.block_hist, b.digit_tot, b.nsort, st);
             shift += bits;
         }
     }

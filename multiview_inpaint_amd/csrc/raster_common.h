@@ -24,11 +24,13 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTEps = 0.0001f;
 constexpr float kDepthSentinel = 15.0f;    // gs-simp/gen_seq.py:50
 
-constexpr int kSortTile = 2048;            // keys per block in one radix pass (256 threads x 8)
-constexpr int kSortItems = 8;
-constexpr int kCountTiles = 4;            // sort tiles per block of the count kernel: one 16-byte run per histogram row
-__host__ __device__ inline int sort_blocks(int64_t n) {     // radix-pass blocks, padded so the count kernel writes whole runs
-    int b = (int)((n + kSortTile - 1) / kSortTile);
+constexpr int kSortItems = 8;              // pairs per thread of a radix scatter block
+constexpr int kSortWavesP = 4;             // waves per scatter block: 2048-pair tiles for the P-sized level-1 passes,
+constexpr int kSortWavesD = 8;             //                          4096-pair tiles for the D-sized level-2 passes
+constexpr int kCountTiles = 4;             // sort tiles per block of the count kernel: one 16-byte run per histogram row
+__host__ __device__ inline int sort_blocks(int64_t n, int waves) {   // radix-pass blocks, padded so the count kernel writes whole runs
+    const int tile = 512 * waves;
+    int b = (int)((n + tile - 1) / tile);
     return (b + kCountTiles - 1) / kCountTiles * kCountTiles;
 }
 
@@ -55,6 +57,8 @@ struct GeomView {
     float4* conic_opacity;    // [P]
     float4* rgbd;             // [P] r, g, b, view-space depth (one gather per staged list entry)
     uint32_t* tiles_touched;  // [P]
+    uint2* rect;              // [P] tile rectangle (x0 | y0 << 16, w | h << 16); w * h = tiles touched, 0 when culled:
+                              //     pair emission gathers this one 8-byte record per depth-ordered Gaussian
     uint8_t* clamped;         // [P] bit c set = colour channel c was clamped at 0
     uint32_t* block_sums;     // [npre]   tiles touched per preprocess block (kPB Gaussians)
     uint32_t* block_offsets;  // [npre+1] exclusive scan of block_sums; [npre] = D
@@ -102,11 +106,12 @@ inline GeomView carve_geom(void* base, int P) {
     g.conic_opacity = (float4*)take(16 * n);
     g.rgbd = (float4*)take(16 * n);
     g.tiles_touched = (uint32_t*)take(4 * n);
+    g.rect = (uint2*)take(8 * n);
     g.clamped = (uint8_t*)take(n);
     const size_t npre = (n + kPB - 1) / kPB;
     g.block_sums = (uint32_t*)take(4 * npre);
     g.block_offsets = (uint32_t*)take(4 * (npre + 1));
-    g.nsortP = sort_blocks(n);
+    g.nsortP = sort_blocks(n, kSortWavesP);
     for (int i = 0; i < 2; ++i) { g.dkeys[i] = (uint32_t*)take(4 * n); g.dvals[i] = (uint32_t*)take(4 * n); }
     g.dhist = (uint32_t*)take(4 * 256 * (size_t)g.nsortP);
     g.dtot = (uint32_t*)take(4 * 256);
@@ -139,7 +144,7 @@ inline BinningView carve_binning(void* base, int64_t D, int W, int H) {
     char* p = (char*)base;
     size_t o = 0;
     size_t n = (size_t)(D > 0 ? D : 1);
-    v.nsort = sort_blocks(n);
+    v.nsort = sort_blocks(n, kSortWavesD);
     v.key_bits = tile_bits(W, H);
     v.passes = (v.key_bits + 7) / 8;
     auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };

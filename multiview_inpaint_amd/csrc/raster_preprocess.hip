@@ -229,6 +229,8 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
     for (int k = 0; k < 16; ++k) { V[k] = f.view[k]; PM[k] = f.proj[k]; }
 
     uint32_t touched = 0;
+    uint2 rect = make_uint2(0u, 0u);
+    float depth_key = 0.0f;
     int rad_out = 0;
     if (i < f.P) {
         do {
@@ -309,13 +311,19 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
             g.clamped[i] = (uint8_t)clamp_bits;
             g.rgbd[i] = make_float4(r0, r1, r2, vz);
             g.depths[i] = vz;
+            depth_key = vz;
             g.xy[i] = make_float2(pix_x, pix_y);
             g.conic_opacity[i] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opac);
             rad_out = rad;
             touched = (uint32_t)((x1 - x0) * (y1 - y0));
+            rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
         } while (false);
         radii[i] = rad_out;
         g.tiles_touched[i] = touched;
+        g.rect[i] = rect;
+        // level-1 sort input (binning): depth bits (monotonic for depth > 0.2), culled Gaussians last
+        g.dkeys[0][i] = touched ? __float_as_uint(depth_key) : 0xFFFFFFFFu;
+        g.dvals[0][i] = (uint32_t)i;
     }
     uint32_t wsum = wave_sum_u32(touched);
     if ((tid & 63) == 0 && wsum) atomicAdd(&s_sum, wsum);

@@ -8,8 +8,8 @@ import re
 import sys
 
 d, tag = sys.argv[1], sys.argv[2]
-STAGE = {"preprocess_forward_kernel": "preprocess_forward", "scan_block_sums_kernel": "scan_block_sums",
-         "depth_keys_kernel": "radix_sort", "radix_count_kernel": "radix_sort", "radix_scan_rows_kernel": "radix_sort",
+STAGE = {"preprocess_forward_kernel": "preprocess_forward", "total_block_sums_kernel": "scan_block_sums",
+         "scan_block_sums_kernel": "duplicate_keys", "depth_keys_kernel": "radix_sort", "radix_count_kernel": "radix_sort", "radix_scan_rows_kernel": "radix_sort",
          "radix_scatter_kernel": "radix_sort", "perm_block_sums_kernel": "duplicate_keys", "emit_pairs_kernel": "duplicate_keys",
          "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward",
          "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
@@ -19,7 +19,7 @@ STEPS = 6          # bench.py --steps 5 --warmup 1
 def parse(path):
     out, k = {}, None
     for line in open(path):
-        if line.startswith("mvi::"):
+        if line.startswith(("mvi::", "void mvi::")):
             k = line.strip().split("::")[1]
             out[k] = {}
         else:
@@ -32,6 +32,10 @@ def parse(path):
 f, w = parse(os.path.join(d, "pmc_fetch.txt")), parse(os.path.join(d, "pmc_write.txt"))
 per_kernel, per_stage = {}, {}
 for k in sorted(f):
+    if k not in STAGE:
+        # templated kernels appear as name<...>
+        base = k.split("<")[0]
+        STAGE[k] = STAGE.get(base, "other")
     fv, n = f[k]["FETCH_SIZE"]
     wv = w[k]["WRITE_SIZE"][0]
     lps = n / STEPS
