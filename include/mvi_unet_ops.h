@@ -121,6 +121,19 @@ int mvi_add_lerp(const void* x, const void* h, const void* base, const float* al
 int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64_t N, int32_t C, int64_t spatial,
                              int32_t dtype, void* stream);
 
+/* The same two attention ops reading q, k, v with a token stride larger than H*D — for q, k, v taken straight out of
+ * ONE packed projection [.., 3*H*D] = (q | k | v) (token stride 3*H*D, base pointers H*D apart): the three bias-free
+ * Linear layers of a self-attention (svd_inpaint1/sgm/modules/attention.py:281-300) then run as one GEMM over the
+ * activations instead of three. Strides are in elements, 0 = H*D (contiguous); they must be multiples of 16 bytes.
+ * Tokens of one batch entry are consecutive (batch stride = S * token stride). */
+int mvi_attention_forward_strided(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                                  int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype,
+                                  int64_t q_token_stride, int64_t kv_token_stride, int64_t out_token_stride,
+                                  void* stream);
+int mvi_attention_temporal_strided(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                                   int32_t S, int32_t H, int32_t D, float scale, int32_t dtype,
+                                   int64_t qkv_token_stride, int64_t out_token_stride, void* stream);
+
 /* x[r, :] = softmax(scale * x[r, :]) in place, x [rows, cols] contiguous, scale > 0, fp32 statistics. The scaled
  * softmax between the two library GEMMs of the first-stage autoencoder's single-head attention with D = C = 512
  * (svd_inpaint1/sgm/modules/diffusionmodules/model.py:180-195, scaled_dot_product_attention with one head): the

@@ -18,6 +18,10 @@ def bind(L):
     L.mvi_attention_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.mvi_attention_temporal.restype = C.c_int
     L.mvi_attention_temporal.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.mvi_attention_forward_strided.restype = C.c_int
+    L.mvi_attention_forward_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i64, i64, i64, vp]
+    L.mvi_attention_temporal_strided.restype = C.c_int
+    L.mvi_attention_temporal_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i64, i64, vp]
     L.mvi_geglu.restype = C.c_int
     L.mvi_geglu.argtypes = [vp, vp, i64, i32, i32, vp]
     L.mvi_bias_residual_add.restype = C.c_int

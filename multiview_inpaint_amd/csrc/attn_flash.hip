@@ -83,7 +83,8 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WPE, MVI_ATTN_WPE))) void attn_flash_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                    const T* __restrict__ v, T* __restrict__ out, int H,
                                                                    int Sq, int Sk, float scale_log2e, int q_blocks,
-                                                                   int total_blocks) {
+                                                                   int total_blocks, int64_t q_rs, int64_t kv_rs,
+                                                                   int64_t o_rs) {
     using M = Mma<T>;
     using frag = typename M::frag;
     __shared__ __attribute__((aligned(16))) uint16_t s_k[2][kFK * kKStride];
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
     const int bh = bid / q_blocks;
     const int h = bh % H;
     const int64_t b = bh / H;
-    const int64_t hd = (int64_t)H * kFD;
+    // q_rs / kv_rs / o_rs: elements between consecutive tokens of q, of k and v, of out (H * 64 when contiguous;
+    // 3 * H * 64 for q, k, v taken out of one packed projection)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int qcol = lane & 31, hh = lane >> 5;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
 
     frag qf[4];
     {
-        const T* qp = q + ((b * Sq + (qrow < Sq ? qrow : 0)) * hd + (int64_t)h * kFD + 8 * hh);
+        const T* qp = q + ((b * Sq + (qrow < Sq ? qrow : 0)) * q_rs + (int64_t)h * kFD + 8 * hh);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 raw = qrow < Sq ? *reinterpret_cast<const u32x4*>(qp + 16 * s) : u32x4{0, 0, 0, 0};
@@ -118,21 +120,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
 
     const int kr = tid >> 2, ks = tid & 3;
     const int vp = tid >> 3, vs = tid & 7;
-    const T* kbase = k + (b * Sk * hd + (int64_t)h * kFD);
-    const T* vbase = v + (b * Sk * hd + (int64_t)h * kFD);
+    const T* kbase = k + (b * Sk * kv_rs + (int64_t)h * kFD);
+    const T* vbase = v + (b * Sk * kv_rs + (int64_t)h * kFD);
     u32x4 rk0, rk1, rv0, rv1;
     const u32x4 z4 = {0, 0, 0, 0};
     auto load_k = [&](int k0) {
         int r = k0 + kr;
-        const T* p = kbase + (int64_t)r * hd + 16 * ks;
+        const T* p = kbase + (int64_t)r * kv_rs + 16 * ks;
         rk0 = r < Sk ? *reinterpret_cast<const u32x4*>(p) : z4;
         rk1 = r < Sk ? *reinterpret_cast<const u32x4*>(p + 8) : z4;
     };
     auto load_v = [&](int k0) {
         int r0 = k0 + 2 * vp;
-        const T* pv = vbase + (int64_t)r0 * hd + 8 * vs;
+        const T* pv = vbase + (int64_t)r0 * kv_rs + 8 * vs;
         rv0 = r0 < Sk ? *reinterpret_cast<const u32x4*>(pv) : z4;
-        rv1 = r0 + 1 < Sk ? *reinterpret_cast<const u32x4*>(pv + hd) : z4;
+        rv1 = r0 + 1 < Sk ? *reinterpret_cast<const u32x4*>(pv + kv_rs) : z4;
     };
     auto store_k = [&](int buf) {
         uint16_t* sk = s_k[buf];
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
     l += __shfl_xor(l, 32);
     if (qrow < Sq) {
         const float inv = 1.0f / l;
-        T* op = out + ((b * Sq + qrow) * hd + (int64_t)h * kFD);
+        T* op = out + ((b * Sq + qrow) * o_rs + (int64_t)h * kFD);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -256,21 +258,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
 
 template <typename T>
 int attn_flash_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
-                      float scale, hipStream_t st) {
+                      float scale, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
+    const int64_t hd = (int64_t)H * kFD;
+    if (q_rs == 0) q_rs = hd;
+    if (kv_rs == 0) kv_rs = hd;
+    if (o_rs == 0) o_rs = hd;
     const int q_blocks = (Sq + kFQ - 1) / kFQ;
     const int64_t total = (int64_t)B * H * q_blocks;
     if (total > 0x7FFFFFFFll) return MVI_EINVAL;
     hipLaunchKernelGGL((attn_flash_kernel<T>), dim3((unsigned)total), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total);
+                       (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
-template int attn_flash_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
-template int attn_flash_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t);
+template int attn_flash_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
+template int attn_flash_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
 
 // rowtile kernel (attn_rowtile.hip)
 template <typename T>
 int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
-                        float scale, hipStream_t st, int temporal_inner);
+                        float scale, hipStream_t st, int temporal_inner, int64_t q_ts, int64_t kv_ts, int64_t o_ts);
 int unet_fail(int code, const char* msg);
 
 }  // namespace mvi
@@ -279,45 +285,78 @@ extern "C" int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int3
     return (dtype != MVI_DT_F32 && D == mvi::kFD && Sk > 32) ? 1 : 0;
 }
 
-extern "C" int mvi_attention_forward(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
-                                     int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype, void* stream) {
+static int attention_forward_impl(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Sq,
+                                  int32_t Sk, int32_t D, float scale, int32_t dtype, int64_t q_ts, int64_t kv_ts, int64_t o_ts,
+                                  void* stream) {
     if (B < 0 || H <= 0 || Sq < 0 || Sk <= 0 || D <= 0) return mvi::unet_fail(MVI_EINVAL, "attention: bad shape");
     if (B == 0 || Sq == 0) return MVI_OK;
     if (!q || !k || !v || !out) return mvi::unet_fail(MVI_EINVAL, "attention: NULL pointer");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 != 0)
         return mvi::unet_fail(MVI_EINVAL, "attention: pointers must be 16-byte aligned");
+    const int64_t hd = (int64_t)H * D;
+    const int esz = dtype == MVI_DT_F32 ? 4 : 2;
+    if (q_ts < 0 || kv_ts < 0 || o_ts < 0 || (q_ts && q_ts < hd) || (kv_ts && kv_ts < hd) || (o_ts && o_ts < hd) ||
+        (q_ts * esz) % 16 || (kv_ts * esz) % 16 || (o_ts * esz) % 16)
+        return mvi::unet_fail(MVI_EINVAL, "attention: token strides must be 0 or >= H*D elements and 16-byte multiples");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (mvi_attention_kernel_kind(Sq, Sk, D, dtype) == 1) {
-        rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st)
-                                  : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st);
+        rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
+                                  : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
     } else {
         if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "attention: head dim must be 16, 32 or 64");
         switch (dtype) {
-            case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0); break;
-            case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0); break;
-            case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0); break;
+            case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0, q_ts, kv_ts, o_ts); break;
+            case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0, q_ts, kv_ts, o_ts); break;
+            case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, Sq, Sk, D, scale, st, 0, q_ts, kv_ts, o_ts); break;
             default: return mvi::unet_fail(MVI_EINVAL, "attention: unknown dtype");
         }
     }
     return rc ? mvi::unet_fail(rc, "attention: kernel launch failed") : MVI_OK;
 }
 
-extern "C" int mvi_attention_temporal(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
-                                      int32_t S, int32_t H, int32_t D, float scale, int32_t dtype, void* stream) {
+extern "C" int mvi_attention_forward(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                                     int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype, void* stream) {
+    return attention_forward_impl(q, k, v, out, B, H, Sq, Sk, D, scale, dtype, 0, 0, 0, stream);
+}
+
+extern "C" int mvi_attention_forward_strided(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                                             int32_t Sq, int32_t Sk, int32_t D, float scale, int32_t dtype,
+                                             int64_t q_token_stride, int64_t kv_token_stride, int64_t out_token_stride,
+                                             void* stream) {
+    return attention_forward_impl(q, k, v, out, B, H, Sq, Sk, D, scale, dtype, q_token_stride, kv_token_stride,
+                                  out_token_stride, stream);
+}
+
+static int attention_temporal_impl(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T, int32_t S,
+                                   int32_t H, int32_t D, float scale, int32_t dtype, int64_t qkv_ts, int64_t o_ts, void* stream) {
     if (Bo < 0 || T <= 0 || S <= 0 || H <= 0 || D <= 0) return mvi::unet_fail(MVI_EINVAL, "temporal attention: bad shape");
     if (Bo == 0) return MVI_OK;
     if (!q || !k || !v || !out) return mvi::unet_fail(MVI_EINVAL, "temporal attention: NULL pointer");
     if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "temporal attention: head dim must be 16, 32 or 64");
     if ((int64_t)Bo * S > 0x7FFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "temporal attention: too many problems");
+    const int64_t hd = (int64_t)H * D;
+    if (qkv_ts < 0 || o_ts < 0 || (qkv_ts && qkv_ts < hd) || (o_ts && o_ts < hd))
+        return mvi::unet_fail(MVI_EINVAL, "temporal attention: token strides must be 0 or >= H*D elements");
     hipStream_t st = (hipStream_t)stream;
     const int B = Bo * S;
     int rc;
     switch (dtype) {
-        case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, T, T, D, scale, st, S); break;
-        case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, T, T, D, scale, st, S); break;
-        case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, T, T, D, scale, st, S); break;
+        case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, T, T, D, scale, st, S, qkv_ts, qkv_ts, o_ts); break;
+        case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, T, T, D, scale, st, S, qkv_ts, qkv_ts, o_ts); break;
+        case MVI_DT_F16: rc = mvi::attn_rowtile_launch<__half>(q, k, v, out, B, H, T, T, D, scale, st, S, qkv_ts, qkv_ts, o_ts); break;
         default: return mvi::unet_fail(MVI_EINVAL, "temporal attention: unknown dtype");
     }
     return rc ? mvi::unet_fail(rc, "temporal attention: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_attention_temporal(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                                      int32_t S, int32_t H, int32_t D, float scale, int32_t dtype, void* stream) {
+    return attention_temporal_impl(q, k, v, out, Bo, T, S, H, D, scale, dtype, 0, 0, stream);
+}
+
+extern "C" int mvi_attention_temporal_strided(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                                              int32_t S, int32_t H, int32_t D, float scale, int32_t dtype,
+                                              int64_t qkv_token_stride, int64_t out_token_stride, void* stream) {
+    return attention_temporal_impl(q, k, v, out, Bo, T, S, H, D, scale, dtype, qkv_token_stride, out_token_stride, stream);
 }

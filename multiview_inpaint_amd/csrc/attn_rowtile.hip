@@ -42,7 +42,7 @@ constexpr int kRtWaves = 4;      // waves (= independent problems) per block
 //   inner = S, inner_stride = H*D, outer_stride = T*S*H*D, row_stride = S*H*D, rows = frames.
 struct RtLayout {
     int inner;
-    int64_t q_outer, q_inner, q_row, k_outer, k_inner, k_row;
+    int64_t q_outer, q_inner, q_row, k_outer, k_inner, k_row, o_outer, o_inner, o_row;
 };
 
 template <typename T, int DV>
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
     const int64_t bo = b / L.inner, bi = b % L.inner;
     const int64_t qbase = bo * L.q_outer + bi * L.q_inner + (int64_t)h * D;
     const int64_t kbase = bo * L.k_outer + bi * L.k_inner + (int64_t)h * D;
+    const int64_t obase = bo * L.o_outer + bi * L.o_inner + (int64_t)h * D;
 
     float qr[DV][4], acc[DV][4];
 #pragma unroll
@@ -138,27 +139,37 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
         for (int i = 0; i < DV; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                out[qbase + row * L.q_row + 16 * i + 4 * p + c] = from_f<T>(acc[i][c] * inv);
+                out[obase + row * L.o_row + 16 * i + 4 * p + c] = from_f<T>(acc[i][c] * inv);
     }
 }
 
+// q_ts / kv_ts / o_ts: elements between consecutive tokens of q, of k and v, of out (0 = H*D, the contiguous
+// [.., H, D] layout). A packed projection [.., 3 H D] = (q | k | v) is addressed with q_ts = kv_ts = 3 H D and the
+// three base pointers H D apart.
 template <typename T>
 int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
-                        float scale, hipStream_t st, int temporal_inner) {
+                        float scale, hipStream_t st, int temporal_inner, int64_t q_ts, int64_t kv_ts, int64_t o_ts) {
     RtLayout L;
     const int64_t hd = (int64_t)H * D;
-    if (temporal_inner > 0) {   // B = outer * temporal_inner problems; rows are frames strided by inner * H*D
+    if (q_ts == 0) q_ts = hd;
+    if (kv_ts == 0) kv_ts = hd;
+    if (o_ts == 0) o_ts = hd;
+    if (temporal_inner > 0) {   // B = outer * temporal_inner problems; rows are frames strided by inner tokens
         L.inner = temporal_inner;
-        L.q_inner = L.k_inner = hd;
-        L.q_row = L.k_row = (int64_t)temporal_inner * hd;
-        L.q_outer = (int64_t)Sq * temporal_inner * hd;
-        L.k_outer = (int64_t)Sk * temporal_inner * hd;
+        L.q_inner = q_ts; L.k_inner = kv_ts; L.o_inner = o_ts;
+        L.q_row = (int64_t)temporal_inner * q_ts;
+        L.k_row = (int64_t)temporal_inner * kv_ts;
+        L.o_row = (int64_t)temporal_inner * o_ts;
+        L.q_outer = (int64_t)Sq * L.q_row;
+        L.k_outer = (int64_t)Sk * L.k_row;
+        L.o_outer = (int64_t)Sq * L.o_row;
     } else {
         L.inner = 1;
-        L.q_inner = L.k_inner = 0;
-        L.q_row = L.k_row = hd;
-        L.q_outer = (int64_t)Sq * hd;
-        L.k_outer = (int64_t)Sk * hd;
+        L.q_inner = L.k_inner = L.o_inner = 0;
+        L.q_row = q_ts; L.k_row = kv_ts; L.o_row = o_ts;
+        L.q_outer = (int64_t)Sq * q_ts;
+        L.k_outer = (int64_t)Sk * kv_ts;
+        L.o_outer = (int64_t)Sq * o_ts;
     }
     const int q_tiles = (Sq + 15) / 16;
     const int64_t n = (int64_t)B * H * q_tiles;
@@ -178,8 +189,8 @@ int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, 
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
-template int attn_rowtile_launch<float>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int);
-template int attn_rowtile_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int);
-template int attn_rowtile_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int);
+template int attn_rowtile_launch<float>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int, int64_t, int64_t, int64_t);
+template int attn_rowtile_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int, int64_t, int64_t, int64_t);
+template int attn_rowtile_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, int, int64_t, int64_t, int64_t);
 
 }  // namespace mvi

@@ -43,6 +43,15 @@ __device__ __forceinline__ bool quad_overlap(float2 c, float4 co, float t2, floa
     return f <= t2;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id, and every XCD has its own L2. Tile t of a launch of
+// `tiles` workgroups is chosen so that XCD x works through ONE contiguous band of tiles (rows of the image): the ~11
+// tiles a Gaussian touches then gather its 40 bytes through the same L2 (and their gradient atomics meet there)
+// instead of through up to 8 of them.
+__device__ __forceinline__ int xcd_band_tile(int bid, int tiles) {
+    const int q = tiles >> 3, r = tiles & 7, x = bid & 7, i = bid >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
@@ -85,8 +94,9 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     __shared__ float4 s_cd[kBlock];                 // r, g, b, depth
     __shared__ float4 w_a[4][64], w_co[4][64], w_cd[4][64];   // per-wave compacted strip: (x, y, list position, -)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile = blockIdx.y * f.gx + blockIdx.x;
-    const int qx0 = blockIdx.x * kTile + 8 * (wave & 1), qy0 = blockIdx.y * kTile + 8 * (wave >> 1);
+    const int tile = xcd_band_tile(blockIdx.x, f.gx * f.gy);
+    const int tile_y = tile / f.gx, tile_x = tile - tile_y * f.gx;
+    const int qx0 = tile_x * kTile + 8 * (wave & 1), qy0 = tile_y * kTile + 8 * (wave >> 1);
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < f.W && pyi < f.H;
     const float pfx = (float)pxi, pfy = (float)pyi;
@@ -169,7 +179,7 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
                           float* out_color, float* out_depth, hipStream_t st) {
     if (f.W <= 0 || f.H <= 0) return 0;
     const uint32_t* plist = b.vals[b.passes & 1];
-    hipLaunchKernelGGL(render_forward_kernel, dim3(f.gx, f.gy), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
+    hipLaunchKernelGGL(render_forward_kernel, dim3(f.gx * f.gy), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
                        g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
@@ -241,8 +251,9 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     __shared__ int s_slot[2][8];
     __shared__ uint32_t s_blast[2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tile = blockIdx.y * f.gx + blockIdx.x;
-    const int hx0 = blockIdx.x * kTile, hy0 = blockIdx.y * kTile + 8 * wave;          // this wave's 16 x 8 half tile
+    const int tile = xcd_band_tile(blockIdx.x, f.gx * f.gy);
+    const int tile_y = tile / f.gx, tile_x = tile - tile_y * f.gx;
+    const int hx0 = tile_x * kTile, hy0 = tile_y * kTile + 8 * wave;                  // this wave's 16 x 8 half tile
     const int pxi = hx0 + (lane & 15), py0 = hy0 + 2 * (lane >> 4), py1 = py0 + 1;
     const bool in0 = pxi < f.W && py0 < f.H, in1 = pxi < f.W && py1 < f.H;
     const float pfx = (float)pxi;
@@ -402,7 +413,7 @@ int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView 
                            const float* dL_dpix, float* grad_rows, hipStream_t st) {
     if (f.W <= 0 || f.H <= 0 || D <= 0) return 0;
     const uint32_t* plist = b.vals[b.passes & 1];
-    hipLaunchKernelGGL(render_backward_kernel, dim3(f.gx, f.gy), dim3(kB2), 0, st, f, im.ranges, plist, g.xy,
+    hipLaunchKernelGGL(render_backward_kernel, dim3(f.gx * f.gy), dim3(kB2), 0, st, f, im.ranges, plist, g.xy,
                        g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, dL_dpix, grad_rows);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }

@@ -152,6 +152,44 @@ def attention(q, k, v, heads):
     return out
 
 
+def attention_packed(qkv, heads):
+    """Self-attention on ONE packed projection qkv [B, S, 3*H*D] = (q | k | v) -> [B, S, H*D]: the kernels read q, k, v in
+    place with a token stride of 3*H*D (mvi_attention_forward_strided), so the three projections are one GEMM."""
+    L = _lib.lib()
+    if qkv.dtype not in _DT or not qkv.is_contiguous():
+        raise TypeError("attention_packed: contiguous fp32/bf16/f16 [B, S, 3*H*D] expected")
+    B, S, C3 = qkv.shape
+    HD = C3 // 3
+    D = HD // heads
+    out = torch.empty(B, S, HD, dtype=qkv.dtype, device=qkv.device)
+    es = qkv.element_size()
+    kind = "attention_mfma" if L.mvi_attention_kernel_kind(S, S, D, _DT[qkv.dtype]) == 1 else "attention_rowtile"
+    p = qkv.data_ptr()
+    with torch.cuda.device(qkv.device), _Timed(kind, 4.0 * B * heads * S * S * D, qkv.device):
+        _check(L.mvi_attention_forward_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), B, heads, S, S, D,
+                                               float(D) ** -0.5, _DT[qkv.dtype], C3, C3, HD, _stream(qkv.device)),
+               "attention (packed)")
+    return out
+
+
+def attention_temporal_packed(qkv, heads, T):
+    """attention_temporal on a packed projection qkv [(bo*T), S, 3*H*D] -> [(bo*T), S, H*D]."""
+    L = _lib.lib()
+    if qkv.dtype not in _DT or not qkv.is_contiguous():
+        raise TypeError("attention_temporal_packed: contiguous fp32/bf16/f16 [(bo T), S, 3*H*D] expected")
+    BT, S, C3 = qkv.shape
+    HD = C3 // 3
+    D = HD // heads
+    out = torch.empty(BT, S, HD, dtype=qkv.dtype, device=qkv.device)
+    es = qkv.element_size()
+    p = qkv.data_ptr()
+    with torch.cuda.device(qkv.device), _Timed("attention_temporal", 4.0 * (BT // T) * S * heads * T * T * D, qkv.device):
+        _check(L.mvi_attention_temporal_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), BT // T, T, S, heads, D,
+                                                float(D) ** -0.5, _DT[qkv.dtype], C3, HD, _stream(qkv.device)),
+               "attention_temporal (packed)")
+    return out
+
+
 def softmax_rows_(x, scale):
     """x [..., cols] contiguous: softmax(scale * x) over the last axis, in place."""
     L = _lib.lib()

@@ -87,6 +87,29 @@ def attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, Sq, HD)
 
 
+def packed_ok(x, heads, dim_head):
+    """Whether the self-attention of x can take the packed-projection path (GPU inference, kernel-supported head dim)."""
+    return x.is_cuda and not torch.is_grad_enabled() and dim_head in (16, 32, 64) and (heads * dim_head * x.element_size()) % 16 == 0
+
+
+def attention_packed(qkv, heads):
+    """Self-attention on one packed projection qkv [B, S, 3*H*D] = (q | k | v) -> [B, S, H*D]."""
+    if qkv.is_cuda and not _needs_autograd(qkv):
+        from . import hip_ops
+        return hip_ops.attention_packed(qkv.contiguous(), heads)
+    q, k, v = qkv.chunk(3, dim=-1)
+    return attention(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+
+
+def attention_temporal_packed(qkv, heads, T):
+    """attention_temporal on a packed projection [(bo*T), S, 3*H*D]."""
+    if qkv.is_cuda and not _needs_autograd(qkv):
+        from . import hip_ops
+        return hip_ops.attention_temporal_packed(qkv.contiguous(), heads, T)
+    q, k, v = qkv.chunk(3, dim=-1)
+    return attention_temporal(q.contiguous(), k.contiguous(), v.contiguous(), heads, T)
+
+
 def attention_wide(q, k, v):
     """Single-head attention whose head is the whole channel axis (model.py:180-195: D = C = 512): q [B,Sq,D],
     k/v [B,Sk,D] -> [B,Sq,D]."""

@@ -68,6 +68,10 @@ class CrossAttention(nn.Module):
             # projection is applied to that one row and the result broadcast over the queries (the
             # residual add broadcasts it) — also keeps zero-stride operands out of the GEMM library.
             return self.to_out(self.to_v(ctx)).expand(-1, x.shape[1], -1)
+        if context is None and not n_times_crossframe_attn_in_self and not n_extra and ops.packed_ok(x, self.heads, self.dim_head):
+            # self-attention at inference: one GEMM [.., C] x [C, 3 H D] instead of three passes over the activations;
+            # the attention kernel reads q, k, v out of the packed result in place
+            return self.to_out(ops.attention_packed(F.linear(x, self._packed_qkv_weight()), self.heads))
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if n_times_crossframe_attn_in_self:
             n = n_times_crossframe_attn_in_self
@@ -80,8 +84,21 @@ class CrossAttention(nn.Module):
         return self.to_out(out)
 
 
+    def _packed_qkv_weight(self):
+        """cat(to_q.weight, to_k.weight, to_v.weight) [3 H D, C], rebuilt only when a weight changes (inference weights
+        are static; not a parameter or buffer, so the state-dict keys stay the reference's)."""
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        hit = getattr(self, "_wqkv", None)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+            self._wqkv = hit
+        return hit[1]
+
     def forward_temporal(self, x, T):
         """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back."""
+        if ops.packed_ok(x, self.heads, self.dim_head) and self.to_k.in_features == self.to_q.in_features:
+            return self.to_out(ops.attention_temporal_packed(F.linear(x, self._packed_qkv_weight()), self.heads, T))
         return self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
 
     def single_token(self, ctx):

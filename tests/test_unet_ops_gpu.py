@@ -321,3 +321,62 @@ def test_groupnorm_token_major_output(ops, dtype, tol, N, C, H, W, silu, with_bi
     y = ops.group_norm_silu_tokens(x.cuda(), 32, w.cuda(), b.cuda(), 1e-6, silu, chan_bias=None if cb is None else cb.cuda())
     assert y.shape == (N, H * W, C) and y.dtype == dtype and y.is_contiguous()
     assert rel(y, ref.flatten(2).transpose(1, 2)) < tol
+
+
+# ---- packed q | k | v projections read in place (mvi_attention_*_strided) --------------------------------------------
+
+@pytest.mark.parametrize("dtype,B,S,H,D", [(torch.float32, 3, 77, 2, 16), (torch.float32, 2, 130, 3, 64),
+                                           (torch.bfloat16, 2, 300, 5, 64), (torch.float16, 3, 129, 2, 64),
+                                           (torch.bfloat16, 2, 20, 4, 32)])
+def test_attention_packed_equals_separate_tensors(ops, dtype, B, S, H, D):
+    g = torch.Generator().manual_seed(S * H + D)
+    qkv = torch.randn(B, S, 3 * H * D, generator=g).to(dtype).cuda()
+    q, k, v = (t.contiguous() for t in qkv.chunk(3, dim=-1))
+    want = ops.attention(q, k, v, H)
+    got = ops.attention_packed(qkv, H)
+    assert got.shape == want.shape and got.is_contiguous()
+    assert torch.equal(got, want)                       # same kernel, same arithmetic, only the addressing differs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_temporal_packed_equals_separate_tensors(ops, dtype):
+    bo, T, S, H, D = 2, 5, 37, 3, 32
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(bo * T, S, 3 * H * D, generator=g).to(dtype).cuda()
+    q, k, v = (t.contiguous() for t in qkv.chunk(3, dim=-1))
+    assert torch.equal(ops.attention_temporal_packed(qkv, H, T), ops.attention_temporal(q, k, v, H, T))
+
+
+def test_attention_strided_rejects_bad_strides(ops):
+    from multiview_inpaint_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(1, 64, 3 * 64, device="cuda", dtype=torch.bfloat16)
+    o = torch.zeros(1, 64, 64, device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    # token stride smaller than H*D, and one that is not a 16-byte multiple
+    assert L.mvi_attention_forward_strided(x.data_ptr(), x.data_ptr(), x.data_ptr(), o.data_ptr(), 1, 1, 64, 64, 64, 0.125, 1,
+                                           32, 192, 64, st) != 0
+    assert L.mvi_attention_forward_strided(x.data_ptr(), x.data_ptr(), x.data_ptr(), o.data_ptr(), 1, 1, 64, 64, 64, 0.125, 1,
+                                           196, 196, 64, st) != 0
+
+
+def test_self_attention_module_takes_the_packed_path_and_matches(ops):
+    """CrossAttention self-attention at inference = one packed GEMM + in-place reads; equal to the three-projection path
+    up to the GEMM library's blocking (same weights, same kernel)."""
+    from multiview_inpaint_amd.svd.transformer import CrossAttention
+    torch.manual_seed(3)
+    m = CrossAttention(query_dim=64, heads=2, dim_head=32).cuda().eval()
+    x = torch.randn(4, 50, 64, device="cuda")
+    with torch.no_grad():
+        got = m(x)
+        q, k, v = m.to_q(x), m.to_k(x), m.to_v(x)
+        want = m.to_out(ops.attention(q, k, v, 2))
+        assert rel(got, want) < 1e-5
+        w1 = m._packed_qkv_weight()
+        assert m._packed_qkv_weight() is w1                 # cached
+        m.to_k.weight.mul_(2.0)
+        assert m._packed_qkv_weight() is not w1             # rebuilt after an in-place weight update
+        assert "_wqkv" not in m.state_dict() and len(m.state_dict()) == 5
+        got_t = m.forward_temporal(x, 2)
+        want_t = m.to_out(ops.attention_temporal(m.to_q(x), m.to_k(x), m.to_v(x), 2, 2))
+        assert rel(got_t, want_t) < 1e-5
