@@ -245,7 +245,7 @@ def main():
             t = bucket = st = g_img = None
             torch.cuda.empty_cache()
             from multiview_inpaint_amd import bench_train
-            out["train_iteration"] = bench_train.run_both(steps=10, warmup=2)
+            out["train_iteration"] = bench_train.run_both(steps=20, warmup=5)
         if world == 1 and args.path in ("both", "svd"):
             # second half of the BASELINE.json metric: SVD 14-frame 576x1024 denoise steps/s
             t = bucket = st = g_img = None

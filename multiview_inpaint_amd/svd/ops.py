@@ -35,6 +35,8 @@ def group_norm(x, num_groups, weight, bias, eps, silu=False, chan_bias=None):
     chan_bias [N, C] (optional) is added to x first (the ResBlock's timestep-embedding bias)."""
     if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
+        if hip_ops.is_channels_last(x) and hip_ops.nhwc_supported(x.shape[1], num_groups, x.dtype):
+            return hip_ops.group_norm_nhwc(x, 1, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
         return hip_ops.group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
     xf = x.float()
     if chan_bias is not None:
@@ -47,9 +49,13 @@ def group_norm_tokens(x, num_groups, weight, bias, eps, silu=False, chan_bias=No
     """group_norm(...) returned token-major: [N, C, *spatial] -> [N, prod(spatial), C] ("b c h w -> b (h w) c"
     fused into the normalisation's write)."""
     S = x[0, 0].numel()
-    if (x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias) and x.shape[1] % 8 == 0 and S % 8 == 0):
+    if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
-        return hip_ops.group_norm_silu_tokens(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+        if hip_ops.is_channels_last(x) and hip_ops.nhwc_supported(x.shape[1], num_groups, x.dtype):
+            # channels-last activations ARE token-major: no transpose at all
+            return hip_ops.group_norm_nhwc(x, 1, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, tokens_out=True)
+        if x.shape[1] % 8 == 0 and S % 8 == 0:
+            return hip_ops.group_norm_silu_tokens(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
     return group_norm(x, num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
 
 
@@ -61,6 +67,8 @@ def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False, chan_bias
     convolution evaluated as one 1x1 convolution."""
     if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
+        if hip_ops.is_channels_last(x) and hip_ops.nhwc_supported(x.shape[1], num_groups, x.dtype):
+            return hip_ops.group_norm_nhwc(x, T, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, stack3=stack3)
         return hip_ops.group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, stack3=stack3)
     bt, c = x.shape[:2]
     xf = x.float()
@@ -152,6 +160,8 @@ def bias_residual_add(h, bias=None, x=None):
     """h [N, C, *spatial] + bias[c] + x in one pass (conv bias and ResBlock skip add, openaimodel.py:354)."""
     if h.is_cuda and not _needs_autograd(h, bias, x):
         from . import hip_ops
+        if hip_ops.is_channels_last(h) and h.shape[1] % 8 == 0 and (x is None or hip_ops.is_channels_last(x)):
+            return hip_ops.bias_residual_add_nhwc(h, bias, x)
         return hip_ops.bias_residual_add(h, bias, x)
     out = h
     if bias is not None:
@@ -196,7 +206,10 @@ def add_lerp(x, h, base, alpha):
 
 def tokens_to_planes_add(tok, x_in):
     """tok [B, (h w), C] -> [B, C, h, w] plus x_in, one pass (SpatialTransformer's exit)."""
-    if tok.is_cuda and not _needs_autograd(tok, x_in) and tok.shape[-1] % 8 == 0 and tok.shape[1] % 8 == 0:
+    if tok.is_cuda and not _needs_autograd(tok, x_in):
         from . import hip_ops
-        return hip_ops.tokens_to_planes_add(tok, x_in)
+        if hip_ops.is_channels_last(x_in) and tok.is_contiguous() and tok.shape[-1] % 8 == 0:
+            return hip_ops.bias_residual_add_nhwc(tok, None, x_in)        # same memory layout: a plain add
+        if tok.shape[-1] % 8 == 0 and tok.shape[1] % 8 == 0:
+            return hip_ops.tokens_to_planes_add(tok, x_in)
     return tok.transpose(1, 2).reshape(x_in.shape) + x_in
