@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
     uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask, const uint32_t* __restrict__ block_hist,
     int nblk, const uint32_t* __restrict__ digit_tot) {
     constexpr int kNT = 64 * kW, kTileW = 512 * kW;
+    static_assert(kW >= 4, "the 256 digits are kept by the first 256 threads of the block");
     __shared__ uint32_t s_wave_hist[kW][256];
     __shared__ uint32_t s_digit_base[256];     // global position of this block's first pair of digit d
     __shared__ uint32_t s_local_start[256];    // position of digit d's run inside the block-sorted tile
