@@ -61,7 +61,23 @@ template <> struct Mma<__half> {
 };
 
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
+template <typename T> __device__ __forceinline__ constexpr uint32_t kOnes2();                      // two 1.0 in the I/O type
+template <> __device__ __forceinline__ constexpr uint32_t kOnes2<__hip_bfloat16>() { return 0x3F803F80u; }
+template <> __device__ __forceinline__ constexpr uint32_t kOnes2<__half>() { return 0x3C003C00u; }
 
+// Build variants kept for A/B runs (tools/ab_attention.sh; micro-benchmark B28 H5 S9216 / B28 H10 S2304, bf16, TFLOP/s):
+//   PIPE=1 WPE=3 (default)            781 / 761     QK^T of tile t+1 issued under the softmax of tile t
+//   PIPE=0 WPE=3                      768 / 738     one score accumulator, overlap left to the SIMD's other waves
+//   PIPE=0 WPE=4                      783 / 744     ... at 4 waves per SIMD (128 VGPRs, 7 spilled)
+//   PIPE=0 WPE=3 MFMA_ROWSUM=1        699 / 690     row sums as 4 extra MFMAs per tile instead of 33 v_add_f32
+// The last line shows the matrix pipe is NOT idle enough to take 25 % more work: the loop is balanced between the two
+// pipes at ~780 TFLOP/s, which is why removing VALU instructions alone (the first three lines) does not move it.
+#ifndef MVI_ATTN_PIPE
+#define MVI_ATTN_PIPE 1           // 1: QK^T of tile t+1 issued under the softmax of tile t (second score accumulator)
+#endif
+#ifndef MVI_ATTN_MFMA_ROWSUM
+#define MVI_ATTN_MFMA_ROWSUM 0    // (non-pipelined variant only) softmax row sums as 4 extra MFMAs per tile
+#endif
 #ifndef MVI_ATTN_WPE
 #define MVI_ATTN_WPE 3            // waves per SIMD the kernel is compiled for (register budget 512 / MVI_ATTN_WPE)
 #endif
@@ -167,6 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
         }
     };
 
+#if MVI_ATTN_PIPE
     const int n_tiles = (Sk + kFK - 1) / kFK;
     // prologue: K_0, V_0 -> buffers 0; K_1 -> buffer 1; scores of tile 0
     load_k(0); load_v(0);
@@ -241,7 +258,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
     };
     for (int t = 0; t + 1 < n_tiles; ++t) tile(t, std::true_type{});
     tile(n_tiles - 1, std::false_type{});
-    l += __shfl_xor(l, 32);
+#else
+    const int n_tiles = (Sk + kFK - 1) / kFK;
+    // Variant without the intra-wave software pipeline (MVI_ATTN_PIPE=0): QK^T of tile t is computed at the start of
+    // tile t into the ONE score accumulator; overlap of MFMA and VALU work comes from the other waves of the SIMD.
+    load_k(0); load_v(0);
+    store_k(0); store_v(0);
+    __syncthreads();
+    f32x16 st[2];
+#if MVI_ATTN_MFMA_ROWSUM
+    // Row sums on the matrix pipe: ones[32 x 16] . P^T[16 x 32] adds the 16 (rounded) probabilities of a k-step for every
+    // query column into all 32 rows of an accumulator — 4 extra MFMAs per tile instead of 33 v_add_f32 on the issue
+    // port that bounds the kernel. l is then the sum of exactly the values P.V uses.
+    f32x16 lacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+    const frag ones = as_frag<frag>(u32x4{kOnes2<T>(), kOnes2<T>(), kOnes2<T>(), kOnes2<T>()});
+#endif
+    for (int t = 0; t < n_tiles; ++t) {
+        const bool has_next = t + 1 < n_tiles;
+        const int k0 = t * kFK;
+        if (has_next) { load_k((t + 1) * kFK); load_v((t + 1) * kFK); }
+        qk(s_k[t & 1], st);
+        if (!has_next && k0 + kFK > Sk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) st[kb][r] = -INFINITY;
+        }
+        float rmax = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) rmax = fmaxf(rmax, fmaxf(st[0][r], st[1][r]));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32)) * scale_log2e;
+        const bool grow = rmax > m + kRescaleThreshold;
+        if (__ballot(grow) != 0ull) {
+            const float m_new = grow ? rmax : m;
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#if MVI_ATTN_MFMA_ROWSUM
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
+#endif
+            m = m_new;
+        }
+        const uint16_t* sv = s_vt[t & 1];
+        float rsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 pr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][8 * s2 + 2 * i], scale_log2e, -m));
+                    float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][8 * s2 + 2 * i + 1], scale_log2e, -m));
+#if !MVI_ATTN_MFMA_ROWSUM
+                    rsum += p0 + p1;
+#endif
+                    pr[i] = M::pack2(p0, p1);
+                }
+                const frag pf = as_frag<frag>(pr);
+#if MVI_ATTN_MFMA_ROWSUM
+                lacc = M::mfma(ones, pf, lacc);
+#endif
+                const int koff = 32 * kb + 16 * s2 + 4 * hh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const uint16_t* row = &sv[(32 * db + qcol) * kVStride + koff];
+                    u32x2 a0 = *reinterpret_cast<const u32x2*>(row);
+                    u32x2 a1 = *reinterpret_cast<const u32x2*>(row + 8);
+                    u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+                    o[db] = M::mfma(as_frag<frag>(av), pf, o[db]);
+                }
+            }
+        l += rsum;
+        if (has_next) {
+            store_k((t + 1) & 1);                                // buffers (t+1)&1 were last read in tile t-1
+            store_v((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+#if MVI_ATTN_MFMA_ROWSUM
+    l = lacc[0];            // every row of the accumulator holds the column's sum (lane halves hold the same D element rows)
+#endif
+#endif
+#if MVI_ATTN_PIPE || !MVI_ATTN_MFMA_ROWSUM
+    l += __shfl_xor(l, 32);                                  // the two lane halves hold disjoint keys of every k-step
+#endif
     if (qrow < Sq) {
         const float inv = 1.0f / l;
         T* op = out + ((b * Sq + qrow) * o_rs + (int64_t)h * kFD);
