@@ -26,12 +26,40 @@ template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
 template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+// four consecutive elements (8-byte aligned for the 2-byte types, 16-byte for fp32) as floats
+__device__ __forceinline__ void ld4(const float* p, float* o) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void ld4(const __hip_bfloat16* p, float* o) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ void ld4(const __half* p, float* o) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    const __half2* h = reinterpret_cast<const __half2*>(&v);
+    const float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+__device__ __forceinline__ void st4(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ void st4(__hip_bfloat16* p, const float* o) {
+    const __hip_bfloat16 a = __float2bfloat16(o[0]), b = __float2bfloat16(o[1]), c = __float2bfloat16(o[2]), d = __float2bfloat16(o[3]);
+    uint2 v;
+    v.x = (uint32_t)*reinterpret_cast<const uint16_t*>(&a) | ((uint32_t)*reinterpret_cast<const uint16_t*>(&b) << 16);
+    v.y = (uint32_t)*reinterpret_cast<const uint16_t*>(&c) | ((uint32_t)*reinterpret_cast<const uint16_t*>(&d) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void st4(__half* p, const float* o) {
+    uint2 v;
+    __half2* h = reinterpret_cast<__half2*>(&v);
+    h[0] = __floats2half2_rn(o[0], o[1]);
+    h[1] = __floats2half2_rn(o[2], o[3]);
+    *reinterpret_cast<uint2*>(p) = v;
+}
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
 
-constexpr int kRtKeys = 32;      // keys per LDS tile
+constexpr int kRtKeysMax = 32;   // keys per LDS tile (16 for short sequences: the temporal attention has Sk = T = 14)
 constexpr int kRtWaves = 4;      // waves (= independent problems) per block
 
 // DV = D / 16 : number of 4-channel vectors a lane owns (D in {16, 32, 64, 128})
@@ -45,14 +73,14 @@ struct RtLayout {
     int64_t q_outer, q_inner, q_row, k_outer, k_inner, k_row, o_outer, o_inner, o_row;
 };
 
-template <typename T, int DV>
+template <typename T, int DV, int kRtKeys>
 __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                      const T* __restrict__ v, T* __restrict__ out,
                                                                      int B, int H, int Sq, int Sk, float scale,
                                                                      int64_t n_problems, int q_tiles, RtLayout L) {
     constexpr int D = DV * 16;
-    __shared__ float s_k[kRtWaves][kRtKeys][D];
-    __shared__ float s_v[kRtWaves][kRtKeys][D];
+    __shared__ __attribute__((aligned(16))) float s_k[kRtWaves][kRtKeys][D];
+    __shared__ __attribute__((aligned(16))) float s_v[kRtWaves][kRtKeys][D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t prob = (int64_t)blockIdx.x * kRtWaves + wave;        // (b, h, q_tile)
     if (prob >= n_problems) return;                                     // whole wave exits together
@@ -71,10 +99,15 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
 #pragma unroll
     for (int i = 0; i < DV; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            acc[i][c] = 0.f;
-            qr[i][c] = row_ok ? to_f<T>(q[qbase + row * L.q_row + 16 * i + 4 * p + c]) * scale : 0.f;
+        for (int c = 0; c < 4; ++c) { acc[i][c] = 0.f; qr[i][c] = 0.f; }
+    if (row_ok) {
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            ld4(q + (qbase + row * L.q_row + 16 * i + 4 * p), qr[i]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qr[i][c] *= scale;
         }
+    }
     float m = -INFINITY, l = 0.f;
 
     for (int k0 = 0; k0 < Sk; k0 += kRtKeys) {
@@ -84,11 +117,11 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
             int kr = e / (D / 4), dv = e % (D / 4);
             const T* kp = k + (kbase + (int64_t)(k0 + kr) * L.k_row + 4 * dv);
             const T* vp = v + (kbase + (int64_t)(k0 + kr) * L.k_row + 4 * dv);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s_k[wave][kr][4 * dv + c] = to_f<T>(kp[c]);
-                s_v[wave][kr][4 * dv + c] = to_f<T>(vp[c]);
-            }
+            float kf[4], vf[4];
+            ld4(kp, kf);
+            ld4(vp, vf);
+            *reinterpret_cast<float4*>(&s_k[wave][kr][4 * dv]) = make_float4(kf[0], kf[1], kf[2], kf[3]);
+            *reinterpret_cast<float4*>(&s_v[wave][kr][4 * dv]) = make_float4(vf[0], vf[1], vf[2], vf[3]);
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): this wave's LDS writes have landed
@@ -136,10 +169,12 @@ __global__ __launch_bounds__(64 * kRtWaves) void attn_rowtile_kernel(const T* __
     if (row_ok) {
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int i = 0; i < DV; ++i)
+        for (int i = 0; i < DV; ++i) {
+            float o4[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                out[obase + row * L.o_row + 16 * i + 4 * p + c] = from_f<T>(acc[i][c] * inv);
+            for (int c = 0; c < 4; ++c) o4[c] = acc[i][c] * inv;
+            st4(out + (obase + row * L.o_row + 16 * i + 4 * p), o4);
+        }
     }
 }
 
@@ -176,9 +211,13 @@ int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, 
     const int64_t blocks = (n + kRtWaves - 1) / kRtWaves;
     if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     dim3 grid((unsigned)blocks), blk(64 * kRtWaves);
-#define MVI_RT(DVV)                                                                                              \
-    hipLaunchKernelGGL((attn_rowtile_kernel<T, DVV>), grid, blk, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, \
-                       B, H, Sq, Sk, scale, n, q_tiles, L)
+#define MVI_RT(DVV)                                                                                                     \
+    if (Sk <= 16)                                                                                                       \
+        hipLaunchKernelGGL((attn_rowtile_kernel<T, DVV, 16>), grid, blk, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, \
+                           B, H, Sq, Sk, scale, n, q_tiles, L);                                                         \
+    else                                                                                                                \
+        hipLaunchKernelGGL((attn_rowtile_kernel<T, DVV, kRtKeysMax>), grid, blk, 0, st, (const T*)q, (const T*)k, (const T*)v, \
+                           (T*)out, B, H, Sq, Sk, scale, n, q_tiles, L)
     switch (D) {
         case 16: MVI_RT(1); break;
         case 32: MVI_RT(2); break;
