@@ -3,6 +3,8 @@ steps/s"). One step = one CFG-doubled (batch 28) evaluation of ControlNet + Cont
 through Denoiser.forward, bf16 autocast, synthetic tensors of the shapes in SURVEY.md §8d, seeded
 N(0, 0.02) weights (no pretrained weights exist offline). Configuration = the reference YAML
 svd_inpaint1/configs/test/svd_f_est_ctrl_simp1.yaml:19-61."""
+import os
+import sys
 import time
 
 import torch
@@ -51,6 +53,40 @@ def inputs(device, T=14, h=72, w=128, seed=0, cfg_doubled=True):
     return r(B, 4, h, w), cond, torch.zeros(B // T if not cfg_doubled else B // (2 * T), T, device=device)
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def enable_gemm_tuning(tune_ms=int(os.environ.get("MVI_SVD_GEMM_TUNING_MS", "0"))):
+    """PyTorch-ROCm's TunableOp for the library GEMMs behind the Linear layers (hipBLASLt / rocBLAS, ~40 shapes per step):
+    the GEMM counterpart of MIOpen's solver search for the convolutions. Tuning inside the benchmark proved unreliable with
+    budgets that fit a warm-up step (20 ms per shape: from 206 to 285 ms per step depending on the run, against 212
+    untuned), so the solutions are selected OFFLINE with a generous budget (tools/tune_svd_gemms.sh on the MI355X box ->
+    multiview_inpaint_amd/svd/tunableop_gfx950.csv: op signature -> library solution index, validated against the
+    PyTorch / hipBLASLt / rocBLAS versions recorded in its header) and only LOOKED UP here: no tuning at run time.
+    MVI_SVD_GEMM_TUNING_MS > 0 re-tunes in place instead (what the tuning script does); MVI_SVD_TUNED_GEMMS=0 runs the
+    library defaults."""
+    if os.environ.get("MVI_SVD_TUNED_GEMMS", "1") == "0":
+        return False
+    try:
+        import torch.cuda.tunable as tn
+        if tune_ms > 0:
+            tn.enable(True)
+            tn.tuning_enable(True)
+            tn.set_max_tuning_duration(tune_ms)
+            tn.set_max_tuning_iterations(int(os.environ.get("MVI_SVD_GEMM_TUNING_ITERS", "30")))
+            tn.set_filename(os.environ.get("MVI_SVD_GEMM_TUNING_OUT", os.path.join(os.environ.get("TMPDIR", "/tmp"), "mvi_tunableop.csv")))
+            return True
+        if not os.path.exists(TUNED_GEMMS):
+            return False
+        tn.enable(True)
+        tn.tuning_enable(False)                              # look-up only
+        tn.set_filename(TUNED_GEMMS)
+        return True
+    except Exception as e:                                  # an older PyTorch: run untuned
+        print(f"[mvi] TunableOp unavailable ({e}); GEMMs run with the library's default solutions", file=sys.stderr)
+        return False
+
+
 def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, weights="bf16"):
     """weights="bf16": parameters stored in bf16, no autocast (nothing is re-cast per step; GroupNorm
     statistics, softmax and LayerNorm still accumulate in fp32 inside their kernels).
@@ -65,6 +101,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     torch.backends.cudnn.benchmark = not _Encoder.channels_last
     if _Encoder.channels_last:
         warmup = max(warmup, 2)     # MIOpen still builds kernels during the second call of a shape on a cold kernel cache
+    tuned = enable_gemm_tuning()
     eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)
     x, cond, ind = inputs(device, T, h, w)
     if weights == "bf16":
@@ -90,7 +127,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     prof = hip_ops.profile_summary()
     hip_ops.PROFILE = None
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
-               controlnet=with_control,
+               controlnet=with_control, gemm_tuning=bool(tuned),
                dtype=("bf16 weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights == "bf16"
                       else "bf16 autocast over fp32 weights, fp32 GroupNorm statistics / softmax"),
                finite=bool(torch.isfinite(out).all()))
