@@ -136,6 +136,12 @@ int mvi_groupnorm_silu_nhwc(const void* x, void* y, const float* weight, const f
                             void* stream);
 int mvi_groupnorm_nhwc_supported(int32_t C, int32_t groups, int32_t dtype);
 
+/* out = silu(h + bias[c]) for h [N, C, spatial]: convolution bias + SiLU of the ControlNet hint stem
+ * (svd_inpaint1/models/csvd.py:234-250: eight convolutions with SiLU between, at up to 576x1024) in one pass instead of
+ * the library's broadcast bias add followed by a separate activation. out may alias h. */
+int mvi_bias_silu(const void* h, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial, int32_t dtype,
+                  void* stream);
+
 /* out[r, c] = h[r, c] + bias[c] (+ x[r, c]) on channels-last rows [rows, C] (mvi_bias_residual_add for that layout;
  * with bias NULL it is also "tokens + planes" of the transformer exit). */
 int mvi_bias_residual_add_nhwc(const void* h, const void* x, const float* bias, void* out, int64_t rows, int32_t C,

@@ -30,6 +30,8 @@ def bind(L):
     L.mvi_groupnorm_nhwc_supported.argtypes = [i32, i32, i32]
     L.mvi_bias_residual_add_nhwc.restype = C.c_int
     L.mvi_bias_residual_add_nhwc.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
+    L.mvi_bias_silu.restype = C.c_int
+    L.mvi_bias_silu.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp]
     L.mvi_geglu.restype = C.c_int
     L.mvi_geglu.argtypes = [vp, vp, i64, i32, i32, vp]
     L.mvi_bias_residual_add.restype = C.c_int

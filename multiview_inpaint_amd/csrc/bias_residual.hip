@@ -59,7 +59,7 @@ template <> struct BVec<__half> {
     __device__ static void st1(__half* p, float v) { *p = __float2half(v); }
 };
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool SILU = false>
 __global__ __launch_bounds__(256) void bias_residual_kernel(const T* __restrict__ h, const T* __restrict__ x,
                                                             const float* __restrict__ bias, T* __restrict__ out,
                                                             int64_t total, int C, int64_t S) {
@@ -78,19 +78,23 @@ __global__ __launch_bounds__(256) void bias_residual_kernel(const T* __restrict_
                 for (int k = 0; k < N; ++k) a[k] += r[k];
             }
 #pragma unroll
-            for (int k = 0; k < N; ++k) a[k] += b;
+            for (int k = 0; k < N; ++k) {
+                a[k] += b;
+                if (SILU) a[k] = a[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[k]));
+            }
             BVec<T>::store(out + e, a);
         }
     } else {
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
             float a = BVec<T>::ld1(h + e) + (bias ? bias[(e / S) % C] : 0.0f);
             if (x) a += BVec<T>::ld1(x + e);
+            if (SILU) a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-a));
             BVec<T>::st1(out + e, a);
         }
     }
 }
 
-template <typename T>
+template <typename T, bool SILU = false>
 static int bias_residual_launch(const void* h, const void* x, const float* bias, void* out, int64_t total, int C, int64_t S,
                                 hipStream_t st) {
     constexpr int N = BVec<T>::N;
@@ -100,9 +104,9 @@ static int bias_residual_launch(const void* h, const void* x, const float* bias,
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
     if (vec)
-        hipLaunchKernelGGL((bias_residual_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S);
+        hipLaunchKernelGGL((bias_residual_kernel<T, true, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S);
     else
-        hipLaunchKernelGGL((bias_residual_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S);
+        hipLaunchKernelGGL((bias_residual_kernel<T, false, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 }  // namespace mvi
@@ -122,4 +126,21 @@ extern "C" int mvi_bias_residual_add(const void* h, const void* x, const float* 
         default: return mvi::unet_fail(MVI_EINVAL, "bias_residual_add: unknown dtype");
     }
     return rc ? mvi::unet_fail(MVI_EHIP, "bias_residual_add: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_bias_silu(const void* h, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial, int32_t dtype,
+                             void* stream) {
+    if (N < 0 || C <= 0 || spatial < 0) return mvi::unet_fail(MVI_EINVAL, "bias_silu: bad shape");
+    const int64_t total = N * C * spatial;
+    if (total == 0) return MVI_OK;
+    if (!h || !out) return mvi::unet_fail(MVI_EINVAL, "bias_silu: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::bias_residual_launch<float, true>(h, nullptr, bias, out, total, C, spatial, st); break;
+        case MVI_DT_BF16: rc = mvi::bias_residual_launch<__hip_bfloat16, true>(h, nullptr, bias, out, total, C, spatial, st); break;
+        case MVI_DT_F16: rc = mvi::bias_residual_launch<__half, true>(h, nullptr, bias, out, total, C, spatial, st); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "bias_silu: unknown dtype");
+    }
+    return rc ? mvi::unet_fail(MVI_EHIP, "bias_silu: kernel launch failed") : MVI_OK;
 }

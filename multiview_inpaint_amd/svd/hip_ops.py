@@ -324,6 +324,21 @@ def bias_residual_add(h, bias, x):
     return out
 
 
+def bias_silu(h, bias):
+    """silu(h + bias[c]) for h [N, C, *spatial], in place on h's (contiguous) memory."""
+    L = _lib.lib()
+    if h.dtype not in _DT:
+        raise TypeError(f"bias_silu: unsupported dtype {h.dtype}")
+    hc = h if h.is_contiguous() else h.contiguous()
+    N, Cc = hc.shape[0], hc.shape[1]
+    S = hc.numel() // max(N * Cc, 1)
+    b = None if bias is None else _f32(bias)
+    with torch.cuda.device(h.device), _Timed("bias_silu", 2.0 * hc.numel() * hc.element_size(), h.device):
+        _check(L.mvi_bias_silu(hc.data_ptr(), None if b is None else b.data_ptr(), hc.data_ptr(), N, Cc, S, _DT[h.dtype],
+                               _stream(h.device)), "bias_silu")
+    return hc
+
+
 def layernorm_supported(C_, dtype):
     return dtype in _DT and bool(_lib.lib().mvi_layernorm_supported(int(C_), _DT[dtype]))
 

@@ -171,6 +171,16 @@ def bias_residual_add(h, bias=None, x=None):
     return out
 
 
+def bias_silu(h, bias):
+    """silu(h + bias[c]) for a convolution output h [N, C, *spatial] whose bias was withheld (one pass; may reuse h)."""
+    if h.is_cuda and not _needs_autograd(h, bias) and h.is_contiguous():
+        from . import hip_ops
+        return hip_ops.bias_silu(h, bias)
+    if bias is not None:
+        h = h + bias.to(h.dtype).reshape(1, -1, *([1] * (h.ndim - 2)))
+    return F.silu(h)
+
+
 def add_layer_norm(x, norm, h=None, row=None, ret_pre=False):
     """Residual add(s) fused with the next LayerNorm: s_pre = x + h, s = s_pre + row, y = norm(s) for token-major
     x [B, S, C]; `row` [G, 1, C] (G divides B*S) is broadcast over equal runs of rows — the single-token

@@ -470,3 +470,17 @@ def test_temporal_conv_and_1x1_conv_on_channels_last_rows():
         c1 = nn.Conv2d(C, 40, 1).cuda()
         assert rel(layers.conv_no_bias(c1, _cl(x), c1.bias), c1(x)) < 1e-5
         assert rel(layers.conv_no_bias(c1, _cl(x)), c1(x) - c1.bias.view(1, -1, 1, 1)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40), (3, 7, 5, 9), (1, 96, 18, 32)])
+def test_bias_silu(ops, dtype, tol, shape):
+    """Convolution bias + SiLU of the ControlNet hint stem in one pass."""
+    g = torch.Generator().manual_seed(sum(shape))
+    h = (torch.randn(*shape, generator=g) * 2).to(dtype)
+    b = torch.randn(shape[1], generator=g)
+    want = F.silu(h.double() + b.double().view(1, -1, 1, 1))
+    got = ops.bias_silu(h.cuda().clone(), b.cuda())
+    assert rel(got, want) < tol
+    got = ops.bias_silu(h.cuda().clone(), None)
+    assert rel(got, F.silu(h.double())) < tol
