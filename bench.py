@@ -101,6 +101,10 @@ def main():
                     help="hot-path halves to run at N=1 (the SVD denoise loop is replicas-only across GPUs)")
     ap.add_argument("--svd-steps", type=int, default=2)
     args = ap.parse_args()
+    if args.path in ("both", "svd"):
+        # library tables (MIOpen find-db) must be in place before the process first touches MIOpen
+        from multiview_inpaint_amd.svd import bench_svd as _bs
+        _bs.use_shipped_miopen_db()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

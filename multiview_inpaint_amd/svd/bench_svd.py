@@ -53,6 +53,27 @@ def inputs(device, T=14, h=72, w=128, seed=0, cfg_doubled=True):
     return r(B, 4, h, w), cond, torch.zeros(B // T if not cfg_doubled else B // (2 * T), T, device=device)
 
 
+MIOPEN_USERDB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_userdb")
+
+
+def use_shipped_miopen_db():
+    """Points MIOpen at a private copy of the find-db recorded on the MI355X box for this step's convolution shapes
+    (multiview_inpaint_amd/svd/miopen_userdb/*.ufdb.txt / *.udb.txt: problem -> fastest solver, written by MIOpen itself
+    during a run with an empty MIOPEN_USER_DB_PATH). With it the solver search of the warm-up step is a look-up (bench
+    start-up 60 -> 44 s) and every run uses the same convolution kernels instead of whatever a noisy search picked
+    (observed 205 ... 225 ms per step across runs). Must be called before the process touches MIOpen; does nothing when
+    MIOPEN_USER_DB_PATH is already set or MVI_SVD_MIOPEN_DB=0. The copy keeps MIOpen's own updates out of the repository."""
+    if os.environ.get("MVI_SVD_MIOPEN_DB", "1") == "0" or "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(MIOPEN_USERDB):
+        return os.environ.get("MIOPEN_USER_DB_PATH")
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mvi_miopen_")
+    for f in os.listdir(MIOPEN_USERDB):
+        shutil.copy(os.path.join(MIOPEN_USERDB, f), os.path.join(d, f))
+    os.environ["MIOPEN_USER_DB_PATH"] = d
+    return d
+
+
 TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
 
 
@@ -101,6 +122,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     torch.backends.cudnn.benchmark = not _Encoder.channels_last
     if _Encoder.channels_last:
         warmup = max(warmup, 2)     # MIOpen still builds kernels during the second call of a shape on a cold kernel cache
+    use_shipped_miopen_db()
     tuned = enable_gemm_tuning()
     eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)
     x, cond, ind = inputs(device, T, h, w)
