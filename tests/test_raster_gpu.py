@@ -116,6 +116,15 @@ def test_forward_parity_small(R, ro, seed, deg, pose, N, W, H):
     _check_forward(R, ro, cam, sc, bg)
 
 
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 127, 129, 257, 4097])
+def test_forward_parity_block_boundaries_and_large_footprints(R, ro, N):
+    """Gaussian counts around the kernels' block sizes (64-thread preprocess blocks, 256-entry emission blocks,
+    2048 / 4096-pair sort tiles) with LARGE footprints — every Gaussian covers many tiles, one Gaussian's pairs span
+    emission rounds and sort tiles: binning integers bit-exact, image within tolerance."""
+    cam, sc, bg = small_scene(100 + N, N=N, W=176, H=112, deg=1, pose=True, log_scale=np.log(0.6))
+    _check_forward(R, ro, cam, sc, bg)
+
+
 @pytest.mark.parametrize("seed,deg,mode", [(0, 3, "sh"), (4, 1, "sh"), (5, 2, "precomp"), (6, 0, "sh")])
 def test_backward_parity_small(R, ro, seed, deg, mode):
     cam, sc, bg = small_scene(seed, N=1500, W=160, H=112, deg=deg, log_scale=np.log(0.05))
