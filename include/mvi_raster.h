@@ -143,12 +143,13 @@ typedef struct mvi_raster_views {
     const float* rgbd;            /* [P,4] r, g, b, depth */
     const uint32_t* tiles_touched;/* [P] */
     const uint8_t* clamped;       /* [P] bit c = colour channel c clamped at 0 */
-    const uint32_t* tile_ids_sorted; /* [D] high word of the sort key; the full key of pair i is
-                                      * tile_ids_sorted[i] << 32 | bits(depths[point_list[i]]) */
+    const void* tile_ids_sorted;  /* [D] high word of the sort key, tile_id_bytes (2 or 4) per entry; the full key of
+                                   * pair i is tile_ids_sorted[i] << 32 | bits(depths[point_list[i]]) */
     const uint32_t* point_list;   /* [D] Gaussian index per sorted pair */
     const uint32_t* ranges;       /* [tiles,2] */
     const float* final_T;         /* [H,W] */
     const uint32_t* n_contrib;    /* [H,W] */
+    int32_t tile_id_bytes;        /* 2 (uint16) while the image has at most 65536 tiles, else 4 (uint32) */
 } mvi_raster_views;
 int mvi_raster_get_views(int32_t P, int64_t num_rendered, int32_t image_width, int32_t image_height,
                          const void* geom, const void* binning, const void* image,

@@ -25,7 +25,7 @@ class RasterViews(C.Structure):
     """struct mvi_raster_views"""
     _fields_ = [(n, C.c_void_p) for n in (
         "depths", "means2D", "cov3D_a", "cov3D_b", "conic_opacity", "rgbd", "tiles_touched", "clamped",
-        "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")]
+        "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")] + [("tile_id_bytes", C.c_int32)]
 
 
 class AdamGroup(C.Structure):

@@ -323,6 +323,7 @@ int mvi_raster_get_views(int32_t P, int64_t D, int32_t W, int32_t H, const void*
         mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, W, H);
         int fin = b.passes & 1;
         out->tile_ids_sorted = b.keys[fin]; out->point_list = b.vals[fin];
+        out->tile_id_bytes = b.key_bytes;
     }
     if (image) {
         mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), W, H);

@@ -64,9 +64,10 @@ __global__ __launch_bounds__(kBlock) void perm_block_sums_kernel(int P, const ui
 // slots are written coalesced (slot j finds its Gaussian by binary search over the in-block scan; measured against a
 // mark + max-scan ownership pass per 256 slots with reciprocal-multiply coordinates: 81 vs 88 us for the stage — the three
 // barriers per round cost more than the eight dependent LDS probes, which hide behind the stores)
+template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g, const uint32_t* __restrict__ order,
                                                             const uint32_t* __restrict__ block_offsets,
-                                                            uint32_t* __restrict__ tile_keys,
+                                                            KeyT* __restrict__ tile_keys,
                                                             uint32_t* __restrict__ vals) {
     __shared__ uint32_t s_off[kBlock];
     __shared__ uint32_t s_wave[4];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
         uint32_t k = j - s_off[lo];
         int w = s_w[lo];
         int y = s_y0[lo] + (int)(k / (uint32_t)w), x = s_x0[lo] + (int)(k % (uint32_t)w);
-        tile_keys[base + j] = (uint32_t)(y * f.gx + x);
+        tile_keys[base + j] = (KeyT)(y * f.gx + x);
         vals[base + j] = s_gi[lo];
     }
 }
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
 // Count: one 1024-thread block = kCountTiles (4) consecutive sort tiles, one per 256-thread group. Row d of block_hist
 // then receives 4 consecutive counts as one 16-byte store instead of four 4-byte words at a stride of nblk words
 // (measured before: 23 MB written per launch for 3 MB of counts).
-template <int kW>
-__global__ __launch_bounds__(1024) void radix_count_kernel(const uint32_t* __restrict__ keys, int64_t D, int shift,
+template <int kW, typename KeyT>
+__global__ __launch_bounds__(1024) void radix_count_kernel(const KeyT* __restrict__ keys, int64_t D, int shift,
                                                            uint32_t mask, uint32_t* __restrict__ block_hist,
                                                            int nblk) {
     constexpr int kItems = 2 * kW;                       // per thread of a 256-thread group
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(1024) void radix_count_kernel(const uint32_t* __res
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
         const int64_t idx = base + it * 256 + t;
-        key[it] = idx < D ? keys[idx] : 0xFFFFFFFFu;
+        key[it] = idx < D ? (uint32_t)keys[idx] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int it = 0; it < kItems; ++it)
@@ -184,9 +185,9 @@ __global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restr
 // digit order in LDS, then written out by consecutive lanes: every digit's run leaves as one
 // contiguous, coalesced segment instead of 64 scattered dwords per wave-instruction.
 // The per-digit bookkeeping (256 digits) is done by the first 256 threads of the block.
-template <int kW>
+template <int kW, typename KeyT>
 __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask, const uint32_t* __restrict__ block_hist,
     int nblk, const uint32_t* __restrict__ digit_tot) {
     constexpr int kNT = 64 * kW, kTileW = 512 * kW;
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
     __shared__ uint32_t s_digit_base[256];     // global position of this block's first pair of digit d
     __shared__ uint32_t s_local_start[256];    // position of digit d's run inside the block-sorted tile
     __shared__ uint32_t s_w4[4];
-    __shared__ uint32_t s_key[kTileW], s_val[kTileW];
+    __shared__ KeyT s_key[kTileW];
+    __shared__ uint32_t s_val[kTileW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool digit_thread = tid < 256;
 #pragma unroll
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
     for (int it = 0; it < kSortItems; ++it) {
         int64_t idx = base + it * 64 + lane;
         bool valid = idx < D;
-        key[it] = valid ? keys_in[idx] : 0u;
+        key[it] = valid ? (uint32_t)keys_in[idx] : 0u;
         val[it] = valid ? vals_in[idx] : 0u;
         uint32_t d = (key[it] >> shift) & mask;
         dig[it] = valid ? d : 0xFFFFFFFFu;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
         if (dig[it] != 0xFFFFFFFFu) {
             uint32_t d = dig[it];
             uint32_t lp = s_local_start[d] + s_wave_hist[wave][d] + rank[it];
-            s_key[lp] = key[it];
+            s_key[lp] = (KeyT)key[it];
             s_val[lp] = val[it];
         }
     }
@@ -288,16 +290,18 @@ __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
     for (int it = 0; it < kSortItems; ++it) {
         int lp = it * kNT + tid;
         if (lp < count) {
-            uint32_t k = s_key[lp];
+            const KeyT kk = s_key[lp];
+            uint32_t k = (uint32_t)kk;
             uint32_t d = (k >> shift) & mask;
             uint32_t dst = s_digit_base[d] + ((uint32_t)lp - s_local_start[d]);
-            keys_out[dst] = k;
+            keys_out[dst] = kk;
             vals_out[dst] = s_val[lp];
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t D,
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const KeyT* __restrict__ tile_keys, int64_t D,
                                                              uint32_t* __restrict__ ranges) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= D) return;
@@ -337,13 +341,13 @@ int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
 
 // one stable pass over n pairs in tiles of 512 * kW; nsort = sort_blocks(n, kW); returns the index (0/1) of the buffer
 // holding the result
-template <int kW>
-static int radix_pass(uint32_t* const keys[2], uint32_t* const vals[2], int cur, int64_t n, int shift, int bits,
+template <int kW, typename KeyT>
+static int radix_pass(KeyT* const keys[2], uint32_t* const vals[2], int cur, int64_t n, int shift, int bits,
                       uint32_t* hist, uint32_t* tot, int nsort, hipStream_t st) {
     uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL((radix_count_kernel<kW>), dim3(nsort / kCountTiles), dim3(1024), 0, st, keys[cur], n, shift, mask, hist, nsort);
+    hipLaunchKernelGGL((radix_count_kernel<kW, KeyT>), dim3(nsort / kCountTiles), dim3(1024), 0, st, keys[cur], n, shift, mask, hist, nsort);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, hist, nsort, tot);
-    hipLaunchKernelGGL((radix_scatter_kernel<kW>), dim3(nsort), dim3(64 * kW), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
+    hipLaunchKernelGGL((radix_scatter_kernel<kW, KeyT>), dim3(nsort), dim3(64 * kW), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
                        vals[cur ^ 1], n, shift, mask, hist, nsort, tot);
     return cur ^ 1;
 }
@@ -359,7 +363,7 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st) {
         // the keys (depth bits, 0xFFFFFFFF for culled) and indices were written by the preprocess kernel
         int cur = 0;
         for (int p = 0; p < 4; ++p)
-            cur = radix_pass<kSortWavesP>(g.dkeys, g.dvals, cur, f.P, 8 * p, 8, g.dhist, g.dtot, g.nsortP, st);
+            cur = radix_pass<kSortWavesP, uint32_t>(g.dkeys, g.dvals, cur, f.P, 8 * p, 8, g.dhist, g.dtot, g.nsortP, st);
     }
     StageTimer tm(kStDup, st);
     hipLaunchKernelGGL(perm_block_sums_kernel, dim3(nblk), dim3(kBlock), 0, st, f.P, g.dvals[0], g.tiles_touched,
@@ -370,16 +374,16 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st) {
 
 // Emission in depth order + level 2. After this call the sorted pairs are in b.keys[b.passes & 1]
 // (tile ids), b.vals[b.passes & 1].
-int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
-                   int64_t D, hipStream_t st) {
-    size_t tiles = (size_t)f.gx * f.gy;
-    if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
-    if (D <= 0 || f.P <= 0) return 0;
+// Emission in depth order + level 2 + tile ranges for one tile-id type. After this call the sorted pairs are in
+// b.keys[b.passes & 1] (tile ids), b.vals[b.passes & 1].
+template <typename KeyT>
+static int binning_typed(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D, hipStream_t st) {
+    KeyT* const keys[2] = {(KeyT*)b.keys[0], (KeyT*)b.keys[1]};
     const int nblk = (f.P + kBlock - 1) / kBlock;
     {
         StageTimer tm(kStDup, st);
-        hipLaunchKernelGGL(emit_pairs_kernel, dim3(nblk), dim3(kBlock), 0, st, f, g, g.dvals[0], g.perm_offsets,
-                           b.keys[0], b.vals[0]);
+        hipLaunchKernelGGL((emit_pairs_kernel<KeyT>), dim3(nblk), dim3(kBlock), 0, st, f, g, g.dvals[0], g.perm_offsets,
+                           keys[0], b.vals[0]);
     }
     int cur = 0;
     {   // level 2: stable partition by tile id
@@ -390,14 +394,24 @@ int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView
         for (int p = 0; p < b.passes; ++p) {
             const int left = b.passes - p;
             const int bits = (b.key_bits - shift + left - 1) / left;
-            cur = radix_pass<kSortWavesD>(b.keys, b.vals, cur, D, shift, bits, b.block_hist, b.digit_tot, b.nsort, st);
+            cur = radix_pass<kSortWavesD, KeyT>(keys, b.vals, cur, D, shift, bits, b.block_hist, b.digit_tot, b.nsort, st);
             shift += bits;
         }
     }
     int nrb = (int)((D + kBlock - 1) / kBlock);
     StageTimer tm(kStRanges, st);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(nrb), dim3(kBlock), 0, st, b.keys[cur], D, im.ranges);
+    hipLaunchKernelGGL((tile_ranges_kernel<KeyT>), dim3(nrb), dim3(kBlock), 0, st, keys[cur], D, im.ranges);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+// Tile ids travel as 16-bit words whenever the image has at most 65536 tiles (any image up to 4096 x 4096): a pair is then
+// 6 bytes instead of 8 in every pass of emission, partition and range finding (36 instead of 52 bytes per pair in all).
+int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
+                   int64_t D, hipStream_t st) {
+    size_t tiles = (size_t)f.gx * f.gy;
+    if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
+    if (D <= 0 || f.P <= 0) return 0;
+    return b.key_bytes == 2 ? binning_typed<uint16_t>(f, g, b, im, D, st) : binning_typed<uint32_t>(f, g, b, im, D, st);
 }
 
 }  // namespace mvi

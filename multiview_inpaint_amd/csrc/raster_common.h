@@ -80,8 +80,9 @@ struct ImageView {
     size_t bytes;
 };
 struct BinningView {
-    uint32_t* keys[2];    // ping-pong [D] tile ids (the 64-bit (tile|depth) key is implicit: pairs are
+    void* keys[2];        // ping-pong [D] tile ids, key_bytes each (the 64-bit (tile|depth) key is implicit: pairs are
                           // emitted in depth order and stably partitioned by tile)
+    int key_bytes;        // 2 while the image has at most 65536 tiles, else 4
     uint32_t* vals[2];    // ping-pong [D] Gaussian indices
     uint32_t* block_hist; // [256 * nsort]  digit-major per-block digit counts / offsets
     uint32_t* digit_tot;  // [256]
@@ -149,8 +150,10 @@ inline BinningView carve_binning(void* base, int64_t D, int W, int H) {
     v.key_bits = tile_bits(W, H);
     v.passes = (v.key_bits + 7) / 8;
     auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
-    v.keys[0] = (uint32_t*)take(4 * n);
-    v.keys[1] = (uint32_t*)take(4 * n);
+    const unsigned tiles = (unsigned)(((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile));
+    v.key_bytes = tiles <= 65536u ? 2 : 4;
+    v.keys[0] = take((size_t)v.key_bytes * n);
+    v.keys[1] = take((size_t)v.key_bytes * n);
     v.vals[0] = (uint32_t*)take(4 * n);
     v.vals[1] = (uint32_t*)take(4 * n);
     v.block_hist = (uint32_t*)take(4 * 256 * (size_t)v.nsort);

@@ -75,10 +75,14 @@ class RasterState:
 
     def tensor(self, name, shape, dtype):
         """Copy of one intermediate array as a torch tensor (tests only)."""
-        addr = getattr(self.views(), name)
+        v = self.views()
+        addr = getattr(v, name)
         n = 1
         for s in shape:
             n *= s
+        if name == "tile_ids_sorted" and v.tile_id_bytes == 2 and torch.empty(0, dtype=dtype).element_size() == 4:
+            raw = self.tensor(name, tuple(shape) + (2,), torch.uint8).to(torch.int32)       # little-endian uint16 words
+            return (raw[..., 0] | (raw[..., 1] << 8)).to(dtype)
         out = torch.empty(shape, dtype=dtype, device=self.geom.device)
         if n:
             nbytes = n * out.element_size()
