@@ -61,9 +61,11 @@ __global__ __launch_bounds__(kBlock) void perm_block_sums_kernel(int P, const ui
 }
 
 // ---- pair emission in depth order: block = 256 consecutive entries of `order`; the block's output
-// slots are written coalesced (slot j finds its Gaussian by binary search over the in-block scan; measured against a
-// mark + max-scan ownership pass per 256 slots with reciprocal-multiply coordinates: 81 vs 88 us for the stage — the three
-// barriers per round cost more than the eight dependent LDS probes, which hide behind the stores)
+// slots are written coalesced (a thread finds the Gaussian of its first slot by binary search over the in-block scan and
+// walks from there; a mark + max-scan ownership pass per 256 slots measured slower: three barriers per round)
+constexpr int kEmitRun = 8;                    // consecutive slots a thread produces per chunk
+constexpr int kEmitChunk = kBlock * kEmitRun;  // slots staged in LDS per round
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g, const uint32_t* __restrict__ order,
                                                             const uint32_t* __restrict__ block_offsets,
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
     __shared__ uint32_t s_off[kBlock];
     __shared__ uint32_t s_wave[4];
     __shared__ int s_x0[kBlock], s_y0[kBlock], s_w[kBlock];
-    __shared__ uint32_t s_gi[kBlock];
+    __shared__ uint32_t s_gi[kBlock], s_t[kBlock];
+    __shared__ KeyT s_outk[kEmitChunk + kEmitChunk / kEmitRun];
+    __shared__ uint32_t s_outv[kEmitChunk + kEmitChunk / kEmitRun];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = blockIdx.x * kBlock + tid;
     uint32_t t = 0, gi = 0;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
         x1 = x0 + w;
         t = (uint32_t)(w * h);
     }
-    s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0; s_gi[tid] = gi;
+    s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0; s_gi[tid] = gi; s_t[tid] = t;
     uint32_t inc = t;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -100,17 +104,46 @@ __global__ __launch_bounds__(kBlock) void emit_pairs_kernel(Frame f, GeomView g,
     const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
     const uint32_t base = block_offsets[blockIdx.x];
-    for (uint32_t j = tid; j < total; j += kBlock) {
-        int lo = 0, hi = kBlock - 1;                      // largest entry with s_off <= j (it has t > 0)
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
+    // Chunks of kEmitChunk slots: every thread produces kEmitRun CONSECUTIVE slots — one binary search for the first,
+    // then it walks (x, y) through the rectangle and on to the following Gaussians — into a padded LDS image, and the
+    // block writes the chunk out with consecutive lanes on consecutive slots. One search + one division per kEmitRun
+    // slots instead of per slot.
+    for (uint32_t c0 = 0; c0 < total; c0 += kEmitChunk) {
+        const uint32_t j0 = c0 + (uint32_t)tid * kEmitRun;
+        if (j0 < total) {
+            int lo = 0, hi = kBlock - 1;                      // largest entry with s_off <= j0 (it has t > 0)
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= j0) lo = mid; else hi = mid - 1;
+            }
+            uint32_t k = j0 - s_off[lo];
+            int w = s_w[lo], x = (int)(k % (uint32_t)w), y = (int)(k / (uint32_t)w);
+            uint32_t left = s_t[lo] - k;                      // slots of this Gaussian from here on
+            int rowbase = (s_y0[lo] + y) * f.gx + s_x0[lo];
+            uint32_t gcur = s_gi[lo];
+            const int n = (int)min((uint32_t)kEmitRun, total - j0);
+            const int p0 = tid * (kEmitRun + 1);              // stride kEmitRun + 1: conflict-free writes
+            for (int i = 0; i < n; ++i) {
+                s_outk[p0 + i] = (KeyT)(rowbase + x);
+                s_outv[p0 + i] = gcur;
+                if (--left == 0) {                            // next Gaussian that covers any tile
+                    while (lo < kBlock - 1) { ++lo; if (s_t[lo]) break; }   // (past the last one only when no slot is left)
+                    w = s_w[lo]; x = 0; left = s_t[lo]; gcur = s_gi[lo];
+                    rowbase = s_y0[lo] * f.gx + s_x0[lo];
+                } else if (++x == w) {
+                    x = 0;
+                    rowbase += f.gx;
+                }
+            }
         }
-        uint32_t k = j - s_off[lo];
-        int w = s_w[lo];
-        int y = s_y0[lo] + (int)(k / (uint32_t)w), x = s_x0[lo] + (int)(k % (uint32_t)w);
-        tile_keys[base + j] = (KeyT)(y * f.gx + x);
-        vals[base + j] = s_gi[lo];
+        __syncthreads();
+        const uint32_t cn = min((uint32_t)kEmitChunk, total - c0);
+        for (uint32_t q = tid; q < cn; q += kBlock) {
+            const uint32_t pq = q + q / kEmitRun;             // padded position
+            tile_keys[base + c0 + q] = s_outk[pq];
+            vals[base + c0 + q] = s_outv[pq];
+        }
+        __syncthreads();
     }
 }
 
