@@ -161,6 +161,9 @@ int mvi_raster_get_views(int32_t P, int64_t num_rendered, int32_t image_width, i
  * ([MVI_RASTER_NSTAGES] each, caller-zeroed) and forgets them. Not thread-safe. */
 #define MVI_RASTER_NSTAGES 8
 int mvi_raster_timing_enable(int enable);
+/* The same for a subset of the stages (bit s of stage_mask = stage s). Every bracketed stage boundary costs ~10 us of idle
+ * GPU (the event record serialises the queue), so a throughput measurement brackets only the kernel it needs. */
+int mvi_raster_timing_enable_stages(uint32_t stage_mask);
 int mvi_raster_timing_read(float* ms_sum_host, int32_t* calls_host);
 const char* mvi_raster_stage_name(int stage);
 

@@ -92,6 +92,8 @@ def lib():
     L.mvi_raster_get_views.argtypes = [i32, i64, i32, i32, vp, vp, vp, C.POINTER(RasterViews)]
     L.mvi_raster_timing_enable.restype = C.c_int
     L.mvi_raster_timing_enable.argtypes = [C.c_int]
+    L.mvi_raster_timing_enable_stages.restype = C.c_int
+    L.mvi_raster_timing_enable_stages.argtypes = [C.c_uint32]
     L.mvi_raster_timing_read.restype = C.c_int
     L.mvi_raster_timing_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.mvi_raster_stage_name.restype = C.c_char_p

@@ -8,7 +8,8 @@
 #include "raster_common.h"
 
 namespace mvi {
-int launch_scan_block_sums(GeomView g, int P, hipStream_t st);
+int launch_scan_block_sums(GeomView g, int P, uint32_t* total_host_devptr, hipStream_t st);
+int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 }
 
@@ -18,7 +19,7 @@ static thread_local char g_err[512] = "";
 #include <vector>
 namespace {
 struct Rec { int stage; hipEvent_t a, b; };
-bool g_timing = false;
+uint32_t g_timing_mask = 0;        // bit s = stage s is bracketed by events
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open[MVI_RASTER_NSTAGES];
@@ -29,12 +30,12 @@ hipEvent_t get_event() {
 }  // namespace
 namespace mvi {
 void stage_begin(int stage, hipStream_t st) {
-    if (!g_timing) return;
+    if (!((g_timing_mask >> stage) & 1u)) return;
     g_open[stage] = get_event();
     (void)hipEventRecord(g_open[stage], st);
 }
 void stage_end(int stage, hipStream_t st) {
-    if (!g_timing) return;
+    if (!((g_timing_mask >> stage) & 1u)) return;
     hipEvent_t b = get_event();
     (void)hipEventRecord(b, st);
     g_recs.push_back({stage, g_open[stage], b});
@@ -72,7 +73,8 @@ extern "C" {
 
 const char* mvi_raster_last_error(void) { return g_err; }
 
-int mvi_raster_timing_enable(int enable) { g_timing = enable != 0; return MVI_OK; }
+int mvi_raster_timing_enable(int enable) { g_timing_mask = enable ? (1u << MVI_RASTER_NSTAGES) - 1u : 0u; return MVI_OK; }
+int mvi_raster_timing_enable_stages(uint32_t stage_mask) { g_timing_mask = stage_mask & ((1u << MVI_RASTER_NSTAGES) - 1u); return MVI_OK; }
 int mvi_raster_timing_read(float* ms_sum, int32_t* calls) {
     if (!ms_sum || !calls) return fail(MVI_EINVAL, "NULL timing outputs%s");
     for (auto& r : g_recs) {
@@ -155,23 +157,22 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
                                            cov3D_precomp, g, radii, st))
             return hip_fail("preprocess_forward", hipGetLastError());
     }
-    {
-        mvi::StageTimer tm(mvi::kStScan, st);
-        if (mvi::launch_scan_block_sums(g, P, st)) return hip_fail("scan_block_sums", hipGetLastError());
-    }
-    int nblk = (P + mvi::kPB - 1) / mvi::kPB;
-    // read num_rendered back through a pinned word + an event recorded right behind the copy, then
-    // queue binning level 1 (independent of num_rendered): the host wakes up as soon as the count is
-    // there and allocates / launches stage 2 while the device is still sorting
+    // num_rendered comes back through a pinned, device-mapped word that the totalling kernel writes itself + an event
+    // recorded right behind it; binning level 1 (independent of num_rendered) is queued before the host waits: the host
+    // wakes up as soon as the count is there and allocates / launches stage 2 while the device is still sorting
     static thread_local uint32_t* pinned = nullptr;
+    static thread_local uint32_t* pinned_dev = nullptr;
     static thread_local hipEvent_t ev = nullptr;
     hipError_t e;
     if (!pinned) {
-        if ((e = hipHostMalloc((void**)&pinned, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return hip_fail("hipHostMalloc", e);
+        if ((e = hipHostMalloc((void**)&pinned, sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return hip_fail("hipHostMalloc", e);
+        if ((e = hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0)) != hipSuccess) return hip_fail("hipHostGetDevicePointer", e);
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail("hipEventCreate", e);
     }
-    e = hipMemcpyAsync(pinned, g.block_offsets + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return hip_fail("copy num_rendered", e);
+    {
+        mvi::StageTimer tm(mvi::kStScan, st);
+        if (mvi::launch_scan_block_sums(g, P, pinned_dev, st)) return hip_fail("scan_block_sums", hipGetLastError());
+    }
     if ((e = hipEventRecord(ev, st)) != hipSuccess) return hip_fail("event record", e);
     if (mvi::launch_binning_level1(f, g, st)) return hip_fail("binning level 1", hipGetLastError());
     e = hipEventSynchronize(ev);
@@ -272,7 +273,7 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
     hipStream_t st = (hipStream_t)stream;
     float* grad_rows = dL_dconic_scratch;             // [P][16] accumulation rows
     hipError_t e;
-    if ((e = hipMemsetAsync(grad_rows, 0, sizeof(float) * mvi::kGradRow * (size_t)P, st)) != hipSuccess) return hip_fail("memset", e);
+    if (mvi::launch_zero_fill(grad_rows, sizeof(float) * mvi::kGradRow * (size_t)P, st)) return hip_fail("zero grad rows", hipGetLastError());
     {
         mvi::StageTimer tm(mvi::kStRenderBwd, st);
         if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, grad_rows, st))

@@ -14,6 +14,20 @@
 
 namespace mvi {
 
+// In-stream zero fill (16 B per lane). hipMemsetAsync goes through the runtime's blit path and leaves ~6 us of idle GPU
+// on either side of it (tools/experiments/raster_gaps.sh); an ordinary kernel does not. `bytes` is a multiple of 16.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int launch_zero_fill(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    const size_t n16 = (bytes + 15) / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n16);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
 // ---- exclusive scan of per-block sums (one 1024-thread block) ---------------------------------
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ sums,
                                                                uint32_t* __restrict__ offsets, int n) {
@@ -351,7 +365,8 @@ __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const KeyT* __restr
 // the depth-ordered sums): one block adds them up with no barrier inside the loop and leaves the total where the
 // scan used to put it (offsets[n]).
 __global__ __launch_bounds__(1024) void total_block_sums_kernel(const uint32_t* __restrict__ sums,
-                                                                uint32_t* __restrict__ offsets, int n) {
+                                                                uint32_t* __restrict__ offsets, int n,
+                                                                uint32_t* __restrict__ total_host) {
     __shared__ uint32_t s_wave[16];
     uint32_t acc = 0;
     for (int i = threadIdx.x; i < n; i += 1024) acc += sums[i];
@@ -363,12 +378,16 @@ __global__ __launch_bounds__(1024) void total_block_sums_kernel(const uint32_t* 
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += s_wave[w];
         offsets[n] = t;
+        // num_rendered goes straight into the caller's pinned, device-mapped word: no D2H copy launch (its blit path idles
+        // the queue like the memset's); the event recorded behind this kernel makes the store visible to the host
+        if (total_host) __hip_atomic_store(total_host, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-int launch_scan_block_sums(GeomView g, int P, hipStream_t st) {
+int launch_scan_block_sums(GeomView g, int P, uint32_t* total_host_devptr, hipStream_t st) {
     int nblk = (P + kPB - 1) / kPB;
-    hipLaunchKernelGGL(total_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_offsets, nblk);
+    hipLaunchKernelGGL(total_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_offsets, nblk,
+                       total_host_devptr);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -442,7 +461,7 @@ static int binning_typed(const Frame& f, GeomView g, BinningView b, ImageView im
 int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
                    int64_t D, hipStream_t st) {
     size_t tiles = (size_t)f.gx * f.gy;
-    if (hipMemsetAsync(im.ranges, 0, 8 * tiles, st) != hipSuccess) return MVI_EHIP;
+    if (launch_zero_fill(im.ranges, 8 * tiles, st)) return MVI_EHIP;
     if (D <= 0 || f.P <= 0) return 0;
     return b.key_bytes == 2 ? binning_typed<uint16_t>(f, g, b, im, D, st) : binning_typed<uint32_t>(f, g, b, im, D, st);
 }
