@@ -140,12 +140,17 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize(device)
-    hip_ops.PROFILE = []
+    # timed region: no per-op events (an event record idles the GPU for several microseconds, and a step has ~480 HIP ops)
     t0 = time.perf_counter()
     for i in range(steps):
         out = step(i)
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
+    # separate instrumented pass of the same steps: every HIP op bracketed by events on its launch stream -> per-op table
+    hip_ops.PROFILE = []
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(device)
     prof = hip_ops.profile_summary()
     hip_ops.PROFILE = None
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
