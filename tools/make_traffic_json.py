@@ -13,7 +13,8 @@ STAGE = {"preprocess_forward_kernel": "preprocess_forward", "total_block_sums_ke
          "radix_scatter_kernel": "radix_sort", "perm_block_sums_kernel": "duplicate_keys", "emit_pairs_kernel": "duplicate_keys",
          "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward",
          "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
-STEPS = 6          # bench.py --steps 5 --warmup 1
+STEPS = None       # launches of a once-per-step kernel in the profiled run (bench.py --steps 5 --warmup 1: 1 warm-up + 5
+                   # instrumented + 5 timed = 11), read from the render_backward_kernel entry
 
 
 def parse(path):
@@ -30,6 +31,7 @@ def parse(path):
 
 
 f, w = parse(os.path.join(d, "pmc_fetch.txt")), parse(os.path.join(d, "pmc_write.txt"))
+STEPS = f["render_backward_kernel"]["FETCH_SIZE"][1]
 per_kernel, per_stage = {}, {}
 for k in sorted(f):
     if k not in STAGE:
