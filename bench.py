@@ -155,10 +155,14 @@ def main():
 
     def step():
         color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
-        R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, sh_grad="factor" if factored else "dense", **kw)
         if factored:
-            bucket.exchange(t["means3D"], rs.campos)
-        elif distributed:
+            # the all-gather of the colour factors starts right behind the render backward and runs under the chain rule
+            R.rasterize_backward_split(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], bucket.views,
+                                       after_render=lambda: bucket.begin_gather(rs.campos))
+            bucket.finish(t["means3D"])
+            return st, radii
+        R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, sh_grad="dense", **kw)
+        if distributed:
             bucket.all_reduce()
         return st, radii
 

@@ -132,6 +132,22 @@ int mvi_raster_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_
 int mvi_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                             const float* projmatrix, uint8_t* visible, void* stream);
 
+/* The two halves of mvi_raster_backward, for callers that start exchanging part of the result before the rest exists
+ * (view-parallel training, SURVEY.md §8e: the colour factors of the SH gradient are all-gathered while the per-Gaussian
+ * chain rule still runs). mvi_raster_backward_render: zeroes grad_rows_scratch [P][16], runs the render backward, and —
+ * when dL_dcolor_factor [P,3] is given — writes what mvi_raster_backward would later put into dL_dcolors (the clamp-masked
+ * colour gradient; sh_input != 0 applies the SH clamp mask). mvi_raster_backward_geom: the per-Gaussian chain rule from
+ * those rows (arguments as in mvi_raster_backward). render + geom is what mvi_raster_backward runs. */
+int mvi_raster_backward_render(const mvi_raster_settings* s, int32_t P, int64_t num_rendered, const int32_t* radii,
+                               const void* geom, const void* binning, const void* image, const float* dL_dout_color,
+                               float* grad_rows_scratch, float* dL_dcolor_factor, int32_t sh_input, void* stream);
+int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* scales, const float* rotations,
+                             const float* cov3D_precomp, const int32_t* radii, const void* geom,
+                             const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                             float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                             void* stream);
+
 /* Introspection used by the parity tests: copies of intermediate device arrays' addresses.
  * Pointers alias the caller's scratch buffers; valid while those are. */
 typedef struct mvi_raster_views {

@@ -206,6 +206,9 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D
     return MVI_OK;
 }
 
+static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32_t* radii, const void* geom, const void* binning,
+                                const void* image, const float* dL_dout_color, float* grad_rows, float* dL_dcolor_factor,
+                                int sh_input, void* stream);
 static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* scales, const float* rotations,
                          const float* cov3D_precomp, const int32_t* radii, const void* geom, const void* binning,
@@ -267,22 +270,74 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
     if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
         return fail(MVI_EINVAL, "missing covariance gradient output%s");
     if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
+    if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0, stream)) return rc;
+    mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
+    hipStream_t st = (hipStream_t)stream;
+    mvi::StageTimer tm(mvi::kStPreBwd, st);
+    if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, dL_dconic_scratch,
+                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors,
+                                        dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, st, rawx))
+        return hip_fail("preprocess_backward", hipGetLastError());
+    return MVI_OK;
+}
+
+// first half of the backward: zero the accumulation rows, render backward, optionally the colour factors
+static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32_t* radii, const void* geom, const void* binning,
+                                const void* image, const float* dL_dout_color, float* grad_rows, float* dL_dcolor_factor,
+                                int sh_input, void* stream) {
+    if (P == 0) return MVI_OK;
+    if (!radii || !geom || !image || !dL_dout_color || !grad_rows) return fail(MVI_EINVAL, "NULL required pointer in backward%s");
+    if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
     mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
     mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), f.W, f.H);
     mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, f.W, f.H);
     hipStream_t st = (hipStream_t)stream;
-    float* grad_rows = dL_dconic_scratch;             // [P][16] accumulation rows
-    hipError_t e;
     if (mvi::launch_zero_fill(grad_rows, sizeof(float) * mvi::kGradRow * (size_t)P, st)) return hip_fail("zero grad rows", hipGetLastError());
     {
         mvi::StageTimer tm(mvi::kStRenderBwd, st);
         if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, grad_rows, st))
             return hip_fail("render_backward", hipGetLastError());
     }
+    if (dL_dcolor_factor && mvi::launch_color_factors(P, radii, grad_rows, sh_input ? g.clamped : nullptr, dL_dcolor_factor, st))
+        return hip_fail("color_factors", hipGetLastError());
+    return MVI_OK;
+}
+
+int mvi_raster_backward_render(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii, const void* geom,
+                               const void* binning, const void* image, const float* dL_dout_color, float* grad_rows_scratch,
+                               float* dL_dcolor_factor, int32_t sh_input, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, 0, f)) return rc;
+    return backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, grad_rows_scratch, dL_dcolor_factor,
+                                sh_input, stream);
+}
+
+int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* scales, const float* rotations,
+                             const float* cov3D_precomp, const int32_t* radii, const void* geom,
+                             const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                             float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                             void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, M, f)) return rc;
+    if (P == 0) return MVI_OK;
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(MVI_EINVAL, "Please provide excatly one of either SHs or precomputed colors!%s");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(MVI_EINVAL, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!%s");
+    if (!means3D || !radii || !geom || !grad_rows_scratch || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity)
+        return fail(MVI_EINVAL, "NULL required pointer in backward%s");
+    if (shs && !dL_dshs && !dL_dcolors)
+        return fail(MVI_EINVAL, "dL_dshs and dL_dcolors are both NULL but shs was a forward input%s");
+    if (colors_precomp && !dL_dcolors) return fail(MVI_EINVAL, "dL_dcolors is NULL but colors_precomp was a forward input%s");
+    if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
+        return fail(MVI_EINVAL, "missing covariance gradient output%s");
+    mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
+    hipStream_t st = (hipStream_t)stream;
     mvi::StageTimer tm(mvi::kStPreBwd, st);
-    if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, grad_rows,
-                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors,
-                                        dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, st, rawx))
+    if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, grad_rows_scratch,
+                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales,
+                                        dL_drotations, st, mvi::RawBackwardExtra()))
         return hip_fail("preprocess_backward", hipGetLastError());
     return MVI_OK;
 }

@@ -244,5 +244,6 @@ constexpr int kGradRow = 16;   // floats per Gaussian in the backward accumulati
 int launch_sh_backward_views(int P, int M, int deg, int n_views, const float* means3D, const float* campos,
                              int64_t campos_stride, const float* gcol, int64_t gcol_stride, float* dL_dshs, hipStream_t st);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st);
+int launch_color_factors(int P, const int32_t* radii, const float* grad_rows, const uint8_t* clamped, float* out, hipStream_t st);
 
 }  // namespace mvi

@@ -680,6 +680,30 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
     float vz = affine3(view[2], view[6], view[10], view[14], means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
     visible[i] = vz > kNearZ;
 }
+// Colour factor of the rank-1 SH gradient (or the colour gradient for precomputed colours) straight from the render
+// backward's accumulation rows: what preprocess_backward writes into dL_dcolors, available one kernel earlier so that a
+// view-parallel trainer can start exchanging it while preprocess_backward runs (dist.FactoredGradExchange).
+__global__ __launch_bounds__(256) void color_factor_kernel(int P, const int32_t* __restrict__ radii,
+                                                           const float* __restrict__ grad_rows,
+                                                           const uint8_t* __restrict__ clamped, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float r = 0.f, g_ = 0.f, b = 0.f;
+    if (radii[i] > 0) {
+        const float* row = grad_rows + (size_t)i * kGradRow;
+        const uint32_t cl = clamped ? clamped[i] : 0u;
+        r = (cl & 1u) ? 0.0f : row[6];
+        g_ = (cl & 2u) ? 0.0f : row[7];
+        b = (cl & 4u) ? 0.0f : row[8];
+    }
+    out[3 * (size_t)i] = r; out[3 * (size_t)i + 1] = g_; out[3 * (size_t)i + 2] = b;
+}
+int launch_color_factors(int P, const int32_t* radii, const float* grad_rows, const uint8_t* clamped, float* out, hipStream_t st) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(color_factor_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, grad_rows, clamped, out);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* visible, hipStream_t st) {
     if (P <= 0) return 0;
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kPB - 1) / kPB), dim3(kPB), 0, st, P, means3D, view, visible);

@@ -168,6 +168,24 @@ class FactoredGradExchange:
         """Factored beats one big all-reduce when (W-1)*3 < 2 (W-1)/W * 3M, i.e. W < 2M."""
         return M > 1 and world < 2 * M
 
+    def begin_gather(self, campos: torch.Tensor):
+        """Starts the all-gather of the colour factors (+ this rank's camera centre). Call as soon as
+        views["sh_color_factor"] is final — with raster.rasterize_backward_split that is right after the render
+        backward, so the transfer runs under the per-Gaussian chain rule."""
+        self.send[3 * self.P:].copy_(campos.reshape(3).to(self.send.dtype))
+        self._gather = td.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.group, async_op=True)
+
+    def finish(self, means3D: torch.Tensor):
+        """All-reduces the other 11 floats per Gaussian, waits for the gather begun earlier and rebuilds dL/dSH."""
+        td.all_reduce(self.small, op=td.ReduceOp.SUM, group=self.group)
+        self._gather.wait()
+        self._gather = None
+        factors = self.recv[:, :3 * self.P].view(self.world, self.P, 3)
+        sh_grad_from_factors(means3D, self.recv[:, 3 * self.P:], factors, self.M, self.deg, out=self.shs)
+        g = {n: self.views[n] for n, _ in self.SMALL}
+        g["shs"] = self.shs
+        return g
+
     def exchange(self, means3D: torch.Tensor, campos: torch.Tensor):
         """means3D [P,3] (replicated parameters), campos [3] = this rank's camera centre. Returns the gradient dict
         {means3D, shs, opacities, scales, rotations} summed over ranks (views of the internal buffers)."""

@@ -179,6 +179,40 @@ def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_
     return g
 
 
+def rasterize_backward_split(rs: GaussianRasterizationSettings, st: RasterState, grad_color, means3D, shs, scales, rotations,
+                             out, after_render=None):
+    """rasterize_backward(..., sh_grad="factor") in two halves: after the render backward the colour factors are already
+    in out["sh_color_factor"] and `after_render()` runs (dist.FactoredGradExchange starts its all-gather there), then the
+    per-Gaussian chain rule fills the other gradients. Same kernels and results as the one-call form."""
+    L = _lib.lib()
+    fr = _Frame(rs)
+    dev = means3D.device
+    P = st.P
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = {k: out[k] for k in ("means3D", "means2D", "opacities", "scales", "rotations", "sh_color_factor")}
+    for k, shape in (("means3D", (P, 3)), ("means2D", (P, 3)), ("opacities", (P, 1)), ("scales", (P, 3)), ("rotations", (P, 4)),
+                     ("sh_color_factor", (P, 3))):
+        t = g[k]
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"out[{k!r}] must be a contiguous fp32 {shape} tensor on {dev}")
+    scratch = torch.empty(P, 16, **f32)
+    spare = torch.empty(P, 3, **f32)                  # the chain-rule kernel writes the factors again: not into the buffer in flight
+    grad_color = grad_color.to(torch.float32).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_backward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), _ptr(st.binning),
+                                                _ptr(st.image), _ptr(grad_color), _ptr(scratch), _ptr(g["sh_color_factor"]), 1,
+                                                stream), "rasterize backward (render)")
+        if after_render is not None:
+            after_render()
+        _lib.check(L.mvi_raster_backward_geom(C.byref(fr.c), P, st.M, _ptr(means3D), _ptr(shs), None, _ptr(scales),
+                                              _ptr(rotations), None, _ptr(st.radii), _ptr(st.geom), _ptr(scratch),
+                                              _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["opacities"]), None, _ptr(spare),
+                                              _ptr(g["scales"]), _ptr(g["rotations"]), None, stream),
+                   "rasterize backward (geom)")
+    return g
+
+
 def sh_backward_views(means3D, campos, color_factors, M, sh_degree, out=None):
     """Sum over views of the SH gradient rebuilt from per-view colour factors:
     out[g,k,c] = sum_v Y_k(normalize(means3D[g] - campos[v])) * color_factors[v,g,c]  ->  [P,M,3].

@@ -84,6 +84,16 @@ def _worker(rank, world, port, out_dir):
         assert float(got["shs"][:, nb:].abs().max() if nb < Mx else 0.0) == 0.0
         for n, _ in md.FactoredGradExchange.SMALL:
             assert torch.allclose(got[n], sum(small[r][n] for r in range(world)), rtol=1e-5, atol=1e-6), n
+        # the overlapped form (gather begun before the other gradients exist) gives the same sums
+        ex2 = md.FactoredGradExchange(P, Mx, deg, "cpu")
+        ex2.views["sh_color_factor"].copy_(fac[rank])
+        ex2.begin_gather(cams[rank])
+        for n, v in small[rank].items():                  # "the chain rule" finishes after the gather has started
+            ex2.views[n].copy_(v)
+        got2 = ex2.finish(means)
+        assert torch.equal(got2["shs"], got["shs"])
+        for n, _ in md.FactoredGradExchange.SMALL:
+            assert torch.equal(got2[n], got[n]), n
     assert md.FactoredGradExchange.pays(16, 8) and not md.FactoredGradExchange.pays(4, 8) and not md.FactoredGradExchange.pays(1, 2)
     torch.save(dict(flat=bucket.flat, accum=accum, shs=got["shs"]), os.path.join(out_dir, f"r{rank}.pt"))
     td.destroy_process_group()

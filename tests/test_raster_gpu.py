@@ -388,3 +388,33 @@ def test_raw_parameter_path_equals_activations_plus_standard_path(R, deg, store_
             continue                                                   # degree 0: features_rest is [P,0,3]
         frac, worst = _close_frac(g1[k].cpu().numpy(), g0[k].cpu().numpy())
         assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+
+
+def test_split_backward_equals_one_call_and_factors_come_early(R):
+    """mvi_raster_backward_render + mvi_raster_backward_geom == mvi_raster_backward (to the order of the float atomics), and
+    the colour factors are final when the `after_render` hook runs (what dist.FactoredGradExchange.begin_gather relies on)."""
+    cam, sc, bg = small_scene(7, N=3000, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
+    t = _to_dev(sc)
+    rs = _settings(R, cam, bg, 3)
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                  rotations=t["rotations"])
+    g_img = torch.randn(3, cam["H"], cam["W"], device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    one = R.rasterize_backward(rs, st, g_img, t["means3D"], sh_grad="factor", **kw)
+    P = t["means3D"].shape[0]
+    z = lambda *s: torch.full(s, float("nan"), device="cuda")
+    out = dict(means3D=z(P, 3), means2D=z(P, 3), opacities=z(P, 1), scales=z(P, 3), rotations=z(P, 4), sh_color_factor=z(P, 3))
+    seen = {}
+
+    def hook():
+        torch.cuda.synchronize()
+        seen["factors"] = out["sh_color_factor"].clone()
+        seen["others_untouched"] = bool(torch.isnan(out["means3D"]).all())
+    two = R.rasterize_backward_split(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], out, after_render=hook)
+    torch.cuda.synchronize()
+    # the factors were final at the hook (the chain-rule kernel does not touch that buffer afterwards)
+    assert seen["others_untouched"] and torch.equal(seen["factors"], two["sh_color_factor"])
+    # two runs of the render backward differ in the order of their float atomics: equal to summation order
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations", "sh_color_factor"):
+        a, b = two[k].double(), one[k].double()
+        assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) < 1e-5, k
