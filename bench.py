@@ -154,7 +154,7 @@ def main():
     bucket = mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev)
 
     def step():
-        color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+        color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **kw)
         if factored:
             # the all-gather of the colour factors starts right behind the render backward and runs under the chain rule
             R.rasterize_backward_split(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], bucket.views,

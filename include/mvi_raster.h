@@ -81,12 +81,20 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t n
                               const int32_t* radii, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                               void* image, size_t image_bytes, float* out_color, float* out_depth,
                               void* stream);
+/* The same, and additionally ZEROES grad_rows_scratch [P][16] — the accumulation rows a following backward needs —
+ * inside the render kernel (issue-bound, memory pipes nearly idle: the 64 bytes per Gaussian cost nothing there, against a
+ * 96 MB fill pass in front of the render backward). Pass the same buffer to the backward with grad_rows_prezeroed = 1. */
+int mvi_raster_forward_render_prepare(const mvi_raster_settings* s, int32_t P, int64_t num_rendered,
+                                      const int32_t* radii, void* geom, size_t geom_bytes, void* binning,
+                                      size_t binning_bytes, void* image, size_t image_bytes, float* out_color,
+                                      float* out_depth, float* grad_rows_scratch, void* stream);
 
 /* Backward. dL_dout_color [3,H,W]. Gradient outputs are overwritten (not accumulated):
  * dL_dmeans3D [P,3], dL_dmeans2D [P,3] (x,y = NDC-scaled screen gradient, z = 0; consumer
  * gs-simp/scene/gaussian_model.py:482-484), dL_dopacity [P], and
  * dL_dshs [P,M,3] | dL_dcolors [P,3], dL_dscales [P,3] + dL_drotations [P,4] | dL_dcov3D [P,6]
- * (pass NULL for the member of each pair that was not a forward input).
+ * (pass NULL for the member of each pair that was not a forward input). grad_rows_prezeroed != 0: the scratch rows were
+ * zeroed by mvi_raster_forward_render_prepare (and not used since); otherwise the backward zeroes them itself.
  * With shs as the forward input, dL_dcolors is an OPTIONAL extra output: the colour factor of the rank-1 SH
  * gradient, dL/dSH[k][c] = Y_k(dir) * dL_dcolors[c] (clamped channels zeroed); dL_dshs may then be NULL and the
  * dense gradient is rebuilt — summed over views — by mvi_raster_sh_backward_views (view-parallel training).
@@ -98,7 +106,7 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
                         const void* image, const float* dL_dout_color, float* dL_dmeans3D,
                         float* dL_dmeans2D, float* dL_dopacity, float* dL_dshs, float* dL_dcolors,
                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                        float* grad_rows_scratch, void* stream);
+                        float* grad_rows_scratch, int32_t grad_rows_prezeroed, void* stream);
 
 /* Raw-parameter forms ("fused activation + pack pre-pass"): the same two calls fed with the
  * GaussianModel's UN-activated parameters exactly as it stores them (gs-simp/scene/gaussian_model.py:95-115, :44-59):
@@ -116,7 +124,8 @@ int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, 
                             const float* raw_scaling, const float* raw_rotation, const int32_t* radii, const void* geom,
                             const void* binning, const void* image, const float* dL_dout_color, float* dL_dxyz,
                             float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
-                            float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch, void* stream);
+                            float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch, 
+                            int32_t grad_rows_prezeroed, void* stream);
 
 /* View-parallel training (no counterpart in the reference, which is single-GPU: gs-simp/train.sh:1):
  * dL_dshs[g,k,c] = sum over views v of Y_k(normalize(means3D[g] - campos[v])) * dL_dcolors[v,g,c] for k < (deg+1)^2,
@@ -140,7 +149,8 @@ int mvi_raster_mark_visible(int32_t P, const float* means3D, const float* viewma
  * those rows (arguments as in mvi_raster_backward). render + geom is what mvi_raster_backward runs. */
 int mvi_raster_backward_render(const mvi_raster_settings* s, int32_t P, int64_t num_rendered, const int32_t* radii,
                                const void* geom, const void* binning, const void* image, const float* dL_dout_color,
-                               float* grad_rows_scratch, float* dL_dcolor_factor, int32_t sh_input, void* stream);
+                               float* grad_rows_scratch, float* dL_dcolor_factor, int32_t sh_input,
+                               int32_t grad_rows_prezeroed, void* stream);
 int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations,
                              const float* cov3D_precomp, const int32_t* radii, const void* geom,

@@ -78,16 +78,18 @@ def lib():
     L.mvi_raster_forward_geom.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 7 + [vp, sz, vp, C.POINTER(i64), vp]
     L.mvi_raster_forward_render.restype = C.c_int
     L.mvi_raster_forward_render.argtypes = [C.POINTER(RasterSettings), i32, i64, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp]
+    L.mvi_raster_forward_render_prepare.restype = C.c_int
+    L.mvi_raster_forward_render_prepare.argtypes = [C.POINTER(RasterSettings), i32, i64, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     L.mvi_raster_backward.restype = C.c_int
-    L.mvi_raster_backward.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 21
+    L.mvi_raster_backward.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 20 + [i32, vp]
     L.mvi_raster_backward_render.restype = C.c_int
-    L.mvi_raster_backward_render.argtypes = [C.POINTER(RasterSettings), i32, i64] + [vp] * 7 + [i32, vp]
+    L.mvi_raster_backward_render.argtypes = [C.POINTER(RasterSettings), i32, i64] + [vp] * 7 + [i32, i32, vp]
     L.mvi_raster_backward_geom.restype = C.c_int
     L.mvi_raster_backward_geom.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 18
     L.mvi_raster_forward_geom_raw.restype = C.c_int
     L.mvi_raster_forward_geom_raw.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 6 + [vp, sz, vp, C.POINTER(i64), vp]
     L.mvi_raster_backward_raw.restype = C.c_int
-    L.mvi_raster_backward_raw.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 20
+    L.mvi_raster_backward_raw.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 19 + [i32, vp]
     L.mvi_raster_sh_backward_views.restype = C.c_int
     L.mvi_raster_sh_backward_views.argtypes = [i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp]
     L.mvi_raster_mark_visible.restype = C.c_int

@@ -182,9 +182,9 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     return MVI_OK;
 }
 
-int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii,
-                              void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
-                              size_t image_bytes, float* out_color, float* out_depth, void* stream) {
+static int forward_render_impl(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii,
+                               void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
+                               size_t image_bytes, float* out_color, float* out_depth, float* grad_rows_to_zero, void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, 0, f)) return rc;
     if (!image || !out_color || !out_depth) return fail(MVI_EINVAL, "NULL image/out_color/out_depth%s");
@@ -200,15 +200,30 @@ int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D
     if (int rc = mvi::launch_binning(f, g, radii, b, im, D, st)) return hip_fail("binning", hipGetLastError());
     {
         mvi::StageTimer tm(mvi::kStRenderFwd, st);
-        if (mvi::launch_render_forward(f, g, b, im, D, out_color, out_depth, st))
+        if (mvi::launch_render_forward(f, g, b, im, D, out_color, out_depth, st, grad_rows_to_zero))
             return hip_fail("render_forward", hipGetLastError());
     }
     return MVI_OK;
 }
 
+int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii,
+                              void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
+                              size_t image_bytes, float* out_color, float* out_depth, void* stream) {
+    return forward_render_impl(s, P, D, radii, geom, geom_bytes, binning, binning_bytes, image, image_bytes, out_color, out_depth,
+                               nullptr, stream);
+}
+
+int mvi_raster_forward_render_prepare(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii,
+                                      void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
+                                      size_t image_bytes, float* out_color, float* out_depth, float* grad_rows_scratch,
+                                      void* stream) {
+    return forward_render_impl(s, P, D, radii, geom, geom_bytes, binning, binning_bytes, image, image_bytes, out_color, out_depth,
+                               grad_rows_scratch, stream);
+}
+
 static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32_t* radii, const void* geom, const void* binning,
                                 const void* image, const float* dL_dout_color, float* grad_rows, float* dL_dcolor_factor,
-                                int sh_input, void* stream);
+                                int sh_input, int rows_prezeroed, void* stream);
 static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* scales, const float* rotations,
                          const float* cov3D_precomp, const int32_t* radii, const void* geom, const void* binning,
@@ -222,12 +237,15 @@ int mvi_raster_backward(const mvi_raster_settings* s, int32_t P, int32_t M, int6
                         const void* geom, const void* binning, const void* image,
                         const float* dL_dout_color, float* dL_dmeans3D, float* dL_dmeans2D,
                         float* dL_dopacity, float* dL_dshs, float* dL_dcolors, float* dL_dscales,
-                        float* dL_drotations, float* dL_dcov3D, float* dL_dconic_scratch, void* stream) {
+                        float* dL_drotations, float* dL_dcov3D, float* dL_dconic_scratch, int32_t grad_rows_prezeroed,
+                        void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, M, f)) return rc;
+    mvi::RawBackwardExtra rawx;
+    rawx.rows_prezeroed = grad_rows_prezeroed;
     return backward_impl(f, P, D, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, radii, geom, binning, image,
                          dL_dout_color, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dshs, dL_dcolors, dL_dscales, dL_drotations,
-                         dL_dcov3D, dL_dconic_scratch, stream, mvi::RawBackwardExtra());
+                         dL_dcov3D, dL_dconic_scratch, stream, rawx);
 }
 
 int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t D, const float* xyz,
@@ -235,7 +253,8 @@ int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, 
                             const float* raw_scaling, const float* raw_rotation, const int32_t* radii, const void* geom,
                             const void* binning, const void* image, const float* dL_dout_color, float* dL_dxyz,
                             float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
-                            float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch, void* stream) {
+                            float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch,
+                            int32_t grad_rows_prezeroed, void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, M, f)) return rc;
     if (P > 0 && (!features_dc || (M > 1 && (!features_rest || !dL_dfeatures_rest)) || !raw_opacity || !dL_dfeatures_dc))
@@ -245,6 +264,7 @@ int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, 
     mvi::RawBackwardExtra rawx;
     rawx.raw_opacity = raw_opacity;
     rawx.dL_dshs_rest = dL_dfeatures_rest;
+    rawx.rows_prezeroed = grad_rows_prezeroed;
     return backward_impl(f, P, D, xyz, features_dc, nullptr, raw_scaling, raw_rotation, nullptr, radii, geom, binning, image,
                          dL_dout_color, dL_dxyz, dL_dmeans2D, dL_draw_opacity, dL_dfeatures_dc, nullptr, dL_draw_scaling,
                          dL_draw_rotation, nullptr, grad_rows_scratch, stream, rawx);
@@ -270,7 +290,8 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
     if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
         return fail(MVI_EINVAL, "missing covariance gradient output%s");
     if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
-    if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0, stream)) return rc;
+    if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0,
+                                      rawx.rows_prezeroed, stream)) return rc;
     mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
     hipStream_t st = (hipStream_t)stream;
     mvi::StageTimer tm(mvi::kStPreBwd, st);
@@ -284,7 +305,7 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
 // first half of the backward: zero the accumulation rows, render backward, optionally the colour factors
 static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32_t* radii, const void* geom, const void* binning,
                                 const void* image, const float* dL_dout_color, float* grad_rows, float* dL_dcolor_factor,
-                                int sh_input, void* stream) {
+                                int sh_input, int rows_prezeroed, void* stream) {
     if (P == 0) return MVI_OK;
     if (!radii || !geom || !image || !dL_dout_color || !grad_rows) return fail(MVI_EINVAL, "NULL required pointer in backward%s");
     if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
@@ -292,7 +313,8 @@ static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32
     mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), f.W, f.H);
     mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, f.W, f.H);
     hipStream_t st = (hipStream_t)stream;
-    if (mvi::launch_zero_fill(grad_rows, sizeof(float) * mvi::kGradRow * (size_t)P, st)) return hip_fail("zero grad rows", hipGetLastError());
+    if (!rows_prezeroed && mvi::launch_zero_fill(grad_rows, sizeof(float) * mvi::kGradRow * (size_t)P, st))
+        return hip_fail("zero grad rows", hipGetLastError());
     {
         mvi::StageTimer tm(mvi::kStRenderBwd, st);
         if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, grad_rows, st))
@@ -305,11 +327,11 @@ static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32
 
 int mvi_raster_backward_render(const mvi_raster_settings* s, int32_t P, int64_t D, const int32_t* radii, const void* geom,
                                const void* binning, const void* image, const float* dL_dout_color, float* grad_rows_scratch,
-                               float* dL_dcolor_factor, int32_t sh_input, void* stream) {
+                               float* dL_dcolor_factor, int32_t sh_input, int32_t grad_rows_prezeroed, void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, 0, f)) return rc;
     return backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, grad_rows_scratch, dL_dcolor_factor,
-                                sh_input, stream);
+                                sh_input, grad_rows_prezeroed, stream);
 }
 
 int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D, const float* shs,

@@ -227,7 +227,7 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               const float* rotations, const float* cov3D_precomp, GeomView g,
                               int32_t* radii, hipStream_t st);
 // raw mode only: raw_opacity [P] (chain rule of the sigmoid), dL_dshs_rest [P,M-1,3]
-struct RawBackwardExtra { const float* raw_opacity = nullptr; float* dL_dshs_rest = nullptr; };
+struct RawBackwardExtra { const float* raw_opacity = nullptr; float* dL_dshs_rest = nullptr; int rows_prezeroed = 0; };
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
                                const float* scales, const float* rotations, const float* cov3D_precomp,
                                const int32_t* radii, GeomView g, const float* grad_rows, float* dL_dmeans3D,
@@ -237,7 +237,7 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
 int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
                    int64_t D, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
-                          float* out_color, float* out_depth, hipStream_t st);
+                          float* out_color, float* out_depth, hipStream_t st, float* zero_rows = nullptr);
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                            const float* dL_dpix, float* grad_rows, hipStream_t st);
 constexpr int kGradRow = 16;   // floats per Gaussian in the backward accumulation rows (64 B)

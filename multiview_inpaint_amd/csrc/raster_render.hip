@@ -87,13 +87,19 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth) {
+    float* __restrict__ out_depth, uint4* __restrict__ zero_rows, uint32_t zero_per_block, size_t zero_n16) {
     __shared__ float2 s_xy[kBlock];
     __shared__ float s_t2[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_cd[kBlock];                 // r, g, b, depth
     __shared__ float4 w_a[4][64], w_co[4][64], w_cd[4][64];   // per-wave compacted strip: (x, y, list position, -)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (zero_rows) {
+        // the backward's accumulation rows are zeroed HERE: this kernel is issue-bound with the memory pipes nearly idle, so
+        // the 64 bytes per Gaussian ride along for free instead of costing a 96 MB fill pass in front of the render backward
+        const size_t z0 = (size_t)blockIdx.x * zero_per_block;
+        for (uint32_t i = tid; i < zero_per_block && z0 + i < zero_n16; i += kBlock) zero_rows[z0 + i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const int tile = xcd_band_tile(blockIdx.x, f.gx * f.gy);
     const int tile_y = tile / f.gx, tile_x = tile - tile_y * f.gx;
     const int qx0 = tile_x * kTile + 8 * (wave & 1), qy0 = tile_y * kTile + 8 * (wave >> 1);
@@ -175,12 +181,16 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     }
 }
 
+int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
-                          float* out_color, float* out_depth, hipStream_t st) {
-    if (f.W <= 0 || f.H <= 0) return 0;
+                          float* out_color, float* out_depth, hipStream_t st, float* zero_rows) {
+    const size_t zero_n16 = zero_rows ? (size_t)f.P * kGradRow * sizeof(float) / 16 : 0;
+    if (f.W <= 0 || f.H <= 0) return zero_rows ? launch_zero_fill(zero_rows, zero_n16 * 16, st) : 0;
     const uint32_t* plist = b.vals[b.passes & 1];
-    hipLaunchKernelGGL(render_forward_kernel, dim3(f.gx * f.gy), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
-                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth);
+    const unsigned blocks = (unsigned)(f.gx * f.gy);
+    const uint32_t per = (uint32_t)((zero_n16 + blocks - 1) / blocks);
+    hipLaunchKernelGGL(render_forward_kernel, dim3(blocks), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
+                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth, (uint4*)zero_rows, per, zero_n16);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

@@ -64,7 +64,15 @@ class _Frame:
 
 class RasterState:
     """Scratch buffers one forward leaves behind for its backward (and for the parity tests)."""
-    __slots__ = ("P", "M", "D", "W", "H", "geom", "binning", "image", "radii")
+    __slots__ = ("P", "M", "D", "W", "H", "geom", "binning", "image", "radii", "grad_rows", "rows_clean")
+
+    def take_rows(self, dev):
+        """(accumulation rows [P,16], prezeroed flag) for one backward: the rows the forward zeroed inside its render kernel
+        if it was asked to (`prepare_backward`) and nobody used them yet, else a fresh buffer the backward zeroes itself."""
+        if getattr(self, "grad_rows", None) is not None and getattr(self, "rows_clean", False):
+            self.rows_clean = False
+            return self.grad_rows, 1
+        return torch.empty(self.P, 16, dtype=torch.float32, device=dev), 0
 
     def views(self):
         L = _lib.lib()
@@ -95,9 +103,25 @@ class RasterState:
         return out
 
 
+def _forward_render(L, fr, st, color, depth, stream, prepare_backward, dev):
+    st.grad_rows, st.rows_clean = None, False
+    if prepare_backward and st.P > 0:
+        st.grad_rows = torch.empty(st.P, 16, dtype=torch.float32, device=dev)
+        _lib.check(L.mvi_raster_forward_render_prepare(C.byref(fr.c), st.P, st.D, _ptr(st.radii), _ptr(st.geom), st.geom.numel(),
+                                                       _ptr(st.binning), st.binning.numel(), _ptr(st.image), st.image.numel(),
+                                                       _ptr(color), _ptr(depth), _ptr(st.grad_rows), stream),
+                   "rasterize forward (render)")
+        st.rows_clean = True
+        return
+    _lib.check(L.mvi_raster_forward_render(C.byref(fr.c), st.P, st.D, _ptr(st.radii), _ptr(st.geom), st.geom.numel(),
+                                           _ptr(st.binning), st.binning.numel(), _ptr(st.image), st.image.numel(),
+                                           _ptr(color), _ptr(depth), stream), "rasterize forward (render)")
+
+
 def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
-                      scales=None, rotations=None, cov3D_precomp=None):
-    """Runs the HIP forward. Returns (color [3,H,W], radii [P] int32, depth [1,H,W], RasterState)."""
+                      scales=None, rotations=None, cov3D_precomp=None, prepare_backward=False):
+    """Runs the HIP forward. Returns (color [3,H,W], radii [P] int32, depth [1,H,W], RasterState). prepare_backward: a
+    backward will follow — its accumulation rows (64 B per Gaussian) are allocated now and zeroed inside the render kernel."""
     L = _lib.lib()
     fr = _Frame(rs)
     dev = means3D.device
@@ -123,9 +147,7 @@ def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs
                    "rasterize forward (geom)")
         st.D = int(D.value)
         st.binning = torch.empty(L.mvi_raster_binning_bytes(st.D, W, H) if st.D else 0, **u8)
-        _lib.check(L.mvi_raster_forward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), st.geom.numel(),
-                                               _ptr(st.binning), st.binning.numel(), _ptr(st.image), st.image.numel(),
-                                               _ptr(color), _ptr(depth), stream), "rasterize forward (render)")
+        _forward_render(L, fr, st, color, depth, stream, prepare_backward, dev)
     return color, st.radii, depth, st
 
 
@@ -166,7 +188,7 @@ def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_
         g["cov3D_precomp"] = buf("cov3D_precomp", P, 6)
     else:
         g["scales"], g["rotations"] = buf("scales", P, 3), buf("rotations", P, 4)
-    scratch = torch.empty(P, 16, **f32)              # 64-byte accumulation row per Gaussian
+    scratch, clean = st.take_rows(dev)               # 64-byte accumulation row per Gaussian
     grad_color = grad_color.to(torch.float32).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
@@ -174,7 +196,7 @@ def rasterize_backward(rs: GaussianRasterizationSettings, st: RasterState, grad_
             C.byref(fr.c), P, st.M, st.D, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(scales), _ptr(rotations),
             _ptr(cov3D_precomp), _ptr(st.radii), _ptr(st.geom), _ptr(st.binning), _ptr(st.image), _ptr(grad_color),
             _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["opacities"]), _ptr(g["shs"]), _ptr(dcolors),
-            _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(scratch), stream),
+            _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(scratch), clean, stream),
             "rasterize backward")
     return g
 
@@ -195,14 +217,14 @@ def rasterize_backward_split(rs: GaussianRasterizationSettings, st: RasterState,
         t = g[k]
         if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
             raise RuntimeError(f"out[{k!r}] must be a contiguous fp32 {shape} tensor on {dev}")
-    scratch = torch.empty(P, 16, **f32)
+    scratch, clean = st.take_rows(dev)
     spare = torch.empty(P, 3, **f32)                  # the chain-rule kernel writes the factors again: not into the buffer in flight
     grad_color = grad_color.to(torch.float32).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
         _lib.check(L.mvi_raster_backward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), _ptr(st.binning),
                                                 _ptr(st.image), _ptr(grad_color), _ptr(scratch), _ptr(g["sh_color_factor"]), 1,
-                                                stream), "rasterize backward (render)")
+                                                clean, stream), "rasterize backward (render)")
         if after_render is not None:
             after_render()
         _lib.check(L.mvi_raster_backward_geom(C.byref(fr.c), P, st.M, _ptr(means3D), _ptr(shs), None, _ptr(scales),
@@ -248,7 +270,7 @@ def sh_backward_views(means3D, campos, color_factors, M, sh_degree, out=None):
 
 
 def rasterize_forward_raw(rs: GaussianRasterizationSettings, xyz, features_dc, features_rest, raw_opacity, raw_scaling,
-                          raw_rotation):
+                          raw_rotation, prepare_backward=False):
     """HIP forward fed with the GaussianModel's un-activated parameters (gaussian_model.py:95-115 happens in the
     kernels). Returns (color, radii, depth, RasterState) like rasterize_forward."""
     L = _lib.lib()
@@ -278,9 +300,7 @@ def rasterize_forward_raw(rs: GaussianRasterizationSettings, xyz, features_dc, f
                    "rasterize forward raw (geom)")
         st.D = int(D.value)
         st.binning = torch.empty(L.mvi_raster_binning_bytes(st.D, W, H) if st.D else 0, **u8)
-        _lib.check(L.mvi_raster_forward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), st.geom.numel(),
-                                               _ptr(st.binning), st.binning.numel(), _ptr(st.image), st.image.numel(),
-                                               _ptr(color), _ptr(depth), stream), "rasterize forward (render)")
+        _forward_render(L, fr, st, color, depth, stream, prepare_backward, dev)
     return color, st.radii, depth, st
 
 
@@ -295,7 +315,7 @@ def rasterize_backward_raw(rs: GaussianRasterizationSettings, st: RasterState, g
     g = dict(xyz=torch.empty(P, 3, **f32), means2D=torch.empty(P, 3, **f32), opacity=torch.empty(P, 1, **f32),
              features_dc=torch.empty(P, 1, 3, **f32), features_rest=torch.empty(P, M - 1, 3, **f32),
              scaling=torch.empty(P, 3, **f32), rotation=torch.empty(P, 4, **f32))
-    scratch = torch.empty(P, 16, **f32)
+    scratch, clean = st.take_rows(dev)
     grad_color = grad_color.to(torch.float32).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
@@ -303,7 +323,7 @@ def rasterize_backward_raw(rs: GaussianRasterizationSettings, st: RasterState, g
             C.byref(fr.c), P, M, st.D, _ptr(xyz), _ptr(features_dc), _ptr(features_rest), _ptr(raw_opacity), _ptr(raw_scaling),
             _ptr(raw_rotation), _ptr(st.radii), _ptr(st.geom), _ptr(st.binning), _ptr(st.image), _ptr(grad_color),
             _ptr(g["xyz"]), _ptr(g["means2D"]), _ptr(g["opacity"]), _ptr(g["features_dc"]), _ptr(g["features_rest"]),
-            _ptr(g["scaling"]), _ptr(g["rotation"]), _ptr(scratch), stream), "rasterize backward raw")
+            _ptr(g["scaling"]), _ptr(g["rotation"]), _ptr(scratch), clean, stream), "rasterize backward raw")
     return g
 
 
@@ -312,7 +332,8 @@ class _RasterizeRaw(torch.autograd.Function):
     def forward(ctx, xyz, means2D, features_dc, features_rest, raw_opacity, raw_scaling, raw_rotation, rs):
         a = [t.detach().to(torch.float32).contiguous() for t in (xyz, features_dc, features_rest, raw_opacity, raw_scaling,
                                                                   raw_rotation)]
-        color, radii, depth, st = rasterize_forward_raw(rs, *a)
+        need = any(ctx.needs_input_grad[:7])               # a backward will follow: zero its rows inside the render kernel
+        color, radii, depth, st = rasterize_forward_raw(rs, *a, prepare_backward=need)
         ctx.rs, ctx.st, ctx.a = rs, st, a
         ctx.mark_non_differentiable(radii, depth)
         return color, radii, depth
@@ -342,7 +363,8 @@ class _Rasterize(torch.autograd.Function):
         if a["means3D"] is None:
             a["means3D"] = means3D.to(torch.float32).reshape(0, 3)
         color, radii, depth, st = rasterize_forward(rs, a["means3D"], a["opacities"], a["shs"], a["colors_precomp"],
-                                                    a["scales"], a["rotations"], a["cov3D_precomp"])
+                                                    a["scales"], a["rotations"], a["cov3D_precomp"],
+                                                    prepare_backward=any(ctx.needs_input_grad[:8]))
         ctx.rs, ctx.st, ctx.a = rs, st, a
         ctx.mark_non_differentiable(radii, depth)
         return color, radii, depth
