@@ -299,3 +299,27 @@ def prune_optimizer_state(optimizer, keep_mask, extra=()):
             optimizer.state[g["params"][0]] = stt
         new[g.get("name", len(new))] = g["params"][0]
     return new, list(it)
+
+
+def extend_optimizer_state(optimizer, tensors_dict):
+    """cat_tensors_to_optimizer (gs-simp/scene/gaussian_model.py:384-404) for torch.optim.Adam / FusedAdam whose groups hold
+    one named parameter each: every parameter gets the new rows of tensors_dict[group name] appended, its Adam moments get
+    zero rows, optimizer.state is re-keyed like the reference does. Appending is a device-to-device copy per tensor (nothing
+    to fuse); this helper exists so densify_and_clone / densify_and_split run against FusedAdam unchanged.
+    Returns {group name: new nn.Parameter}."""
+    new = {}
+    for g in optimizer.param_groups:
+        assert len(g["params"]) == 1
+        old = g["params"][0]
+        ext = tensors_dict[g["name"]]
+        stt = optimizer.state.get(old, None)
+        if stt is not None:
+            if "exp_avg" in stt:
+                stt["exp_avg"] = torch.cat((stt["exp_avg"], torch.zeros_like(ext)), dim=0)
+                stt["exp_avg_sq"] = torch.cat((stt["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+            del optimizer.state[old]
+        g["params"][0] = torch.nn.Parameter(torch.cat((old.data, ext), dim=0).requires_grad_(True))
+        if stt is not None:
+            optimizer.state[g["params"][0]] = stt
+        new[g["name"]] = g["params"][0]
+    return new

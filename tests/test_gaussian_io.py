@@ -101,3 +101,39 @@ def test_checkpoint_tuple_matches_capture_order(tmp_path):
     assert args[10]["param_groups"][0]["name"] == "xyz"
     st, it2 = gio.load_checkpoint(path)
     assert it2 == 30000 and torch.equal(st["_xyz"], p) and st["optimizer_state_dict"]["state"][0]["step"] == 1
+
+
+def test_extend_optimizer_state_matches_cat_tensors_to_optimizer():
+    """densification_postfix's optimizer surgery (gaussian_model.py:384-404) on torch.optim.Adam: parameters grow, moments
+    get zero rows, stepping continues identically to the reference's own loop."""
+    from multiview_inpaint_amd.train_ops import extend_optimizer_state
+    shapes = {"xyz": (3,), "f_dc": (1, 3), "opacity": (1,)}
+
+    def make():
+        g = torch.Generator().manual_seed(1)
+        ps = {k: torch.nn.Parameter(torch.randn(7, *s, generator=g)) for k, s in shapes.items()}
+        opt = torch.optim.Adam([{"params": [p], "lr": 1e-2, "name": k} for k, p in ps.items()], lr=0.0, eps=1e-15)
+        for p in ps.values():
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+        return opt
+    g2 = torch.Generator().manual_seed(2)
+    ext = {k: torch.randn(3, *s, generator=g2) for k, s in shapes.items()}
+    a, b = make(), make()
+    new = extend_optimizer_state(a, ext)
+    for grp in b.param_groups:                               # the reference's loop
+        e = ext[grp["name"]]
+        st = b.state.get(grp["params"][0], None)
+        st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(e)), dim=0)
+        st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(e)), dim=0)
+        del b.state[grp["params"][0]]
+        grp["params"][0] = torch.nn.Parameter(torch.cat((grp["params"][0], e), dim=0).requires_grad_(True))
+        b.state[grp["params"][0]] = st
+    for ga, gb in zip(a.param_groups, b.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert new[ga["name"]] is pa and pa.shape[0] == 10 and torch.equal(pa, pb)
+        assert torch.equal(a.state[pa]["exp_avg"], b.state[pb]["exp_avg"]) and (a.state[pa]["exp_avg"][7:] == 0).all()
+        pa.grad, pb.grad = torch.ones_like(pa), torch.ones_like(pb)
+    a.step(); b.step()
+    for ga, gb in zip(a.param_groups, b.param_groups):
+        assert torch.equal(ga["params"][0], gb["params"][0])
