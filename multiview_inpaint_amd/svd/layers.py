@@ -45,12 +45,26 @@ def maybe_checkpoint(fn, enabled, *args):
     return fn(*args)
 
 
+_FREQS = {}
+
+
+def _embedding_freqs(half, max_period, device):
+    """The frequency table, computed on the CPU as the reference does (same values to the last bit) but uploaded once per
+    device: the reference's per-call pageable upload is a host synchronisation in every denoise step and cannot be
+    captured into a HIP graph."""
+    key = (half, max_period, str(device))
+    f = _FREQS.get(key)
+    if f is None:
+        f = _FREQS[key] = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(device)
+    return f
+
+
 def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
     """[N] -> [N, dim], cosine half first, then sine (util.py:207-231)."""
     if repeat_only:
         return timesteps[:, None].expand(-1, dim)
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(timesteps.device)
+    freqs = _embedding_freqs(half, max_period, timesteps.device)
     ang = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
     if dim % 2:

@@ -329,6 +329,19 @@ class SpatialVideoTransformer(SpatialTransformer):
                                             linear(in_channels * 4, in_channels))
         self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy)
 
+    def _frame_embedding(self, T, b, device):
+        """Sinusoidal embedding of the frame index, [b*T, in_channels] in the MLP's dtype. It depends only on the
+        shape, so it is built once per (T, b, device, dtype) instead of with eight small kernels per call."""
+        wd = self.time_pos_embed[0].weight.dtype
+        key = (T, b, str(device), wd)
+        cache = self.__dict__.setdefault("_pe_cache", {})
+        pe = cache.get(key)
+        if pe is None:
+            frame_idx = torch.arange(T, device=device).repeat(b)
+            pe = timestep_embedding(frame_idx, self.in_channels, repeat_only=False, max_period=self.max_time_embed_period)
+            pe = cache[key] = pe.to(wd)
+        return pe
+
     def forward(self, x, context=None, time_context=None, timesteps=None, image_only_indicator=None):
         _, _, h, w = x.shape
         T = int(timesteps)
@@ -346,9 +359,7 @@ class SpatialVideoTransformer(SpatialTransformer):
             if time_context.ndim == 2:
                 time_context = time_context[:, None]
         t = self._tokens_in(x)
-        frame_idx = torch.arange(T, device=x.device).repeat(x.shape[0] // T)
-        pe = timestep_embedding(frame_idx, self.in_channels, repeat_only=False, max_period=self.max_time_embed_period)
-        emb = self.time_pos_embed(pe.to(self.time_pos_embed[0].weight.dtype))[:, None, :]
+        emb = self.time_pos_embed(self._frame_embedding(T, x.shape[0] // T, x.device))[:, None, :]
         alpha = None
         for blk, mix in zip(self.transformer_blocks, self.time_stack):
             if in_place:
