@@ -101,7 +101,13 @@ def enable_gemm_tuning(tune_ms=int(os.environ.get("MVI_SVD_GEMM_TUNING_MS", "0")
             return False
         tn.enable(True)
         tn.tuning_enable(False)                              # look-up only
-        tn.set_filename(TUNED_GEMMS)
+        # a private copy, as for MIOpen: TunableOp may rewrite its results file, and under torch.distributed.run every
+        # rank would do that to the same in-tree file
+        import shutil
+        import tempfile
+        private = os.path.join(tempfile.mkdtemp(prefix="mvi_tunableop_"), os.path.basename(TUNED_GEMMS))
+        shutil.copy(TUNED_GEMMS, private)
+        tn.set_filename(private)
         return True
     except Exception as e:                                  # an older PyTorch: run untuned
         print(f"[mvi] TunableOp unavailable ({e}); GEMMs run with the library's default solutions", file=sys.stderr)
