@@ -93,6 +93,14 @@ int mvi_geglu(const void* h, void* out, int64_t rows, int32_t inner, int32_t dty
 int mvi_bias_residual_add(const void* h, const void* x, const float* bias, void* out, int64_t N, int32_t C,
                           int64_t spatial, int32_t dtype, void* stream);
 
+/* out[n, c, p] = x[n, c, p] + (1 - alpha[n]) * (h[n, c, p] + bias[c]): the tail of a VideoResBlock in one pass — the
+ * temporal ResBlock's `x + h` (openaimodel.py:354) blended with its input by AlphaBlender,
+ * alpha * x_spatial + (1 - alpha) * x_temporal (svd_inpaint1/sgm/modules/diffusionmodules/util.py:358-372,
+ * video_model.py:67-81). alpha: fp32 [N] on the device (one value per frame: sigmoid(mix_factor), or 1 for image-only
+ * frames); bias optional (NULL). out may alias h. */
+int mvi_bias_residual_blend(const void* h, const void* x, const float* bias, const float* alpha, void* out, int64_t N,
+                            int32_t C, int64_t spatial, int32_t dtype, void* stream);
+
 /* ---- token-row kernels of the transformer blocks: t [R, C] token-major, contiguous ------------------------------
  * Residual add(s) + the NEXT LayerNorm in one pass (svd_inpaint1/sgm/modules/attention.py:544-572 `x = attn(norm(x)) + x`
  * chains; video_attention.py:110-141):

@@ -59,18 +59,25 @@ template <> struct BVec<__half> {
     __device__ static void st1(__half* p, float v) { *p = __float2half(v); }
 };
 
+// alpha (optional, [N] fp32): out = x + (1 - alpha[n]) * (h + bias) — the AlphaBlender of a VideoResBlock applied to the
+// temporal ResBlock's tail, alpha * x + (1 - alpha) * (x + h + bias), without materialising x + h + bias.
 template <typename T, bool VEC, bool SILU = false>
 __global__ __launch_bounds__(256) void bias_residual_kernel(const T* __restrict__ h, const T* __restrict__ x,
                                                             const float* __restrict__ bias, T* __restrict__ out,
-                                                            int64_t total, int C, int64_t S) {
+                                                            int64_t total, int C, int64_t S,
+                                                            const float* __restrict__ alpha = nullptr) {
     constexpr int N = BVec<T>::N;
     if (VEC) {
         const int64_t nvec = total / N;
         for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
             const int64_t e = v * N;
-            const float b = bias ? bias[(e / S) % C] : 0.0f;          // S % N == 0: one channel per vector
+            const int64_t nc = e / S;                                  // S % N == 0: one channel per vector
+            const float b = bias ? bias[nc % C] : 0.0f;
+            const float wgt = alpha ? 1.0f - alpha[nc / C] : 1.0f;
             float a[N];
             BVec<T>::load(h + e, a);
+#pragma unroll
+            for (int k = 0; k < N; ++k) a[k] = alpha ? wgt * (a[k] + b) : a[k];
             if (x) {
                 float r[N];
                 BVec<T>::load(x + e, r);
@@ -79,14 +86,16 @@ __global__ __launch_bounds__(256) void bias_residual_kernel(const T* __restrict_
             }
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                a[k] += b;
+                if (!alpha) a[k] += b;
                 if (SILU) a[k] = a[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[k]));
             }
             BVec<T>::store(out + e, a);
         }
     } else {
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-            float a = BVec<T>::ld1(h + e) + (bias ? bias[(e / S) % C] : 0.0f);
+            const int64_t nc = e / S;
+            float a = BVec<T>::ld1(h + e) + (bias ? bias[nc % C] : 0.0f);
+            if (alpha) a *= 1.0f - alpha[nc / C];
             if (x) a += BVec<T>::ld1(x + e);
             if (SILU) a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-a));
             BVec<T>::st1(out + e, a);
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256) void bias_residual_kernel(const T* __restrict_
 
 template <typename T, bool SILU = false>
 static int bias_residual_launch(const void* h, const void* x, const float* bias, void* out, int64_t total, int C, int64_t S,
-                                hipStream_t st) {
+                                hipStream_t st, const float* alpha = nullptr) {
     constexpr int N = BVec<T>::N;
     const bool vec = (S % N == 0) && (((uintptr_t)h | (uintptr_t)x | (uintptr_t)out) % 16 == 0);
     int64_t work = vec ? total / N : total;
@@ -104,9 +113,9 @@ static int bias_residual_launch(const void* h, const void* x, const float* bias,
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
     if (vec)
-        hipLaunchKernelGGL((bias_residual_kernel<T, true, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S);
+        hipLaunchKernelGGL((bias_residual_kernel<T, true, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S, alpha);
     else
-        hipLaunchKernelGGL((bias_residual_kernel<T, false, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S);
+        hipLaunchKernelGGL((bias_residual_kernel<T, false, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S, alpha);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 }  // namespace mvi
@@ -126,6 +135,23 @@ extern "C" int mvi_bias_residual_add(const void* h, const void* x, const float* 
         default: return mvi::unet_fail(MVI_EINVAL, "bias_residual_add: unknown dtype");
     }
     return rc ? mvi::unet_fail(MVI_EHIP, "bias_residual_add: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_bias_residual_blend(const void* h, const void* x, const float* bias, const float* alpha, void* out, int64_t N,
+                                       int32_t C, int64_t spatial, int32_t dtype, void* stream) {
+    if (N < 0 || C <= 0 || spatial < 0) return mvi::unet_fail(MVI_EINVAL, "bias_residual_blend: bad shape");
+    const int64_t total = N * C * spatial;
+    if (total == 0) return MVI_OK;
+    if (!h || !x || !alpha || !out) return mvi::unet_fail(MVI_EINVAL, "bias_residual_blend: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::bias_residual_launch<float>(h, x, bias, out, total, C, spatial, st, alpha); break;
+        case MVI_DT_BF16: rc = mvi::bias_residual_launch<__hip_bfloat16>(h, x, bias, out, total, C, spatial, st, alpha); break;
+        case MVI_DT_F16: rc = mvi::bias_residual_launch<__half>(h, x, bias, out, total, C, spatial, st, alpha); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "bias_residual_blend: unknown dtype");
+    }
+    return rc ? mvi::unet_fail(MVI_EHIP, "bias_residual_blend: kernel launch failed") : MVI_OK;
 }
 
 extern "C" int mvi_bias_silu(const void* h, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial, int32_t dtype,

@@ -89,7 +89,7 @@ class SVDInpaintEngine(nn.Module):
             controls = self.control_model(x=xin, hint=hint, timesteps=timesteps, context=context, y=y,
                                           time_context=time_context, num_video_frames=num_video_frames,
                                           image_only_indicator=image_only_indicator)
-            controls = [c * s for c, s in zip(controls, self.control_scales)]
+            controls = [c if s == 1.0 else c * s for c, s in zip(controls, self.control_scales)]   # x * 1.0 is x: skip the pass
             if self.global_average_pooling:
                 controls = [c.mean(dim=(2, 3), keepdim=True) for c in controls]
         return self.model.diffusion_model(x=xin, timesteps=timesteps, context=context, y=y, time_context=time_context,

@@ -324,6 +324,28 @@ def bias_residual_add(h, bias, x):
     return out
 
 
+def bias_residual_blend(h, bias, x, alpha):
+    """x + (1 - alpha[n]) * (h + bias[c]); alpha: [N] (any float dtype), one blend factor per sample of h [N, C, *spatial]."""
+    L = _lib.lib()
+    if h.dtype not in _DT:
+        raise TypeError(f"bias_residual_blend: unsupported dtype {h.dtype}")
+    if x.shape != h.shape or x.dtype != h.dtype:
+        raise ValueError("bias_residual_blend: x must match h in shape and dtype")
+    if alpha.numel() != h.shape[0]:
+        raise ValueError(f"bias_residual_blend: alpha has {alpha.numel()} entries for {h.shape[0]} samples")
+    hc = h if h.is_contiguous() else h.contiguous()
+    xc = x if x.is_contiguous() else x.contiguous()
+    N, Cc = hc.shape[0], hc.shape[1]
+    S = hc.numel() // max(N * Cc, 1)
+    b = None if bias is None else _f32(bias)
+    a = alpha.detach().reshape(-1).float().contiguous()
+    out = torch.empty_like(hc)
+    with torch.cuda.device(h.device), _Timed("bias_residual", 3.0 * hc.numel() * hc.element_size(), h.device):
+        _check(L.mvi_bias_residual_blend(hc.data_ptr(), xc.data_ptr(), None if b is None else b.data_ptr(), a.data_ptr(),
+                                         out.data_ptr(), N, Cc, S, _DT[h.dtype], _stream(h.device)), "bias_residual_blend")
+    return out
+
+
 def bias_silu(h, bias):
     """silu(h + bias[c]) for h [N, C, *spatial], in place on h's (contiguous) memory."""
     L = _lib.lib()

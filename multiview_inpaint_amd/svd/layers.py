@@ -144,8 +144,23 @@ class AlphaBlender(nn.Module):
         if self.merge_strategy == "learned":
             return torch.sigmoid(self.mix_factor)
         assert image_only_indicator is not None, "need image_only_indicator ..."
+        # five tiny kernels per call and ~55 calls per denoise step: without a graph being recorded the result is kept until
+        # the indicator or the mix factor changes (storage address + in-place version counters; the cache holds the
+        # indicator it was computed from, so that address cannot be handed to another tensor meanwhile)
+        m, cacheable = self.mix_factor, not torch.is_grad_enabled()
+        key = (image_only_indicator.data_ptr(), image_only_indicator._version, tuple(image_only_indicator.shape),
+               image_only_indicator.dtype, m.data_ptr(), m._version, m.dtype)
+        hit = self.__dict__.get("_alpha_cache")
+        if cacheable and hit is not None and hit[0] == key:
+            return hit[1]
         ind = image_only_indicator.bool()
         a = torch.where(ind, torch.ones(1, 1, device=ind.device), torch.sigmoid(self.mix_factor)[..., None])
+        a = self._arrange(a)
+        if cacheable:
+            self.__dict__["_alpha_cache"] = (key, a, image_only_indicator)
+        return a
+
+    def _arrange(self, a):
         b, t = a.shape
         if self.rearrange_pattern == "b t -> (b t) 1 1":
             return a.reshape(b * t, 1, 1)
@@ -372,7 +387,7 @@ class VideoResBlock(ResBlock):
                 and tuple(conv.stride) == (1, 1, 1) and not ts.updown and not ts.use_scale_shift_norm and not ts.skip_t_emb
                 and isinstance(ts.skip_connection, nn.Identity))
 
-    def _time_stack_frames(self, x, emb, T):
+    def _time_stack_frames(self, x, emb, T, blend=None):
         """The temporal ResBlock (video_model.py:41-54, openaimodel.py:328-354 with dims=3 and
         exchange_temb_dims) evaluated on x [(b T), c, h, w]: temporal GroupNorm+SiLU with strided
         statistics, (3,1,1) convolutions as channel-stacked 1x1 convolutions, per-frame embedding bias."""
@@ -386,6 +401,8 @@ class VideoResBlock(ResBlock):
             e = e + c1.bias.float()
         h3 = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, stack3=True)
         h = temporal_conv3_stacked(ts.out_layers[2](h3), c2, with_bias=False)
+        if blend is not None:                                      # AlphaBlender folded into the skip add
+            return ops.bias_residual_blend(h, c2.bias, x, blend)
         return ops.bias_residual_add(h, c2.bias, x)
 
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):
@@ -393,12 +410,12 @@ class VideoResBlock(ResBlock):
         t = int(num_video_frames)
         bt, c, h, w = x.shape
         if self._frames_path_ok():
-            xt = self._time_stack_frames(x, emb, t)
             a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)
             if a.ndim == 5:
                 if a.size(0) != bt // t:
                     a = torch.cat([a] * 2)                                 # CFG-doubled batch (util.py:365-367)
-                a = a.transpose(1, 2).reshape(bt, 1, 1, 1)
+                return self._time_stack_frames(x, emb, t, blend=a.reshape(bt))    # (b, t) order = frame-major rows
+            xt = self._time_stack_frames(x, emb, t)
             return torch.lerp(xt, x, a.to(x.dtype))
         xs = x.reshape(bt // t, t, c, h, w).transpose(1, 2)          # b c t h w (view)
         xt = self.time_stack(xs, emb.reshape(bt // t, t, *emb.shape[1:]))

@@ -171,6 +171,17 @@ def bias_residual_add(h, bias=None, x=None):
     return out
 
 
+def bias_residual_blend(h, bias, x, alpha):
+    """alpha * x + (1 - alpha) * (x + h + bias[c]) = x + (1 - alpha) * (h + bias[c]) in one pass; alpha [N] per sample
+    (the temporal ResBlock's skip add followed by AlphaBlender, video_model.py:67-81, util.py:358-372)."""
+    if h.is_cuda and not _needs_autograd(h, bias, x, alpha):
+        from . import hip_ops
+        if not hip_ops.is_channels_last(h):
+            return hip_ops.bias_residual_blend(h, bias, x, alpha)
+    xt = bias_residual_add(h, bias, x)
+    return torch.lerp(xt, x, alpha.reshape(-1, *([1] * (h.ndim - 1))).to(x.dtype))
+
+
 def bias_silu(h, bias):
     """silu(h + bias[c]) for a convolution output h [N, C, *spatial] whose bias was withheld (one pass; may reuse h)."""
     if h.is_cuda and not _needs_autograd(h, bias) and h.is_contiguous():

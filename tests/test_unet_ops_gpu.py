@@ -240,6 +240,26 @@ def test_bias_residual_add(ops, dtype, tol):
             assert out.dtype == dtype and rel(out, ref) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_bias_residual_blend(ops, dtype, tol):
+    """x + (1 - alpha[n]) (h + bias) against AlphaBlender's alpha x + (1 - alpha)(x + h + bias) in fp64; rows with
+    alpha == 1 (image-only frames) return x exactly."""
+    g = torch.Generator().manual_seed(12)
+    for shape in [(6, 64, 24, 16), (4, 96, 5, 7), (28, 320, 9, 16)]:
+        h = torch.randn(shape, generator=g).to(dtype)
+        x = torch.randn(shape, generator=g).to(dtype)
+        b = torch.randn(shape[1], generator=g)
+        a = torch.rand(shape[0], generator=g)
+        a[1] = 1.0
+        av = a.double().view(-1, 1, 1, 1)
+        for bb in (b, None):
+            xt = x.double() + h.double() + (0 if bb is None else bb.double().view(1, -1, 1, 1))
+            ref = av * x.double() + (1 - av) * xt
+            out = ops.bias_residual_blend(h.cuda(), None if bb is None else bb.cuda(), x.cuda(), a.cuda())
+            assert out.dtype == dtype and rel(out, ref) < tol
+            assert torch.equal(out[1].cpu(), x[1])
+
+
 LN_CASES = [(2, 36, 320), (3, 16, 640), (2, 8, 1280), (4, 6, 32), (2, 5, 64), (2, 7, 48), (1, 3, 24), (28, 2304, 640)]
 
 
