@@ -125,6 +125,25 @@ def test_forward_parity_block_boundaries_and_large_footprints(R, ro, N):
     _check_forward(R, ro, cam, sc, bg)
 
 
+def test_parity_with_more_than_65536_tiles(R, ro):
+    """4112 x 4096 pixels = 257 x 256 tiles: tile ids no longer fit the 16-bit sort keys the binning uses up to 65536
+    tiles, so this runs its 32-bit instantiation (emission, both radix passes, tile ranges) — integers bit-exact, image
+    and gradients within tolerance, and pairs with tile ids above 65535 must exist for the case to mean anything."""
+    cam, sc, bg = small_scene(77, N=600, W=4112, H=4096, deg=1, pose=True, log_scale=np.log(0.02))
+    f, p, rs, t, st = _check_forward(R, ro, cam, sc, bg)
+    assert st.views().tile_id_bytes == 4
+    assert ((f["keys_sorted"] >> np.uint64(32)) > 65535).sum() > 100
+    g_img = np.random.default_rng(77).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
+    okw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    b = ro.backward(p, f, g_img, sc["means3D"], **okw)
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
+                             rotations=t["rotations"])
+    torch.cuda.synchronize()
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
+        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+
+
 @pytest.mark.parametrize("seed,deg,mode", [(0, 3, "sh"), (4, 1, "sh"), (5, 2, "precomp"), (6, 0, "sh")])
 def test_backward_parity_small(R, ro, seed, deg, mode):
     cam, sc, bg = small_scene(seed, N=1500, W=160, H=112, deg=deg, log_scale=np.log(0.05))
