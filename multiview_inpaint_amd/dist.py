@@ -14,7 +14,6 @@ FactoredGradExchange all-gathers the 3-float colour factor g of every view (+ th
 the summed SH gradient locally (mvi_raster_sh_backward_views): (W-1) * 12 B + all-reduce of 11 floats per
 Gaussian instead of an all-reduce of 59, i.e. 241 MB instead of 620 MB in and out of each GPU at W = 8, M = 16.
 """
-import math
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch

@@ -7,7 +7,7 @@ own the VAE, the conditioner and checkpoint plumbing (out of scope, SURVEY.md §
 harness owns exactly the per-step hot path: ControlNet -> scaled residuals -> ControlledVideoUNet,
 wrapped by Denoiser and driven by the sampler.
 """
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.nn as nn

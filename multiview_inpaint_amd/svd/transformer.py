@@ -11,7 +11,6 @@ Both attention-mode strings ("softmax", "softmax-xformers") map to the same Cros
 softmax(QK^T/sqrt(d))V runs in ops.attention (HIP on the GPU). No mask is ever passed on the hot
 path; a mask is rejected rather than ignored.
 """
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -10,7 +10,7 @@ The encoder (time/label embedding, input blocks, middle block) is built once by 
 shared by the UNet and the ControlNet, which the reference writes out twice.
 """
 import os
-from typing import List, Optional, Union
+from typing import List, Optional
 
 import torch
 import torch.nn as nn

@@ -14,7 +14,6 @@ same gradient the extension returns:
   * means2D receives d(loss)/d(ndc offset): pixel-space gradient times W/2, H/2
     (consumer: gs-simp/scene/gaussian_model.py:482-484).
 """
-import math
 
 import torch
 

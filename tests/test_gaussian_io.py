@@ -2,7 +2,6 @@
 :267-313) and the (capture(), iteration) checkpoint tuple (:61-93, train.py:132). The reference writes through the absent
 third-party `plyfile`, so the file layout is checked byte for byte against the PLY specification it follows (header text
 + packed little-endian float32 records) and through save -> load round trips in the model's own layouts."""
-import os
 import struct
 
 import numpy as np

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from multiview_inpaint_amd import synthetic as syn
-from raster_helpers import oracle_params, rel_err, small_scene
+from raster_helpers import oracle_params, small_scene
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4

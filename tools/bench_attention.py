@@ -2,7 +2,6 @@
 Usage (GPU box): python tools/bench_attention.py"""
 import os
 import sys
-import time
 
 import torch
 

@@ -1,7 +1,5 @@
 """Vendor-library 3x3 convolution rates at the SVD UNet shapes (bf16), under the layout / autotune switches
 PyTorch exposes. Usage (GPU box): python tools/bench_conv.py"""
-import sys
-import time
 
 import torch
 import torch.nn.functional as F
