@@ -197,3 +197,38 @@ def test_single_key_cross_attention_shortcut_is_exact():
     assert torch.allclose(fast, ref, atol=1e-6)
     with pytest.raises(NotImplementedError):
         att(x, context=ctx, mask=torch.ones(3, 10, 1, dtype=torch.bool))
+
+
+def test_step_invariant_caches_follow_their_inputs():
+    """The per-step tensors that depend only on shapes or on rarely-changing inputs are cached (blend factors of
+    AlphaBlender, the sinusoidal frequency table, the frame-index embedding): the cached values equal the uncached
+    formulas (util.py:207-231, :343-356) and follow in-place changes of their inputs."""
+    import math
+
+    from multiview_inpaint_amd.svd.layers import AlphaBlender, timestep_embedding
+    t = torch.tensor([0.0, 3.5, 999.0])
+    for _ in range(2):                                        # second call is served from the table cache
+        got = timestep_embedding(t, 320)
+        freqs = torch.exp(-math.log(10000) * torch.arange(160, dtype=torch.float32) / 160)
+        ang = t[:, None].float() * freqs[None]
+        assert torch.equal(got, torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1))
+    ab = AlphaBlender(0.3, "learned_with_images", "b t -> b 1 t 1 1")
+    ind = torch.zeros(2, 3)
+    ind[1, 2] = 1.0
+
+    def formula(i):
+        return torch.where(i.bool(), torch.ones(1, 1), torch.sigmoid(ab.mix_factor.detach())[..., None]).reshape(2, 1, 3, 1, 1)
+    with torch.no_grad():
+        a0 = ab.get_alpha(ind)
+        assert torch.equal(a0, formula(ind)) and ab.get_alpha(ind) is a0          # hit
+        ind[0, 0] = 1.0                                                            # in-place change of the indicator
+        a1 = ab.get_alpha(ind)
+        assert a1 is not a0 and torch.equal(a1, formula(ind))
+        ab.mix_factor.add_(0.5)                                                    # an optimizer step
+        a2 = ab.get_alpha(ind)
+        assert a2 is not a1 and torch.equal(a2, formula(ind))
+        other = ind.clone()
+        other[1, 1] = 1.0
+        assert torch.equal(ab.get_alpha(other), formula(other))                    # another tensor
+    a3 = ab.get_alpha(ind)                                                         # autograd on: never cached, differentiable
+    assert a3.requires_grad and torch.equal(a3.detach(), formula(ind))
