@@ -103,4 +103,9 @@ class SVDInpaintEngine(nn.Module):
     @torch.no_grad()
     def sample(self, x, cond: Dict, uc: Optional[Dict] = None, batch_size: int = 16, shape=None, **kwargs):
         randn = torch.randn(batch_size, *shape).to(self.device)     # global torch RNG, as csvd.py:1269
-        return self.sampler(lambda inp, sigma, c: self.denoise(inp, sigma, c, **kwargs), randn, cond, uc=uc)
+        fn = lambda inp, sigma, c: self.denoise(inp, sigma, c, **kwargs)
+        cache = getattr(self.control_model, "hint_cache", None)
+        if cache is None:
+            return self.sampler(fn, randn, cond, uc=uc)
+        with cache():                                               # the hint stem runs once per sample, not per step
+            return self.sampler(fn, randn, cond, uc=uc)

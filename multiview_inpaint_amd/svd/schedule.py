@@ -179,6 +179,25 @@ def _double_cond(c: Dict, uc: Dict, keys: Sequence[str]) -> Dict:
     return out
 
 
+def _cond_key(c: Dict, uc: Dict):
+    return tuple((k, v.data_ptr(), v._version, tuple(v.shape), v.dtype) if torch.is_tensor(v) else (k, id(v))
+                 for d in (c, uc) for k, v in d.items())
+
+
+def _double_cond_cached(guider, c: Dict, uc: Dict, keys: Sequence[str]) -> Dict:
+    """_double_cond, kept while the conditioning tensors are unchanged (storage address + in-place version; the cache
+    holds the dictionaries it was built from). A sampling loop passes the same c / uc in every step: the reference
+    concatenates them again each time (guiders.py:48-57, :87-99) — at 576x1024 the 7-channel control hint alone is a
+    0.7 GB copy per step — and a fresh tensor per step would also defeat the ControlNet's hint-stem cache."""
+    key = _cond_key(c, uc)
+    hit = guider.__dict__.get("_cond_cache")
+    if hit is not None and hit[0] == key:
+        return dict(hit[1])
+    out = _double_cond(c, uc, keys)
+    guider.__dict__["_cond_cache"] = (key, out, c, uc)
+    return dict(out)
+
+
 class IdentityGuider(Guider):
     def __call__(self, x, sigma):
         return x
@@ -196,7 +215,7 @@ class VanillaCFG(Guider):
         return x_u + self.scale * (x_c - x_u)
 
     def prepare_inputs(self, x, s, c, uc):
-        return torch.cat([x] * 2), torch.cat([s] * 2), _double_cond(c, uc, _BATCHED_KEYS)
+        return torch.cat([x] * 2), torch.cat([s] * 2), _double_cond_cached(self, c, uc, _BATCHED_KEYS)
 
 
 class LinearPredictionGuider(Guider):
@@ -214,13 +233,15 @@ class LinearPredictionGuider(Guider):
         t = self.num_frames
         x_u = x_u.reshape(-1, t, *x_u.shape[1:])
         x_c = x_c.reshape(-1, t, *x_c.shape[1:])
-        scale = append_dims(self.scale.expand(x_u.shape[0], t), x_u.ndim).to(x_u.device)
+        if self.scale.device != x_u.device:
+            self.scale = self.scale.to(x_u.device)             # once, not a pageable upload (= queue drain) per step
+        scale = append_dims(self.scale.expand(x_u.shape[0], t), x_u.ndim)
         out = x_u + scale * (x_c - x_u)
         return out.reshape(-1, *out.shape[2:])
 
     def prepare_inputs(self, x, s, c, uc):
         keys = list(_BATCHED_KEYS) + self.additional_cond_keys
-        return torch.cat([x] * 2), torch.cat([s] * 2), _double_cond(c, uc, keys)
+        return torch.cat([x] * 2), torch.cat([s] * 2), _double_cond_cached(self, c, uc, keys)
 
 
 class LinearPredictionGuider2(LinearPredictionGuider):

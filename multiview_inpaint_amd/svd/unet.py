@@ -9,6 +9,7 @@ reference so `load_state_dict` of svd.safetensors and of ControlNet checkpoints 
 The encoder (time/label embedding, input blocks, middle block) is built once by `_Encoder` and
 shared by the UNet and the ControlNet, which the reference writes out twice.
 """
+import contextlib
 import os
 from typing import List, Optional
 
@@ -258,6 +259,33 @@ class ControlNet(_Encoder):
                 i += 1
         return h
 
+    @contextlib.contextmanager
+    def hint_cache(self):
+        """Within this context the output of input_hint_block is computed once per hint instead of once per denoise step.
+        The stem is convolutions and SiLU only (csvd.py:234-250) — it sees neither the timestep embedding nor the
+        latent — so over the 25 steps of one sample its [b T, 320, h, w] output is the same tensor 25 times; at
+        576x1024 it is the most expensive full-resolution part of the step. The cache is keyed on the hint's storage
+        and in-place version and on the stem parameters' versions, never used while autograd records, and dropped at
+        exit. SVDInpaintEngine.sample() enters it; a bare forward() (and bench.py's per-step metric) does not."""
+        self.__dict__["_hint_slot"] = [None]
+        try:
+            yield self
+        finally:
+            self.__dict__.pop("_hint_slot", None)
+
+    def _hint_stem_cached(self, hint, emb, context):
+        slot = self.__dict__.get("_hint_slot")
+        plain = all(isinstance(m, (nn.Conv2d, nn.SiLU)) for m in self.input_hint_block)
+        if slot is None or not plain or torch.is_grad_enabled() or not torch.is_tensor(hint):
+            return self._hint_stem(hint, emb, context)
+        key = (hint.data_ptr(), hint._version, tuple(hint.shape), hint.dtype) + tuple(
+            (p.data_ptr(), p._version) for p in self.input_hint_block.parameters())
+        if slot[0] is not None and slot[0][0] == key:
+            return slot[0][1]
+        guided = self._hint_stem(hint, emb, context)
+        slot[0] = (key, guided, hint)               # holds the hint: its address cannot be reused meanwhile
+        return guided
+
     def make_zero_conv(self, channels):
         return TimestepEmbedSequential(zero_module(conv_nd(self.dims, channels, channels, 1, padding=0)))
 
@@ -266,7 +294,7 @@ class ControlNet(_Encoder):
         emb = self._embed(x, timesteps, y)
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
-        guided = self._hint_stem(hint, emb, context)             # 7-channel full-resolution stem: stays NCHW
+        guided = self._hint_stem_cached(hint, emb, context)      # 7-channel full-resolution stem: stays NCHW
         x, cl = self._enter_channels_last(x)
         outs, h = [], x
         for blk, zc in zip(self.input_blocks, self.zero_convs):

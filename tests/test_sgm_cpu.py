@@ -158,6 +158,22 @@ def test_euler_sampler_trajectory_with_controlnet(G, nets):
     assert rel(traj[0].numpy(), G["sample_denoised_step0"]) < RTOL
     assert rel(traj[4].numpy(), G["sample_denoised_step4"]) < 5 * RTOL
     assert rel(xs.numpy(), G["sample_final"]) < 5 * RTOL
+    # the same loop with the hint stem cached per sample (what SVDInpaintEngine.sample() does): identical trajectory,
+    # the stem evaluated once instead of once per step
+    calls, stem = [0], cnet._hint_stem
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return stem(*a, **k)
+    cnet._hint_stem = counted
+    try:
+        first, traj[:] = list(traj), []
+        with torch.no_grad(), cnet.hint_cache():
+            xs2 = sampler(denoiser, one["x"].clone(), c, uc=uc)
+    finally:
+        del cnet._hint_stem
+    assert calls[0] == 1 and torch.equal(xs2, xs) and all(torch.equal(a, b) for a, b in zip(first, traj))
+    assert "_hint_slot" not in cnet.__dict__
 
 
 def test_full_size_parameter_counts_on_meta():

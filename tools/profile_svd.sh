@@ -9,7 +9,7 @@ cat > /tmp/svd_step.py <<PY
 import sys, torch
 sys.path.insert(0, "$R")
 from multiview_inpaint_amd.svd import bench_svd
-r = bench_svd.run_gpu(torch.device("cuda"), steps=2, warmup=1)
+r = bench_svd.run_gpu(torch.device("cuda"), steps=2, warmup=1, sample_steps=0)
 print(r)
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /tmp/svd_step.py > $OUT/run.log 2>&1
