@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", choices=["both", "raster", "svd"], default="both",
                     help="hot-path halves to run at N=1 (the SVD denoise loop is replicas-only across GPUs)")
-    ap.add_argument("--svd-steps", type=int, default=2)
+    ap.add_argument("--svd-steps", type=int, default=5)
     args = ap.parse_args()
     if args.path in ("both", "svd"):
         # library tables (MIOpen find-db) must be in place before the process first touches MIOpen
@@ -278,7 +278,7 @@ def main():
             t = bucket = st = g_img = None
             torch.cuda.empty_cache()
             from multiview_inpaint_amd.svd import bench_svd
-            svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=1)
+            svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=2)     # 2: the caching allocator still grows in the second call
             svd["metric"] = "SVD 14-frame 576x1024 denoise steps/s (ControlNet + ControlledVideoUNet, CFG batch 28)"
             if not args.no_cpu_baseline:
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()

@@ -174,11 +174,15 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
         step(i)
     torch.cuda.synchronize(device)
     # timed region: no per-op events (an event record idles the GPU for several microseconds, and a step has ~480 HIP ops)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # one record per 200 ms step: no measurable idle
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):
         out = step(i)
+        marks[i + 1].record()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
+    per_step = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
     # separate instrumented pass of the same steps: every HIP op bracketed by events on its launch stream -> per-op table
     hip_ops.PROFILE = []
     for i in range(steps):
@@ -187,7 +191,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     prof = hip_ops.profile_summary()
     hip_ops.PROFILE = None
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
-               controlnet=with_control, gemm_tuning=bool(tuned),
+               step_ms=per_step, controlnet=with_control, gemm_tuning=bool(tuned),
                dtype=("bf16 weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights == "bf16"
                       else "bf16 autocast over fp32 weights, fp32 GroupNorm statistics / softmax"),
                finite=bool(torch.isfinite(out).all()))
