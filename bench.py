@@ -278,7 +278,7 @@ def main():
             t = bucket = st = g_img = None
             torch.cuda.empty_cache()
             from multiview_inpaint_amd.svd import bench_svd
-            svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=2)     # 2: the caching allocator still grows in the second call
+            svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=2)     # one warm-up step left an occasional slow first timed step
             svd["metric"] = "SVD 14-frame 576x1024 denoise steps/s (ControlNet + ControlledVideoUNet, CFG batch 28)"
             if not args.no_cpu_baseline:
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
