@@ -7,6 +7,7 @@ own the VAE, the conditioner and checkpoint plumbing (out of scope, SURVEY.md §
 harness owns exactly the per-step hot path: ControlNet -> scaled residuals -> ControlledVideoUNet,
 wrapped by Denoiser and driven by the sampler.
 """
+import contextlib
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -104,8 +105,9 @@ class SVDInpaintEngine(nn.Module):
     def sample(self, x, cond: Dict, uc: Optional[Dict] = None, batch_size: int = 16, shape=None, **kwargs):
         randn = torch.randn(batch_size, *shape).to(self.device)     # global torch RNG, as csvd.py:1269
         fn = lambda inp, sigma, c: self.denoise(inp, sigma, c, **kwargs)
-        cache = getattr(self.control_model, "hint_cache", None)
-        if cache is None:
-            return self.sampler(fn, randn, cond, uc=uc)
-        with cache():                                               # the hint stem runs once per sample, not per step
-            return self.sampler(fn, randn, cond, uc=uc)
+        cache = getattr(self.control_model, "hint_cache", contextlib.nullcontext)
+        try:
+            with cache():                                           # the hint stem runs once per sample, not per step
+                return self.sampler(fn, randn, cond, uc=uc)
+        finally:                                                    # the guider's doubled conditioning (0.5 GB at 576x1024)
+            getattr(self.sampler, "guider", self.sampler).__dict__.pop("_cond_cache", None)
