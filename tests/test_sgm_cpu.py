@@ -174,6 +174,15 @@ def test_euler_sampler_trajectory_with_controlnet(G, nets):
         del cnet._hint_stem
     assert calls[0] == 1 and torch.equal(xs2, xs) and all(torch.equal(a, b) for a, b in zip(first, traj))
     assert "_hint_slot" not in cnet.__dict__
+    # SVDInpaintEngine.sample(): draws the start from the global RNG (csvd.py:1269), runs the same loop inside the cache
+    torch.manual_seed(5)
+    xs3 = eng.sample(None, c, uc=uc, batch_size=one["x"].shape[0], shape=tuple(one["x"].shape[1:]), num_video_frames=T,
+                     image_only_indicator=one["image_only_indicator"])
+    assert "_hint_slot" not in cnet.__dict__ and "_cond_cache" not in sampler.guider.__dict__      # released with the sample
+    torch.manual_seed(5)
+    with torch.no_grad():
+        xs4 = sampler(denoiser, torch.randn(*one["x"].shape), c, uc=uc)
+    assert torch.equal(xs3, xs4)
 
 
 def test_full_size_parameter_counts_on_meta():
