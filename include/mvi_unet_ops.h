@@ -98,6 +98,13 @@ int mvi_bias_residual_add(const void* h, const void* x, const float* bias, void*
  * alpha * x_spatial + (1 - alpha) * x_temporal (svd_inpaint1/sgm/modules/diffusionmodules/util.py:358-372,
  * video_model.py:67-81). alpha: fp32 [N] on the device (one value per frame: sigmoid(mix_factor), or 1 for image-only
  * frames); bias optional (NULL). out may alias h. */
+/* out[n] = (h[n] | skip[n] + ctrl[n]) concatenated along channels: h [N, C1, spatial], skip and ctrl [N, C2, spatial],
+ * out [N, C1 + C2, spatial], all contiguous; ctrl optional (NULL: a plain concatenation). The decoder's
+ * `h = th.cat([h, hs.pop() + control.pop()], dim=1)` (svd_inpaint1/models/csvd.py:79-91) in one pass instead of an add
+ * and a copy; the sum is rounded once to the storage type, as the reference's separate add does. N < 65536. */
+int mvi_concat_add(const void* h, const void* skip, const void* ctrl, void* out, int64_t N, int32_t C1, int32_t C2,
+                   int64_t spatial, int32_t dtype, void* stream);
+
 int mvi_bias_residual_blend(const void* h, const void* x, const float* bias, const float* alpha, void* out, int64_t N,
                             int32_t C, int64_t spatial, int32_t dtype, void* stream);
 

@@ -34,6 +34,8 @@ def bind(L):
     L.mvi_bias_silu.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp]
     L.mvi_geglu.restype = C.c_int
     L.mvi_geglu.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.mvi_concat_add.restype = C.c_int
+    L.mvi_concat_add.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i32, vp]
     L.mvi_bias_residual_blend.restype = C.c_int
     L.mvi_bias_residual_blend.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i32, vp]
     L.mvi_bias_residual_add.restype = C.c_int

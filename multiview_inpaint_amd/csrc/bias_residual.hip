@@ -118,7 +118,75 @@ static int bias_residual_launch(const void* h, const void* x, const float* bias,
         hipLaunchKernelGGL((bias_residual_kernel<T, false, SILU>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)h, (const T*)x, bias, (T*)out, total, C, S, alpha);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
+// out[n] = (h[n] | skip[n] + ctrl[n]) along channels: the decoder's `torch.cat([h, hs.pop() + control.pop()], dim=1)`
+// (models/csvd.py:79-91) without materialising the sum. blockIdx.y = sample; lanes walk the output row of that sample.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void concat_add_kernel(const T* __restrict__ h, const T* __restrict__ skip,
+                                                         const T* __restrict__ ctrl, T* __restrict__ out,
+                                                         int64_t n1, int64_t n2) {      // n1 = C1 * S, n2 = C2 * S
+    constexpr int N = VEC ? BVec<T>::N : 1;
+    const int64_t n = blockIdx.y;
+    const T* __restrict__ hp = h + n * n1;
+    const T* __restrict__ sp = skip + n * n2;
+    const T* __restrict__ cp = ctrl ? ctrl + n * n2 : nullptr;
+    T* __restrict__ op = out + n * (n1 + n2);
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * N; e < n1 + n2; e += (int64_t)gridDim.x * 256 * N) {
+        if (VEC) {
+            float a[BVec<T>::N];
+            if (e < n1) {
+                BVec<T>::load(hp + e, a);
+            } else {
+                BVec<T>::load(sp + (e - n1), a);
+                if (cp) {
+                    float r[BVec<T>::N];
+                    BVec<T>::load(cp + (e - n1), r);
+#pragma unroll
+                    for (int k = 0; k < BVec<T>::N; ++k) a[k] += r[k];
+                }
+            }
+            BVec<T>::store(op + e, a);
+        } else {
+            float a = e < n1 ? BVec<T>::ld1(hp + e) : BVec<T>::ld1(sp + (e - n1)) + (cp ? BVec<T>::ld1(cp + (e - n1)) : 0.0f);
+            BVec<T>::st1(op + e, a);
+        }
+    }
+}
+
+template <typename T>
+static int concat_add_launch(const void* h, const void* skip, const void* ctrl, void* out, int64_t N_, int64_t n1, int64_t n2,
+                             hipStream_t st) {
+    constexpr int V = BVec<T>::N;
+    const bool vec = n1 % V == 0 && n2 % V == 0 &&
+                     (((uintptr_t)h | (uintptr_t)skip | (uintptr_t)ctrl | (uintptr_t)out) % 16 == 0);
+    int64_t work = vec ? (n1 + n2) / V : n1 + n2;
+    int64_t bx = (work + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    if (bx < 1) bx = 1;
+    const dim3 grid((unsigned)bx, (unsigned)N_);
+    if (vec)
+        hipLaunchKernelGGL((concat_add_kernel<T, true>), grid, dim3(256), 0, st, (const T*)h, (const T*)skip, (const T*)ctrl, (T*)out, n1, n2);
+    else
+        hipLaunchKernelGGL((concat_add_kernel<T, false>), grid, dim3(256), 0, st, (const T*)h, (const T*)skip, (const T*)ctrl, (T*)out, n1, n2);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
 }  // namespace mvi
+
+extern "C" int mvi_concat_add(const void* h, const void* skip, const void* ctrl, void* out, int64_t N, int32_t C1, int32_t C2,
+                              int64_t spatial, int32_t dtype, void* stream) {
+    if (N < 0 || N > 65535 || C1 < 0 || C2 < 0 || spatial < 0) return mvi::unet_fail(MVI_EINVAL, "concat_add: bad shape (N must be below 65536)");
+    const int64_t n1 = (int64_t)C1 * spatial, n2 = (int64_t)C2 * spatial;
+    if (N == 0 || n1 + n2 == 0) return MVI_OK;
+    if ((n1 && !h) || (n2 && !skip) || !out) return mvi::unet_fail(MVI_EINVAL, "concat_add: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::concat_add_launch<float>(h, skip, ctrl, out, N, n1, n2, st); break;
+        case MVI_DT_BF16: rc = mvi::concat_add_launch<__hip_bfloat16>(h, skip, ctrl, out, N, n1, n2, st); break;
+        case MVI_DT_F16: rc = mvi::concat_add_launch<__half>(h, skip, ctrl, out, N, n1, n2, st); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "concat_add: unknown dtype");
+    }
+    return rc ? mvi::unet_fail(MVI_EHIP, "concat_add: kernel launch failed") : MVI_OK;
+}
 
 extern "C" int mvi_bias_residual_add(const void* h, const void* x, const float* bias, void* out, int64_t N, int32_t C,
                                      int64_t spatial, int32_t dtype, void* stream) {

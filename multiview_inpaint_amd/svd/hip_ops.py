@@ -324,6 +324,25 @@ def bias_residual_add(h, bias, x):
     return out
 
 
+def concat_add(h, skip, ctrl):
+    """cat([h, skip + ctrl], dim=1) in one pass; ctrl may be None. All operands contiguous [N, C, *spatial], one dtype."""
+    L = _lib.lib()
+    if h.dtype not in _DT or skip.dtype != h.dtype or (ctrl is not None and ctrl.dtype != h.dtype):
+        raise TypeError("concat_add: operands must share a supported dtype")
+    if skip.shape[0] != h.shape[0] or skip.shape[2:] != h.shape[2:] or (ctrl is not None and ctrl.shape != skip.shape):
+        raise ValueError("concat_add: shapes do not line up")
+    if not (h.is_contiguous() and skip.is_contiguous() and (ctrl is None or ctrl.is_contiguous())):
+        raise ValueError("concat_add: operands must be contiguous")
+    N, C1, C2 = h.shape[0], h.shape[1], skip.shape[1]
+    S = h.numel() // max(N * C1, 1) if C1 else skip.numel() // max(N * C2, 1)
+    out = torch.empty((N, C1 + C2, *h.shape[2:]), dtype=h.dtype, device=h.device)
+    nbytes = (2.0 * h.numel() + (2.0 + (ctrl is not None)) * skip.numel()) * h.element_size()
+    with torch.cuda.device(h.device), _Timed("concat_add", nbytes, h.device):
+        _check(L.mvi_concat_add(h.data_ptr(), skip.data_ptr(), None if ctrl is None else ctrl.data_ptr(), out.data_ptr(),
+                                N, C1, C2, S, _DT[h.dtype], _stream(h.device)), "concat_add")
+    return out
+
+
 def bias_residual_blend(h, bias, x, alpha):
     """x + (1 - alpha[n]) * (h + bias[c]); alpha: [N] (any float dtype), one blend factor per sample of h [N, C, *spatial]."""
     L = _lib.lib()

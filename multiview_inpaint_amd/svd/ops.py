@@ -171,6 +171,17 @@ def bias_residual_add(h, bias=None, x=None):
     return out
 
 
+def concat_add(h, skip, ctrl=None):
+    """torch.cat([h, skip + ctrl], dim=1) — the decoder's skip concatenation with the ControlNet residual added on the
+    way (models/csvd.py:79-91) — as one pass over contiguous NCHW activations."""
+    if (h.is_cuda and not _needs_autograd(h, skip, ctrl) and h.dtype == skip.dtype and (ctrl is None or ctrl.dtype == h.dtype)
+            and h.is_contiguous() and skip.is_contiguous() and (ctrl is None or (ctrl.is_contiguous() and ctrl.shape == skip.shape))
+            and h.shape[0] < 65536):
+        from . import hip_ops
+        return hip_ops.concat_add(h, skip, ctrl)
+    return torch.cat([h, skip if ctrl is None else skip + ctrl], dim=1)
+
+
 def bias_residual_blend(h, bias, x, alpha):
     """alpha * x + (1 - alpha) * (x + h + bias[c]) = x + (1 - alpha) * (h + bias[c]) in one pass; alpha [N] per sample
     (the temporal ResBlock's skip add followed by AlphaBlender, video_model.py:67-81, util.py:358-372)."""

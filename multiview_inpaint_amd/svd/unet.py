@@ -19,6 +19,7 @@ import torch.nn as nn
 from .layers import (Downsample, TimestepEmbedSequential, Timestep, Upsample, VideoResBlock, conv_nd, linear,
                      norm_act, normalization, timestep_embedding, zero_module)
 from .transformer import SpatialVideoTransformer
+from . import ops
 
 
 class _Encoder(nn.Module):
@@ -198,9 +199,7 @@ class VideoUNet(_Encoder):
             h = h + control.pop()                          # consumes the caller's list (csvd.py:79-91)
         for blk in self.output_blocks:
             skip = hs.pop()
-            if control is not None:
-                skip = skip + control.pop()
-            h = blk(torch.cat([h, skip], dim=1), emb, **kw)
+            h = blk(ops.concat_add(h, skip, control.pop() if control is not None else None), emb, **kw)
         h = h.type(x.dtype)
         out = self.out[2](norm_act(self.out, h))
         return out.contiguous() if cl else out

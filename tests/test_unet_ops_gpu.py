@@ -311,6 +311,21 @@ def test_bias_residual_blend(ops, dtype, tol):
             assert torch.equal(out[1].cpu(), x[1])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_concat_add_is_bit_exact(ops, dtype):
+    """cat([h, skip + ctrl], 1) in one pass: bit-identical to the two PyTorch ops (one rounding of the sum), with and
+    without ctrl, vector and scalar paths (odd spatial sizes), and C1 != C2."""
+    g = torch.Generator().manual_seed(13)
+    for N, C1, C2, sp in [(4, 64, 64, (24, 16)), (3, 96, 32, (5, 7)), (28, 320, 320, (9, 16)), (2, 7, 5, (3, 3))]:
+        h = torch.randn(N, C1, *sp, generator=g).to(dtype).cuda()
+        sk = torch.randn(N, C2, *sp, generator=g).to(dtype).cuda()
+        ct = torch.randn(N, C2, *sp, generator=g).to(dtype).cuda()
+        assert torch.equal(ops.concat_add(h, sk, ct), torch.cat([h, sk + ct], 1))
+        assert torch.equal(ops.concat_add(h, sk, None), torch.cat([h, sk], 1))
+    with pytest.raises(ValueError):
+        ops.concat_add(h, sk[:, :, :2], None)
+
+
 LN_CASES = [(2, 36, 320), (3, 16, 640), (2, 8, 1280), (4, 6, 32), (2, 5, 64), (2, 7, 48), (1, 3, 24), (28, 2304, 640)]
 
 
