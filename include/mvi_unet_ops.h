@@ -136,31 +136,11 @@ int mvi_add_lerp(const void* x, const void* h, const void* base, const float* al
 int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64_t N, int32_t C, int64_t spatial,
                              int32_t dtype, void* stream);
 
-/* GroupNorm(+SiLU) on CHANNELS-LAST activations x [(videos*T), spatial, C] (the memory of a torch.channels_last
- * [N, C, H, W] tensor = the token-major [N, (h w), C] tensor of the transformer stems): statistics per (video, group)
- * over T frames x spatial positions x C/groups channels (T = 1: the ordinary GroupNorm), optional chan_bias [(videos*T), C]
- * added first, optional SiLU, output in the same layout or — stack3 — as rows of 3C channels (frame t-1 | t | t+1,
- * zeros at the ends) for the (3,1,1) temporal convolution evaluated as one GEMM. Same reference lines as
- * mvi_groupnorm_silu_ex. With the UNet in this layout the library convolutions run their NHWC kernels without layout
- * transposes and "b c h w <-> b (h w) c" is free. C must be a multiple of the 16-byte vector (4 fp32 / 8 bf16, f16);
- * mvi_groupnorm_nhwc_supported tells whether a (C, groups, dtype) is handled. */
-size_t mvi_groupnorm_nhwc_workspace_bytes(int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups);
-int mvi_groupnorm_silu_nhwc(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
-                            int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups, float eps,
-                            int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace, size_t workspace_bytes,
-                            void* stream);
-int mvi_groupnorm_nhwc_supported(int32_t C, int32_t groups, int32_t dtype);
-
 /* out = silu(h + bias[c]) for h [N, C, spatial]: convolution bias + SiLU of the ControlNet hint stem
  * (svd_inpaint1/models/csvd.py:234-250: eight convolutions with SiLU between, at up to 576x1024) in one pass instead of
  * the library's broadcast bias add followed by a separate activation. out may alias h. */
 int mvi_bias_silu(const void* h, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial, int32_t dtype,
                   void* stream);
-
-/* out[r, c] = h[r, c] + bias[c] (+ x[r, c]) on channels-last rows [rows, C] (mvi_bias_residual_add for that layout;
- * with bias NULL it is also "tokens + planes" of the transformer exit). */
-int mvi_bias_residual_add_nhwc(const void* h, const void* x, const float* bias, void* out, int64_t rows, int32_t C,
-                               int32_t dtype, void* stream);
 
 /* The same two attention ops reading q, k, v with a token stride larger than H*D — for q, k, v taken straight out of
  * ONE packed projection [.., 3*H*D] = (q | k | v) (token stride 3*H*D, base pointers H*D apart): the three bias-free

@@ -22,14 +22,6 @@ def bind(L):
     L.mvi_attention_forward_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i64, i64, i64, vp]
     L.mvi_attention_temporal_strided.restype = C.c_int
     L.mvi_attention_temporal_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i64, i64, vp]
-    L.mvi_groupnorm_nhwc_workspace_bytes.restype = sz
-    L.mvi_groupnorm_nhwc_workspace_bytes.argtypes = [i64, i32, i32, i64, i32]
-    L.mvi_groupnorm_silu_nhwc.restype = C.c_int
-    L.mvi_groupnorm_silu_nhwc.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i32, f32, i32, i32, i32, vp, sz, vp]
-    L.mvi_groupnorm_nhwc_supported.restype = C.c_int
-    L.mvi_groupnorm_nhwc_supported.argtypes = [i32, i32, i32]
-    L.mvi_bias_residual_add_nhwc.restype = C.c_int
-    L.mvi_bias_residual_add_nhwc.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
     L.mvi_bias_silu.restype = C.c_int
     L.mvi_bias_silu.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp]
     L.mvi_geglu.restype = C.c_int

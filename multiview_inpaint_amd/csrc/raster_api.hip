@@ -8,7 +8,7 @@
 #include "raster_common.h"
 
 namespace mvi {
-int launch_scan_block_sums(GeomView g, int P, uint32_t* total_host_devptr, hipStream_t st);
+int launch_scan_block_sums(GeomView g, int P, unsigned long long* total_host_devptr, hipStream_t st);
 int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 }
@@ -160,15 +160,26 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     // num_rendered comes back through a pinned, device-mapped word that the totalling kernel writes itself + an event
     // recorded right behind it; binning level 1 (independent of num_rendered) is queued before the host waits: the host
     // wakes up as soon as the count is there and allocates / launches stage 2 while the device is still sorting
-    static thread_local uint32_t* pinned = nullptr;
-    static thread_local uint32_t* pinned_dev = nullptr;
-    static thread_local hipEvent_t ev = nullptr;
+    // The word and the event belong to ONE device: a thread that drives several GPUs gets one set per device (the mapped
+    // pointer is only valid on the device it was obtained for, and an event cannot be recorded on another device's stream).
+    struct Readback { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; };
+    constexpr int kMaxDevices = 64;
+    static thread_local Readback readbacks[kMaxDevices];
     hipError_t e;
-    if (!pinned) {
-        if ((e = hipHostMalloc((void**)&pinned, sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return hip_fail("hipHostMalloc", e);
-        if ((e = hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0)) != hipSuccess) return hip_fail("hipHostGetDevicePointer", e);
-        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail("hipEventCreate", e);
+    int device = -1;
+    if ((e = hipGetDevice(&device)) != hipSuccess) return hip_fail("hipGetDevice", e);
+    if (device < 0 || device >= kMaxDevices) return fail(MVI_EINVAL, "device index out of range%s: %lld", "", (long long)device);
+    Readback& rb = readbacks[device];
+    if (!rb.host) {
+        unsigned long long* h = nullptr;
+        if ((e = hipHostMalloc((void**)&h, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess) return hip_fail("hipHostMalloc", e);
+        if ((e = hipHostGetDevicePointer((void**)&rb.dev, h, 0)) != hipSuccess) { (void)hipHostFree(h); return hip_fail("hipHostGetDevicePointer", e); }
+        if ((e = hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming)) != hipSuccess) { (void)hipHostFree(h); return hip_fail("hipEventCreate", e); }
+        rb.host = h;
     }
+    unsigned long long* const pinned = rb.host;
+    unsigned long long* const pinned_dev = rb.dev;
+    const hipEvent_t ev = rb.ev;
     {
         mvi::StageTimer tm(mvi::kStScan, st);
         if (mvi::launch_scan_block_sums(g, P, pinned_dev, st)) return hip_fail("scan_block_sums", hipGetLastError());
@@ -177,7 +188,10 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     if (mvi::launch_binning_level1(f, g, st)) return hip_fail("binning level 1", hipGetLastError());
     e = hipEventSynchronize(ev);
     if (e != hipSuccess) return hip_fail("forward_geom sync", e);
-    const uint32_t total = *pinned;
+    const unsigned long long total = *pinned;
+    // pair offsets, tile ranges and the sort's scatter positions are 32-bit: more pairs than that cannot be binned
+    if (total > 0xFFFFFFFFull)
+        return fail(MVI_EINVAL, "num_rendered exceeds the 32-bit pair offsets%s: %lld pairs", "", (long long)total);
     *num_rendered_host = (int64_t)total;
     return MVI_OK;
 }

@@ -366,25 +366,26 @@ __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const KeyT* __restr
 // scan used to put it (offsets[n]).
 __global__ __launch_bounds__(1024) void total_block_sums_kernel(const uint32_t* __restrict__ sums,
                                                                 uint32_t* __restrict__ offsets, int n,
-                                                                uint32_t* __restrict__ total_host) {
-    __shared__ uint32_t s_wave[16];
-    uint32_t acc = 0;
+                                                                unsigned long long* __restrict__ total_host) {
+    __shared__ unsigned long long s_wave[16];
+    unsigned long long acc = 0;                       // 64-bit: the host rejects totals the 32-bit pair offsets cannot hold
     for (int i = threadIdx.x; i < n; i += 1024) acc += sums[i];
-    acc = wave_sum_u32(acc);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
+        unsigned long long t = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += s_wave[w];
-        offsets[n] = t;
+        offsets[n] = (uint32_t)t;
         // num_rendered goes straight into the caller's pinned, device-mapped word: no D2H copy launch (its blit path idles
         // the queue like the memset's); the event recorded behind this kernel makes the store visible to the host
         if (total_host) __hip_atomic_store(total_host, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-int launch_scan_block_sums(GeomView g, int P, uint32_t* total_host_devptr, hipStream_t st) {
+int launch_scan_block_sums(GeomView g, int P, unsigned long long* total_host_devptr, hipStream_t st) {
     int nblk = (P + kPB - 1) / kPB;
     hipLaunchKernelGGL(total_block_sums_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_offsets, nblk,
                        total_host_devptr);

@@ -61,8 +61,10 @@ def save_ply(path: str, xyz, features_dc, features_rest, opacity, scaling, rotat
 
 
 def read_ply_vertices(path: str) -> Dict[str, np.ndarray]:
-    """Minimal PLY reader for the files this pipeline exchanges: one `vertex` element of scalar properties,
-    `binary_little_endian` or `ascii`. Returns {property name: [N] array}."""
+    """Minimal PLY reader for the files this pipeline exchanges: a leading `vertex` element of scalar properties,
+    `binary_little_endian`, `binary_big_endian` or `ascii`. Elements declared after `vertex` (the `element face 0`
+    MeshLab / Open3D / CloudCompare write) are ignored: the vertex block comes first in the body, only its n records
+    are read — as plyfile, which the reference's load_ply uses, does. Returns {property name: [N] array}."""
     with open(path, "rb") as f:
         if f.readline().strip() != b"ply":
             raise ValueError(f"{path}: not a PLY file")
@@ -77,26 +79,27 @@ def read_ply_vertices(path: str) -> Dict[str, np.ndarray]:
             if tok[0] == "format":
                 fmt = tok[1]
             elif tok[0] == "element":
-                if in_vertex:
-                    raise ValueError(f"{path}: only a single vertex element is supported")
-                in_vertex = tok[1] == "vertex"
-                if in_vertex:
-                    n = int(tok[2])
+                if tok[1] == "vertex" and n is None:
+                    in_vertex, n = True, int(tok[2])
                 elif n is None:
                     raise ValueError(f"{path}: the first element must be `vertex`")
+                else:
+                    in_vertex = False                           # a later element: its properties are not ours
             elif tok[0] == "property":
-                if tok[1] == "list":
-                    raise ValueError(f"{path}: list properties are not supported")
                 if in_vertex:
+                    if tok[1] == "list":
+                        raise ValueError(f"{path}: list properties on the vertex element are not supported")
                     props.append((tok[2], _PLY_TYPES[tok[1]]))
             elif tok[0] == "end_header":
                 break
         if n is None:
             raise ValueError(f"{path}: no vertex element")
-        if fmt == "binary_little_endian":
+        if fmt in ("binary_little_endian", "binary_big_endian"):
             rec = np.dtype(props)
+            if fmt == "binary_big_endian":
+                rec = rec.newbyteorder(">")
             data = np.frombuffer(f.read(n * rec.itemsize), dtype=rec, count=n)
-            return {name: np.asarray(data[name]) for name, _ in props}
+            return {name: np.ascontiguousarray(data[name]).astype(np.dtype(t), copy=False) for name, t in props}
         if fmt == "ascii":
             rows = np.loadtxt(f, dtype=np.float64, max_rows=n, ndmin=2)
             return {name: rows[:, i].astype(np.dtype(t)) for i, (name, t) in enumerate(props)}

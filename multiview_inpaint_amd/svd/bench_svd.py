@@ -148,13 +148,8 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     (it uses fp16 autocast, models/csvd.py:27-31)."""
     from . import hip_ops
     from .schedule import EDMDiscretization
-    # NCHW: let MIOpen time its convolution solvers during warm-up (+10 % on the 3x3 convolutions, ~1 min of search).
-    # Channels-last (the default on the GPU): its immediate-mode choice is already the fastest NHWC kernel (measured:
-    # 238 ms / step with and without the search, which takes 250 s for these shapes), so no search.
-    from .unet import _Encoder
-    torch.backends.cudnn.benchmark = not _Encoder.channels_last
-    if _Encoder.channels_last:
-        warmup = max(warmup, 2)     # MIOpen still builds kernels during the second call of a shape on a cold kernel cache
+    # let MIOpen time its convolution solvers during warm-up (+10 % on the 3x3 convolutions; with the shipped find-db a look-up)
+    torch.backends.cudnn.benchmark = True
     use_shipped_miopen_db()
     tuned = enable_gemm_tuning()
     eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)

@@ -106,8 +106,16 @@ class SVDInpaintEngine(nn.Module):
         randn = torch.randn(batch_size, *shape).to(self.device)     # global torch RNG, as csvd.py:1269
         fn = lambda inp, sigma, c: self.denoise(inp, sigma, c, **kwargs)
         cache = getattr(self.control_model, "hint_cache", contextlib.nullcontext)
-        try:
-            with cache():                                           # the hint stem runs once per sample, not per step
-                return self.sampler(fn, randn, cond, uc=uc)
-        finally:                                                    # the guider's doubled conditioning (0.5 GB at 576x1024)
-            getattr(self.sampler, "guider", self.sampler).__dict__.pop("_cond_cache", None)
+        if not torch.is_autocast_enabled():
+            # reduced-precision parameters without autocast: cast the step-invariant conditioning ONCE per sample, not
+            # in every apply_model call (a fresh 0.7 GB hint tensor per step would also miss the hint-stem cache, which
+            # is keyed on the hint's storage)
+            wd = self.model.diffusion_model.time_embed[0].weight.dtype
+            once = lambda d: None if d is None else {k: (v.to(wd) if torch.is_tensor(v) and v.is_floating_point() and k in
+                                                         ("control_hint", "concat", "crossattn", "vector") else v) for k, v in d.items()}
+            shared_hint = uc is not None and cond.get("control_hint") is not None and uc.get("control_hint") is cond.get("control_hint")
+            cond, uc = once(cond), once(uc)
+            if shared_hint:
+                uc["control_hint"] = cond["control_hint"]           # still ONE tensor in both halves, as the caller passed it
+        with cache():                                               # the hint stem runs once per sample, not per step
+            return self.sampler(fn, randn, cond, uc=uc)             # (the sampler drops the guider's doubled conditioning)

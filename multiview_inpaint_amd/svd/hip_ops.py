@@ -1,6 +1,7 @@
 """GPU implementations of multiview_inpaint_amd.svd.ops through the C-ABI HIP library
 (include/mvi_unet_ops.h). Importing this module without libmvi_hip.so raises."""
 import ctypes as C
+import weakref
 
 import torch
 
@@ -65,18 +66,21 @@ _f32_cache = {}
 
 
 def _f32(p):
-    """fp32 contiguous copy of a (small) parameter, cached per (storage, version): the kernels take their affine
-    parameters in fp32, the bf16-weights model stores them in bf16, and converting on every call costs a launch."""
+    """fp32 contiguous copy of a (small) parameter, cached per parameter object: the kernels take their affine
+    parameters in fp32, the bf16-weights model stores them in bf16, and converting on every call costs a launch.
+    The entry holds a weak reference to the parameter it was made from: Python reuses object ids and the caching
+    allocator reuses addresses, so (id, data_ptr, version) of a freed model's parameter can all recur in the next
+    model — a dead or different referent is a miss."""
     if p.dtype == torch.float32 and p.is_contiguous():
         return p.detach()
     key = (p.data_ptr(), p._version, p.dtype, tuple(p.shape), p.device)
     hit = _f32_cache.get(id(p))
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[2]() is p:
         return hit[1]
     t = p.detach().float().contiguous()
     if len(_f32_cache) > 8192:
         _f32_cache.clear()
-    _f32_cache[id(p)] = (key, t)
+    _f32_cache[id(p)] = (key, t, weakref.ref(p))
     return t
 
 
@@ -101,60 +105,6 @@ def _gn(x, T, num_groups, weight, bias, eps, silu, chan_bias, stack3):
                                        int(bool(silu)), int(bool(stack3)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
                                        _stream(xc.device)), "group_norm")
     return y
-
-
-def is_channels_last(x):
-    """A 4-D tensor whose memory is [N, H, W, C] (and not also plain contiguous, e.g. C == 1 or H == W == 1)."""
-    return x.ndim == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
-
-
-def nhwc_supported(C_, num_groups, dtype):
-    return dtype in _DT and bool(_lib.lib().mvi_groupnorm_nhwc_supported(int(C_), int(num_groups), _DT[dtype]))
-
-
-def group_norm_nhwc(x, T, num_groups, weight, bias, eps, silu, chan_bias=None, stack3=False, tokens_out=False):
-    """GroupNorm(+SiLU) of a channels-last x [(b T), C, H, W] (memory [(b T), H, W, C]); statistics per (video, group)
-    over the T frames. Returns a channels-last [(b T), C or 3C, H, W] tensor, or the same memory as tokens
-    [(b T), H*W, C] with tokens_out."""
-    L = _lib.lib()
-    if x.dtype not in _DT:
-        raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
-    N, Cc, H, W = x.shape
-    S = H * W
-    Co = 3 * Cc if stack3 else Cc
-    y = torch.empty((N, H, W, Co), dtype=x.dtype, device=x.device)
-    cb = None
-    if chan_bias is not None:
-        cb = chan_bias.detach().float().contiguous()
-        if cb.shape != (N, Cc):
-            raise ValueError(f"group_norm: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
-    ws = _workspace(x.device, L.mvi_groupnorm_nhwc_workspace_bytes(N // T, int(T), Cc, S, num_groups))
-    kind = "groupnorm_tokens" if tokens_out else "groupnorm"
-    with torch.cuda.device(x.device), _Timed(kind, (2.0 + 2.0 * bool(stack3)) * x.numel() * x.element_size(), x.device):
-        _check(L.mvi_groupnorm_silu_nhwc(x.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
-                                         None if cb is None else cb.data_ptr(), N // T, int(T), Cc, S, num_groups, float(eps),
-                                         int(bool(silu)), int(bool(stack3)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
-                                         _stream(x.device)), "group_norm (channels-last)")
-    return y.view(N, S, Co) if tokens_out else y.permute(0, 3, 1, 2)
-
-
-def bias_residual_add_nhwc(h, bias, x):
-    """h + bias[c] + x for channels-last h, x [N, C, H, W] (or token rows [N, S, C] for either): returns a channels-last
-    [N, C, H, W] tensor shaped like the 4-D operand."""
-    L = _lib.lib()
-    ref = h if h.ndim == 4 else x
-    N, Cc, H, W = ref.shape
-    if h.dtype not in _DT or (x is not None and x.dtype != h.dtype):
-        raise TypeError("bias_residual_add: h and x must share a supported dtype")
-    if h.numel() != ref.numel() or (x is not None and x.numel() != ref.numel()):
-        raise ValueError("bias_residual_add: operand sizes differ")
-    out = torch.empty((N, H, W, Cc), dtype=h.dtype, device=h.device)
-    b = None if bias is None else _f32(bias)
-    with torch.cuda.device(h.device), _Timed("bias_residual", (2.0 + (x is not None)) * h.numel() * h.element_size(), h.device):
-        _check(L.mvi_bias_residual_add_nhwc(h.data_ptr(), None if x is None else x.data_ptr(), None if b is None else b.data_ptr(),
-                                            out.data_ptr(), N * H * W, Cc, _DT[h.dtype], _stream(h.device)),
-               "bias_residual_add (channels-last)")
-    return out.permute(0, 3, 1, 2)
 
 
 def group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=None):

@@ -87,24 +87,9 @@ def normalization(channels):
     return GroupNorm32(32, channels)
 
 
-def _is_cl(x):
-    return x.is_cuda and x.ndim == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
-
-
-def _rows_linear(x, w2d, bias):
-    """1x1 convolution of a channels-last x [N, Ci, H, W] as a GEMM over its token rows; channels-last result."""
-    N, Ci, H, W = x.shape
-    y = F.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, Ci), w2d, bias)
-    return y.view(N, H, W, -1).permute(0, 3, 1, 2)
-
-
 def conv_no_bias(conv, x, bias=None):
     """The convolution with its bias withheld (or replaced): the caller folds the bias into the next fused op,
-    because PyTorch-ROCm otherwise adds it in a separate broadcast pass over the whole activation. A 1x1 convolution of
-    a channels-last tensor is a plain GEMM over the token rows (measured faster than the library's NHWC 1x1 kernel)."""
-    if (_is_cl(x) and isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
-            and conv.padding == (0, 0) and conv.groups == 1 and not torch.is_grad_enabled()):
-        return _rows_linear(x, conv.weight.reshape(conv.out_channels, conv.in_channels), bias)
+    because PyTorch-ROCm otherwise adds it in a separate broadcast pass over the whole activation."""
     return conv._conv_forward(x, conv.weight, bias)
 
 
@@ -334,8 +319,6 @@ def temporal_conv3_stacked(x3, conv: nn.Conv3d, with_bias=True):
         hit = (key, w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(conv.out_channels, ci3).contiguous())
         conv._w_stacked = hit
     wt = hit[1] if not (torch.is_grad_enabled() and w.requires_grad) else w[:, :, :, 0, 0].permute(0, 2, 1).reshape(conv.out_channels, ci3)
-    if _is_cl(x3) and not torch.is_grad_enabled():
-        return _rows_linear(x3, wt, conv.bias if with_bias else None)
     return F.conv2d(x3, wt.reshape(conv.out_channels, ci3, 1, 1), conv.bias if with_bias else None)
 
 

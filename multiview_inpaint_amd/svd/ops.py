@@ -11,12 +11,38 @@ Reference ops: GroupNorm32 + SiLU (sgm/modules/diffusionmodules/util.py:259-276,
 openaimodel.py:257-261,292-305), Normalize (sgm/modules/attention.py:125-128),
 softmax(QK^T d^-1/2)V (sgm/modules/attention.py:332-336, :427-439).
 """
+import os
+
 import torch
 import torch.nn.functional as F
+
+# Strict mode (MVI_STRICT=1, or ops.STRICT = True): a GPU tensor that would leave the HIP path — a shape / contiguity
+# gate that fails, or a tensor that requires grad — raises instead of running PyTorch-ROCm's ops. The GPU tests and
+# bench_svd.run_gpu run with it, so "the full-size step took the HIP branch everywhere" is asserted, not assumed.
+STRICT = os.environ.get("MVI_STRICT", "0") == "1"
+FALLBACKS = []          # (op, reason) of every GPU-tensor fallback taken when not strict (diagnostics)
+
+
+class HipPathError(RuntimeError):
+    pass
+
+
+def _fallback(t, op, reason):
+    """Called right before a PyTorch substitute runs. CPU tensors: that IS the CPU path. GPU tensors: raise in strict
+    mode, otherwise record."""
+    if t is not None and t.is_cuda:
+        if STRICT:
+            raise HipPathError(f"{op}: GPU tensor left the HIP path ({reason}); MVI_STRICT forbids the PyTorch substitute")
+        if len(FALLBACKS) < 4096:
+            FALLBACKS.append((op, reason))
 
 
 def _needs_autograd(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _why(*ts):
+    return "requires grad" if _needs_autograd(*ts) else "shape / layout gate"
 
 
 def _stack3(y, T):
@@ -35,9 +61,8 @@ def group_norm(x, num_groups, weight, bias, eps, silu=False, chan_bias=None):
     chan_bias [N, C] (optional) is added to x first (the ResBlock's timestep-embedding bias)."""
     if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
-        if hip_ops.is_channels_last(x) and hip_ops.nhwc_supported(x.shape[1], num_groups, x.dtype):
-            return hip_ops.group_norm_nhwc(x, 1, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
         return hip_ops.group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+    _fallback(x, "group_norm", _why(x, weight, bias, chan_bias))
     xf = x.float()
     if chan_bias is not None:
         xf = xf + chan_bias.float().reshape(*chan_bias.shape, *([1] * (x.ndim - 2)))
@@ -51,11 +76,11 @@ def group_norm_tokens(x, num_groups, weight, bias, eps, silu=False, chan_bias=No
     S = x[0, 0].numel()
     if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
-        if hip_ops.is_channels_last(x) and hip_ops.nhwc_supported(x.shape[1], num_groups, x.dtype):
-            # channels-last activations ARE token-major: no transpose at all
-            return hip_ops.group_norm_nhwc(x, 1, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, tokens_out=True)
         if x.shape[1] % 8 == 0 and S % 8 == 0:
             return hip_ops.group_norm_silu_tokens(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+        # odd channel / token counts: the plain HIP GroupNorm, then PyTorch's transpose copy (small tensors only)
+        return hip_ops.group_norm_silu(x, num_groups, weight, bias, eps, silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
+    _fallback(x, "group_norm_tokens", _why(x, weight, bias, chan_bias))
     return group_norm(x, num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
 
 
@@ -67,9 +92,8 @@ def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False, chan_bias
     convolution evaluated as one 1x1 convolution."""
     if x.is_cuda and not _needs_autograd(x, weight, bias, chan_bias):
         from . import hip_ops
-        if hip_ops.is_channels_last(x) and hip_ops.nhwc_supported(x.shape[1], num_groups, x.dtype):
-            return hip_ops.group_norm_nhwc(x, T, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, stack3=stack3)
         return hip_ops.group_norm_silu_frames(x, T, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, stack3=stack3)
+    _fallback(x, "group_norm_frames", _why(x, weight, bias, chan_bias))
     bt, c = x.shape[:2]
     xf = x.float()
     if chan_bias is not None:
@@ -89,6 +113,7 @@ def attention(q, k, v, heads):
     if q.is_cuda and not _needs_autograd(q, k, v):
         from . import hip_ops
         return hip_ops.attention(q, k, v, heads)
+    _fallback(q, "attention", _why(q, k, v))
     D = HD // heads
     qh, kh, vh = (t.reshape(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
     o = F.scaled_dot_product_attention(qh, kh, vh)
@@ -105,6 +130,7 @@ def attention_packed(qkv, heads):
     if qkv.is_cuda and not _needs_autograd(qkv):
         from . import hip_ops
         return hip_ops.attention_packed(qkv.contiguous(), heads)
+    _fallback(qkv, "attention_packed", _why(qkv))
     q, k, v = qkv.chunk(3, dim=-1)
     return attention(q.contiguous(), k.contiguous(), v.contiguous(), heads)
 
@@ -114,6 +140,7 @@ def attention_temporal_packed(qkv, heads, T):
     if qkv.is_cuda and not _needs_autograd(qkv):
         from . import hip_ops
         return hip_ops.attention_temporal_packed(qkv.contiguous(), heads, T)
+    _fallback(qkv, "attention_temporal_packed", _why(qkv))
     q, k, v = qkv.chunk(3, dim=-1)
     return attention_temporal(q.contiguous(), k.contiguous(), v.contiguous(), heads, T)
 
@@ -126,6 +153,7 @@ def attention_wide(q, k, v):
         if q.shape[-1] <= 64 and q.shape[-1] in (16, 32, 64):
             return hip_ops.attention(q, k, v, 1)
         return hip_ops.attention_wide(q.contiguous(), k.contiguous(), v.contiguous())
+    _fallback(q, "attention_wide", _why(q, k, v))
     return F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
 
 
@@ -138,6 +166,7 @@ def attention_temporal(q, k, v, heads, T):
     if q.is_cuda and not _needs_autograd(q, k, v):
         from . import hip_ops
         return hip_ops.attention_temporal(q, k, v, heads, T)
+    _fallback(q, "attention_temporal", _why(q, k, v))
     bo = BT // T
 
     def regroup(t):
@@ -152,6 +181,7 @@ def geglu(h):
     if h.is_cuda and not _needs_autograd(h) and inner % 8 == 0:
         from . import hip_ops
         return hip_ops.geglu(h)
+    _fallback(h, "geglu", _why(h))
     a, gate = h.chunk(2, dim=-1)
     return a * F.gelu(gate)
 
@@ -160,9 +190,8 @@ def bias_residual_add(h, bias=None, x=None):
     """h [N, C, *spatial] + bias[c] + x in one pass (conv bias and ResBlock skip add, openaimodel.py:354)."""
     if h.is_cuda and not _needs_autograd(h, bias, x):
         from . import hip_ops
-        if hip_ops.is_channels_last(h) and h.shape[1] % 8 == 0 and (x is None or hip_ops.is_channels_last(x)):
-            return hip_ops.bias_residual_add_nhwc(h, bias, x)
         return hip_ops.bias_residual_add(h, bias, x)
+    _fallback(h, "bias_residual_add", _why(h, bias, x))
     out = h
     if bias is not None:
         out = out + bias.to(h.dtype).reshape(1, -1, *([1] * (h.ndim - 2)))
@@ -179,6 +208,7 @@ def concat_add(h, skip, ctrl=None):
             and h.shape[0] < 65536):
         from . import hip_ops
         return hip_ops.concat_add(h, skip, ctrl)
+    _fallback(h, "concat_add", _why(h, skip, ctrl))
     return torch.cat([h, skip if ctrl is None else skip + ctrl], dim=1)
 
 
@@ -187,8 +217,8 @@ def bias_residual_blend(h, bias, x, alpha):
     (the temporal ResBlock's skip add followed by AlphaBlender, video_model.py:67-81, util.py:358-372)."""
     if h.is_cuda and not _needs_autograd(h, bias, x, alpha):
         from . import hip_ops
-        if not hip_ops.is_channels_last(h):
-            return hip_ops.bias_residual_blend(h, bias, x, alpha)
+        return hip_ops.bias_residual_blend(h, bias, x, alpha)
+    _fallback(h, "bias_residual_blend", _why(h, bias, x, alpha))
     xt = bias_residual_add(h, bias, x)
     return torch.lerp(xt, x, alpha.reshape(-1, *([1] * (h.ndim - 1))).to(x.dtype))
 
@@ -198,6 +228,7 @@ def bias_silu(h, bias):
     if h.is_cuda and not _needs_autograd(h, bias) and h.is_contiguous():
         from . import hip_ops
         return hip_ops.bias_silu(h, bias)
+    _fallback(h, "bias_silu", _why(h, bias))
     if bias is not None:
         h = h + bias.to(h.dtype).reshape(1, -1, *([1] * (h.ndim - 2)))
     return F.silu(h)
@@ -214,6 +245,7 @@ def add_layer_norm(x, norm, h=None, row=None, ret_pre=False):
         if norm.elementwise_affine and hip_ops.layernorm_supported(C_, x.dtype):
             y, s, s_pre = hip_ops.add_layer_norm(x, norm.weight, norm.bias, norm.eps, h=h, row=row, ret_pre=ret_pre)
             return y, (x if s is None else s), s_pre
+    _fallback(x, "add_layer_norm", _why(x, h, row, norm.weight, norm.bias))
     s_pre = x if h is None else x + h
     s = s_pre
     if row is not None:
@@ -229,6 +261,7 @@ def add_lerp(x, h, base, alpha):
     if x.is_cuda and not _needs_autograd(x, h, base, alpha) and x.shape[-1] % 8 == 0:
         from . import hip_ops
         return hip_ops.add_lerp(x, h, base, alpha)
+    _fallback(x, "add_lerp", _why(x, h, base, alpha))
     t = x if h is None else x + h
     C_ = x.shape[-1]
     G = alpha.numel()
@@ -240,8 +273,7 @@ def tokens_to_planes_add(tok, x_in):
     """tok [B, (h w), C] -> [B, C, h, w] plus x_in, one pass (SpatialTransformer's exit)."""
     if tok.is_cuda and not _needs_autograd(tok, x_in):
         from . import hip_ops
-        if hip_ops.is_channels_last(x_in) and tok.is_contiguous() and tok.shape[-1] % 8 == 0:
-            return hip_ops.bias_residual_add_nhwc(tok, None, x_in)        # same memory layout: a plain add
         if tok.shape[-1] % 8 == 0 and tok.shape[1] % 8 == 0:
             return hip_ops.tokens_to_planes_add(tok, x_in)
+    _fallback(tok, "tokens_to_planes_add", _why(tok, x_in))
     return tok.transpose(1, 2).reshape(x_in.shape) + x_in

@@ -186,7 +186,8 @@ def _cond_key(c: Dict, uc: Dict):
 
 def _double_cond_cached(guider, c: Dict, uc: Dict, keys: Sequence[str]) -> Dict:
     """_double_cond, kept while the conditioning tensors are unchanged (storage address + in-place version; the cache
-    holds the dictionaries it was built from). A sampling loop passes the same c / uc in every step: the reference
+    holds the VALUE tensors it was built from, so their addresses cannot be reused while the entry lives, and the
+    samplers drop the entry when their loop ends). A sampling loop passes the same c / uc in every step: the reference
     concatenates them again each time (guiders.py:48-57, :87-99) — at 576x1024 the 7-channel control hint alone is a
     0.7 GB copy per step — and a fresh tensor per step would also defeat the ControlNet's hint-stem cache."""
     key = _cond_key(c, uc)
@@ -194,7 +195,7 @@ def _double_cond_cached(guider, c: Dict, uc: Dict, keys: Sequence[str]) -> Dict:
     if hit is not None and hit[0] == key:
         return dict(hit[1])
     out = _double_cond(c, uc, keys)
-    guider.__dict__["_cond_cache"] = (key, out, c, uc)
+    guider.__dict__["_cond_cache"] = (key, out, [v for d in (c, uc) for v in d.values()])
     return dict(out)
 
 
@@ -323,11 +324,18 @@ class EDMSampler(SingleStepDiffusionSampler):
         dt = append_dims(next_sigma - sigma_hat, x.ndim)
         return self.possible_correction_step(self.euler_step(x, d, dt), x, d, dt, next_sigma, denoiser, cond, uc)
 
+    def _drop_cond_cache(self):
+        """The guider's doubled conditioning lives exactly as long as one sampling loop (0.5-0.7 GB at 576x1024)."""
+        getattr(self, "guider", self).__dict__.pop("_cond_cache", None)
+
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
         x, s_in, sigmas, n, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(n):
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc,
-                                  self._gamma(sigmas[i], n))
+        try:
+            for i in self.get_sigma_gen(n):
+                x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc,
+                                      self._gamma(sigmas[i], n))
+        finally:
+            self._drop_cond_cache()
         return x
 
 
@@ -360,9 +368,12 @@ class EDMSampler2(EDMSampler):
 
     def __call__(self, denoiser, z, mask, masked_z, x, cond, uc=None, num_steps=None):
         x, s_in, sigmas, n, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(n):
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, z, mask, masked_z, x, cond, uc,
-                                  self._gamma(sigmas[i], n))
+        try:
+            for i in self.get_sigma_gen(n):
+                x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, z, mask, masked_z, x, cond, uc,
+                                      self._gamma(sigmas[i], n))
+        finally:
+            self._drop_cond_cache()
         return x
 
 

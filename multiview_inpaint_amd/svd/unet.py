@@ -23,31 +23,7 @@ from . import ops
 
 
 class _Encoder(nn.Module):
-    """Everything VideoUNet and ControlNet have in common up to and including the middle block.
-
-    Optional channels-last execution (`channels_last = True`, or MVI_SVD_CHANNELS_LAST=1 in the environment): GPU inference
-    then runs the whole network on channels-last activations — the library convolutions use their NHWC kernels without
-    layout transposes, the transformer stems' "b c h w <-> b (h w) c" is a view, and 1x1 / (3,1,1) convolutions are
-    GEMMs over the token rows. Inputs are converted on entry, the result is returned contiguous; parameters keep their
-    names and shapes (Conv2d weights are re-strided once, lazily). Off by default: measured on MI355X at 14 x 576x1024
-    the step is no faster than NCHW with MIOpen's solver search (245 vs 220 ms; the NHWC kernels MIOpen picks in
-    immediate mode are slower than its searched NCHW choices + transposes, and this build's channels-last GroupNorm
-    reaches 1 TB/s against 3 TB/s for the NCHW kernel), and on a cold kernel cache MIOpen spends ~235 s building the
-    NHWC kernels of these shapes. Results are identical (tested against the reference golden in both layouts)."""
-    channels_last = os.environ.get("MVI_SVD_CHANNELS_LAST", "0") == "1"
-
-    def _enter_channels_last(self, x):
-        if not (self.channels_last and x.is_cuda and x.ndim == 4 and not torch.is_grad_enabled()):
-            return x, False
-        p = next(self.parameters())
-        token = (p.device, p.dtype, p.data_ptr())
-        if getattr(self, "_cl_token", None) != token:
-            for m in self.modules():
-                if isinstance(m, nn.Conv2d):
-                    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
-            p = next(self.parameters())
-            self._cl_token = (p.device, p.dtype, p.data_ptr())
-        return x.contiguous(memory_format=torch.channels_last), True
+    """Everything VideoUNet and ControlNet have in common up to and including the middle block."""
 
     def _build_encoder(self, *, in_channels, model_channels, num_res_blocks, attention_resolutions, dropout,
                        channel_mult, conv_resample, dims, num_classes, use_checkpoint, num_heads, num_head_channels,
@@ -189,7 +165,6 @@ class VideoUNet(_Encoder):
         emb = self._embed(x, timesteps, y)
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
-        x, cl = self._enter_channels_last(x)
         hs, h = [], x
         for blk in self.input_blocks:
             h = blk(h, emb, **kw)
@@ -202,7 +177,7 @@ class VideoUNet(_Encoder):
             h = blk(ops.concat_add(h, skip, control.pop() if control is not None else None), emb, **kw)
         h = h.type(x.dtype)
         out = self.out[2](norm_act(self.out, h))
-        return out.contiguous() if cl else out
+        return out
 
 
 class ControlledVideoUNet(VideoUNet):
@@ -293,14 +268,11 @@ class ControlNet(_Encoder):
         emb = self._embed(x, timesteps, y)
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
-        guided = self._hint_stem_cached(hint, emb, context)      # 7-channel full-resolution stem: stays NCHW
-        x, cl = self._enter_channels_last(x)
+        guided = self._hint_stem_cached(hint, emb, context)
         outs, h = [], x
         for blk, zc in zip(self.input_blocks, self.zero_convs):
             h = blk(h, emb, **kw)
             if guided is not None:
-                if cl:
-                    guided = guided.contiguous(memory_format=torch.channels_last)
                 h = h + guided                              # added once, after the first input block (:471-473)
                 guided = None
             outs.append(zc(h, emb, context))

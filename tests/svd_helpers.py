@@ -14,6 +14,14 @@ SMALL_CTRL["hint_channels"] = 7
 T_FRAMES = 3
 LATENT_HW = (16, 8)
 
+# Second small configuration with the PRODUCTION head width (num_head_channels 64,
+# configs/test/svd_f_est_ctrl_simp1.yaml:31): every spatial self-attention has D = 64 and S_k = 256 / 64 > 32,
+# so in bf16/f16 it runs the MFMA flash kernel (mvi_attention_kernel_kind == 1) inside the module graph.
+SMALL_UNET64 = dict(SMALL_UNET, model_channels=64, num_head_channels=64)
+SMALL_CTRL64 = {k: v for k, v in SMALL_UNET64.items() if k != "out_channels"}
+SMALL_CTRL64["hint_channels"] = 7
+LATENT_HW64 = (16, 16)
+
 
 def seeded_state_dict(module, seed):
     """Every parameter/buffer re-drawn (zero-initialised ones too, SURVEY.md §8c caveat) in sorted-key order."""

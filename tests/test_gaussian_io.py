@@ -73,9 +73,12 @@ def test_ply_reader_rejects_other_files(tmp_path):
     p.write_bytes(b"plx\n")
     with pytest.raises(ValueError):
         gio.read_ply_vertices(str(p))
-    p.write_bytes(b"ply\nformat binary_big_endian 1.0\nelement vertex 0\nproperty float x\nend_header\n")
+    p.write_bytes(b"ply\nformat binary_middle_endian 1.0\nelement vertex 0\nproperty float x\nend_header\n")
     with pytest.raises(ValueError):
         gio.read_ply_vertices(str(p))
+    p.write_bytes(b"ply\nformat ascii 1.0\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n")
+    with pytest.raises(ValueError):
+        gio.read_ply_vertices(str(p))                      # vertex must be the first element
     p.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 0\nproperty float x\nend_header\n")
     assert gio.read_ply_vertices(str(p))["x"].shape == (0,)
 
@@ -136,3 +139,19 @@ def test_extend_optimizer_state_matches_cat_tensors_to_optimizer():
     a.step(); b.step()
     for ga, gb in zip(a.param_groups, b.param_groups):
         assert torch.equal(ga["params"][0], gb["params"][0])
+
+
+def test_ply_reader_ignores_trailing_elements_and_reads_big_endian(tmp_path):
+    """Files written by MeshLab / Open3D / CloudCompare declare `element face 0` (with a list property) after the vertex
+    element; plyfile — what the reference's load_ply uses (gaussian_model.py:267-270) — reads them, and so must this
+    reader. Big-endian bodies are converted."""
+    xyz = np.arange(6, dtype=np.float32).reshape(2, 3) + 0.25
+    head = ("ply\nformat {fmt} 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
+            "element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+    for fmt, body in (("binary_little_endian", xyz.astype("<f4").tobytes()), ("binary_big_endian", xyz.astype(">f4").tobytes())):
+        p = tmp_path / f"{fmt}.ply"
+        p.write_bytes(head.format(fmt=fmt).encode() + body)
+        v = gio.read_ply_vertices(str(p))
+        assert sorted(v) == ["x", "y", "z"]
+        np.testing.assert_array_equal(np.stack([v["x"], v["y"], v["z"]], 1), xyz)
+        assert v["x"].dtype == np.float32 and v["x"].dtype.byteorder in "=<|"
