@@ -146,8 +146,9 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     statistics, softmax and LayerNorm still accumulate in fp32 inside their kernels).
     weights="fp32": fp32 parameters under torch.autocast(bf16), the reference's mixed-precision recipe
     (it uses fp16 autocast, models/csvd.py:27-31)."""
-    from . import hip_ops
+    from . import hip_ops, ops
     from .schedule import EDMDiscretization
+    ops.STRICT = True               # every op of the timed step runs its HIP kernel or the run fails (svd/ops.py)
     # let MIOpen time its convolution solvers during warm-up (+10 % on the 3x3 convolutions; with the shipped find-db a look-up)
     torch.backends.cudnn.benchmark = True
     use_shipped_miopen_db()

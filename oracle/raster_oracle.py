@@ -116,6 +116,18 @@ def forward(params, means3D, opacities, shs=None, colors_precomp=None, scales=No
     return o
 
 
+def margins(params, fwd, rel_margin=2e-5):
+    """Per-pixel bitmask [H, W] u8 of decisions taken within `rel_margin` of their threshold (orc_render_margins): bit 0
+    colour / final_T / n_contrib, bit 1 median depth. rel_margin covers the 1-2 ulp of an exp() plus the rounding that a
+    product of a few hundred (1 - alpha) factors accumulates in T."""
+    L = lib()
+    out = np.zeros((params.H, params.W), np.uint8)
+    vs = np.ascontiguousarray(fwd["point_list"]) if fwd["num_rendered"] else np.zeros(1, np.uint32)
+    L.orc_render_margins(C.byref(params), _p(fwd["ranges"]), _p(vs), _p(fwd["xy"]), _p(fwd["conic_opacity"]),
+                         C.c_float(rel_margin), _p(out))
+    return out
+
+
 def backward(params, fwd, dL_dcolor_img, means3D, shs=None, colors_precomp=None, scales=None,
              rotations=None, cov3D_precomp=None):
     """Analytic backward. `fwd` is the dict returned by forward(). Returns the gradients the

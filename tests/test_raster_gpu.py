@@ -2,14 +2,16 @@
 
 Bars (BASELINE.json north_star): bit-exact on integer outputs (radii, tiles touched, sort keys,
 sorted order, tile ranges) — and, because the per-Gaussian arithmetic contract is shared, bit-exact
-on the per-Gaussian floats too; 1e-4 relative on RGB-D and on every gradient.
+on the per-Gaussian floats too; 1e-4 relative, ELEMENTWISE, on RGB-D and on every gradient:
+|got - ref| <= 1e-4 * max(|ref|, floor), with the floor stated at each use.
 
-The compositing loop takes three hard decisions per (pixel, Gaussian) pair (power > 0,
-alpha < 1/255, T(1-alpha) < 1e-4) and one for the median depth (T crossing 0.5). exp() differs by
-~1 ulp between v_exp_f32 and glibc, so a handful of pairs per 10^8 can take the other branch; such a
-pixel then differs by up to alpha*T*c <= 4e-3 in colour (or picks the neighbouring Gaussian's depth).
-FLIP_FRAC bounds the fraction of pixels allowed outside the 1e-4 band for that reason; every other
-pixel must be inside it."""
+The compositing loop takes three hard decisions per (pixel, Gaussian) pair (power > 0, alpha < 1/255,
+T(1-alpha) < 1e-4) and one for the median depth (T crossing 0.5). exp() differs by ~1 ulp between
+v_exp_f32 and glibc, so a pair whose tested quantity sits within rounding distance of its threshold
+can take the other branch. The oracle says which pixels hold such a pair (raster_oracle.margins, relative
+margin 2e-5): every OTHER pixel must meet the full tolerance (depth and n_contrib: exactly), and the
+marginal pixels that differ are COUNTED against a small allowance (expected flips ~ 2e-8 per evaluated
+pair: 0 at the small test sizes, a few at 100k Gaussians / 800x800)."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +21,40 @@ from raster_helpers import oracle_params, small_scene
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
-FLIP_FRAC = 2e-4
+GRAD_FLOOR = 1e-2          # gradient floor as a fraction of the array's largest |value|: float atomics reorder sums of
+                           # hundreds of terms, so an element that cancels to ~0 is held to 1e-6 of the largest element
+
+
+def _flip_allowance(n_pairs):
+    """Pixels allowed to differ because a decision flipped: 2 + 1e-7 per evaluated (pixel, Gaussian) pair."""
+    return 2 + int(1e-7 * n_pairs)
+
+
+def _viol(got, ref, floor):
+    """Elementwise bar: boolean array of violations of |got - ref| <= RTOL * max(|ref|, floor), and the worst ratio."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    tol = RTOL * np.maximum(np.abs(ref), floor)
+    d = np.abs(got - ref)
+    return d > tol, (float((d / tol).max()) if d.size else 0.0)
+
+
+def _grad_check(name, got, ref, n_flips_allowed):
+    """A gradient array against the oracle's: rows (Gaussians) with any element outside the elementwise bar are counted
+    against the flip allowance (a flipped pair changes that Gaussian's gradient and little else); nothing may be off by
+    more than 1e-2 of the array's scale."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.abs(ref).max() + 1e-30
+    bad, worst = _viol(got, ref, GRAD_FLOOR * scale)
+    rows = bad.reshape(bad.shape[0], -1).any(1).sum() if bad.ndim > 1 else bad.sum()
+    assert rows <= 2 * n_flips_allowed, (name, int(rows), worst)
+    assert np.abs(got - ref).max() <= 1e-2 * scale, (name, float(np.abs(got - ref).max() / scale))
+    return worst
+
+
+def _same_to_summation_order(a, b, tol=2e-5):
+    """Two GPU evaluations of the same sums (float atomics in a different order): max |a - b| relative to the scale."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)) <= tol
 
 
 @pytest.fixture(scope="module")
@@ -46,13 +81,6 @@ def _settings(R, cam, bg, deg, scale_modifier=1.0):
 
 def _to_dev(sc):
     return {k: torch.tensor(v, device="cuda") for k, v in sc.items() if k != "sh_degree"}
-
-
-def _close_frac(a, b, rtol=RTOL):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    scale = np.abs(b).max() + 1e-12
-    bad = np.abs(a - b) > rtol * scale
-    return bad.mean(), np.abs(a - b).max() / scale
 
 
 def _check_forward(R, ro, cam, sc, bg, full=True):
@@ -95,17 +123,28 @@ def _check_forward(R, ro, cam, sc, bg, full=True):
     cl = st.tensor("clamped", (P,), torch.uint8).cpu().numpy()
     want = (f["clamped"][:, 0] | (f["clamped"][:, 1] << 1) | (f["clamped"][:, 2] << 2)).astype(np.uint8)
     assert np.array_equal(cl[vis], want[vis])
-    # ---- image outputs: 1e-4 rel outside threshold flips
-    frac, worst = _close_frac(color.cpu().numpy(), f["color"])
-    assert frac <= FLIP_FRAC and worst < 2e-2, (frac, worst)
+    # ---- image outputs: elementwise 1e-4 on every pixel the oracle does not mark marginal; marginal ones are counted
+    fr = ro.margins(p, f)
+    colour_marginal, any_marginal = (fr & 1) != 0, fr != 0
+    assert any_marginal.mean() < 5e-3, "margin too wide: the test would excuse too many pixels"
+    allow = _flip_allowance(int(f["n_contrib"].sum()))
+    bad_c, worst_c = _viol(color.cpu().numpy(), f["color"], 1.0)                       # floor 1.0: colours are O(1)
+    bad_c = bad_c.any(0)
+    assert not (bad_c & ~colour_marginal).any(), ("colour off on a pixel with no marginal decision", worst_c)
     nc = st.tensor("n_contrib", (H, W), torch.int32).cpu().numpy().view(np.uint32)
-    assert (nc != f["n_contrib"]).mean() <= FLIP_FRAC
-    dfrac, _ = _close_frac(depth.cpu().numpy(), f["depth"])
-    assert dfrac <= FLIP_FRAC
-    assert (depth.cpu().numpy()[0][f["n_contrib"] == 0] == 15.0).all()
+    bad_n = nc != f["n_contrib"]
+    assert not (bad_n & ~colour_marginal).any(), "n_contrib differs on a pixel with no marginal decision"
     ft = st.tensor("final_T", (H, W), torch.float32).cpu().numpy()
-    tfrac, _ = _close_frac(ft, f["final_T"])
-    assert tfrac <= FLIP_FRAC
+    bad_t, worst_t = _viol(ft, f["final_T"], 1e-4)                                     # floor = the loop's own T cut-off
+    assert not (bad_t & ~colour_marginal).any(), ("final_T off on a pixel with no marginal decision", worst_t)
+    dg = depth.cpu().numpy()[0]
+    bad_d = dg != f["depth"][0]                                                        # a selected Gaussian's depth: exact
+    assert not (bad_d & ~any_marginal).any(), "median depth differs on a pixel with no marginal decision"
+    flips = int((bad_c | bad_n | bad_t | bad_d).sum())
+    assert flips <= allow, (flips, allow)
+    assert np.abs(color.cpu().numpy() - f["color"]).max() <= 4e-3 * max(1.0, np.abs(f["rgb"]).max()), "a flip moves a pixel by <= alpha T c"
+    assert (dg[f["n_contrib"] == 0] == 15.0).all()
+    f["_flips_allowed"] = allow
     return f, p, rs, t, st
 
 
@@ -140,8 +179,7 @@ def test_parity_with_more_than_65536_tiles(R, ro):
                              rotations=t["rotations"])
     torch.cuda.synchronize()
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
-        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
-        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
 
 
 @pytest.mark.parametrize("seed,deg,mode", [(0, 3, "sh"), (4, 1, "sh"), (5, 2, "precomp"), (6, 0, "sh")])
@@ -160,6 +198,7 @@ def test_backward_parity_small(R, ro, seed, deg, mode):
         okw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
         gkw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
     f = ro.forward(p, sc["means3D"], sc["opacities"], **okw)
+    f["_flips_allowed"] = _flip_allowance(int(f["n_contrib"].sum()))
     b = ro.backward(p, f, g_img, sc["means3D"], **okw)
     color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **gkw)
     g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], **gkw)
@@ -168,8 +207,7 @@ def test_backward_parity_small(R, ro, seed, deg, mode):
         if b[k] is None:
             assert g[k] is None, k
             continue
-        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
-        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
 
 
 def test_autograd_module_contract(R, ro):
@@ -241,8 +279,7 @@ def test_bringup_config_100k_800(R, ro):
     g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
                              rotations=t["rotations"])
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
-        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
-        assert frac <= 5e-4, (k, frac, worst)
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
 
 
 def test_full_size_properties_1p5M_1080p(R):
@@ -311,12 +348,13 @@ def test_partial_sh_degree_scale_modifier_and_background_gradient(R, ro):
     g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
                              rotations=t["rotations"])
     assert np.array_equal(radii.cpu().numpy(), f["radii"])
-    frac, worst = _close_frac(color.cpu().numpy(), f["color"])
-    assert frac <= FLIP_FRAC, (frac, worst)
+    bad, worst = _viol(color.cpu().numpy(), f["color"], 1.0)
+    fr = ro.margins(p, f)
+    f["_flips_allowed"] = _flip_allowance(int(f["n_contrib"].sum()))
+    assert not (bad.any(0) & ((fr & 1) == 0)).any() and bad.any(0).sum() <= f["_flips_allowed"], worst
     assert (g["shs"][:, 4:] == 0).all()                   # inactive coefficients get exactly zero gradient
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
-        frac, worst = _close_frac(g[k].cpu().numpy(), b[k])
-        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
 
 
 @pytest.mark.parametrize("deg,store_deg", [(3, 3), (1, 3), (0, 0)])
@@ -344,13 +382,10 @@ def test_factored_sh_gradient_and_multi_view_rebuild(R, deg, store_deg):
         gf = R.rasterize_backward(rs, st, g_img, t["means3D"], sh_grad="factor", **kw)
         assert gf["shs"] is None and gf["sh_color_factor"].shape == (P, 3)
         for k in ("means3D", "opacities", "scales", "rotations"):
-            frac, worst = _close_frac(gf[k].cpu().numpy(), gd[k].cpu().numpy())
-            assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)          # atomics: summation order only
-        frac, worst = _close_frac(gf["sh_color_factor"].cpu().numpy(), gb["sh_color_factor"].cpu().numpy())
-        assert frac <= 5e-4 and worst < 5e-2
+            assert _same_to_summation_order(gf[k].cpu().numpy(), gd[k].cpu().numpy()), k     # atomics: summation order only
+        assert _same_to_summation_order(gf["sh_color_factor"].cpu().numpy(), gb["sh_color_factor"].cpu().numpy())
         # the degree-0 coefficient of the dense gradient is C0 * factor
-        frac, worst = _close_frac((gb["sh_color_factor"] * 0.28209479177387814).cpu().numpy(), gb["shs"][:, 0].cpu().numpy())
-        assert frac <= 1e-5 and worst < 1e-5
+        assert _same_to_summation_order((gb["sh_color_factor"] * 0.28209479177387814).cpu().numpy(), gb["shs"][:, 0].cpu().numpy(), 1e-6)
         dense.append(gb["shs"])
         factors.append(gb["sh_color_factor"])
         campos.append(rs.campos)
@@ -358,8 +393,7 @@ def test_factored_sh_gradient_and_multi_view_rebuild(R, deg, store_deg):
     for n_views in (1, 2):
         out = R.sh_backward_views(t["means3D"], cp[:n_views], both[:n_views], M, deg)
         want = sum(dense[:n_views])
-        frac, worst = _close_frac(out.cpu().numpy(), want.cpu().numpy(), rtol=1e-5)
-        assert out.shape == (P, M, 3) and frac == 0.0, (n_views, frac, worst)
+        assert out.shape == (P, M, 3) and _same_to_summation_order(out.cpu().numpy(), want.cpu().numpy(), 1e-5), n_views
     # strided inputs, as they sit in the all-gathered buffer [W, 3P + 3]
     packed = torch.zeros(2, 3 * P + 3, device="cuda")
     packed[:, :3 * P] = both.reshape(2, -1)
@@ -405,8 +439,7 @@ def test_raw_parameter_path_equals_activations_plus_standard_path(R, deg, store_
         assert g1[k] is not None and g1[k].shape == g0[k].shape, k
         if g0[k].numel() == 0:
             continue                                                   # degree 0: features_rest is [P,0,3]
-        frac, worst = _close_frac(g1[k].cpu().numpy(), g0[k].cpu().numpy())
-        assert frac <= 5e-4 and worst < 5e-2, (k, frac, worst)
+        assert _same_to_summation_order(g1[k].cpu().numpy(), g0[k].cpu().numpy()), k
 
 
 def test_split_backward_equals_one_call_and_factors_come_early(R):
@@ -437,3 +470,85 @@ def test_split_backward_equals_one_call_and_factors_come_early(R):
     for k in ("means3D", "means2D", "opacities", "scales", "rotations", "sh_color_factor"):
         a, b = two[k].double(), one[k].double()
         assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) < 1e-5, k
+
+
+# ---- edge cases the per-quadrant cull and the clamps rely on --------------------------------------------------------------
+
+def _fwd_bwd_vs_oracle(R, ro, cam, sc, bg, seed):
+    f, p, rs, t, st = _check_forward(R, ro, cam, sc, bg)
+    g_img = np.random.default_rng(seed).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
+    kw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    b = ro.backward(p, f, g_img, sc["means3D"], **kw)
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
+                             rotations=t["rotations"])
+    torch.cuda.synchronize()
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
+    return f
+
+
+def test_edge_opacity_one_and_centres_on_quadrant_corners(R, ro):
+    """Opacity exactly 1 (alpha clamps at 0.99), and Gaussians whose pixel centre sits exactly on the corner shared by
+    four 8x8 quadrants (x = 8q - 0.5) or exactly on a pixel (x = 8q): the per-quadrant exact cull (quad_overlap) decides
+    on the minimum of the quadratic form over the quadrant's box, and these centres put that minimum on the box edge."""
+    W, H = 128, 96
+    cam = syn.make_camera(W, H, 50.0)                        # camera at the origin looking down +z: ndc = X / (Z tanfov)
+    sc = syn.make_scene(1400, cam, 1, seed=5, log_scale_mean=np.log(0.03), zmin=1.0, zmax=5.0)
+    rng = np.random.default_rng(5)
+    n = 700
+    z = sc["means3D"][:n, 2]
+    qx, qy = rng.integers(0, W // 8 + 1, n), rng.integers(0, H // 8 + 1, n)
+    on_pixel = rng.random(n) < 0.5                           # half on the corner between pixels, half on the pixel 8q
+    px = 8.0 * qx - np.where(on_pixel, 0.0, 0.5)
+    py = 8.0 * qy - np.where(on_pixel, 0.0, 0.5)
+    sc["means3D"][:n, 0] = (((2.0 * px + 1.0) / W - 1.0) * z * cam["tanfovx"]).astype(np.float32)
+    sc["means3D"][:n, 1] = (((2.0 * py + 1.0) / H - 1.0) * z * cam["tanfovy"]).astype(np.float32)
+    sc["opacities"][::3] = 1.0
+    sc["scales"][:n:5] *= 6.0                                # some of them large enough to span many quadrants
+    f = _fwd_bwd_vs_oracle(R, ro, cam, sc, np.array([0.1, 0.2, 0.3], np.float32), 5)
+    on_corner = np.abs(f["xy"][:n] * 2 - np.round(f["xy"][:n] * 2)).max(1) < 1e-3
+    assert on_corner.mean() > 0.9 and (f["radii"][:n] > 0).mean() > 0.8
+
+
+def test_edge_cov3D_precomp_huge_indefinite_and_degenerate(R, ro):
+    """cov3D_precomp straight from the caller (compute_cov3D_python, gaussian_renderer/__init__.py:62-65) is not
+    guaranteed to be a covariance: huge entries (radius >> image), an indefinite matrix (negative determinant of the 2-D
+    projection: conic with negative entries, power > 0 everywhere) and a rank-deficient one (det == 0 -> skipped).
+    Integers bit-exact, image and gradients within tolerance, nothing non-finite."""
+    cam, sc, bg = small_scene(31, N=600, W=144, H=96, deg=0, log_scale=np.log(0.05))
+    p = oracle_params(ro, cam, sc, bg)
+    f0 = ro.forward(p, sc["means3D"], sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], render=False)
+    c6 = f0["cov3D"].copy()
+    c6[0:20] *= 3e4                                         # huge footprints: clipped to the image, hundreds of tiles each
+    c6[20:40, [0, 3, 5]] *= -1.0                            # negative diagonal: indefinite
+    c6[40:60] = 0.0                                         # rank 0: only the +0.3 dilation is left
+    c6[60:80, 1] = 10.0 * np.sqrt(np.abs(c6[60:80, 0] * c6[60:80, 3]))     # |xy| > sqrt(xx yy): indefinite, off-diagonal
+    cp = np.abs(np.random.default_rng(31).normal(0.5, 0.3, (p.P, 3))).astype(np.float32)
+    f = ro.forward(p, sc["means3D"], sc["opacities"], colors_precomp=cp, cov3D_precomp=c6)
+    f["_flips_allowed"] = _flip_allowance(int(f["n_contrib"].sum()))
+    rs = _settings(R, cam, bg, 0)
+    t = _to_dev(sc)
+    gkw = dict(colors_precomp=torch.tensor(cp, device="cuda"), cov3D_precomp=torch.tensor(c6, device="cuda"))
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **gkw)
+    torch.cuda.synchronize()
+    assert st.D == f["num_rendered"] and np.array_equal(radii.cpu().numpy(), f["radii"])
+    assert np.array_equal(st.tensor("point_list", (st.D,), torch.int32).cpu().numpy().view(np.uint32), f["point_list"])
+    assert (f["radii"][0:20] > 100).any()
+    bad, worst = _viol(color.cpu().numpy(), f["color"], 1.0)
+    fr = ro.margins(p, f)
+    assert not (bad.any(0) & ((fr & 1) == 0)).any() and bad.any(0).sum() <= f["_flips_allowed"], worst
+    assert torch.isfinite(color).all() and torch.isfinite(depth).all()
+    g_img = np.random.default_rng(3).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
+    b = ro.backward(p, f, g_img, sc["means3D"], colors_precomp=cp, cov3D_precomp=c6)
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], **gkw)
+    for k in ("means3D", "means2D", "opacities", "colors_precomp", "cov3D_precomp"):
+        assert torch.isfinite(g[k]).all(), k
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
+
+
+def test_edge_1080p_scale_image_not_a_multiple_of_the_tile(R, ro):
+    """1912 x 1075: neither side a multiple of 16 (nor of the 8-pixel quadrants) at the headline image scale — the last
+    tile column / row is partial, tile ids run to 120 x 68 - 1; forward and backward against the oracle."""
+    cam = syn.make_camera(1912, 1075, 50.0)
+    sc = syn.make_scene(120_000, cam, 1, seed=3)
+    _fwd_bwd_vs_oracle(R, ro, cam, sc, np.array([0.2, 0.1, 0.4], np.float32), 3)

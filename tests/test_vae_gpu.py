@@ -14,6 +14,13 @@ import torch.nn.functional as F
 import svd_helpers as H
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _strict_hip_path(monkeypatch):
+    """MVI_STRICT for every test of this module: a GPU tensor that would leave the HIP path raises (svd/ops.py)."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    monkeypatch.setattr(dev_ops, "STRICT", True)
 DROPIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiview_inpaint_amd", "dropin")
 if DROPIN not in sys.path:
     sys.path.insert(0, DROPIN)
