@@ -21,7 +21,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # the softmax reads them in place (no v_accvgpr_read/write shuffling between the two MFMA products)
 # -fno-honor-nans: scores are finite or -inf (masked tail), never NaN; lets fmaxf become v_max3_f32 without the
 # canonicalising v_max x,x the IEEE lowering inserts in front of every MFMA output
-EXTRA = {"attn_flash.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"] + os.environ.get("MVI_ATTN_FLAGS", "").split()}
+_ATTN = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"] + os.environ.get("MVI_ATTN_FLAGS", "").split()
+# -fno-slp-vectorize: the SLP vectoriser packs the softmax row sums into v_pk_add_f32, which issue slower beside MFMAs
+# than the scalar adds they replace (MI355X_MICROARCH.md, cycle constants)
+EXTRA = {"attn_flash.hip": _ATTN, "attn_flash8.hip": _ATTN + ["-fno-slp-vectorize"]}
 
 
 def sources():

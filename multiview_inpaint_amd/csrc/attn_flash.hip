@@ -18,6 +18,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/mvi_raster.h"
@@ -379,6 +380,11 @@ int attn_flash_launch(const void* q, const void* k, const void* v, void* out, in
 template int attn_flash_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
 template int attn_flash_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
 
+// 8-wave kernel for long sequences (attn_flash8.hip)
+template <typename T>
+int attn_flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
+                       float scale, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs);
+
 // rowtile kernel (attn_rowtile.hip)
 template <typename T>
 int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
@@ -407,8 +413,15 @@ static int attention_forward_impl(const void* q, const void* k, const void* v, v
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (mvi_attention_kernel_kind(Sq, Sk, D, dtype) == 1) {
-        rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
-                                  : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
+        // 256-row blocks pay off once there are enough of them and the padding of the last block is small
+        static const int variant = getenv("MVI_ATTN_VARIANT") ? atoi(getenv("MVI_ATTN_VARIANT")) : 0;   // 4 / 8: force a kernel (A/B runs)
+        const bool long_seq = variant == 8 || (variant != 4 && Sq >= 1024 && Sk >= 256);
+        if (long_seq)
+            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash8_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
+                                      : mvi::attn_flash8_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
+        else
+            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
+                                      : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
     } else {
         if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "attention: head dim must be 16, 32 or 64");
         switch (dtype) {

@@ -1,0 +1,169 @@
+// Standalone check + timing of the attention kernels through the C-ABI (no Python): used while developing
+// csrc/attn_flash8.hip. Build:  hipcc -O2 --offload-arch=gfx950 tools/attn_dev/attn_check.cpp -Iinclude
+//                                     -Lmultiview_inpaint_amd/csrc -lmvi_hip -Wl,-rpath,'$ORIGIN/../../multiview_inpaint_amd/csrc' -o tools/attn_dev/attn_check
+// Run:    MVI_ATTN_VARIANT=8 tools/attn_dev/attn_check            (4 = the 4-wave kernel, 8 = the 8-wave kernel)
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "mvi_raster.h"
+#include "mvi_unet_ops.h"
+
+static uint16_t f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7FFF + ((u >> 16) & 1);
+    return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+// softmax(q k^T / sqrt(D)) v for one (b, h) on the CPU in double, from bf16-rounded inputs; token strides in elements
+static void ref_head(const std::vector<uint16_t>& q, const std::vector<uint16_t>& k, const std::vector<uint16_t>& v, int b, int h,
+                     int Sq, int Sk, int H, int64_t qrs, int64_t krs, size_t qo, size_t ko, size_t vo, std::vector<double>& out) {
+    const int D = 64;
+    out.assign((size_t)Sq * D, 0.0);
+    std::vector<double> s(Sk);
+    for (int i = 0; i < Sq; ++i) {
+        double mx = -1e300;
+        for (int j = 0; j < Sk; ++j) {
+            double a = 0;
+            for (int d = 0; d < D; ++d)
+                a += (double)bf2f(q[qo + ((size_t)b * Sq + i) * qrs + h * D + d]) * bf2f(k[ko + ((size_t)b * Sk + j) * krs + h * D + d]);
+            s[j] = a * 0.125;
+            mx = std::max(mx, s[j]);
+        }
+        double l = 0;
+        for (int j = 0; j < Sk; ++j) { s[j] = std::exp(s[j] - mx); l += s[j]; }
+        for (int j = 0; j < Sk; ++j) {
+            const double p = s[j] / l;
+            for (int d = 0; d < D; ++d) out[(size_t)i * D + d] += p * bf2f(v[vo + ((size_t)b * Sk + j) * krs + h * D + d]);
+        }
+    }
+}
+
+static int check(int B, int H, int Sq, int Sk, bool packed, int peaky, unsigned seed) {
+    const int D = 64, HD = H * D;
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    const int64_t rs = packed ? 3 * HD : HD;
+    std::vector<uint16_t> hq, hk, hv;
+    size_t qo = 0, ko = 0, vo = 0;
+    std::vector<uint16_t> buf;
+    if (packed) {
+        buf.resize((size_t)B * Sq * 3 * HD);
+        for (auto& x : buf) x = f2bf(nd(rng));
+        qo = 0; ko = HD; vo = 2 * HD;
+    } else {
+        buf.resize((size_t)B * Sq * HD + 2 * (size_t)B * Sk * HD);
+        for (auto& x : buf) x = f2bf(nd(rng));
+        qo = 0; ko = (size_t)B * Sq * HD; vo = ko + (size_t)B * Sk * HD;
+    }
+    if (peaky) {   // growing peaks along the key axis for a block of queries + very negative scores for another block
+        for (int d = 0; d < D; ++d) {
+            for (int i = 0; i < std::min(Sq, 96); ++i) { size_t a = qo + (size_t)i * rs + d; buf[a] = f2bf(bf2f(buf[a]) + (d == 3 ? 6.f : 0.f)); }
+        }
+        for (int j = 0; j < Sk; j += 97) {
+            const float c = 6.f + (peaky == 2 ? 250.f : 60.f) * j / Sk;
+            for (int d = 0; d < D; ++d) buf[ko + (size_t)j * rs + d] = f2bf(d == 3 ? c : 0.f);
+        }
+        for (int i = 100; i < std::min(Sq, 140); ++i)
+            for (int d = 0; d < D; ++d) { size_t a = qo + (size_t)i * rs + d; buf[a] = f2bf(bf2f(buf[a]) * 12.f); }
+    }
+    uint16_t* dbuf; uint16_t* dout;
+    CK(hipMalloc(&dbuf, buf.size() * 2));
+    CK(hipMalloc(&dout, (size_t)B * Sq * HD * 2));
+    CK(hipMemcpy(dbuf, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(dout, 0xFF, (size_t)B * Sq * HD * 2));
+    int rc = packed ? mvi_attention_forward_strided(dbuf + qo, dbuf + ko, dbuf + vo, dout, B, H, Sq, Sk, D, 0.125f, MVI_DT_BF16, rs, rs, HD, nullptr)
+                    : mvi_attention_forward(dbuf + qo, dbuf + ko, dbuf + vo, dout, B, H, Sq, Sk, D, 0.125f, MVI_DT_BF16, nullptr);
+    if (rc) { printf("launch failed rc=%d: %s\n", rc, mvi_unet_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<uint16_t> ho((size_t)B * Sq * HD);
+    CK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+    double worst = 0, worst_row = 0; int bad = 0;
+    std::vector<double> ref;
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H; ++h) {
+            ref_head(buf, buf, buf, b, h, Sq, Sk, H, rs, rs, qo, ko, vo, ref);
+            double scale = 0;
+            for (double x : ref) scale = std::max(scale, std::fabs(x));
+            for (int i = 0; i < Sq; ++i) {
+                double rowmax = 1e-3, rowerr = 0;
+                for (int d = 0; d < D; ++d) {
+                    const double g = bf2f(ho[((size_t)b * Sq + i) * HD + h * D + d]), r = ref[(size_t)i * D + d];
+                    if (!std::isfinite(g)) { ++bad; continue; }
+                    worst = std::max(worst, std::fabs(g - r) / scale);
+                    rowmax = std::max(rowmax, std::fabs(r)); rowerr = std::max(rowerr, std::fabs(g - r));
+                }
+                worst_row = std::max(worst_row, rowerr / rowmax);
+            }
+        }
+    // peaky cases put the whole logit on ONE head dimension: the worst case for the rounding of Q * scale * log2(e) to
+    // bf16 in the 8-wave kernel (error ~ |logit| * 2^-9 in the exponent), hence the wider bound there
+    const bool ok = bad == 0 && worst < (peaky ? 4e-2 : 2e-2) && worst_row < (peaky ? 8e-2 : 4e-2);
+    printf("%s B=%d H=%d Sq=%d Sk=%d %s%s: max err %.3e (of max), worst row-relative %.3e, non-finite %d\n", ok ? "ok  " : "FAIL", B, H, Sq,
+           Sk, packed ? "packed" : "plain", peaky ? " peaky" : "", worst, worst_row, bad);
+    CK(hipFree(dbuf)); CK(hipFree(dout));
+    return ok ? 0 : 1;
+}
+
+static bool g_zero_data = false;     // "bench0": all-zero operands — the clock the chip holds depends on the data (DVFS)
+static void bench(int B, int H, int S, int iters) {
+    const int D = 64, HD = H * D;
+    const size_t n = (size_t)B * S * 3 * HD;
+    std::vector<uint16_t> buf(n);
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (size_t i = 0; i < n; ++i) buf[i] = g_zero_data ? 0 : f2bf(nd(rng));
+    uint16_t *d, *o;
+    CK(hipMalloc(&d, n * 2)); CK(hipMalloc(&o, (size_t)B * S * HD * 2));
+    CK(hipMemcpy(d, buf.data(), n * 2, hipMemcpyHostToDevice));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+    CK(hipEventRecord(b, nullptr));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    ms /= iters;
+    const double fl = 4.0 * B * H * (double)S * S * D;
+    printf("bench B=%d H=%d S=%d: %.3f ms  %.1f TFLOP/s  (%.3f of 2.5 PF)\n", B, H, S, ms, fl / ms * 1e-9, fl / ms * 1e-9 / 2500.0);
+    CK(hipFree(d)); CK(hipFree(o));
+}
+
+int main(int argc, char** argv) {
+    const char* var = getenv("MVI_ATTN_VARIANT");
+    printf("MVI_ATTN_VARIANT=%s\n", var ? var : "(default)");
+    int fails = 0;
+    if (argc >= 2 && !strcmp(argv[1], "bench0")) {
+        g_zero_data = true;
+        bench(28, 5, 9216, 10);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "bench1")) {       // one shape, few launches: the target of the PMC passes
+        bench(28, 5, 9216, 3);
+        return 0;
+    }
+    if (argc < 2 || strcmp(argv[1], "bench")) {
+        fails += check(1, 2, 256, 256, false, 0, 1);
+        fails += check(1, 1, 300, 200, false, 0, 2);      // ragged q block, ragged last key tile (200 = 3 * 64 + 8)
+        fails += check(2, 3, 577, 577, true, 0, 3);       // packed (needs Sq == Sk), ragged (577 = 9 * 64 + 1)
+        fails += check(1, 2, 1024, 1024, true, 1, 4);     // peaky: forced rescales along the key axis
+        fails += check(1, 1, 260, 97, false, 1, 5);       // 2 tiles, second mostly masked
+        fails += check(1, 1, 64, 33, false, 0, 6);        // one ragged tile
+        fails += check(1, 2, 1300, 1300, false, 0, 7);    // 21 tiles: ring wraps, ragged everywhere
+        fails += check(1, 2, 1024, 1024, false, 2, 8);    // logits climb by > 2^100 over the first block: the 8-wave kernel's safe repeat
+        printf(fails ? "CHECKS FAILED: %d\n" : "all checks passed\n", fails);
+    }
+    {
+        bench(28, 5, 9216, 5);
+        bench(28, 10, 2304, 20);
+    }
+    return fails ? 1 : 0;
+}
