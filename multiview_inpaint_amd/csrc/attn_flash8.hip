@@ -100,7 +100,11 @@ template <int N, bool kBarrier = true> __device__ __forceinline__ void wait_vm_t
 // kWaves = 8: one 512-thread block per CU (2 waves per SIMD, 256 query rows share a K/V tile) — the shipped form.
 // (kWaves = 6, two 384-thread blocks per CU = 3 waves per SIMD with independent barriers, measured 17 % SLOWER with the
 // one-quarter-ahead fragment prefetch and does not fit 168 registers with the two-quarter one: not instantiated.)
-template <typename T, int kWaves, int kX = 0>   // kX != 0: timing experiments that drop one kind of work (results are wrong on purpose)
+// kExact: the softmax scale is applied to the fp32 scores (one v_mul per score) instead of being rounded into Q. Folding
+// scale * log2(e) into Q saves those 32 multiplies per wave and tile but rounds Q a second time to bf16: an error of
+// |logit| * 2^-9 in the exponent, i.e. a few per cent on P where two keys with logits of ~60 compete (2.7e-2 of the
+// output scale on the adversarial rows of tests/test_unet_ops_gpu.py, against 5e-3 with the exact form).
+template <typename T, int kWaves, bool kExact = true, int kX = 0>   // kX != 0: timing experiments that drop one kind of work (results are wrong on purpose)
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves == 8 ? 2 : 3, kWaves == 8 ? 2 : 3)))
 void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
                         int H, int Sq, int Sk, float scale_log2e, int q_blocks, int total_blocks, int64_t q_rs,
@@ -124,7 +128,8 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     const int qcol = lane & 31, hh = lane >> 5;
     const int qrow = qb * kQB + wave * 32 + qcol;
 
-    // ---- Q' = round(Q * scale * log2 e): B operand of S^T = K Q^T, element j of lane (qcol, hh), d-step s: Q[qrow][16 s + 8 hh + j]
+    const float sc_mul = kExact ? scale_log2e : 1.0f;            // what a score is multiplied by on its way into exp2
+    // ---- Q' = Q (exact form) or round(Q * scale * log2 e): B operand of S^T = K Q^T, element j of lane (qcol, hh), d-step s: Q[qrow][16 s + 8 hh + j]
     frag qf[4];
     {
         const T* qp = q + ((b * Sq + (qrow < Sq ? qrow : 0)) * q_rs + (int64_t)h * kD + 8 * hh);
@@ -132,7 +137,8 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         for (int s = 0; s < 4; ++s) {
             u32x4 raw = qrow < Sq ? *reinterpret_cast<const u32x4*>(qp + 16 * s) : u32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) raw[i] = M::pack2(M::lo(raw[i]) * scale_log2e, M::hi(raw[i]) * scale_log2e);
+            for (int i = 0; i < 4; ++i)
+                if (!kExact) raw[i] = M::pack2(M::lo(raw[i]) * scale_log2e, M::hi(raw[i]) * scale_log2e);
             qf[s] = as_frag<frag>(raw);
         }
     }
@@ -228,8 +234,8 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     // Moves the reference exponent of the lanes in `grow` up by their block's excess over it: O, l, the block's scores
     // and the -m operand all follow (first: O = l = 0, nothing to scale — and 0 * 2^big would be NaN)
     auto rescale = [&](f32x16& sc, bool grow, float rmax, bool first) __attribute__((always_inline)) {
-        const float delta = grow ? rmax : 0.f;
-        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        const float delta = grow ? rmax : 0.f;               // in score units (the scores carry -m in the same units)
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta * sc_mul);
         l = (l + rsum) * alpha;
         rsum = 0.f;
 #pragma unroll
@@ -276,8 +282,10 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         u32x4 pr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float p0 = kX == 1 ? sc[8 * s2 + 2 * i] : __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * i]);
-            const float p1 = kX == 1 ? sc[8 * s2 + 2 * i + 1] : __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * i + 1]);
+            const float x0 = kExact ? sc[8 * s2 + 2 * i] * sc_mul : sc[8 * s2 + 2 * i];
+            const float x1 = kExact ? sc[8 * s2 + 2 * i + 1] * sc_mul : sc[8 * s2 + 2 * i + 1];
+            const float p0 = kX == 1 ? x0 : __builtin_amdgcn_exp2f(x0);
+            const float p1 = kX == 1 ? x1 : __builtin_amdgcn_exp2f(x1);
             if (kX != 2) rsum += p0 + p1;
             pr[i] = M::pack2(p0, p1);
         }
@@ -364,7 +372,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         auto decide = [&](f32x16& sc) __attribute__((always_inline)) {
             if (!kSafe) return;
             const float rmax = block_max(sc);
-            const bool grow = rmax > kRescaleThreshold;
+            const bool grow = rmax * sc_mul > kRescaleThreshold;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(grow) != 0ull, 0)) rescale(sc, grow, rmax, false);   // wave-uniform, rare
         };
         // Fragments are requested TWO quarters before their use (measured: an MFMA that waits on its K fragment costs 19 %
@@ -460,8 +468,11 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
     static unsigned long long attr_set = 0ull;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
+    static const bool fold = getenv("MVI_ATTN_FOLD_SCALE") && atoi(getenv("MVI_ATTN_FOLD_SCALE")) != 0;   // see kExact
     if (!((attr_set >> dev) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, kWaves, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes + 16) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, kWaves, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes + 16) != hipSuccess)
             return MVI_EHIP;
         attr_set |= 1ull << dev;
@@ -475,21 +486,26 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
                                (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
         };
         switch (xp) {
-            case 1: go(&attn_flash8_kernel<T, kWaves, 1>); break;
-            case 2: go(&attn_flash8_kernel<T, kWaves, 2>); break;
-            case 3: go(&attn_flash8_kernel<T, kWaves, 3>); break;
-            case 4: go(&attn_flash8_kernel<T, kWaves, 4>); break;
-            case 5: go(&attn_flash8_kernel<T, kWaves, 5>); break;
-            case 7: go(&attn_flash8_kernel<T, kWaves, 7>); break;
-            case 9: go(&attn_flash8_kernel<T, kWaves, 9>); break;
-            default: go(&attn_flash8_kernel<T, kWaves, 6>); break;
+            case 1: go(&attn_flash8_kernel<T, kWaves, false, 1>); break;
+            case 2: go(&attn_flash8_kernel<T, kWaves, false, 2>); break;
+            case 3: go(&attn_flash8_kernel<T, kWaves, false, 3>); break;
+            case 4: go(&attn_flash8_kernel<T, kWaves, false, 4>); break;
+            case 5: go(&attn_flash8_kernel<T, kWaves, false, 5>); break;
+            case 7: go(&attn_flash8_kernel<T, kWaves, false, 7>); break;
+            case 9: go(&attn_flash8_kernel<T, kWaves, false, 9>); break;
+            default: go(&attn_flash8_kernel<T, kWaves, false, 6>); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
     }
 #endif
-    hipLaunchKernelGGL((attn_flash8_kernel<T, kWaves>), dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q,
-                       (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs,
-                       o_rs);
+    if (fold)
+        hipLaunchKernelGGL((attn_flash8_kernel<T, kWaves, false>), dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q,
+                           (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs,
+                           kv_rs, o_rs);
+    else
+        hipLaunchKernelGGL((attn_flash8_kernel<T, kWaves, true>), dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q,
+                           (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs,
+                           kv_rs, o_rs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
