@@ -221,12 +221,20 @@ def main():
         dom_gbs = round(stage_bytes[dom] / dom_ms / 1e6, 1)
         # HBM bytes per launch of the dominant stage from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
         # separate rocprofv3 --pmc runs, gfx950 correction applied: profiles/raster_traffic.json); null if absent
-        traffic = None
+        # ... and only while they were measured on THIS build (digest of the rasterizer sources recorded in the file)
+        traffic, issue = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "raster_traffic.json")) as fh:
-                traffic = json.load(fh)["per_step_bytes_by_stage"].get(dom)
+                tj = json.load(fh)
+            if tj.get("build") == _lib.raster_source_digest():
+                traffic = tj["per_step_bytes_by_stage"].get(dom)
+                issue = next((v for k, v in tj.get("issue_per_kernel", {}).items() if k.startswith(dom + "_kernel")), None)
         except (OSError, KeyError, ValueError):
             pass
+        # The two render kernels move a fraction of their algorithmic bytes (the tile lists are served from L2) and are
+        # bound by the SIMDs' vector issue port: for them the roofline is VALU issue (PMC: SQ_INSTS_VALU x 4 cycles over
+        # SIMDs x cycles of the launch); every other stage — and the step as a whole — is priced against HBM.
+        valu_bound = dom in ("render_backward", "render_forward") and issue is not None
         ms_step = dt / args.steps * 1e3
         total_bytes = sum(stage_bytes.values())
         ranges = st.tensor("ranges", (T, 2), torch.int32).long()
@@ -253,9 +261,16 @@ def main():
                        "parallelism": f"views x{world}" + ((" + RCCL all-gather of SH colour factors + all-reduce of 11 floats/Gaussian"
                                                             if factored else " + RCCL all-reduce of the gradient bucket")
                                                            if distributed else "")},
-            "roofline": {"bound": "hbm", "kernel": dom,
-                         "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "roofline": {"bound": "valu" if valu_bound else "hbm", "kernel": dom,
+                         **({"achieved": round(issue["SQ_INSTS_VALU"] * 4.0 / issue["cycles"], 1), "peak": 1024.0,
+                             "unit": "SIMD issue cycles per clock (SQ_INSTS_VALU x 4 / launch cycles, 1024 SIMDs)",
+                             "frac": issue["valu_issue_frac"],
+                             "hbm": {"achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(dom_gbs / HBM_PEAK_GBS, 5)}} if valu_bound else
+                            {"achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(dom_gbs / HBM_PEAK_GBS, 5)}),
+                         "traffic": traffic,
+                         "counters_build": _lib.raster_source_digest(),
                          "launch_ms": round(dom_ms, 4),
                          "algorithmic_bytes_per_launch": int(stage_bytes[dom]),
                          "whole_step": {"algorithmic_bytes": int(total_bytes),

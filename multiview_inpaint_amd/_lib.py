@@ -50,6 +50,20 @@ def declared_symbols():
     return sorted(set(names))
 
 
+def raster_source_digest():
+    """sha1 over the rasterizer kernel sources (csrc/raster_*.hip, raster_common.h): the identity of the build that a
+    committed counter file (profiles/raster_traffic.json) was measured on. Sources, not the .so: hipcc's output is not
+    byte-reproducible, and .git does not travel to the GPU box."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(_HERE, "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.startswith("raster_") and fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -1,5 +1,7 @@
 """profiles/raster_traffic.json from the PMC passes of tools/profile_raster.sh.
-Usage: python tools/make_traffic_json.py gpurun_out/<tag> <tag>   (reads pmc_fetch.txt / pmc_write.txt)
+Usage: python tools/make_traffic_json.py gpurun_out/<tag> <tag>   (reads pmc_fetch.txt / pmc_write.txt / pmc_sq.txt / pmc_clk.txt)
+The file records the digest of the rasterizer sources it was measured on (multiview_inpaint_amd/_lib.py:
+raster_source_digest); bench.py prints the counters only while that digest matches the build it runs.
 Correction (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 a 128-B request as 64 B for 16-B/lane reads -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is."""
 import json
@@ -45,8 +47,27 @@ for k in sorted(f):
     corr = int(2 * fb + wb)
     per_kernel[k] = dict(launches_per_step=lps, FETCH_SIZE_bytes=int(fb), WRITE_SIZE_bytes=int(wb), hbm_bytes_corrected=corr)
     per_stage[STAGE[k]] = per_stage.get(STAGE[k], 0) + corr
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum (separate passes), python3 bench.py --steps 5 "
-                 f"--warmup 1 --path raster --no-cpu-baseline, MI355X, round 1 (tools/profile_raster.sh {tag})",
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from multiview_inpaint_amd import _lib as _mvi_lib  # noqa: E402
+
+# VALU issue: SQ_INSTS_VALU wave-instructions x 4 cycles each against SIMDs x cycles (GRBM_GUI_ACTIVE summed over the 8 XCDs
+# / 8 = the dispatch's cycles), per launch — the roof of the two render kernels, whose HBM traffic is far below the
+# algorithmic bytes
+issue = {}
+sq_path, clk_path = os.path.join(d, "pmc_sq.txt"), os.path.join(d, "pmc_clk.txt")
+if os.path.exists(sq_path) and os.path.exists(clk_path):
+    sq, clk = parse(sq_path), parse(clk_path)
+    for k in sorted(sq):
+        if k in clk and "SQ_INSTS_VALU" in sq[k] and "GRBM_GUI_ACTIVE" in clk[k]:
+            cycles = clk[k]["GRBM_GUI_ACTIVE"][0] / 8.0
+            valu = sq[k]["SQ_INSTS_VALU"][0]
+            issue[k] = dict(SQ_INSTS_VALU=valu, cycles=cycles, SQ_WAVE_CYCLES=sq[k].get("SQ_WAVE_CYCLES", (0, 0))[0],
+                            valu_issue_frac=round(valu * 4.0 / (1024.0 * cycles), 4))
+
+out = {"build": _mvi_lib.raster_source_digest(),
+       "issue_per_kernel": issue,
+       "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum (separate passes), python3 bench.py --steps 5 "
+                 f"--warmup 1 --path raster --no-cpu-baseline, MI355X (tools/profile_raster.sh {tag})",
        "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane reads -> read bytes = 2 x FETCH_SIZE x 1024 "
                      "(MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024 as is (includes the 64-B float-atomic requests)",
        "per_step_bytes_by_stage": per_stage, "per_kernel": per_kernel,
