@@ -119,3 +119,67 @@ def test_sh_basis_matches_reference_eval_sh_golden():
         Y = md._sh_basis_cpu(deg, dirs)                                           # [64, nb]
         rgb = torch.clamp_min(torch.einsum("pk,pkc->pc", Y, sh[:, :Y.shape[1]]) + 0.5, 0.0)
         assert torch.allclose(rgb, torch.tensor(G[f"sh_rgb_deg{deg}"]), rtol=1e-5, atol=1e-6), deg
+
+
+def _oracle_view_gradients(rank, world):
+    """Per-rank gradients of a DIFFERENT camera view of ONE small scene, from the CPU oracle (the checker, allowed in
+    tests): what each rank's rasterizer backward hands to the exchange in view-parallel training."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from multiview_inpaint_amd import synthetic as syn
+    from oracle import raster_oracle as ro
+    from raster_helpers import oracle_params
+    rng = np.random.default_rng(5)
+    Rm, T0 = syn.random_rotation(rng), rng.normal(size=3)
+    cams = [syn.make_camera(96, 64, 50.0, Rm, T0 + np.array([0.3 * v, -0.15 * v, 0.05 * v])) for v in range(world)]
+    sc = syn.make_scene(500, cams[0], 3, 5, log_scale_mean=np.log(0.06), zmin=1.0, zmax=6.0)
+    bg = np.array([0.2, 0.3, 0.1], np.float32)
+    out = []
+    for v, cam in enumerate(cams):
+        p = oracle_params(ro, cam, sc, bg)
+        kw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+        f = ro.forward(p, sc["means3D"], sc["opacities"], **kw)
+        g_img = np.random.default_rng(50 + v).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
+        b = ro.backward(p, f, g_img, sc["means3D"], **kw)
+        out.append((cam, b, f))
+    return sc, out[rank], out
+
+
+def _worker_oracle(rank, world, port, out_dir):
+    """The rank-1 identity of the SH gradient, END TO END on real per-view gradients: each rank puts the oracle's gradients
+    of ITS view into the factored exchange (colour factor = dL/dSH[:, 0, :] / C0, the 11 small floats as they are); what
+    comes out must be the sum over ranks of the DENSE per-view gradients, dL/dSH included."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from multiview_inpaint_amd import dist as md
+    sc, (cam, b, f), every = _oracle_view_gradients(rank, world)
+    P, M, deg = sc["means3D"].shape[0], sc["shs"].shape[1], 3
+    assert int((f["radii"] > 0).sum()) > P // 3                      # this view sees a good part of the scene
+    C0 = 0.28209479177387814
+    ex = md.FactoredGradExchange(P, M, deg, "cpu")
+    ex.views["sh_color_factor"].copy_(torch.tensor(b["shs"][:, 0, :] / C0))
+    for n, _ in md.FactoredGradExchange.SMALL:
+        ex.views[n].copy_(torch.tensor(b[n]).reshape(ex.views[n].shape))
+    got = ex.exchange(torch.tensor(sc["means3D"]), torch.tensor(cam["campos"]))
+    for n in ("means3D", "opacities", "scales", "rotations", "shs"):
+        want = sum(torch.tensor(e[1][n]).reshape(got[n].shape) for e in every)
+        scale = float(want.abs().max())
+        err = float((got[n] - want).abs().max())
+        assert err <= 1e-5 * scale, (n, err, scale)                 # SURVEY.md §8e: all-reduced == sum of the single-view gradients, 1e-5 rel
+    # and the dense bucket gives the same sums
+    bucket = md.GradBucket(P, M, "cpu")
+    for n in ("means3D", "opacities", "scales", "rotations", "shs"):
+        bucket.views[n].copy_(torch.tensor(b[n]).reshape(bucket.views[n].shape))
+    bucket.all_reduce()
+    assert float((bucket.views["shs"] - got["shs"]).abs().max()) <= 1e-5 * float(got["shs"].abs().max())
+    torch.save(dict(shs=got["shs"].clone(), means3D=got["means3D"].clone()), os.path.join(out_dir, f"o{rank}.pt"))
+    td.destroy_process_group()
+
+
+def test_factored_exchange_of_real_per_view_gradients_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker_oracle, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(tmp_path / f"o{r}.pt") for r in range(world))
+    assert torch.equal(a["shs"], b["shs"]) and torch.equal(a["means3D"], b["means3D"])   # ranks agree bit for bit
