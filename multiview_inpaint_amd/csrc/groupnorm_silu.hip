@@ -13,6 +13,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/mvi_raster.h"
 #include "../../include/mvi_unet_ops.h"
@@ -22,6 +23,15 @@ namespace mvi {
 
 constexpr int kGnBlock = 256;
 constexpr int kGnVecPerThread = 8;                        // 8 x 16 B per thread
+
+// e / S for 0 <= e < 2^24 (an element index inside one group slice) without the 64-bit integer division the plain
+// expression costs (~100 instructions per vector): reciprocal estimate, then one step of correction either way
+__device__ __forceinline__ int div_small(uint32_t e, uint32_t S, float inv_S) {
+    uint32_t qd = (uint32_t)((float)e * inv_S);
+    if (qd * S > e) --qd;
+    if ((qd + 1) * S <= e) ++qd;
+    return (int)qd;
+}
 
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -68,6 +78,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict_
     float v[kGnVecPerThread * KV];
     int cnt = 0;
     float sum = 0.f;
+    const float inv_S = 1.0f / (float)q.S;
 #pragma unroll
     for (int i = 0; i < kGnVecPerThread; ++i) {
         int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_stats_kernel(const T* __restrict_
                 Io<T>::load(base + e, v + i * KV);
                 cnt += KV;
                 if (cb) {
-                    const float add = cb[e / q.S];
+                    const float add = cb[q.E < (1 << 24) ? div_small((uint32_t)e, (uint32_t)q.S, inv_S) : (int)(e / q.S)];
 #pragma unroll
                     for (int k = 0; k < KV; ++k) v[i * KV + k] += add;
                 }
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
         y_zero = slice == 0 ? y + row * rs + co : nullptr;
     }
     T* y_zero2 = (q.stack3 && slice == q.slices - 1) ? y + row * (3 * (int64_t)C * S) + 2 * (int64_t)C * S + (int64_t)c0 * S : nullptr;
+    const float inv_S = 1.0f / (float)S;
 #pragma unroll
     for (int i = 0; i < kGnVecPerThread; ++i) {
         int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
         float v[KV];
         if (VEC) {
             Io<T>::load(xb + e, v);
-            const int cl = (int)(e / S);                  // S % KV == 0 on this path: one channel per vector
+            const int cl = E < (1 << 24) ? div_small((uint32_t)e, (uint32_t)S, inv_S) : (int)(e / S);   // S % KV == 0 on this path: one channel per vector
             const int c = c0 + cl;
             const float add = cb ? cb[c] : 0.f;
             float w = weight[c] * rstd, b = bias[c] + (add - mean) * w;
@@ -293,6 +305,140 @@ __global__ __launch_bounds__(256) void gn_apply_tokens_kernel(const T* __restric
     }
 }
 
+// Register-resident single pass: ONE 512-thread block per (sample, group) keeps the whole group in registers
+// (NV 16-byte vectors per thread), so x is read from HBM exactly once: sum -> mean, exact centred second moment from the
+// registers, normalise + affine (+ SiLU), store. The two-launch form above reads x twice (1.5x the algorithmic traffic:
+// 165 MB activations do not stay in the 256 MB Infinity Cache between the launches once the output stream passes
+// through it) and reached 0.39 of the HBM peak in the 14 x 576x1024 step; a group of that step is 11 KB ... 368 KB,
+// against 512 KB of vector registers per CU. Groups that do not fit (more than 256 KB in bf16 / f16, 192 KB in fp32), the temporal form and the token-major /
+// stacked outputs keep the two-launch kernels.
+template <typename T, int NV, int kGnResBlock>
+__global__ __launch_bounds__(kGnResBlock) void gn_resident_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                  const float* __restrict__ weight,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ chan_bias, int Cg, int G,
+                                                                  int64_t S, float eps, int silu) {
+    constexpr int KV = Io<T>::kVec;
+    __shared__ float s_red[kGnResBlock / 64];
+    const int64_t g = blockIdx.x;
+    const int64_t n = g / G;
+    const int c0 = (int)(g % G) * Cg, C = Cg * G;
+    const int64_t E = (int64_t)Cg * S;
+    const int nvec = (int)(E / KV);
+    const T* xb = x + (n * C + c0) * S;
+    T* yb = y + (n * C + c0) * S;
+    const float* cb = chan_bias ? chan_bias + n * C + c0 : nullptr;
+    auto block_total = [&](float v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGnResBlock / 64; ++w) t += s_red[w];
+        return t;
+    };
+    // every load is issued unconditionally (index clamped to the group's last vector) so that all NV of them are in
+    // flight together; a predicated load compiles to a branch with s_waitcnt vmcnt(0) behind it, i.e. NV serial round
+    // trips to HBM (measured: 180 us instead of 118 for the two-launch form at 184 KB per group)
+    uint4 r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * kGnResBlock + threadIdx.x;
+        r[i] = *reinterpret_cast<const uint4*>(xb + (int64_t)(vi < nvec ? vi : nvec - 1) * KV);
+    }
+    const float inv_S = 1.0f / (float)S;
+    auto chan_of = [&](int vi) { return div_small((uint32_t)(vi < nvec ? vi : nvec - 1) * KV, (uint32_t)S, inv_S); };   // E < 2^24 (host check)
+    // the vector's channel bias (one channel per vector: S % KV == 0), re-read in every pass (a handful of cached floats)
+    auto chan_add = [&](int vi) { return cb ? cb[chan_of(vi)] : 0.f; };
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float v[KV];
+        Io<T>::load(reinterpret_cast<const T*>(&r[i]), v);
+        const int vi = i * kGnResBlock + threadIdx.x;
+        const float a = chan_add(vi);
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) part += v[k] + a;
+        sum += vi < nvec ? part : 0.f;
+    }
+    const float mean = block_total(sum) / (float)E;
+    // the group stays in registers in its STORAGE type: every pass converts again from r[] (a few VALU ops per vector;
+    // without the opaque barrier the compiler keeps the fp32 copies of the first pass alive: 3x the registers)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(r[i].x), "+v"(r[i].y), "+v"(r[i].z), "+v"(r[i].w));
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float v[KV];
+        Io<T>::load(reinterpret_cast<const T*>(&r[i]), v);
+        const int vi = i * kGnResBlock + threadIdx.x;
+        const float a = chan_add(vi) - mean;
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) { const float d = v[k] + a; part += d * d; }
+        m2 += vi < nvec ? part : 0.f;
+    }
+    const float rstd = rsqrtf(block_total(m2) / (float)E + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(r[i].x), "+v"(r[i].y), "+v"(r[i].z), "+v"(r[i].w));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = i * kGnResBlock + threadIdx.x;
+        float v[KV];
+        Io<T>::load(reinterpret_cast<const T*>(&r[i]), v);
+        const int cl = chan_of(vi);
+        const int c = c0 + cl;
+        const float w = weight[c] * rstd, b = bias[c] + ((cb ? cb[cl] : 0.f) - mean) * w;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const float t = v[k] * w + b;
+            // t * sigmoid(t) with the hardware exp2 / rcp (1 ulp each): 5 instructions instead of the ~15 of expf + IEEE division
+            v[k] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+        }
+        if (vi < nvec) Io<T>::store(yb + (int64_t)vi * KV, v);
+    }
+}
+
+// (block size, NV): 512-thread blocks for groups of up to 12 vectors per thread (<= 96 registers: 3-4 such blocks per
+// CU); larger groups take 1024-thread blocks so that the CU that owns one still has 4 waves per SIMD to hide the
+// dependent-issue latency of the three register passes (at 2 waves per SIMD the 184 KB groups of level 0 took 120 us
+// against 115 for the two-launch form)
+template <typename T, int BS>
+static int gn_resident_launch_bs(const void* x, void* y, const float* w, const float* b, const float* chan_bias, int64_t N, int C,
+                                 int64_t S, int G, float eps, int silu, hipStream_t st, int nv) {
+    const int Cg = C / G;
+    const int64_t blocks = N * G;
+#define MVI_GN_RES(NVV)                                                                                                          \
+    case NVV:                                                                                                                    \
+        hipLaunchKernelGGL((gn_resident_kernel<T, NVV, BS>), dim3((unsigned)blocks), dim3(BS), 0, st, (const T*)x, (T*)y, w, b, chan_bias, \
+                           Cg, G, S, eps, silu);                                                                                  \
+        break;
+    switch (nv) {
+        MVI_GN_RES(2) MVI_GN_RES(4) MVI_GN_RES(8) MVI_GN_RES(12)
+        default: return 1;
+    }
+#undef MVI_GN_RES
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+template <typename T>
+static int gn_resident_launch(const void* x, void* y, const float* w, const float* b, const float* chan_bias, int64_t N, int C,
+                              int64_t S, int G, float eps, int silu, hipStream_t st) {
+    constexpr int KV = Io<T>::kVec;
+    const int64_t nvec = (int64_t)(C / G) * S / KV;
+    if (N * G > 0x7FFFFFFFll || nvec >= (1 << 21)) return 1;      // caller falls back to the two-launch form
+    const int opts[] = {2, 4, 8, 12};
+    for (int bs : {512, 1024}) {
+        const int64_t need = (nvec + bs - 1) / bs;
+        for (int o : opts)
+            if (need <= o)
+                return bs == 512 ? gn_resident_launch_bs<T, 512>(x, y, w, b, chan_bias, N, C, S, G, eps, silu, st, o)
+                                 : gn_resident_launch_bs<T, 1024>(x, y, w, b, chan_bias, N, C, S, G, eps, silu, st, o);
+    }
+    return 1;                                                      // more than 12 vectors per thread of a 1024-thread block
+}
+
 template <typename T>
 static int gn_launch(const void* x, void* y, const float* w, const float* b, const float* chan_bias, int stack3, int64_t N,
                      int slices, int C, int64_t S, int G, float eps, int silu, float* part, hipStream_t st, int tokens = 0) {
@@ -316,6 +462,18 @@ static int gn_launch(const void* x, void* y, const float* w, const float* b, con
                            q, eps, silu, s_tiles, c_tiles);
         return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
     }
+    // measured (tools/bench_groupnorm.py, bf16, MI355X, two launches -> resident): 11 KB groups 21.7 -> 17.8 us, 46 KB
+    // 40.4 -> 27.5, 92 KB 59.0 -> 46.3 and 55.9 -> 44.3, 184 KB (one 1024-thread block per CU: load, three register
+    // passes and store run in series there) 113.8 -> 109.2; larger groups do not fit and keep the two launches
+    static const int resident_kb = getenv("MVI_GN_RESIDENT_KB") ? atoi(getenv("MVI_GN_RESIDENT_KB")) : 192;
+    // (the resident kernel indexes channels with 24-bit arithmetic: groups of up to 256 KB are far below that)
+    if (vec && slices == 1 && !stack3 && (int64_t)q.Cg * S * (int64_t)sizeof(T) <= (int64_t)resident_kb * 1024) {
+        const int rc = gn_resident_launch<T>(x, y, w, b, chan_bias, N, C, S, G, eps, silu, st);
+        if (rc != 1) return rc;
+    }
+    // (Measured and not kept: running the two launches per BAND of samples, sized so that the statistics pass's reads are
+    // still in the 256 MB Infinity Cache when the apply pass reads them again — 48 MB bands: 146 us instead of 116 at
+    // (28, 320, 72, 128) bf16; smaller bands worse: the shorter grids cost more than the cached re-read saves.)
     if (vec) {
         hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, q);
         hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, (T*)y, w, b, part, q, eps, silu);
