@@ -232,7 +232,10 @@ __global__ __launch_bounds__(1024) void radix_scan_rows_kernel(uint32_t* __restr
 // digit order in LDS, then written out by consecutive lanes: every digit's run leaves as one
 // contiguous, coalesced segment instead of 64 scattered dwords per wave-instruction.
 // The per-digit bookkeeping (256 digits) is done by the first 256 threads of the block.
-template <int kW, typename KeyT>
+// kBits = digit width of the pass, known at compile time: the per-wave ranking costs one ballot (two VALU issues) per
+// digit bit and item, and the D-sized passes (6 / 7-bit digits) sit at 71 % VALU issue (profiles/r02d): no ballots for
+// bits the digit does not have.
+template <int kW, typename KeyT, int kBits>
 __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t D, int shift, uint32_t mask, const uint32_t* __restrict__ block_hist,
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(64 * kW) void radix_scatter_kernel(
         dig[it] = valid ? d : 0xFFFFFFFFu;
         uint64_t peers = __ballot(valid);                // lanes of this wave holding the same digit
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < kBits; ++b) {
             uint64_t bit = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? bit : ~bit;
         }
@@ -400,8 +403,19 @@ static int radix_pass(KeyT* const keys[2], uint32_t* const vals[2], int cur, int
     uint32_t mask = (1u << bits) - 1u;
     hipLaunchKernelGGL((radix_count_kernel<kW, KeyT>), dim3(nsort / kCountTiles), dim3(1024), 0, st, keys[cur], n, shift, mask, hist, nsort);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, st, hist, nsort, tot);
-    hipLaunchKernelGGL((radix_scatter_kernel<kW, KeyT>), dim3(nsort), dim3(64 * kW), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
-                       vals[cur ^ 1], n, shift, mask, hist, nsort, tot);
+#define MVI_SCATTER(B)                                                                                                       \
+    case B:                                                                                                                  \
+        hipLaunchKernelGGL((radix_scatter_kernel<kW, KeyT, B>), dim3(nsort), dim3(64 * kW), 0, st, keys[cur], vals[cur],      \
+                           keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, nsort, tot);                                   \
+        break;
+    switch (bits) {
+        MVI_SCATTER(1) MVI_SCATTER(2) MVI_SCATTER(3) MVI_SCATTER(4) MVI_SCATTER(5) MVI_SCATTER(6) MVI_SCATTER(7)
+        default:
+            hipLaunchKernelGGL((radix_scatter_kernel<kW, KeyT, 8>), dim3(nsort), dim3(64 * kW), 0, st, keys[cur], vals[cur],
+                               keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, nsort, tot);
+            break;
+    }
+#undef MVI_SCATTER
     return cur ^ 1;
 }
 

@@ -279,7 +279,12 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
             float mid = 0.5f * (a + c);
             float disc = sqrtf(fmaxf(kLambdaFloor, __builtin_fmaf(mid, mid, -det)));
             float lam1 = mid + disc, lam2 = mid - disc;
-            int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+            int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));     // v_cvt_i32_f32: saturating, NaN -> 0
+            // A covariance that is not positive definite (possible through cov3D_precomp) makes max(lambda) negative and
+            // the radius NaN -> 0. The plug-in then still counts the tile under the centre in num_rendered but emits no key
+            // for it (its duplicateWithKeys tests radii > 0): a slot of UNINITIALISED memory in its sort buffers. There is
+            // no behaviour to match, so such a Gaussian is culled here like any other invisible one.
+            if (rad <= 0) break;
             float pix_x = ((ndx + 1.0f) * (float)f.W - 1.0f) * 0.5f;
             float pix_y = ((ndy + 1.0f) * (float)f.H - 1.0f) * 0.5f;
             int x0, y0, x1, y1;
