@@ -33,6 +33,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -104,13 +105,15 @@ template <int N, bool kBarrier = true> __device__ __forceinline__ void wait_vm_t
 // scale * log2(e) into Q saves those 32 multiplies per wave and tile but rounds Q a second time to bf16: an error of
 // |logit| * 2^-9 in the exponent, i.e. a few per cent on P where two keys with logits of ~60 compete (2.7e-2 of the
 // output scale on the adversarial rows of tests/test_unet_ops_gpu.py, against 5e-3 with the exact form).
-template <typename T, int kWaves, bool kExact = true, int kX = 0>   // kX != 0: timing experiments that drop one kind of work (results are wrong on purpose)
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves == 8 ? 2 : 3, kWaves == 8 ? 2 : 3)))
+template <typename T, int kWaves, bool kExact = true, int kX = 0, int kLoaders = kWaves>   // kX != 0: timing experiments that drop one kind of work (results are wrong on purpose)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves == 6 ? 3 : 2, kWaves == 6 ? 3 : 2)))
 void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
                         int H, int Sq, int Sk, float scale_log2e, int q_blocks, int total_blocks, int64_t q_rs,
                         int64_t kv_rs, int64_t o_rs) {
     using M = Mma<T>;
     using frag = typename M::frag;
+    const uint64_t t_entry = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t t_loop0 = 0, t_loop1 = 0;
     constexpr int kQB = 32 * kWaves;             // query rows per block
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
@@ -148,8 +151,12 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     // 16-byte slot i & 7) with the chunk the image's swizzle assigns to that slot.
     const char* const kbase = reinterpret_cast<const char*>(k + (b * Sk * kv_rs + (int64_t)h * kD));
     const char* const vbase = reinterpret_cast<const char*>(v + (b * Sk * kv_rs + (int64_t)h * kD));
-    constexpr int kMaxPieces = (16 + kWaves - 1) / kWaves;
-    const int n_pieces = (16 - wave + kWaves - 1) / kWaves;          // pieces this wave moves per tile (wave-uniform)
+    // kLoaders < kWaves: only waves 0 .. kLoaders - 1 move pieces, and they do it at the END of a tile. Issuing an LDS-DMA
+    // piece costs its wave ~150 cycles (in-kernel stamps: ~300 of a tile's ~1730 cycles per wave sat between the barrier and
+    // the first quarter), and the first-dispatched half of the workgroup wins the SIMD's arbitration and waits ~500 cycles
+    // per tile at the barrier for the other half: that wait is where the loaders issue.
+    constexpr int kMaxPieces = (16 + kLoaders - 1) / kLoaders;
+    const int n_pieces = wave < kLoaders ? (16 - wave + kLoaders - 1) / kLoaders : 0;   // pieces this wave moves per tile (wave-uniform)
     const uint32_t row_bytes = (uint32_t)(kv_rs * 2);
     const int pslot = lane & 7;
     int p_row[kMaxPieces], p_chunk[kMaxPieces];
@@ -157,7 +164,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     bool p_is_v[kMaxPieces];
 #pragma unroll
     for (int i = 0; i < kMaxPieces; ++i) {
-        const int pc = wave + i * kWaves;                            // wave-uniform
+        const int pc = wave + i * kLoaders;                          // wave-uniform (meaningless for a wave that loads nothing)
         p_is_v[i] = pc >= 8;
         p_row[i] = 8 * (pc & 7) + (lane >> 3);
         p_chunk[i] = p_is_v[i] ? pslot ^ (((p_row[i] >> 1) & 1) << 2) : pslot ^ ((p_row[i] >> 1) & 7);
@@ -188,7 +195,9 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     // counted waits: "at most `tiles_in_flight` tiles' worth of this wave's own pieces still outstanding", then the barrier
     auto wait_tiles_then_barrier = [&](auto tiles_c) __attribute__((always_inline)) {
         constexpr int kT = decltype(tiles_c)::value;
-        if (kMaxPieces == 2 || n_pieces == 2) wait_vm_then_barrier<2 * kT, kX != 7>();
+        if (n_pieces == 0) wait_vm_then_barrier<0, kX != 7>();
+        else if (16 % kLoaders == 0) wait_vm_then_barrier<kMaxPieces * kT, kX != 7>();   // every loader moves 16 / kLoaders pieces
+        else if (n_pieces == 2) wait_vm_then_barrier<2 * kT, kX != 7>();
         else wait_vm_then_barrier<3 * kT, kX != 7>();
     };
 
@@ -273,12 +282,8 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         }
         return f;
     };
-    // One quarter: exp / pack / row sum of registers 8 s2 .. 8 s2 + 7 of `sc`, the S' MFMAs of the other block that
-    // run beside it (d-steps 0, 1, 2 when s_lo == 0, d-step 3 otherwise, into `acc`) and the two P V MFMAs of these 16
-    // keys; the scheduler interleaves them inside the quarter. Measured and not kept: fences that keep the VALU part and
-    // the four MFMAs apart (so that the two waves of a SIMD could settle into opposite phases): 2.3 % slower; a static
-    // s_setprio for one half of the workgroup and a 64-cycle delay of waves 4-7 behind every barrier: within noise.
-    auto quarter = [&](const Frags& f, bool with_k, int s_lo, f32x16& acc, int s2, const f32x16& sc) __attribute__((always_inline)) {
+    // exp / pack / row sum of registers 8 s2 .. 8 s2 + 7 of `sc`: the P fragment of 16 keys
+    auto probs = [&](int s2, const f32x16& sc) __attribute__((always_inline)) {
         u32x4 pr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -291,41 +296,54 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         }
         asm volatile("" : "+v"(rsum));       // the sum is complete HERE: without this, the fast form (which reads rsum only
                                              // after the loop) sinks four tiles' adds — and 128 live P values — to the loop's end
-        const frag pf = as_frag<frag>(pr);
-        if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-        if (with_k && kX != 4) {
-            // first quarter: S'(d 0), PV, S'(d 1), PV, S'(d 2); second: S'(d 3), PV, PV — the S' MFMAs are ONE accumulator
-            // chain, and the P V MFMAs between them cover each link's latency
-            const u32x4 av0 = {f.v[0][0][0], f.v[0][0][1], f.v[0][1][0], f.v[0][1][1]};
-            const u32x4 av1 = {f.v[1][0][0], f.v[1][0][1], f.v[1][1][0], f.v[1][1][1]};
-            if (s_lo == 0) {
-                acc = M::mfma(as_frag<frag>(f.k[0]), qf[0], negm);
-                if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-                o[0] = M::mfma(as_frag<frag>(av0), pf, o[0]);
-                if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-                acc = M::mfma(as_frag<frag>(f.k[1]), qf[1], acc);
-                if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-                o[1] = M::mfma(as_frag<frag>(av1), pf, o[1]);
-                if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-                acc = M::mfma(as_frag<frag>(f.k[2]), qf[2], acc);
-            } else {
-                acc = M::mfma(as_frag<frag>(f.k[0]), qf[3], acc);
-                if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-                o[0] = M::mfma(as_frag<frag>(av0), pf, o[0]);
-                if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-                o[1] = M::mfma(as_frag<frag>(av1), pf, o[1]);
-            }
-            if (kX == 9) __builtin_amdgcn_sched_barrier(0);
-            return;
+        return pr;
+    };
+    // What a quarter leaves for the next one to multiply into O: its P fragment and its four V^T fragments
+    struct Pending { u32x4 p; u32x2 v[2][2]; };
+    // The S' MFMAs that run beside a quarter (one accumulator chain per 32-key block: d-steps 0, 1, 2 beside the block's
+    // first quarter, d-step 3 beside its second) with the two P V MFMAs of `pd` between them
+    auto matrix_part = [&](const Frags& f, bool with_k, int s_lo, f32x16& acc, const Pending& pd, bool with_pv) __attribute__((always_inline)) {
+        const u32x4 av0 = {pd.v[0][0][0], pd.v[0][0][1], pd.v[0][1][0], pd.v[0][1][1]};
+        const u32x4 av1 = {pd.v[1][0][0], pd.v[1][0][1], pd.v[1][1][0], pd.v[1][1][1]};
+        const frag pf = as_frag<frag>(pd.p);
+        const bool qk = with_k && kX != 4;
+        // The S' MFMAs of a block are ONE accumulator chain (3 + 1 over its two quarters) with the P V MFMAs between the
+        // links; the scheduler spreads the quarter's exp / add / pack between them. Measured and not kept: 2 + 2 links per
+        // quarter ordered S', PV, PV, S' behind scheduling fences (two independent MFMAs between dependent ones): the
+        // fences also keep the VALU work out of the gaps, a lone wave went from 857 to 1147 cycles per tile.
+        if (s_lo == 0) {
+            if (qk) acc = M::mfma(as_frag<frag>(f.k[0]), qf[0], negm);
+            if (with_pv) o[0] = M::mfma(as_frag<frag>(av0), pf, o[0]);
+            if (qk) acc = M::mfma(as_frag<frag>(f.k[1]), qf[1], acc);
+            if (with_pv) o[1] = M::mfma(as_frag<frag>(av1), pf, o[1]);
+            if (qk) acc = M::mfma(as_frag<frag>(f.k[2]), qf[2], acc);
+        } else {
+            if (qk) acc = M::mfma(as_frag<frag>(f.k[0]), qf[3], acc);
+            if (with_pv) o[0] = M::mfma(as_frag<frag>(av0), pf, o[0]);
+            if (with_pv) o[1] = M::mfma(as_frag<frag>(av1), pf, o[1]);
         }
-        if (kX == 3) {                       // keep P alive without the matrix work
-            asm volatile("" :: "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]));
-            return;
-        }
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            u32x4 av = {f.v[db][0][0], f.v[db][0][1], f.v[db][1][0], f.v[db][1][1]};
-            o[db] = M::mfma(as_frag<frag>(av), pf, o[db]);
+    };
+    // One quarter of the SAFE form: P of these 16 keys, then the S' MFMAs beside it and its own two P V MFMAs (the rescale
+    // of the next block's decision must find nothing pending).
+    // One quarter of the FAST form (software-pipelined): the MFMAs of this region are the S' MFMAs and the P V MFMAs of
+    // the PREVIOUS quarter (`pend`), the VALU work is the P of THIS quarter — independent of each other, so the scheduler
+    // can put a handful of exp / add / pack behind every MFMA and an in-order wave never waits for its own pack before a
+    // matrix instruction. (A lone wave of the un-pipelined form needed 1495 cycles per 64-key tile against ~570 of issue
+    // and 512 of matrix-pipe work: tools/attn_dev/clk.sh.)
+    auto quarter = [&](auto pipelined_c, const Frags& f, bool with_k, int s_lo, f32x16& acc, int s2, const f32x16& sc,
+                       Pending& pend, bool pend_valid) __attribute__((always_inline)) {
+        constexpr bool kPipe = decltype(pipelined_c)::value;
+        if (kPipe) {
+            matrix_part(f, with_k, s_lo, acc, pend, pend_valid);
+            Pending nx;
+            nx.p = probs(s2, sc);
+            nx.v[0][0] = f.v[0][0]; nx.v[0][1] = f.v[0][1]; nx.v[1][0] = f.v[1][0]; nx.v[1][1] = f.v[1][1];
+            pend = nx;
+        } else {
+            Pending now;
+            now.p = probs(s2, sc);
+            now.v[0][0] = f.v[0][0]; now.v[0][1] = f.v[0][1]; now.v[1][0] = f.v[1][0]; now.v[1][1] = f.v[1][1];
+            matrix_part(f, with_k, s_lo, acc, now, kX != 3);
         }
     };
 
@@ -378,24 +396,37 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         // Fragments are requested TWO quarters before their use (measured: an MFMA that waits on its K fragment costs 19 %
         // of the kernel), also across the tile boundary: while tile t runs, tiles t and t + 1 are complete in LDS (the
         // closing wait of tile t - 1 covered tile t + 1), so its last two quarters request the first two of tile t + 1.
+        uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};                  // (kX 15 / 16: cycles per quarter and per barrier, summed over tiles)
+        const uint64_t clk0 = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memtime() : 0;
+        t_loop0 = clk0;
+        const uint64_t rt0 = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memrealtime() : 0;
+        Pending pend;                                            // fast form: the quarter whose P V is still to be issued
+        pend.p = u32x4{0, 0, 0, 0};
+        pend.v[0][0] = pend.v[0][1] = pend.v[1][0] = pend.v[1][1] = u32x2{0, 0};
+        constexpr std::integral_constant<bool, !kSafe> pipe_c{};
         auto tile = [&](int t, auto slot_c, auto has_next_c) __attribute__((always_inline)) {
             const int slot = slot_c, next = (slot + 1) & (kRing - 1);
             const bool has_next = has_next_c;
             const int k0 = t * kKT;
-            if (has_next) issue_tile(t + 3);                     // slot (t + 3) % 4 held tile t - 1: free since the last barrier
+            // slot (t + 3) % 4 held tile t - 1: nobody reads it after the barrier that opened this tile
+            if (has_next && kLoaders == kWaves) issue_tile(t + 3);
             const bool ragged = !has_next && k0 + kKT > Sk;      // only the last tile can be ragged: keys >= Sk never win
             if (ragged && t > 0) {                               // (tile 0's first block was masked before it set m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((k0 + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) s0[r] = -INFINITY;
             }
+            uint64_t ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+            if (kX >= 15 && kX <= 16) ts0 = __builtin_amdgcn_s_memtime();
             decide(s0);
             Frags f2 = load_frags(next, 0, 0, has_next, slot, 32);
-            quarter(fq0, true, 0, s1, 0, s0);
+            quarter(pipe_c, fq0, true, 0, s1, 0, s0, pend, t > 0);          // (before tile 0 nothing is pending)
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) ts1 = __builtin_amdgcn_s_memtime();
             Frags f3 = load_frags(next, 0, 3, has_next, slot, 48);
-            quarter(fq1, true, 3, s1, 1, s0);
+            quarter(pipe_c, fq1, true, 3, s1, 1, s0, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) ts2 = __builtin_amdgcn_s_memtime();
             if (ragged) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -403,12 +434,27 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             }
             decide(s1);
             if (has_next) fq0 = load_frags(next, 1, 0, true, next, 0);
-            quarter(f2, has_next, 0, s0, 0, s1);
+            quarter(pipe_c, f2, has_next, 0, s0, 0, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) ts3 = __builtin_amdgcn_s_memtime();
             if (has_next) fq1 = load_frags(next, 1, 3, true, next, 16);
-            quarter(f3, has_next, 3, s0, 1, s1);
+            quarter(pipe_c, f3, has_next, 3, s0, 1, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
-            if (has_next) wait_tiles_then_barrier(std::integral_constant<int, 1>{});   // own pieces of tile t + 2 (and everything older) landed
+            if (kX >= 15 && kX <= 16) {
+                ts4 = __builtin_amdgcn_s_memtime();
+                stamp[0] += ts1 - ts0; stamp[1] += ts2 - ts1; stamp[2] += ts3 - ts2; stamp[3] += ts4 - ts3;
+                if (has_next) {
+                    if (kLoaders != kWaves) issue_tile(t + 3);
+                    wait_tiles_then_barrier(std::integral_constant<int, 1>{});
+                    stamp[4] += __builtin_amdgcn_s_memtime() - ts4;
+                    stamp[5] += 1;
+                    return;
+                }
+            }
+            if (has_next) {
+                if (kLoaders != kWaves) issue_tile(t + 3);
+                wait_tiles_then_barrier(std::integral_constant<int, 1>{});   // own pieces of tile t + 2 (and everything older) landed
+            }
         };
         using std::integral_constant;
         using std::true_type;
@@ -421,6 +467,18 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             tile(t + 3, integral_constant<int, 3>{}, true_type{});
         }
         for (; t < n_tiles; ++t) tile(t, t & (kRing - 1), t + 1 < n_tiles);
+        if (kX >= 15 && kX <= 16) t_loop1 = __builtin_amdgcn_s_memtime();
+        if (kX >= 15 && kX <= 16 && !kSafe && lane == 0 && blockIdx.x == 7 && (wave == 0 || wave == kWaves - 1))
+            printf("block %d wave %d: %llu tiles; cycles per tile: q0 %llu q1 %llu q2 %llu q3 %llu wait+barrier %llu; in-kernel clock %.0f MHz\n",
+                   (int)blockIdx.x, wave, (unsigned long long)stamp[5], (unsigned long long)(stamp[0] / stamp[5]),
+                   (unsigned long long)(stamp[1] / stamp[5]), (unsigned long long)(stamp[2] / stamp[5]),
+                   (unsigned long long)(stamp[3] / stamp[5]), (unsigned long long)(stamp[4] / stamp[5]),
+                   100.0 * (double)(__builtin_amdgcn_s_memtime() - clk0) / (double)(__builtin_amdgcn_s_memrealtime() - rt0));
+        if (!kSafe) {                                            // the last quarter's P V
+            Frags none;
+            none.k[0] = none.k[1] = none.k[2] = u32x4{0, 0, 0, 0};
+            matrix_part(none, false, 3, s0, pend, true);
+        }
         l += rsum;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // trailing (unused) pieces must land before the ring is reused / released
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
@@ -451,6 +509,12 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                 *reinterpret_cast<u32x2*>(op + 32 * db + 8 * g + 4 * hh) = w;
             }
     }
+    if (kX >= 15 && kX <= 16 && lane == 0 && blockIdx.x == 3001 && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t_exit = __builtin_amdgcn_s_memtime();
+        printf("block 3001 wave 0: cycles entry->loop %llu, loop (incl. DMA prologue) %llu, loop->exit (vote, epilogue stores) %llu\n",
+               (unsigned long long)(t_loop0 - t_entry), (unsigned long long)(t_loop1 - t_loop0), (unsigned long long)(t_exit - t_loop1));
+    }
 }
 
 }  // namespace f8
@@ -479,6 +543,29 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
     }
 #ifdef MVI_ATTN_EXPERIMENTS
     static const int xp = getenv("MVI_ATTN_EXPERIMENT") ? atoi(getenv("MVI_ATTN_EXPERIMENT")) : 0;
+    if (xp == 16 && std::is_same<T, __hip_bfloat16>::value) {
+        constexpr int kW4 = 4;
+        const int qb4 = (Sq + 32 * kW4 - 1) / (32 * kW4);
+        const int64_t tot4 = (int64_t)B * H * qb4;
+        const int lds = 100 * 1024;
+        auto kern = &attn_flash8_kernel<T, kW4, false, 16>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tot4), dim3(64 * kW4), lds, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, H, Sq, Sk,
+                           scale * 1.4426950408889634f, qb4, (int)tot4, q_rs, kv_rs, o_rs);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
+    if ((xp == 14 || xp == 24) && std::is_same<T, __hip_bfloat16>::value) {
+        // ONE (14) or TWO (24) waves per SIMD running the same program: 4-wave workgroups, residency set through the LDS size
+        constexpr int kW4 = 4;
+        const int qb4 = (Sq + 32 * kW4 - 1) / (32 * kW4);
+        const int64_t tot4 = (int64_t)B * H * qb4;
+        const int lds = xp == 14 ? 100 * 1024 : 70 * 1024;
+        auto kern = &attn_flash8_kernel<T, kW4, false, 0>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tot4), dim3(64 * kW4), lds, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, H, Sq, Sk,
+                           scale * 1.4426950408889634f, qb4, (int)tot4, q_rs, kv_rs, o_rs);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
     if (xp && kWaves == 8 && std::is_same<T, __hip_bfloat16>::value) {
         auto go = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 16);
@@ -493,11 +580,21 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
             case 5: go(&attn_flash8_kernel<T, kWaves, false, 5>); break;
             case 7: go(&attn_flash8_kernel<T, kWaves, false, 7>); break;
             case 9: go(&attn_flash8_kernel<T, kWaves, false, 9>); break;
+            case 15: go(&attn_flash8_kernel<T, kWaves, false, 15>); break;
+            case 17: go(&attn_flash8_kernel<T, kWaves, false, 15, 4>); break;
             default: go(&attn_flash8_kernel<T, kWaves, false, 6>); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
     }
 #endif
+    static const int loaders = getenv("MVI_ATTN_LOADERS") ? atoi(getenv("MVI_ATTN_LOADERS")) : 4;   // 8: every wave loads (A/B runs)
+    if (loaders == 4 && kWaves == 8) {
+        auto kern = fold ? &attn_flash8_kernel<T, kWaves, false, 0, 4> : &attn_flash8_kernel<T, kWaves, true, 0, 4>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 16);
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q, (const T*)k, (const T*)v,
+                           (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
     if (fold)
         hipLaunchKernelGGL((attn_flash8_kernel<T, kWaves, false>), dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q,
                            (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs,
