@@ -151,10 +151,20 @@ def main():
     mode = os.environ.get("MVI_BENCH_EXCHANGE", "auto")
     distributed = world > 1 or force_dist
     factored = distributed and (mode == "factored" or (mode == "auto" and mdist.FactoredGradExchange.pays(M, world)))
-    bucket = mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev)
+    # MVI_BENCH_RANGES=4: the other 11 floats are all-reduced in four Gaussian ranges, each started behind its own
+    # chain-rule kernel (dist.RangedGradExchange). Not the default: on one rank (RCCL group of 1) the four smaller kernels,
+    # the four collective calls and the assembly copy cost 0.19 ms per step (1.60 vs 1.41 ms), about what hiding three
+    # quarters of a 66 MB all-reduce can return at 8 ranks — to be decided on an 8-GPU node, which this round never had
+    n_ranges = int(os.environ.get("MVI_BENCH_RANGES", "1"))
+    ranged = factored and n_ranges > 1
+    bucket = (mdist.RangedGradExchange(N, M, deg, dev, n_ranges=n_ranges) if ranged else
+              mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev))
 
     def step():
         color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **kw)
+        if ranged:
+            R.rasterize_backward_ranged(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], bucket)
+            return st, radii
         if factored:
             # the all-gather of the colour factors starts right behind the render backward and runs under the chain rule
             R.rasterize_backward_split(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], bucket.views,
@@ -259,6 +269,7 @@ def main():
                        "n_contrib_mean": round(float(nc.mean()), 1), "tile_max_contrib_mean": round(float(tile_max.mean()), 1),
                        "pixels_saturated_frac": round(float((ft < 1e-3).float().mean()), 4),
                        "parallelism": f"views x{world}" + ((" + RCCL all-gather of SH colour factors + all-reduce of 11 floats/Gaussian"
+                                                             + (f" in {n_ranges} ranges overlapped with the chain rule" if ranged else "")
                                                             if factored else " + RCCL all-reduce of the gradient bucket")
                                                            if distributed else "")},
             "roofline": {"bound": "valu" if valu_bound else "hbm", "kernel": dom,

@@ -158,6 +158,18 @@ int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M,
                              float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                              void* stream);
 
+/* mvi_raster_backward_geom for the Gaussians [first, first + count) only (first a multiple of 64): every pointer is the
+ * base of the FULL [P, ...] array, as in mvi_raster_backward_geom; only rows of the range are read and written. Lets a
+ * view-parallel trainer run the chain rule in a few ranges and start the all-reduce of a finished range's gradients
+ * while the next range is computed (multiview_inpaint_amd/dist.py: RangedGradExchange). Ranges are independent: the
+ * union of the calls over a partition of [0, P) writes exactly what one mvi_raster_backward_geom call writes. */
+int mvi_raster_backward_geom_range(const mvi_raster_settings* s, int32_t P, int32_t M, int32_t first, int32_t count,
+                                   const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                                   const float* rotations, const float* cov3D_precomp, const int32_t* radii, const void* geom,
+                                   const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                                   float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                                   void* stream);
+
 /* Introspection used by the parity tests: copies of intermediate device arrays' addresses.
  * Pointers alias the caller's scratch buffers; valid while those are. */
 typedef struct mvi_raster_views {

@@ -100,6 +100,8 @@ def lib():
     L.mvi_raster_backward_render.argtypes = [C.POINTER(RasterSettings), i32, i64] + [vp] * 7 + [i32, i32, vp]
     L.mvi_raster_backward_geom.restype = C.c_int
     L.mvi_raster_backward_geom.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 18
+    L.mvi_raster_backward_geom_range.restype = C.c_int
+    L.mvi_raster_backward_geom_range.argtypes = [C.POINTER(RasterSettings), i32, i32, i32, i32] + [vp] * 18
     L.mvi_raster_forward_geom_raw.restype = C.c_int
     L.mvi_raster_forward_geom_raw.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 6 + [vp, sz, vp, C.POINTER(i64), vp]
     L.mvi_raster_backward_raw.restype = C.c_int

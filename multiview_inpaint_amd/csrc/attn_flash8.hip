@@ -130,6 +130,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
     const int qrow = qb * kQB + wave * 32 + qcol;
+    const bool young = wave >= kWaves / 2;       // wave-uniform
 
     const float sc_mul = kExact ? scale_log2e : 1.0f;            // what a score is multiplied by on its way into exp2
     // ---- Q' = Q (exact form) or round(Q * scale * log2 e): B operand of S^T = K Q^T, element j of lane (qcol, hh), d-step s: Q[qrow][16 s + 8 hh + j]
@@ -433,6 +434,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                     if ((k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) s1[r] = -INFINITY;
             }
             decide(s1);
+            if (kX == 18 && young) __builtin_amdgcn_s_setprio(2);        // (experiment) second half of the tile: the late half wins
             if (has_next) fq0 = load_frags(next, 1, 0, true, next, 0);
             quarter(pipe_c, f2, has_next, 0, s0, 0, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
@@ -451,6 +453,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                     return;
                 }
             }
+            if (kX == 18 && young) __builtin_amdgcn_s_setprio(0);
             if (has_next) {
                 if (kLoaders != kWaves) issue_tile(t + 3);
                 wait_tiles_then_barrier(std::integral_constant<int, 1>{});   // own pieces of tile t + 2 (and everything older) landed
@@ -582,6 +585,8 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
             case 9: go(&attn_flash8_kernel<T, kWaves, false, 9>); break;
             case 15: go(&attn_flash8_kernel<T, kWaves, false, 15>); break;
             case 17: go(&attn_flash8_kernel<T, kWaves, false, 15, 4>); break;
+            case 18: go(&attn_flash8_kernel<T, kWaves, false, 18, 4>); break;
+            case 19: go(&attn_flash8_kernel<T, kWaves, false, 0, 4>); break;
             default: go(&attn_flash8_kernel<T, kWaves, false, 6>); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;

@@ -348,15 +348,17 @@ int mvi_raster_backward_render(const mvi_raster_settings* s, int32_t P, int64_t 
                                 sh_input, grad_rows_prezeroed, stream);
 }
 
-int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D, const float* shs,
-                             const float* colors_precomp, const float* scales, const float* rotations,
-                             const float* cov3D_precomp, const int32_t* radii, const void* geom,
-                             const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
-                             float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                             void* stream) {
+static int backward_geom_range_impl(const mvi_raster_settings* s, int32_t P, int32_t M, int32_t first, int32_t count,
+                                    const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii, const void* geom,
+                                    const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                                    float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                                    void* stream) {
     mvi::Frame f;
     if (int rc = make_frame(s, P, M, f)) return rc;
-    if (P == 0) return MVI_OK;
+    if (first < 0 || count < 0 || (int64_t)first + count > P || (first % 64) != 0)
+        return fail(MVI_EINVAL, "backward range out of bounds or not 64-aligned%s: first %lld count %lld", "", first, count);
+    if (P == 0 || count == 0) return MVI_OK;
     if ((shs == nullptr) == (colors_precomp == nullptr))
         return fail(MVI_EINVAL, "Please provide excatly one of either SHs or precomputed colors!%s");
     if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
@@ -368,14 +370,43 @@ int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M,
     if (colors_precomp && !dL_dcolors) return fail(MVI_EINVAL, "dL_dcolors is NULL but colors_precomp was a forward input%s");
     if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
         return fail(MVI_EINVAL, "missing covariance gradient output%s");
+    // per-Gaussian views of the scratch (carved for the full P) and every caller array, moved to the range's first row
     mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
+    const size_t o = (size_t)first;
+    g.depths += o; g.xy += o; g.cov_a += o; g.cov_b += o; g.conic_opacity += o; g.rgbd += o; g.tiles_touched += o; g.rect += o;
+    g.clamped += o;
+    auto at = [o](auto* p, size_t w) { return p ? p + o * w : p; };
+    f.P = count;
     hipStream_t st = (hipStream_t)stream;
     mvi::StageTimer tm(mvi::kStPreBwd, st);
-    if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, grad_rows_scratch,
-                                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dshs, dL_dcov3D, dL_dscales,
-                                        dL_drotations, st, mvi::RawBackwardExtra()))
+    if (mvi::launch_preprocess_backward(f, at(means3D, 3), at(shs, 3 * (size_t)M), at(scales, 3), at(rotations, 4), at(cov3D_precomp, 6),
+                                        at(radii, 1), g, at(grad_rows_scratch, 16), at(dL_dmeans3D, 3), at(dL_dmeans2D, 3),
+                                        at(dL_dopacity, 1), at(dL_dcolors, 3), at(dL_dshs, 3 * (size_t)M), at(dL_dcov3D, 6),
+                                        at(dL_dscales, 3), at(dL_drotations, 4), st, mvi::RawBackwardExtra()))
         return hip_fail("preprocess_backward", hipGetLastError());
     return MVI_OK;
+}
+
+int mvi_raster_backward_geom(const mvi_raster_settings* s, int32_t P, int32_t M, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* scales, const float* rotations,
+                             const float* cov3D_precomp, const int32_t* radii, const void* geom,
+                             const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                             float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                             void* stream) {
+    return backward_geom_range_impl(s, P, M, 0, P, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, radii, geom,
+                                    grad_rows_scratch, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dshs, dL_dcolors, dL_dscales,
+                                    dL_drotations, dL_dcov3D, stream);
+}
+
+int mvi_raster_backward_geom_range(const mvi_raster_settings* s, int32_t P, int32_t M, int32_t first, int32_t count,
+                                   const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                                   const float* rotations, const float* cov3D_precomp, const int32_t* radii, const void* geom,
+                                   const float* grad_rows_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                                   float* dL_dshs, float* dL_dcolors, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                                   void* stream) {
+    return backward_geom_range_impl(s, P, M, first, count, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
+                                    geom, grad_rows_scratch, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dshs, dL_dcolors, dL_dscales,
+                                    dL_drotations, dL_dcov3D, stream);
 }
 
 int mvi_raster_sh_backward_views(int32_t P, int32_t M, int32_t sh_degree, int32_t n_views, const float* means3D,

@@ -197,3 +197,58 @@ class FactoredGradExchange:
         g = {n: self.views[n] for n, _ in self.SMALL}
         g["shs"] = self.shs
         return g
+
+
+class RangedGradExchange(FactoredGradExchange):
+    """FactoredGradExchange whose 11 small floats per Gaussian are exchanged in `n_ranges` pieces, each all-reduced as soon as
+    the chain rule of its Gaussian range has been queued (raster.rasterize_backward_ranged drives it through
+    mvi_raster_backward_geom_range): the collective of range r runs on RCCL's stream under the kernels of ranges r+1 ...,
+    so only the last range's all-reduce (1 / n_ranges of the 44 P bytes) is exposed behind the backward, plus the SH rebuild.
+    The buffer is range-major — range r holds [means3D 3 | opacities 1 | scales 3 | rotations 4] x n_r contiguously — so
+    every piece is ONE contiguous all-reduce. Sums are identical to FactoredGradExchange (same elements, same reduction)."""
+
+    def __init__(self, P: int, M: int, sh_degree: int, device, n_ranges: int = 4, group=None):
+        super().__init__(P, M, sh_degree, device, group=group)
+        per = -(-P // max(1, n_ranges))
+        per = -(-per // 64) * 64                               # range starts are multiples of 64 (the kernels' block of Gaussians)
+        self.ranges = [(a, min(per, P - a)) for a in range(0, P, per)] if P else []
+        self.width = sum(w for _, w in self.SMALL)             # 11
+        self._range_views = []
+        for first, n in self.ranges:
+            seg, o, v = self.small[self.width * first:self.width * (first + n)], 0, {}
+            for name, w in self.SMALL:
+                v[name] = seg[o:o + n * w].view(n, w)
+                o += n * w
+            self._range_views.append(v)
+        # the SoA views of the base class do not describe this layout: assembled by finish()
+        for name, _ in self.SMALL:
+            self.views[name] = None
+        self._works = []
+
+    def range_views(self, r: int):
+        """{means3D, opacities, scales, rotations} -> [n_r, w] tensors the chain rule of range r writes."""
+        return self._range_views[r]
+
+    def reduce_range(self, r: int):
+        """Starts the all-reduce of range r (call right after its chain-rule kernel has been queued)."""
+        first, n = self.ranges[r]
+        self._works.append(td.all_reduce(self.small[self.width * first:self.width * (first + n)], op=td.ReduceOp.SUM,
+                                         group=self.group, async_op=True))
+
+    def finish(self, means3D: torch.Tensor):
+        """Waits for the pieces and the gather begun earlier, rebuilds dL/dSH; returns {means3D, opacities, scales,
+        rotations, shs} as [P, w] tensors (the small ones assembled from the range-major buffer: one 44 P-byte copy)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._gather.wait()
+        self._gather = None
+        factors = self.recv[:, :3 * self.P].view(self.world, self.P, 3)
+        sh_grad_from_factors(means3D, self.recv[:, 3 * self.P:], factors, self.M, self.deg, out=self.shs)
+        g = {name: torch.cat([v[name] for v in self._range_views], 0) if self._range_views
+             else self.small.new_zeros(0, w) for name, w in self.SMALL}
+        g["shs"] = self.shs
+        return g
+
+    def exchange(self, means3D, campos):
+        raise NotImplementedError("RangedGradExchange is driven range by range: begin_gather / reduce_range / finish")

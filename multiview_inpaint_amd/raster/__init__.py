@@ -235,6 +235,47 @@ def rasterize_backward_split(rs: GaussianRasterizationSettings, st: RasterState,
     return g
 
 
+def rasterize_backward_ranged(rs: GaussianRasterizationSettings, st: RasterState, grad_color, means3D, shs, scales, rotations,
+                              exchange, means2D_out=None):
+    """Backward of one view for view-parallel training with the exchange overlapped range by range
+    (dist.RangedGradExchange): render backward -> the colour factors' all-gather starts -> for every Gaussian range the
+    chain rule (mvi_raster_backward_geom_range) writes straight into the exchange buffer and that range's all-reduce starts
+    behind it -> exchange.finish() waits and rebuilds dL/dSH. Returns the summed gradients {means3D, shs, opacities,
+    scales, rotations} and this view's dL/dmeans2D [P, 3] (a per-view densification statistic: not exchanged)."""
+    L = _lib.lib()
+    fr = _Frame(rs)
+    dev = means3D.device
+    P = st.P
+    f32 = dict(dtype=torch.float32, device=dev)
+    if exchange.P != P or exchange.M != st.M:
+        raise RuntimeError(f"exchange was built for P={exchange.P}, M={exchange.M}; this view has P={P}, M={st.M}")
+    factor = exchange.views["sh_color_factor"]
+    m2d = torch.zeros(P, 3, **f32) if means2D_out is None else means2D_out
+    scratch, clean = st.take_rows(dev)
+    spare = torch.empty(P, 3, **f32)                  # the chain-rule kernel writes the factors again: not into the buffer in flight
+    grad_color = grad_color.to(torch.float32).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(L.mvi_raster_backward_render(C.byref(fr.c), P, st.D, _ptr(st.radii), _ptr(st.geom), _ptr(st.binning),
+                                                _ptr(st.image), _ptr(grad_color), _ptr(scratch), _ptr(factor), 1, clean, stream),
+                   "rasterize backward (render)")
+        exchange.begin_gather(rs.campos)
+        for r, (first, n) in enumerate(exchange.ranges):
+            v = exchange.range_views(r)
+            # the C entry takes the base of the FULL [P, w] array and moves to row `first` itself: hand it the address the
+            # range's [n, w] block would have as rows first .. first + n of such an array
+            base = lambda t, w: C.c_void_p(t.data_ptr() - 4 * w * first)
+            _lib.check(L.mvi_raster_backward_geom_range(C.byref(fr.c), P, st.M, first, n, _ptr(means3D), _ptr(shs), None, _ptr(scales),
+                                                        _ptr(rotations), None, _ptr(st.radii), _ptr(st.geom), _ptr(scratch),
+                                                        base(v["means3D"], 3), _ptr(m2d), base(v["opacities"], 1), None, _ptr(spare),
+                                                        base(v["scales"], 3), base(v["rotations"], 4), None, stream),
+                       "rasterize backward (geom range)")
+            exchange.reduce_range(r)
+    g = exchange.finish(means3D)
+    g["means2D"] = m2d
+    return g
+
+
 def sh_backward_views(means3D, campos, color_factors, M, sh_degree, out=None):
     """Sum over views of the SH gradient rebuilt from per-view colour factors:
     out[g,k,c] = sum_v Y_k(normalize(means3D[g] - campos[v])) * color_factors[v,g,c]  ->  [P,M,3].

@@ -183,3 +183,37 @@ def test_factored_exchange_of_real_per_view_gradients_world2(tmp_path):
     mp.spawn(_worker_oracle, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     a, b = (torch.load(tmp_path / f"o{r}.pt") for r in range(world))
     assert torch.equal(a["shs"], b["shs"]) and torch.equal(a["means3D"], b["means3D"])   # ranks agree bit for bit
+
+
+def _worker_ranged(rank, world, port, out_dir):
+    """RangedGradExchange (range-major buffer, one all-reduce per Gaussian range) gives the sums of FactoredGradExchange."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from multiview_inpaint_amd import dist as md
+    P, M, deg = 1000, 16, 3                                  # 1000 rows in 4 ranges: 256, 256, 256, 232 (64-aligned starts)
+    g = [torch.Generator().manual_seed(900 + r) for r in range(world)]
+    means = torch.randn(P, 3, generator=torch.Generator().manual_seed(3)) + torch.tensor([0.0, 0.0, 4.0])
+    cams = [torch.randn(3, generator=g[r]) for r in range(world)]
+    fac = [torch.randn(P, 3, generator=g[r]) for r in range(world)]
+    small = [{n: torch.randn(P, w, generator=g[r]) for n, w in md.FactoredGradExchange.SMALL} for r in range(world)]
+    ex = md.RangedGradExchange(P, M, deg, "cpu", n_ranges=4)
+    assert [a for a, _ in ex.ranges] == [0, 256, 512, 768] and sum(n for _, n in ex.ranges) == P
+    ex.views["sh_color_factor"].copy_(fac[rank])
+    ex.begin_gather(cams[rank])
+    for r, (first, n) in enumerate(ex.ranges):
+        for name, v in ex.range_views(r).items():
+            v.copy_(small[rank][name][first:first + n])
+        ex.reduce_range(r)
+    got = ex.finish(means)
+    ref = md.FactoredGradExchange(P, M, deg, "cpu")
+    ref.views["sh_color_factor"].copy_(fac[rank])
+    for name, v in small[rank].items():
+        ref.views[name].copy_(v)
+    want = ref.exchange(means, cams[rank])
+    for name in ("means3D", "opacities", "scales", "rotations", "shs"):
+        assert got[name].shape == want[name].shape and torch.equal(got[name], want[name]), name
+    td.destroy_process_group()
+
+
+def test_ranged_exchange_equals_factored_exchange_world2(tmp_path):
+    mp.spawn(_worker_ranged, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

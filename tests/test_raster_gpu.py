@@ -561,3 +561,38 @@ def test_edge_1080p_scale_image_not_a_multiple_of_the_tile(R, ro):
     cam = syn.make_camera(1912, 1075, 50.0)
     sc = syn.make_scene(120_000, cam, 1, seed=3)
     _fwd_bwd_vs_oracle(R, ro, cam, sc, np.array([0.2, 0.1, 0.4], np.float32), 3)
+
+
+def test_ranged_backward_with_overlapped_exchange_equals_one_call(R):
+    """rasterize_backward_ranged (render backward, then the chain rule in four Gaussian ranges through
+    mvi_raster_backward_geom_range, each range's all-reduce started behind its kernel: dist.RangedGradExchange) on ONE rank
+    over RCCL: the sums of one rank are the rank's own gradients, so everything must equal rasterize_backward to the order
+    of the float atomics, dL/dSH included (rebuilt from the colour factor and the camera centre)."""
+    import os
+    import socket
+    import torch.distributed as td
+    from multiview_inpaint_amd import dist as md
+    cam, sc, bg = small_scene(9, N=3000, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
+    t = _to_dev(sc)
+    rs = _settings(R, cam, bg, 3)
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+    g_img = torch.randn(3, cam["H"], cam["W"], device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    one = R.rasterize_backward(rs, st, g_img, t["means3D"], **kw)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        P, M = t["means3D"].shape[0], t["shs"].shape[1]
+        ex = md.RangedGradExchange(P, M, 3, "cuda", n_ranges=4)
+        assert len(ex.ranges) == 4 and all(a % 64 == 0 for a, _ in ex.ranges)
+        two = R.rasterize_backward_ranged(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], ex)
+        torch.cuda.synchronize()
+    finally:
+        td.destroy_process_group()
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations", "shs"):
+        assert two[k].shape == one[k].shape, k
+        assert _same_to_summation_order(two[k].cpu().numpy(), one[k].cpu().numpy()), k
