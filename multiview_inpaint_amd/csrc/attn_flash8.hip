@@ -105,6 +105,10 @@ template <int N, bool kBarrier = true> __device__ __forceinline__ void wait_vm_t
 // scale * log2(e) into Q saves those 32 multiplies per wave and tile but rounds Q a second time to bf16: an error of
 // |logit| * 2^-9 in the exponent, i.e. a few per cent on P where two keys with logits of ~60 compete (2.7e-2 of the
 // output scale on the adversarial rows of tests/test_unet_ops_gpu.py, against 5e-3 with the exact form).
+#ifdef MVI_ATTN_EXPERIMENTS
+__device__ uint64_t g_timeline[8 * 8192];      // kX 20: per block {entry, loop start, loop end, exit} in 10 ns ticks, HW_ID, XCC_ID, cycles
+#endif
+
 template <typename T, int kWaves, bool kExact = true, int kX = 0, int kLoaders = kWaves>   // kX != 0: timing experiments that drop one kind of work (results are wrong on purpose)
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves == 6 ? 3 : 2, kWaves == 6 ? 3 : 2)))
 void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
@@ -114,6 +118,9 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     using frag = typename M::frag;
     const uint64_t t_entry = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t t_loop0 = 0, t_loop1 = 0;
+    const uint64_t rt_entry = kX == 20 ? __builtin_amdgcn_s_memrealtime() : 0;       // (kX 20: block timeline)
+    const uint64_t ck_entry = kX == 20 ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t rt_loop0 = 0, rt_loop1 = 0;
     constexpr int kQB = 32 * kWaves;             // query rows per block
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
@@ -400,6 +407,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};                  // (kX 15 / 16: cycles per quarter and per barrier, summed over tiles)
         const uint64_t clk0 = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memtime() : 0;
         t_loop0 = clk0;
+        if (kX == 20 && !kSafe) rt_loop0 = __builtin_amdgcn_s_memrealtime();
         const uint64_t rt0 = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memrealtime() : 0;
         Pending pend;                                            // fast form: the quarter whose P V is still to be issued
         pend.p = u32x4{0, 0, 0, 0};
@@ -471,6 +479,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         }
         for (; t < n_tiles; ++t) tile(t, t & (kRing - 1), t + 1 < n_tiles);
         if (kX >= 15 && kX <= 16) t_loop1 = __builtin_amdgcn_s_memtime();
+        if (kX == 20 && !kSafe) rt_loop1 = __builtin_amdgcn_s_memrealtime();
         if (kX >= 15 && kX <= 16 && !kSafe && lane == 0 && blockIdx.x == 7 && (wave == 0 || wave == kWaves - 1))
             printf("block %d wave %d: %llu tiles; cycles per tile: q0 %llu q1 %llu q2 %llu q3 %llu wait+barrier %llu; in-kernel clock %.0f MHz\n",
                    (int)blockIdx.x, wave, (unsigned long long)stamp[5], (unsigned long long)(stamp[0] / stamp[5]),
@@ -512,6 +521,21 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                 *reinterpret_cast<u32x2*>(op + 32 * db + 8 * g + 4 * hh) = w;
             }
     }
+#ifdef MVI_ATTN_EXPERIMENTS
+    if (kX == 20 && wave == 0 && blockIdx.x < 8192) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t rt_exit = __builtin_amdgcn_s_memrealtime();
+        const uint64_t ck_exit = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            uint64_t* rec = g_timeline + 8 * blockIdx.x;
+            rec[0] = rt_entry; rec[1] = rt_loop0; rec[2] = rt_loop1; rec[3] = rt_exit;
+            rec[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+            rec[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+            rec[6] = ck_exit - ck_entry;
+            rec[7] = 1;
+        }
+    }
+#endif
     if (kX >= 15 && kX <= 16 && lane == 0 && blockIdx.x == 3001 && wave == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t t_exit = __builtin_amdgcn_s_memtime();
@@ -521,6 +545,12 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
 }
 
 }  // namespace f8
+
+#ifdef MVI_ATTN_EXPERIMENTS
+extern "C" int mvi_attn_debug_timeline(uint64_t* host, int n_blocks) {           // tools/attn_dev only
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(f8::g_timeline), sizeof(uint64_t) * 8 * (size_t)(n_blocks < 8192 ? n_blocks : 8192)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <typename T, int kWaves>
 static int flash8_launch_w(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, float scale,
@@ -587,6 +617,7 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
             case 17: go(&attn_flash8_kernel<T, kWaves, false, 15, 4>); break;
             case 18: go(&attn_flash8_kernel<T, kWaves, false, 18, 4>); break;
             case 19: go(&attn_flash8_kernel<T, kWaves, false, 0, 4>); break;
+            case 20: go(&attn_flash8_kernel<T, kWaves, true, 20, 4>); break;       // the shipped form + block timeline
             default: go(&attn_flash8_kernel<T, kWaves, false, 6>); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;

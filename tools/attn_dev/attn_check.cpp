@@ -3,6 +3,9 @@
 //                                     -Lmultiview_inpaint_amd/csrc -lmvi_hip -Wl,-rpath,'$ORIGIN/../../multiview_inpaint_amd/csrc' -o tools/attn_dev/attn_check
 // Run:    MVI_ATTN_VARIANT=8 tools/attn_dev/attn_check            (4 = the 4-wave kernel, 8 = the 8-wave kernel)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -137,6 +140,67 @@ static void bench(int B, int H, int S, int iters) {
     CK(hipFree(d)); CK(hipFree(o));
 }
 
+// "timeline": needs the experiment build (tools/attn_dev/build_x.sh) and MVI_ATTN_EXPERIMENT=20. Every block records when it
+// entered, started / ended its tile loop and left (s_memrealtime, 10 ns ticks) and where it ran (HW_ID, XCC_ID); the host
+// reconstructs the per-CU schedule: how long a CU sits between two blocks, how much of a block is not the tile loop.
+static void timeline(int B, int H, int S) {
+    using fn_t = int (*)(uint64_t*, int);
+    fn_t rd = (fn_t)dlsym(RTLD_DEFAULT, "mvi_attn_debug_timeline");
+    if (!rd) { printf("timeline: this libmvi_hip.so is not the experiment build\n"); return; }
+    const int D = 64, HD = H * D;
+    const size_t n = (size_t)B * S * 3 * HD;
+    std::vector<uint16_t> buf(n);
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (size_t i = 0; i < n; ++i) buf[i] = f2bf(nd(rng));
+    uint16_t *d, *o;
+    CK(hipMalloc(&d, n * 2)); CK(hipMalloc(&o, (size_t)B * S * HD * 2));
+    CK(hipMemcpy(d, buf.data(), n * 2, hipMemcpyHostToDevice));
+    for (int i = 0; i < 6; ++i) mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+    CK(hipDeviceSynchronize());
+    const int nb = B * H * ((S + 255) / 256);
+    std::vector<uint64_t> t(8 * (size_t)std::min(nb, 8192));
+    if (rd(t.data(), nb)) { printf("timeline: read-back failed\n"); return; }
+    const int m = std::min(nb, 8192);
+    uint64_t t0 = ~0ull, t1 = 0;
+    for (int i = 0; i < m; ++i) { t0 = std::min(t0, t[8 * i]); t1 = std::max(t1, t[8 * i + 3]); }
+    std::map<uint32_t, std::vector<int>> cu;                       // (xcc, se, sh, cu) -> blocks
+    double pro = 0, loop = 0, epi = 0, clk = 0;
+    for (int i = 0; i < m; ++i) {
+        const uint32_t hw = (uint32_t)t[8 * i + 4], xcc = (uint32_t)t[8 * i + 5] & 15u;
+        cu[(xcc << 16) | (hw & 0xff00u)].push_back(i);           // cu_id [11:8], sh_id [12], se_id [15:13]
+        pro += (double)(t[8 * i + 1] - t[8 * i]); loop += (double)(t[8 * i + 2] - t[8 * i + 1]); epi += (double)(t[8 * i + 3] - t[8 * i + 2]);
+        clk += (double)t[8 * i + 6] / (double)(t[8 * i + 3] - t[8 * i]);
+    }
+    printf("timeline B=%d H=%d S=%d: %d blocks on %zu CUs; kernel span %.1f us\n", B, H, S, m, cu.size(), (t1 - t0) * 0.01);
+    printf("  mean per block: entry->loop %.2f us, tile loop %.2f us, loop->exit %.2f us; mean in-block clock %.0f MHz\n", pro / m * 0.01,
+           loop / m * 0.01, epi / m * 0.01, clk / m * 100.0);
+    double gap = 0, busy = 0, lead = 0, tail = 0; int ngap = 0, overlap = 0; size_t mn = 1 << 30, mx = 0;
+    std::vector<double> gaps;
+    for (auto& kv : cu) {
+        auto& v = kv.second;
+        std::sort(v.begin(), v.end(), [&](int a, int b) { return t[8 * a] < t[8 * b]; });
+        mn = std::min(mn, v.size()); mx = std::max(mx, v.size());
+        lead += (double)(t[8 * v.front()] - t0); tail += (double)(t1 - t[8 * v.back() + 3]);
+        for (size_t j = 0; j < v.size(); ++j) {
+            busy += (double)(t[8 * v[j] + 3] - t[8 * v[j]]);
+            if (j) {
+                const double g = (double)t[8 * v[j]] - (double)t[8 * v[j - 1] + 3];
+                if (g < 0) ++overlap;
+                gap += g; ++ngap; gaps.push_back(g);
+            }
+        }
+    }
+    std::sort(gaps.begin(), gaps.end());
+    printf("  blocks per CU %zu .. %zu; gap between consecutive blocks of a CU: mean %.2f us, median %.2f, p90 %.2f, max %.2f (%d overlapping pairs)\n",
+           mn, mx, gap / std::max(ngap, 1) * 0.01, gaps.empty() ? 0.0 : gaps[gaps.size() / 2] * 0.01, gaps.empty() ? 0.0 : gaps[gaps.size() * 9 / 10] * 0.01,
+           gaps.empty() ? 0.0 : gaps.back() * 0.01, overlap);
+    const double span = (double)(t1 - t0) * cu.size();
+    printf("  of CU x span: in blocks %.1f %%, of which tile loop %.1f %%; between blocks %.1f %%; before first block %.1f %%; after last block %.1f %%\n",
+           100 * busy / span, 100 * loop / span, 100 * gap / span, 100 * lead / span, 100 * tail / span);
+    CK(hipFree(d)); CK(hipFree(o));
+}
+
 int main(int argc, char** argv) {
     const char* var = getenv("MVI_ATTN_VARIANT");
     printf("MVI_ATTN_VARIANT=%s\n", var ? var : "(default)");
@@ -144,6 +208,11 @@ int main(int argc, char** argv) {
     if (argc >= 2 && !strcmp(argv[1], "bench0")) {
         g_zero_data = true;
         bench(28, 5, 9216, 10);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "timeline")) {
+        timeline(28, 5, 9216);
+        timeline(28, 10, 2304);
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "bench1")) {       // one shape, few launches: the target of the PMC passes

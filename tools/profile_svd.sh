@@ -20,7 +20,7 @@ import csv, collections
 rows = [r for r in csv.DictReader(open("$f"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step contains exactly 23 flash-attention launches; cut at the 23rd-from-last one's step start
-fl = [i for i, r in enumerate(rows) if "attn_flash_kernel" in r["Kernel_Name"]]
+fl = [i for i, r in enumerate(rows) if "attn_flash" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]]
 start_i = fl[-23]
 # walk back to the beginning of that step: the hint stem's first conv comes ~60 kernels earlier; use a time gap instead
 t_first = int(rows[start_i]["Start_Timestamp"])
