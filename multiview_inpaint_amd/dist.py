@@ -252,3 +252,207 @@ class RangedGradExchange(FactoredGradExchange):
 
     def exchange(self, means3D, campos):
         raise NotImplementedError("RangedGradExchange is driven range by range: begin_gather / reduce_range / finish")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded Adam (reduce-scatter -> local step on the owned Gaussians -> all-gather of the updated rows)
+
+class ShardPlan:
+    """Rows (Gaussians) of every parameter tensor split over the ranks: rank r owns rows [r * rows, (r + 1) * rows) of the
+    BODY = world * rows rows, `rows` a multiple of 64 (the kernels' block of Gaussians); the TAIL [body, P) — fewer than
+    64 * world + 63 rows — is kept replicated: its gradient is all-reduced and every rank steps it redundantly. With that,
+    any P shards with equal pieces and no padding, so the collectives work in place on the parameter tensors themselves."""
+
+    def __init__(self, P: int, world: int, rank: int):
+        self.P, self.world, self.rank = P, world, rank
+        self.rows = (P // world) // 64 * 64
+        self.body = self.rows * world
+        self.tail = P - self.body
+        self.first = rank * self.rows
+
+    def own(self, t: torch.Tensor) -> torch.Tensor:
+        return t[self.first:self.first + self.rows]
+
+    def tail_of(self, t: torch.Tensor) -> torch.Tensor:
+        return t[self.body:]
+
+
+class ShardedAdam:
+    """Adam over the reference's parameter groups (gaussian_model.py:154-163: one group per tensor, its own lr, eps 1e-15)
+    for view-parallel training, with optimizer state and the step itself sharded by Gaussian (ShardPlan):
+
+        step(grads):   grads[name] = THIS rank's view gradient, [P, ...]
+          1. reduce-scatter of every gradient's body -> the summed gradient of the owned rows; all-reduce of the tail rows
+          2. the inner optimizer (train_ops.FusedAdam on the GPU) steps the owned rows and the tail: 1 / world of the
+             28 B / parameter of Adam traffic, 1 / world of the moments
+          3. in-place all-gather of the owned rows of every parameter (input = the parameter's own slice)
+
+    After step() every rank holds the same parameters as `inner` would give un-sharded on the summed gradients
+    (bit-identical when the reduction order is: same elements, same kernel). step_factored() is the same with the
+    SH gradient travelling as colour factors (FactoredGradExchange): owners receive the factor slices of all views by
+    all-to-all and rebuild dL/dSH for their rows only.
+
+    Wire per GPU and step, f = floats per Gaussian (11 + 3M), ring collectives: dense all-reduce + replicated step
+    2 (W-1)/W * 4 f P; this class (W-1)/W * 4 f P (reduce-scatter) + (W-1)/W * 4 f P (all-gather) = the same bytes, minus
+    (W-1)/W of the optimizer's HBM traffic. Against FactoredGradExchange it LOSES wire at high SH degree: the parameter
+    all-gather moves all 3M SH floats, the factored gradient exchange only 3 (W-1) — 384 MB against 241 MB at W = 8,
+    M = 16, P = 1.5 M — so bench.py keeps the replicated FusedAdam there and this is for sh_degree 0 / 1 models and for
+    fitting more Gaussians (moments are 8 B / parameter). DESIGN.md §6 has the link arithmetic.
+
+    Densification and checkpoints edit / store full-size moments (gaussian_model.py:335-404, :61-93): full_state()
+    gathers them into torch.optim.Adam's layout, load_full_state() re-shards after the tensors were rebuilt."""
+
+    def __init__(self, named_params: Dict[str, torch.Tensor], lrs, betas=(0.9, 0.999), eps=1e-15, group=None, inner=None):
+        self.group = group
+        self.world, self.rank = td.get_world_size(group), td.get_rank(group)
+        self.betas, self.eps = betas, eps
+        if inner is None:
+            from .train_ops import FusedAdam as inner          # HIP kernel; CPU tests pass torch.optim.Adam
+        self._inner_cls = inner
+        self._lrs = {n: float(lrs[n] if isinstance(lrs, dict) else lrs) for n in named_params}
+        self._bind(named_params)
+
+    # -- construction ------------------------------------------------------------------------------------------
+    def _bind(self, named_params):
+        self.params = dict(named_params)
+        Ps = {t.shape[0] for t in self.params.values()}
+        if len(Ps) != 1:
+            raise ValueError("ShardedAdam: every parameter tensor needs one row per Gaussian")
+        for n, t in self.params.items():
+            if not t.is_contiguous():
+                raise ValueError(f"ShardedAdam: parameter {n} is not contiguous")
+        self.plan = ShardPlan(Ps.pop(), self.world, self.rank)
+        self._own = {n: self.plan.own(t.data) for n, t in self.params.items()}
+        self._tail = {n: self.plan.tail_of(t.data) for n, t in self.params.items()}
+        groups = []
+        for n in self.params:
+            ps = [t for t in (self._own[n], self._tail[n]) if t.numel()]
+            groups.append({"params": ps, "lr": self._lrs[n], "name": n})
+        self.inner = self._inner_cls([g for g in groups if g["params"]], lr=0.0, betas=self.betas, eps=self.eps)
+        self._gown = {n: torch.zeros_like(self._own[n]) for n in self.params}
+
+    def set_lr(self, name: str, lr: float):
+        """The reference re-computes the xyz learning rate every iteration (gaussian_model.py:165-171)."""
+        self._lrs[name] = float(lr)
+        for g in self.inner.param_groups:
+            if g["name"] == name:
+                g["lr"] = float(lr)
+
+    # -- the step ----------------------------------------------------------------------------------------------
+    def _reduce_dense(self, name: str, grad: torch.Tensor, works):
+        pl, w = self.plan, self.params[name][0].numel() if self.plan.P else 0
+        g = grad if grad.is_contiguous() else grad.contiguous()
+        if pl.rows:
+            works.append(td.reduce_scatter_tensor(self._gown[name].view(-1), g.view(-1)[:pl.body * w], op=td.ReduceOp.SUM,
+                                                  group=self.group, async_op=True))
+        if pl.tail:
+            tail = g[pl.body:].clone()
+            works.append(td.all_reduce(tail, op=td.ReduceOp.SUM, group=self.group, async_op=True))
+            return tail
+        return None
+
+    def _apply(self, tails):
+        for n in self.params:
+            if self._own[n].numel():
+                self._own[n].grad = self._gown[n]
+            if self._tail[n].numel():
+                self._tail[n].grad = tails[n]
+        self.inner.step()
+        works = []
+        pl = self.plan
+        if pl.rows:
+            for n, t in self.params.items():
+                w = t[0].numel()
+                full = t.data.view(-1)[:pl.body * w]
+                src = self._own[n].reshape(-1)
+                if td.get_backend(self.group) == "gloo":
+                    src = src.clone()                      # gloo copies input -> output slot; keep it off the aliasing path
+                works.append(td.all_gather_into_tensor(full, src, group=self.group, async_op=True))
+        for h in works:
+            h.wait()
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor]):
+        works, tails = [], {}
+        for n in self.params:
+            tails[n] = self._reduce_dense(n, grads[n], works)
+        for h in works:
+            h.wait()
+        self._apply(tails)
+
+    @torch.no_grad()
+    def step_factored(self, grads: Dict[str, torch.Tensor], sh_color_factor: torch.Tensor, campos: torch.Tensor,
+                      means3D: torch.Tensor, sh_degree: int, dc_name: str = "f_dc", rest_name: str = "f_rest"):
+        """grads: the non-SH gradients of this rank's view ([P, w] each, keys = the other parameter names);
+        sh_color_factor [P, 3] (mvi_raster_backward(..., sh_grad="factor")), campos [3] this view's camera centre,
+        means3D [P, 3] the (replicated) positions the view directions are taken from — call BEFORE they are stepped,
+        i.e. pass the tensor the backward used. The SH gradient of the owned rows is rebuilt from all views' factors."""
+        pl, W = self.plan, self.world
+        works, tails = [], {}
+        for n in self.params:
+            if n not in (dc_name, rest_name):
+                tails[n] = self._reduce_dense(n, grads[n], works)
+        fac = sh_color_factor if sh_color_factor.is_contiguous() else sh_color_factor.contiguous()
+        cams = torch.zeros(W, 3, dtype=fac.dtype, device=fac.device)
+        works.append(td.all_gather_into_tensor(cams.view(-1), campos.reshape(3).to(fac.dtype).contiguous(), group=self.group,
+                                               async_op=True))
+        recv = torch.zeros(W, pl.rows, 3, dtype=fac.dtype, device=fac.device)
+        if pl.rows:
+            works.append(td.all_to_all_single(recv.view(-1), fac.view(-1)[:pl.body * 3], group=self.group, async_op=True))
+        tail_fac = torch.zeros(W, pl.tail, 3, dtype=fac.dtype, device=fac.device)
+        if pl.tail:
+            works.append(td.all_gather_into_tensor(tail_fac.view(-1), fac[pl.body:].reshape(-1).clone(), group=self.group,
+                                                   async_op=True))
+        for h in works:
+            h.wait()
+        M = 1 + (self.params[rest_name].shape[1] if rest_name in self.params else 0)
+        own_means = means3D[pl.first:pl.first + pl.rows]
+        if pl.rows:
+            sh = sh_grad_from_factors(own_means.contiguous(), cams, recv, M, sh_degree)
+            self._gown[dc_name].copy_(sh[:, :1].reshape(self._gown[dc_name].shape))
+            if rest_name in self.params:
+                self._gown[rest_name].copy_(sh[:, 1:].reshape(self._gown[rest_name].shape))
+        if pl.tail:
+            sh_t = sh_grad_from_factors(means3D[pl.body:].contiguous(), cams, tail_fac, M, sh_degree)
+            tails[dc_name] = sh_t[:, :1].reshape(self._tail[dc_name].shape).contiguous()
+            if rest_name in self.params:
+                tails[rest_name] = sh_t[:, 1:].reshape(self._tail[rest_name].shape).contiguous()
+        else:
+            tails[dc_name] = None
+            tails[rest_name] = None
+        self._apply(tails)
+
+    # -- full-size state for densification / checkpoints ----------------------------------------------------------
+    @torch.no_grad()
+    def full_state(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        """{name: {"step", "exp_avg", "exp_avg_sq"}} with full [P, ...] moments on every rank (torch.optim.Adam's layout)."""
+        pl, out = self.plan, {}
+        for n, t in self.params.items():
+            st_o = self.inner.state.get(self._own[n], {}) if self._own[n].numel() else {}
+            st_t = self.inner.state.get(self._tail[n], {}) if self._tail[n].numel() else {}
+            any_st = st_o or st_t
+            entry = {"step": (any_st["step"].clone() if any_st else torch.tensor(0.0))}
+            for key in ("exp_avg", "exp_avg_sq"):
+                full = torch.zeros_like(t.data)
+                if pl.rows:
+                    src = st_o[key] if st_o else torch.zeros_like(self._own[n])
+                    td.all_gather_into_tensor(full.view(-1)[:pl.body * t[0].numel()], src.reshape(-1).clone(), group=self.group)
+                if pl.tail and st_t:
+                    full[pl.body:] = st_t[key]
+                entry[key] = full
+            out[n] = entry
+        return out
+
+    @torch.no_grad()
+    def load_full_state(self, named_params: Dict[str, torch.Tensor], state: Dict[str, Dict[str, torch.Tensor]]):
+        """Re-binds to (possibly rebuilt, differently sized) parameter tensors and shards full-size moments onto the owners."""
+        self._bind(named_params)
+        pl = self.plan
+        for n in self.params:
+            if n not in state:
+                continue
+            for view, sl in ((self._own[n], slice(pl.first, pl.first + pl.rows)), (self._tail[n], slice(pl.body, pl.P))):
+                if view.numel():
+                    self.inner.state[view] = {"step": state[n]["step"].clone(),
+                                              "exp_avg": state[n]["exp_avg"][sl].clone().contiguous(),
+                                              "exp_avg_sq": state[n]["exp_avg_sq"][sl].clone().contiguous()}

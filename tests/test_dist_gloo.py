@@ -217,3 +217,88 @@ def _worker_ranged(rank, world, port, out_dir):
 
 def test_ranged_exchange_equals_factored_exchange_world2(tmp_path):
     mp.spawn(_worker_ranged, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _worker_sharded_adam(rank, world, port, out_dir):
+    """ShardedAdam (reduce-scatter -> owners step -> in-place all-gather) against torch.optim.Adam on the summed gradients:
+    ragged P (body 256 rows in 2 shards + 77 replicated tail rows), per-group learning rates that change between steps,
+    the factored SH form, and the full-size state round trip densification needs (prune to another P, keep stepping)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from multiview_inpaint_amd import dist as md
+    P, M, deg = 333, 4, 1
+    shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, M - 1, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    g0 = torch.Generator().manual_seed(5)
+    init = {n: torch.randn(s, generator=g0) for n, s in shapes.items()}
+    init["xyz"] = init["xyz"] + torch.tensor([0.0, 0.0, 5.0])
+    plan = md.ShardPlan(P, world, rank)
+    assert (plan.rows, plan.body, plan.tail) == (128, 256, 77)
+
+    def make_ref(tensors):
+        ps = {n: torch.nn.Parameter(t.clone()) for n, t in tensors.items()}
+        return ps, torch.optim.Adam([{"params": [p], "lr": lrs[n], "name": n} for n, p in ps.items()], lr=0.0, eps=1e-15)
+
+    ref_p, ref = make_ref(init)
+    mine = {n: t.clone() for n, t in init.items()}
+    opt = md.ShardedAdam(mine, lrs, eps=1e-15, inner=torch.optim.Adam)
+    gens = [torch.Generator().manual_seed(50 + r) for r in range(world)]
+    for it in range(3):
+        per_rank = [{n: torch.randn(s, generator=gens[r]) for n, s in shapes.items()} for r in range(world)]
+        if it == 1:
+            opt.set_lr("xyz", 9e-5)
+            [g for g in ref.param_groups if g["name"] == "xyz"][0]["lr"] = 9e-5
+        opt.step(per_rank[rank])
+        for n, p in ref_p.items():
+            p.grad = sum(per_rank[r][n] for r in range(world))
+        ref.step()
+        for n in shapes:
+            assert torch.equal(mine[n], ref_p[n].data), (it, n)
+    # full-size state, as torch.optim.Adam lays it out
+    full = opt.full_state()
+    for n, p in ref_p.items():
+        assert float(full[n]["step"]) == 3.0
+        assert torch.equal(full[n]["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(full[n]["exp_avg_sq"], ref.state[p]["exp_avg_sq"]), n
+    # prune (the reference's _prune_optimizer on full tensors), re-shard, keep stepping: P 333 -> 201 (body 128, tail 73)
+    keep = torch.rand(P, generator=torch.Generator().manual_seed(9)) > 0.4
+    keep[torch.nonzero(keep)[201:]] = False
+    P2 = int(keep.sum())
+    assert P2 == 201
+    pruned = {n: mine[n][keep].contiguous() for n in shapes}
+    pstate = {n: {"step": full[n]["step"], "exp_avg": full[n]["exp_avg"][keep], "exp_avg_sq": full[n]["exp_avg_sq"][keep]} for n in shapes}
+    opt.load_full_state(pruned, pstate)
+    assert (opt.plan.rows, opt.plan.body, opt.plan.tail) == (64, 128, 73)
+    ref_p2, ref2 = make_ref(pruned)
+    [g for g in ref2.param_groups if g["name"] == "xyz"][0]["lr"] = 9e-5         # the sharded optimizer keeps its learning rates
+    for n, p in ref_p2.items():
+        ref2.state[p] = {"step": torch.tensor(3.0), "exp_avg": pstate[n]["exp_avg"].clone(), "exp_avg_sq": pstate[n]["exp_avg_sq"].clone()}
+    per_rank = [{n: torch.randn((P2,) + s[1:], generator=gens[r]) for n, s in shapes.items()} for r in range(world)]
+    opt.step(per_rank[rank])
+    for n, p in ref_p2.items():
+        p.grad = sum(per_rank[r][n] for r in range(world))
+    ref2.step()
+    for n in shapes:
+        assert torch.equal(pruned[n], ref_p2[n].data), n
+    # factored SH form == dense form on the rank-1 SH gradients it stands for
+    a = {n: t.clone() for n, t in init.items()}
+    b = {n: t.clone() for n, t in init.items()}
+    oa = md.ShardedAdam(a, lrs, eps=1e-15, inner=torch.optim.Adam)
+    ob = md.ShardedAdam(b, lrs, eps=1e-15, inner=torch.optim.Adam)
+    cams = [torch.randn(3, generator=gens[r]) for r in range(world)]
+    fac = [torch.randn(P, 3, generator=gens[r]) * (torch.rand(P, 1, generator=gens[r]) > 0.3) for r in range(world)]
+    small = [{n: torch.randn(shapes[n], generator=gens[r]) for n in ("xyz", "opacity", "scaling", "rotation")} for r in range(world)]
+    dense_sh = md.sh_grad_from_factors(init["xyz"], cams[rank][None], fac[rank][None], M, deg)      # this view's dense dL/dSH
+    dense = dict(small[rank], f_dc=dense_sh[:, :1].contiguous(), f_rest=dense_sh[:, 1:].contiguous())
+    oa.step(dense)
+    ob.step_factored(small[rank], fac[rank], cams[rank], init["xyz"], deg)
+    for n in shapes:
+        assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), n
+    torch.save({n: t for n, t in b.items()}, os.path.join(out_dir, f"s{rank}.pt"))
+    td.destroy_process_group()
+
+
+def test_sharded_adam_world2(tmp_path):
+    mp.spawn(_worker_sharded_adam, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"s{r}.pt") for r in range(2))
+    for n in a:
+        assert torch.equal(a[n], b[n]), n                       # replicas stay bit-identical

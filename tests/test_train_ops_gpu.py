@@ -300,3 +300,61 @@ def test_prune_optimizer_state_matches_the_reference_recipe():
     opt_a.step(); opt_b.step()
     for ga, gb in zip(opt_a.param_groups, opt_b.param_groups):
         assert torch.equal(ga["params"][0], gb["params"][0])
+
+
+def test_sharded_adam_on_one_rank_equals_fused_adam(T):
+    """dist.ShardedAdam with its production inner optimizer (FusedAdam, mvi_adam_step) on ONE rank over RCCL: the
+    reduce-scatter / all-gather are identities there, so parameters and moments must equal plain FusedAdam bit for bit,
+    body and replicated tail rows (P = 10 000: 9 984 + 16), through a learning-rate change; then the factored SH form
+    against the dense one (SH gradient rebuilt by mvi_raster_sh_backward_views from the colour factor)."""
+    import os
+    import socket
+    import torch.distributed as td
+    from multiview_inpaint_amd import dist as md
+    P, M, deg = 10_000, 16, 3
+    shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, M - 1, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    g = torch.Generator("cuda").manual_seed(0)
+    init = {n: torch.randn(s, device="cuda", generator=g) for n, s in shapes.items()}
+    init["xyz"] = init["xyz"] + torch.tensor([0.0, 0.0, 5.0], device="cuda")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        mine = {n: t.clone() for n, t in init.items()}
+        opt = md.ShardedAdam(mine, lrs, eps=1e-15)
+        assert isinstance(opt.inner, T.FusedAdam) and (opt.plan.rows, opt.plan.tail) == (9984, 16)
+        ref_p = {n: torch.nn.Parameter(t.clone()) for n, t in init.items()}
+        ref = T.FusedAdam([{"params": [p], "lr": lrs[n], "name": n} for n, p in ref_p.items()], lr=0.0, eps=1e-15)
+        for it in range(3):
+            grads = {n: torch.randn(sh, device="cuda", generator=g) for n, sh in shapes.items()}
+            if it == 2:
+                opt.set_lr("xyz", 7e-5)
+                [q for q in ref.param_groups if q["name"] == "xyz"][0]["lr"] = 7e-5
+            opt.step(grads)
+            for n, p in ref_p.items():
+                p.grad = grads[n].clone()
+            ref.step()
+            for n in shapes:
+                assert torch.equal(mine[n], ref_p[n].data), (it, n)
+        full = opt.full_state()
+        for n, p in ref_p.items():
+            assert torch.equal(full[n]["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(full[n]["exp_avg_sq"], ref.state[p]["exp_avg_sq"]), n
+        # factored SH gradient == the dense gradient it stands for
+        a = {n: t.clone() for n, t in init.items()}
+        b = {n: t.clone() for n, t in init.items()}
+        oa, ob = md.ShardedAdam(a, lrs, eps=1e-15), md.ShardedAdam(b, lrs, eps=1e-15)
+        cam = torch.tensor([0.3, -0.2, 0.1], device="cuda")
+        fac = torch.randn(P, 3, device="cuda", generator=g)
+        small = {n: torch.randn(shapes[n], device="cuda", generator=g) for n in ("xyz", "opacity", "scaling", "rotation")}
+        sh = md.sh_grad_from_factors(init["xyz"], cam[None], fac[None], M, deg)
+        oa.step(dict(small, f_dc=sh[:, :1].contiguous(), f_rest=sh[:, 1:].contiguous()))
+        ob.step_factored(small, fac, cam, init["xyz"], deg)
+        torch.cuda.synchronize()
+        for n in shapes:
+            assert torch.equal(a[n], b[n]), n
+    finally:
+        td.destroy_process_group()
