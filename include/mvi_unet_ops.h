@@ -56,6 +56,18 @@ int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight, const flo
                           int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* mvi_groupnorm_silu_ex with a sync buffer: groups that do not fit one block's registers (and every temporal / stacked call)
+ * are then normalised in ONE launch that reads x once — K consecutive blocks per group exchange their partial moments through
+ * `workspace` and meet at two counters per group in `sync`. `sync`: mvi_groupnorm_sync_bytes() bytes, zeroed ONCE by the
+ * caller (the kernels leave it zeroed), private to one stream at a time (two launches that overlap in time must not share
+ * it); NULL = the two-launch kernels of mvi_groupnorm_silu_ex. The last word is a sticky flag: non-zero if a block ever gave
+ * up waiting for its group (bounded spin; the output of that call is then undefined). */
+size_t mvi_groupnorm_sync_bytes(void);
+int mvi_groupnorm_silu_ex2(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                           int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups, float eps,
+                           int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace, size_t workspace_bytes,
+                           void* sync, size_t sync_bytes, void* stream);
+
 /* The same norm (x [N, C, spatial], optional chan_bias, optional SiLU) with TOKEN-MAJOR output y [N, spatial, C]:
  * "b c h w -> b (h w) c" (svd_inpaint1/sgm/modules/attention.py:700-707) fused into the apply pass, for consumers that
  * contract over channels (proj_in Linear; a channels-last convolution). C and spatial must be multiples of the 16-byte

@@ -12,6 +12,10 @@ def bind(L):
     L.mvi_groupnorm_silu_temporal.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i32, f32, i32, i32, vp, sz, vp]
     L.mvi_groupnorm_silu_ex.restype = C.c_int
     L.mvi_groupnorm_silu_ex.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i32, f32, i32, i32, i32, vp, sz, vp]
+    L.mvi_groupnorm_sync_bytes.restype = sz
+    L.mvi_groupnorm_sync_bytes.argtypes = []
+    L.mvi_groupnorm_silu_ex2.restype = C.c_int
+    L.mvi_groupnorm_silu_ex2.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i64, i32, f32, i32, i32, i32, vp, sz, vp, sz, vp]
     L.mvi_groupnorm_silu_tokens.restype = C.c_int
     L.mvi_groupnorm_silu_tokens.argtypes = [vp, vp, vp, vp, vp, i64, i32, i64, i32, f32, i32, i32, vp, sz, vp]
     L.mvi_attention_forward.restype = C.c_int

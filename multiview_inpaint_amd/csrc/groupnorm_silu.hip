@@ -13,6 +13,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../../include/mvi_raster.h"
@@ -439,9 +440,229 @@ static int gn_resident_launch(const void* x, void* y, const float* w, const floa
     return 1;                                                      // more than 12 vectors per thread of a 1024-thread block
 }
 
+// Cluster form: ONE launch, x read once, for plain groups that do not fit one block's registers — the 270 ... 552 KB groups
+// of the level-0 / level-1 decoder (the kernel also covers the temporal and stacked forms; gn_cluster_launch says why
+// they are not routed here). A group is handled by K = slices * kps blocks; block j keeps part j % kps of slice j / kps in
+// registers (NV 16-byte vectors per thread), computes its count / mean / centred M2 exactly (two passes over registers),
+// publishes the triple and meets the other K - 1 blocks at a per-group counter; every block then merges the K triples
+// in the same order (Chan) and normalises + stores its part. Two 512-thread blocks fit a CU (<= 128 registers), so one
+// block's wait and store phases run under the other's loads.
+//   * Exchange through memory: the triples and counters move with agent-scope relaxed atomics (the XCDs' L2s are not
+//     coherent with each other); each thread drains its stores before the block arrives.
+//   * Progress: the K blocks of a group are consecutive in ONE XCD's dispatch sequence (ids 8 s + xcd) and an XCD starts
+//     its workgroups in id order, so the oldest unfinished group of an XCD has all its K <= 8 blocks resident (32 CUs)
+//     and finishes; the spin is bounded anyway (kGnSpinLimit, then sync[2 * kGnSyncGroups] is set and the block goes on
+//     with what it has).
+//   * sync = 2 words per group [arrived, departed], zero before the launch and zero again after it: the last block to
+//     leave re-arms them. The caller provides one zeroed buffer per (device, stream) (mvi_groupnorm_sync_bytes()).
+constexpr int kGnClusterBlock = 512;
+constexpr int kGnSyncGroups = 65536;
+constexpr uint32_t kGnSpinLimit = 1u << 22;
+
+template <typename T, int NV>
+__global__ __launch_bounds__(kGnClusterBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void gn_cluster_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                     const float* __restrict__ weight,
+                                                                     const float* __restrict__ bias, GnGeom q, int kps, int vpb,
+                                                                     float eps, int silu, float* part, uint32_t* sync,
+                                                                     int64_t groups) {
+    constexpr int KV = Io<T>::kVec, BS = kGnClusterBlock;
+    __shared__ float s_red[BS / 64];
+    __shared__ float s_stat[2];
+    const int K = q.slices * kps;
+    // workgroup id -> XCD is round-robin (id % 8) and each XCD dispatches its ids in order: the K blocks of a group are
+    // CONSECUTIVE IN ONE XCD's sequence, so they start within a few block-slots of each other (spread over the 8 XCDs their
+    // start times drift apart by up to a whole block and the early ones hold their registers idle: measured 268 us against
+    // 250 us for the two-launch form at (28, 640, 72, 128)), and the triples stay in that XCD's L2
+    const int xcd = blockIdx.x & 7;
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t g = (seq / K) * 8 + xcd;
+    if (g >= groups) return;
+    const int j = (int)(seq % K), slice = j / kps, piece = j % kps;
+    const int Cg = q.Cg, G = q.G, C = Cg * G;
+    const int64_t S = q.S;
+    const int nvec = (int)(q.E / KV);
+    const int v0 = piece * vpb, v1 = min(nvec, v0 + vpb);               // this block's vectors of the slice (v1 > v0: host)
+    const int64_t sb = gn_slice_base(q, g, slice);
+    const int64_t row = (g / G) * q.slices + slice;
+    const int c0 = (int)(g % G) * Cg;
+    const T* xb = x + sb;
+    const float* cb = q.chan_bias ? q.chan_bias + row * C + c0 : nullptr;
+    auto block_total = [&](float v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < BS / 64; ++w) t += s_red[w];
+        return t;
+    };
+    uint4 r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {                                       // unconditional, clamped: all NV loads in flight together
+        const int vi = v0 + i * BS + threadIdx.x;
+        r[i] = *reinterpret_cast<const uint4*>(xb + (int64_t)(vi < v1 ? vi : v1 - 1) * KV);
+    }
+    const float inv_S = 1.0f / (float)S;
+    auto chan_of = [&](int vi) { return div_small((uint32_t)(vi < v1 ? vi : v1 - 1) * KV, (uint32_t)S, inv_S); };   // E < 2^24 (host)
+    auto chan_add = [&](int vi) { return cb ? cb[chan_of(vi)] : 0.f; };
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float v[KV];
+        Io<T>::load(reinterpret_cast<const T*>(&r[i]), v);
+        const int vi = v0 + i * BS + threadIdx.x;
+        const float a = chan_add(vi);
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) p += v[k] + a;
+        sum += vi < v1 ? p : 0.f;
+    }
+    const float cnt_l = (float)(v1 - v0) * (float)KV;
+    const float mean_l = block_total(sum) / cnt_l;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(r[i].x), "+v"(r[i].y), "+v"(r[i].z), "+v"(r[i].w));
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float v[KV];
+        Io<T>::load(reinterpret_cast<const T*>(&r[i]), v);
+        const int vi = v0 + i * BS + threadIdx.x;
+        const float a = chan_add(vi) - mean_l;
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) { const float d = v[k] + a; p += d * d; }
+        m2 += vi < v1 ? p : 0.f;
+    }
+    const float m2_l = block_total(m2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(r[i].x), "+v"(r[i].y), "+v"(r[i].z), "+v"(r[i].w));
+    // publish, meet the group's other blocks, merge
+    float* trip = part + (g * K) * 3;
+    uint32_t* gs = sync + 2 * g;
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(trip + 3 * j + 0, cnt_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(trip + 3 * j + 1, mean_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(trip + 3 * j + 2, m2_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(gs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)K) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kGnSpinLimit) {
+                    __hip_atomic_store(sync + 2 * kGnSyncGroups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");                  // the triples are read after lane 0 left the spin (program order of the wave)
+        // lane i holds block i's triple; lane-order Chan merge, the same in every block of the group
+        const int li = threadIdx.x < K ? threadIdx.x : 0;
+        const float nb_i = __hip_atomic_load(trip + 3 * li + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float mb_i = __hip_atomic_load(trip + 3 * li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float qb_i = __hip_atomic_load(trip + 3 * li + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float n = 0.f, mean = 0.f, M2 = 0.f;
+        for (int i = 0; i < K; ++i) {
+            const float nb = __shfl(nb_i, i), mb = __shfl(mb_i, i), qb = __shfl(qb_i, i);
+            const float nt = n + nb, d = mb - mean;
+            mean += d * (nb / nt);
+            M2 += qb + d * d * (n * nb / nt);
+            n = nt;
+        }
+        if (threadIdx.x == 0) { s_stat[0] = mean; s_stat[1] = rsqrtf(M2 / n + eps); }
+    }
+    __syncthreads();
+    const float mean = s_stat[0], rstd = s_stat[1];
+    // output addressing (as gn_apply_kernel): plain = x's layout; stack3 = rows of 3C channels, taps self / next / prev + zero ends
+    T* yb = y + sb;
+    T *y_self = nullptr, *y_next = nullptr, *y_prev = nullptr, *y_zero = nullptr, *y_zero2 = nullptr;
+    if (q.stack3) {
+        const int64_t rs = 3 * (int64_t)C * S, co = (int64_t)c0 * S;
+        y_self = y + row * rs + (int64_t)C * S + co;
+        y_next = slice + 1 < q.slices ? y + (row + 1) * rs + co : nullptr;
+        y_prev = slice > 0 ? y + (row - 1) * rs + 2 * (int64_t)C * S + co : nullptr;
+        y_zero = slice == 0 ? y + row * rs + co : nullptr;
+        y_zero2 = slice == q.slices - 1 ? y + row * rs + 2 * (int64_t)C * S + co : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = v0 + i * BS + threadIdx.x;
+        float v[KV];
+        Io<T>::load(reinterpret_cast<const T*>(&r[i]), v);
+        const int cl = chan_of(vi);
+        const int c = c0 + cl;
+        const float w = weight[c] * rstd, b = bias[c] + ((cb ? cb[cl] : 0.f) - mean) * w;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const float t = v[k] * w + b;
+            v[k] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+        }
+        if (vi < v1) {
+            const int64_t e = (int64_t)vi * KV;
+            if (!q.stack3) {
+                Io<T>::store(yb + e, v);
+            } else {
+                Io<T>::store(y_self + e, v);
+                if (y_next) Io<T>::store(y_next + e, v);
+                if (y_prev) Io<T>::store(y_prev + e, v);
+                if (y_zero || y_zero2) {
+                    float z[KV];
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) z[k] = 0.f;
+                    if (y_zero) Io<T>::store(y_zero + e, z);
+                    if (y_zero2) Io<T>::store(y_zero2 + e, z);
+                }
+            }
+        }
+    }
+    // the last block to leave re-arms the group's counters for the next launch
+    if (threadIdx.x == 0) {
+        const uint32_t left = __hip_atomic_fetch_add(gs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (uint32_t)K - 1u) {
+            __hip_atomic_store(gs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gs + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// returns 1 when the shape does not take the cluster form (caller falls through to the two-launch kernels)
+template <typename T>
+static int gn_cluster_launch(const void* x, void* y, const float* w, const float* b, const GnGeom& q, int64_t groups, float eps,
+                             int silu, float* part, uint32_t* sync, hipStream_t st) {
+    constexpr int KV = Io<T>::kVec, BS = kGnClusterBlock;
+    if (q.E % KV != 0 || q.E >= (1 << 24) || groups > kGnSyncGroups) return 1;
+    const int64_t nvec = q.E / KV;
+    const int kps = (int)((nvec + 12 * BS - 1) / (12 * BS));
+    const int64_t K = (int64_t)q.slices * kps;
+    // the triples reuse the two-launch form's partial-statistics area: K <= slices * cps (a chunk is 2048 vectors, a block
+    // holds up to 6144)
+    // K <= 8 and one slice: measured on MI355X (tools/bench_groupnorm.py, tools/gn_census.py, bf16, us per call, two launches ->
+    // cluster): plain groups of 360 KB (28, 640, 72, 128) 250 -> 200, 270 KB (28, 1920, 36, 64) 172 -> 148, 184 KB as two
+    // pieces 110 (resident) -> 104; but the temporal groups LOSE — K = 28 (2.5 MB, stacked output) 165 -> 214, K = 14
+    // (1.26 MB) 90 -> 87, (630 KB) 54 -> 60, (158 KB) 22 -> 41: a block waits for the slowest of its K - 1 partners, an XCD
+    // starts the second block of a CU ~10 us after the first (tools/experiments/xcd_probe.cpp), and above 32 blocks per
+    // group the wait did not end at all (K = 53: the bounded spin ran out) — those shapes keep the two launches.
+    if (q.slices != 1 || K > 8 || K > (int64_t)q.cps || (groups + 8) * K > 0x7FFFFFFFll) return 1;
+    const int vpb = (int)((nvec + kps - 1) / kps);
+    if ((int64_t)vpb * (kps - 1) >= nvec) return 1;                      // every block must own at least one vector
+    const int need = (vpb + BS - 1) / BS;
+    const unsigned blocks = (unsigned)(((groups + 7) / 8) * 8 * K);       // groups round-robin over the XCDs; surplus blocks exit
+#define MVI_GN_CL(NVV)                                                                                                        \
+    hipLaunchKernelGGL((gn_cluster_kernel<T, NVV>), dim3(blocks), dim3(BS), 0, st, (const T*)x, (T*)y, w, b, q, kps, vpb, eps, silu, \
+                       part, sync, groups)
+    if (need <= 2) MVI_GN_CL(2);
+    else if (need <= 4) MVI_GN_CL(4);
+    else if (need <= 8) MVI_GN_CL(8);
+    else MVI_GN_CL(12);
+#undef MVI_GN_CL
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
 template <typename T>
 static int gn_launch(const void* x, void* y, const float* w, const float* b, const float* chan_bias, int stack3, int64_t N,
-                     int slices, int C, int64_t S, int G, float eps, int silu, float* part, hipStream_t st, int tokens = 0) {
+                     int slices, int C, int64_t S, int G, float eps, int silu, float* part, hipStream_t st, int tokens = 0,
+                     uint32_t* sync = nullptr) {
     constexpr int KV = Io<T>::kVec;
     constexpr int CH = kGnBlock * kGnVecPerThread * KV;
     GnGeom q;
@@ -469,6 +690,12 @@ static int gn_launch(const void* x, void* y, const float* w, const float* b, con
     // (the resident kernel indexes channels with 24-bit arithmetic: groups of up to 256 KB are far below that)
     if (vec && slices == 1 && !stack3 && (int64_t)q.Cg * S * (int64_t)sizeof(T) <= (int64_t)resident_kb * 1024) {
         const int rc = gn_resident_launch<T>(x, y, w, b, chan_bias, N, C, S, G, eps, silu, st);
+        if (rc != 1) return rc;
+    }
+    // groups from cluster_kb up (and every temporal / stacked call) take the cluster form when the caller gave a sync buffer
+    static const int cluster_kb = getenv("MVI_GN_CLUSTER_KB") ? atoi(getenv("MVI_GN_CLUSTER_KB")) : 0;
+    if (vec && sync && cluster_kb >= 0 && q.E * slices * (int64_t)sizeof(T) >= (int64_t)cluster_kb * 1024) {
+        const int rc = gn_cluster_launch<T>(x, y, w, b, q, N * G, eps, silu, part, sync, st);
         if (rc != 1) return rc;
     }
     // (Measured and not kept: running the two launches per BAND of samples, sized so that the statistics pass's reads are
@@ -509,7 +736,7 @@ extern "C" size_t mvi_groupnorm_workspace_bytes(int64_t N, int32_t C, int64_t sp
 static int gn_dispatch(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int stack3,
                        int64_t Nv, int32_t T, int32_t C,
                        int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t dtype, void* workspace,
-                       size_t workspace_bytes, void* stream, int tokens = 0) {
+                       size_t workspace_bytes, void* stream, int tokens = 0, uint32_t* sync = nullptr) {
     if (Nv < 0 || T <= 0 || C <= 0 || groups <= 0 || spatial < 0 || C % groups != 0)
         return mvi::unet_fail(MVI_EINVAL, "groupnorm: C must be a positive multiple of groups");
     if (Nv == 0 || spatial == 0) return MVI_OK;
@@ -521,9 +748,9 @@ static int gn_dispatch(const void* x, void* y, const float* weight, const float*
     float* part = (float*)workspace;
     int rc;
     switch (dtype) {
-        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens); break;
-        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens); break;
-        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens); break;
+        case MVI_DT_F32: rc = mvi::gn_launch<float>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens, sync); break;
+        case MVI_DT_BF16: rc = mvi::gn_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens, sync); break;
+        case MVI_DT_F16: rc = mvi::gn_launch<__half>(x, y, weight, bias, chan_bias, stack3, Nv, T, C, spatial, groups, eps, fuse_silu, part, st, tokens, sync); break;
         default: return mvi::unet_fail(MVI_EINVAL, "groupnorm: unknown dtype");
     }
     if (rc == MVI_EINVAL)
@@ -550,6 +777,18 @@ extern "C" int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight
                                      size_t workspace_bytes, void* stream) {
     if (stack3 && x == y) return mvi::unet_fail(MVI_EINVAL, "groupnorm: stack3 output cannot alias the input");
     return gn_dispatch(x, y, weight, bias, chan_bias, stack3 ? 1 : 0, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t mvi_groupnorm_sync_bytes(void) { return (2 * (size_t)mvi::kGnSyncGroups + 1) * sizeof(uint32_t); }
+
+extern "C" int mvi_groupnorm_silu_ex2(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                      int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups, float eps,
+                                      int32_t fuse_silu, int32_t stack3, int32_t dtype, void* workspace,
+                                      size_t workspace_bytes, void* sync, size_t sync_bytes, void* stream) {
+    if (stack3 && x == y) return mvi::unet_fail(MVI_EINVAL, "groupnorm: stack3 output cannot alias the input");
+    if (sync && sync_bytes < mvi_groupnorm_sync_bytes()) return mvi::unet_fail(MVI_ENOMEM, "groupnorm: sync buffer too small");
+    return gn_dispatch(x, y, weight, bias, chan_bias, stack3 ? 1 : 0, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace,
+                       workspace_bytes, stream, 0, (uint32_t*)sync);
 }
 
 extern "C" int mvi_groupnorm_silu_tokens(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,

@@ -62,6 +62,29 @@ def _workspace(dev, nbytes):
     return w
 
 
+_gn_sync = {}
+
+
+def _groupnorm_sync(dev):
+    """Zeroed once per (device, stream): the counters of the one-launch cluster GroupNorm (include/mvi_unet_ops.h,
+    mvi_groupnorm_silu_ex2) — the kernels leave them zeroed, and launches that share a stream never overlap."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    b = _gn_sync.get(key)
+    if b is None:
+        b = torch.zeros(_lib.lib().mvi_groupnorm_sync_bytes(), dtype=torch.uint8, device=dev)
+        _gn_sync[key] = b
+    return b
+
+
+def groupnorm_cluster_timeouts(dev=None):
+    """Non-zero if a cluster GroupNorm block ever gave up waiting for its group on any stream of `dev` (sticky flag)."""
+    tot = 0
+    for (di, _), b in _gn_sync.items():
+        if dev is None or di == torch.device(dev).index:
+            tot += int(b[-4:].view(torch.int32).item())
+    return tot
+
+
 _f32_cache = {}
 
 
@@ -99,11 +122,12 @@ def _gn(x, T, num_groups, weight, bias, eps, silu, chan_bias, stack3):
         if cb.shape != (N, Cc):
             raise ValueError(f"group_norm: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
     ws = _workspace(xc.device, L.mvi_groupnorm_workspace_bytes(N, Cc, S, num_groups))
+    sync = _groupnorm_sync(xc.device)
     with torch.cuda.device(xc.device), _Timed("groupnorm", (2.0 + 2.0 * bool(stack3)) * xc.numel() * xc.element_size(), xc.device):
-        _check(L.mvi_groupnorm_silu_ex(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                       None if cb is None else cb.data_ptr(), N // T, int(T), Cc, S, num_groups, float(eps),
-                                       int(bool(silu)), int(bool(stack3)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
-                                       _stream(xc.device)), "group_norm")
+        _check(L.mvi_groupnorm_silu_ex2(xc.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                        None if cb is None else cb.data_ptr(), N // T, int(T), Cc, S, num_groups, float(eps),
+                                        int(bool(silu)), int(bool(stack3)), _DT[x.dtype], ws.data_ptr(), ws.numel(),
+                                        sync.data_ptr(), sync.numel(), _stream(xc.device)), "group_norm")
     return y
 
 

@@ -278,6 +278,32 @@ def test_groupnorm_frames_fused_bias_and_stacked_output(ops, dtype, tol, b, T, C
     assert rel(y2, ref2) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.0 / 128)])
+def test_groupnorm_one_launch_cluster_form(ops, dtype, tol):
+    """Plain groups larger than one block's registers are normalised by up to 8 blocks that exchange partial moments and
+    meet at per-group counters (gn_cluster_kernel): ragged pieces (7 per group in fp32, 4 in bf16) with the fused bias, an odd
+    number of groups (surplus blocks of the XCD round-robin exit), the level-0 decoder shape; results against fp64, the
+    counters re-armed (all zero) after every call, no block ever timed out, a second call gives the same bits."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(3, 64, 90, 104, generator=g) * 1.3 + 0.2).to(dtype)
+    x[0, :5] += 25.0
+    w, bb, cb = torch.randn(64, generator=g), torch.randn(64, generator=g), torch.randn(3, 64, generator=g)
+    ref = dev_ops.group_norm(x.double(), 4, w.double(), bb.double(), 1e-5, silu=True, chan_bias=cb.double())
+    xs = x.cuda()
+    y = ops.group_norm_silu(xs, 4, w.cuda(), bb.cuda(), 1e-5, True, chan_bias=cb.cuda())
+    assert rel(y, ref) < tol
+    assert torch.equal(y, ops.group_norm_silu(xs, 4, w.cuda(), bb.cuda(), 1e-5, True, chan_bias=cb.cuda()))
+    for shape, groups in (((5, 320, 72, 128), 32), ((3, 640, 72, 128), 32), ((1, 96, 64, 96), 3)):
+        x2 = (torch.randn(shape, generator=g) * 2 + 0.7).to(dtype)
+        w2, b2 = torch.randn(shape[1], generator=g), torch.randn(shape[1], generator=g)
+        ref2 = F.group_norm(x2.double(), groups, w2.double(), b2.double(), 1e-6)
+        assert rel(ops.group_norm_silu(x2.cuda(), groups, w2.cuda(), b2.cuda(), 1e-6, False), ref2) < tol
+    torch.cuda.synchronize()
+    assert ops.groupnorm_cluster_timeouts() == 0
+    assert all(int(buf.view(torch.int32).abs().sum()) == 0 for buf in ops._gn_sync.values())
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_bias_residual_add(ops, dtype, tol):
     g = torch.Generator().manual_seed(11)
