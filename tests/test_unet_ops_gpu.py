@@ -110,6 +110,40 @@ def test_attention_half_io(ops, dtype, tol, B, Hh, Sq, Sk, D):
     assert rel(out, _attn_ref(q, k, v, Hh)) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("B,Hh,Sq,Sk", [(1, 2, 1300, 1300), (2, 3, 1024, 300), (1, 1, 1500, 257), (1, 2, 1025, 4100)])
+def test_attention_8wave_kernel_ragged_shapes(ops, dtype, tol, B, Hh, Sq, Sk):
+    """The 8-wave LDS-DMA kernel (S_q >= 1024, S_k >= 256) on shapes that are multiples of nothing: a last query block of
+    20 / 220 / 1 rows, a last key tile of 20 / 44 / 1 / 4 keys (rows past the end are loaded clamped and masked), the K / V
+    ring wrapping 1 ... 16 times; plain and packed-QKV entries."""
+    g = torch.Generator().manual_seed(Sq * 7 + Sk)
+    q, k, v = (torch.randn(B, s, Hh * 64, generator=g).to(dtype) for s in (Sq, Sk, Sk))
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), Hh)
+    assert out.dtype == dtype and rel(out, _attn_ref(q, k, v, Hh)) < tol
+    if Sq == Sk:
+        qkv = torch.cat([q, k, v], -1).cuda()
+        assert torch.equal(ops.attention_packed(qkv, Hh), out)
+
+
+def test_attention_8wave_kernel_repeats_safely_when_the_fixed_exponent_overflows(ops):
+    """The fast path keeps the first tile's row maximum as the exponent reference for the whole row; here the logits climb
+    by ~115 (in log2 units) along the key axis, far past what fp32 holds relative to that reference: the row sums
+    overflow, the block votes, and the whole block is repeated with the online-softmax path. One head climbs, the other is
+    ordinary (its blocks must not be disturbed), and rows of a climbing head see their maximum at different keys."""
+    B, Hh, S, D = 1, 2, 1024, 64
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, S, Hh * D, generator=g)
+    k = torch.randn(B, S, Hh * D, generator=g)
+    v = torch.randn(B, S, Hh * D, generator=g)
+    q[:, :, 0] = 16.0                                                 # head 0, channel 0: logit = 0.125 * 16 * k = 2 k
+    k[:, :, 0] = torch.linspace(0.0, 40.0, S)[None]                   # 0 ... 80 nats = 115 in log2 units
+    q[:, 512:, 0] = -16.0                                             # the second half of the rows peaks at key 0 instead
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    out = ops.attention(qb.cuda(), kb.cuda(), vb.cuda(), Hh)
+    assert torch.isfinite(out).all()
+    assert rel(out, _attn_ref(qb, kb, vb, Hh)) < 2e-2
+
+
 def test_attention_mfma_layout_with_exact_integers(ops):
     """Asymmetric small-integer data: every product and sum is exact in bf16/fp32, so a swapped
     row/column map or a wrong key permutation in the P.V operand shows up as a gross error."""
