@@ -99,6 +99,19 @@ int mvi_attention_temporal(const void* q, const void* k, const void* v, void* ou
  * (svd_inpaint1/sgm/modules/attention.py:87-95). inner must be a multiple of 4 (fp32) / 8 (bf16, f16). */
 int mvi_geglu(const void* h, void* out, int64_t rows, int32_t inner, int32_t dtype, void* stream);
 
+/* GEGLU with its projection in one kernel (csrc/ff_geglu.hip):
+ *   out[r, j] = (x[r, :] . weight[j, :] + bias[j]) * gelu(x[r, :] . weight[inner + j, :] + bias[inner + j])
+ * i.e. `x, gate = F.linear(x, weight, bias).chunk(2, -1); x * F.gelu(gate)` (sgm/modules/attention.py:87-95) without the
+ * [rows, 2 inner] intermediate. x [rows, K] and out [rows, inner] with row strides in elements, weight [2 inner, K] contiguous
+ * (nn.Linear layout), bias fp32 [2 inner] or NULL. Only the shapes mvi_ff_geglu_supported() accepts (K = 320, bf16 / f16,
+ * inner a multiple of 32): the level-0 FeedForward layers; everything else keeps library GEMM + mvi_geglu.
+ * The kernel stores whole blocks of 256 rows without predication: `out` must have room for mvi_ff_geglu_out_rows(rows) rows
+ * (rows rounded up to 256; the surplus rows receive values computed from the last valid row of x). */
+int mvi_ff_geglu_supported(int32_t K, int32_t inner, int32_t dtype);
+int64_t mvi_ff_geglu_out_rows(int64_t rows);
+int mvi_ff_geglu(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
+                 int32_t inner, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
+
 /* out[n, c, p] = h[n, c, p] + bias[c] + x[n, c, p] over [N, C, spatial] activations in one pass; x and bias are
  * optional (NULL). Folds a convolution's bias (PyTorch-ROCm adds it in a separate kernel) and the ResBlock skip
  * add `self.skip_connection(x) + h` (svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:354). out may alias h. */

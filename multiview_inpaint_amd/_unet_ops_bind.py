@@ -30,6 +30,12 @@ def bind(L):
     L.mvi_bias_silu.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp]
     L.mvi_geglu.restype = C.c_int
     L.mvi_geglu.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.mvi_ff_geglu_supported.restype = C.c_int
+    L.mvi_ff_geglu_supported.argtypes = [i32, i32, i32]
+    L.mvi_ff_geglu.restype = C.c_int
+    L.mvi_ff_geglu_out_rows.restype = i64
+    L.mvi_ff_geglu_out_rows.argtypes = [i64]
+    L.mvi_ff_geglu.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i64, i64, i32, vp]
     L.mvi_concat_add.restype = C.c_int
     L.mvi_concat_add.argtypes = [vp, vp, vp, vp, i64, i32, i32, i64, i32, vp]
     L.mvi_bias_residual_blend.restype = C.c_int

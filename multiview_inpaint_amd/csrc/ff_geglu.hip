@@ -1,0 +1,346 @@
+// Fused GEGLU feed-forward projection for gfx950 (bf16 / f16 MFMA), contraction length 320 — the level-0 model width:
+//     out[r, j] = (x[r, :] . W[j, :] + b[j]) * gelu(x[r, :] . W[inner + j, :] + b[inner + j]),   r < rows, j < inner
+// Replaces `x, gate = self.proj(x).chunk(2, dim=-1); return x * F.gelu(gate)` of GEGLU
+// (svd_inpaint1/sgm/modules/attention.py:87-95) for the 21 level-0 FeedForward layers of the 14 x 576x1024 step
+// ([258048, 320] x [320, 2 * 1280]). There the library GEMM is bound by WRITING the [rows, 2 inner] intermediate (1.32 GB per call,
+// 0.60 ms = 0.70 PFLOP/s) which geglu_kernel then reads back (0.35 ms): 0.95 ms per call, 20 ms per step. Here the value and the
+// gate of an output never leave the accumulators.
+//
+// Structure (the QK^T half of attn_flash8.hip with x in the role of Q and W in the role of K):
+//   * block = 8 waves x 32 rows of x; a wave's 32 rows live in registers as the B operand for the whole block (20 k-steps of 16:
+//     80 registers), so x is read from HBM exactly once and never passes through LDS;
+//   * W streams through a 3-slot LDS ring by LDS-DMA in tiles of 64 rows x 640 bytes = the 32 value rows and the 32 gate rows of
+//     32 outputs (40 KiB; 128-byte groups XOR-swizzled on the SOURCE side: chunk c of row r sits at c ^ ((r >> 1) & 7), conflict-free
+//     for ds_read_b128); all 8 waves read the same tile: S^T[w row][x row] = W x^T on v_mfma_f32_32x32x16, 40 MFMAs per wave and step;
+//   * two accumulator sets alternate (steps unrolled by two), so the epilogue of step j — bias, erf-GELU, product, pack, 8-byte stores
+//     — sits in the same scheduling region as the MFMAs of step j + 1: exact-erf GELU costs about as many issue cycles per output
+//     tile as the tile's 40 MFMAs occupy the matrix pipe (K = 320 is short), so it must not run in series with them;
+//   * the bias vector (2 inner floats) sits in LDS; one barrier per step; loader waves (4 of 8) issue the tile two steps ahead at the
+//     END of a step, behind that step's stores, and wait with a COUNTED vmcnt for everything older than the pieces just issued.
+// GELU: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below half an ulp of the bf16 / f16 output by four orders of magnitude)
+// with v_rcp_f32 / v_exp_f32: 14 instructions per output, branch-free.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+
+namespace mvi {
+int unet_fail(int code, const char* msg);
+namespace ffg {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+#define MVI_AS3 __attribute__((address_space(3)))
+
+constexpr int kK = 320;                              // contraction length
+constexpr int kKS = kK / 16;                         // MFMA k-steps
+constexpr int kWaves = 8;
+constexpr int kRows = 32 * kWaves;                   // x rows per block
+constexpr int kStep = 32;                            // outputs per step
+constexpr int kRowBytes = kK * 2;                    // 640
+constexpr int kTileBytes = 2 * kStep * kRowBytes;    // 40960: 32 value rows | 32 gate rows
+constexpr int kPieces = kTileBytes / 1024;           // 40 LDS-DMA pieces of 1 KiB
+constexpr int kRing = 3;
+constexpr int kLoaders = 4;
+constexpr int kPiecesPerLoader = kPieces / kLoaders; // 10
+
+template <typename T> struct Mma;
+template <> struct Mma<__hip_bfloat16> {
+    using frag = bf16x8;
+    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        f32x2 f = {lo, hi};
+        bf16x2 r = __builtin_convertvector(f, bf16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
+    }
+};
+template <> struct Mma<__half> {
+    using frag = f16x8;
+    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        f32x2 f = {lo, hi};
+        f16x2 r = __builtin_convertvector(f, f16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
+    }
+};
+template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
+
+__device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
+
+// v * gelu(g), gelu(g) = g/2 (1 + erf(g / sqrt 2)); erf(z) = sign(z) (1 - (a1 t + ... + a5 t^5) e^(-z^2)), t = 1 / (1 + p |z|), z = g / sqrt 2
+__device__ __forceinline__ float geglu1(float v, float g) {
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(g), 0.3275911f * 0.70710678118654752f, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(g * g * (-0.5f * 1.4426950408889634f));   // e^(-z^2)
+    const float erf_abs = __builtin_fmaf(-p, e, 1.0f);
+    const float hg = 0.5f * g;                                   // g/2 (1 + sign(g) erf|z|) = g/2 + |g|/2 erf|z|
+    return v * __builtin_fmaf(__builtin_fabsf(hg), erf_abs, hg);
+}
+
+template <typename T, int kX = 0>                            // kX != 0: timing experiments that drop one kind of work (wrong results on purpose)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                          int64_t rows, int inner, int64_t x_rs, int64_t o_rs, int n_blocks) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+    MVI_AS3 float* const lbias = (MVI_AS3 float*)(lds + kRing * kTileBytes);      // [2 * inner]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
+    const int64_t row = (int64_t)bid * kRows + wave * 32 + col;
+    const bool row_ok = row < rows;
+
+    // ---- bias -> LDS (visible after the first barrier of the loop prologue)
+    for (int i = tid; i < 2 * inner; i += 64 * kWaves) lbias[i] = bias ? bias[i] : 0.f;
+
+    // ---- x rows: B operand, element j of lane (col, hh), k-step s: x[row][16 s + 8 hh + j]
+    frag xf[kKS];
+    {
+        const T* xp = x + (row_ok ? row : rows - 1) * x_rs + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < kKS; ++s) xf[s] = as_frag<frag>(*reinterpret_cast<const u32x4*>(xp + 16 * s));
+    }
+
+    // ---- LDS-DMA source addressing: piece p of a tile fills LDS bytes [1024 p, 1024 p + 1024) lane-linearly; the lane's 16 bytes are
+    // (tile row r, slot c) and receive source chunk c ^ ((r >> 1) & 7) (low three bits) of W row (step * 32 + r) or (inner + step * 32 + r - 32)
+    const bool loader = wave < kLoaders;
+    uint32_t p_voff[kPiecesPerLoader];
+#pragma unroll
+    for (int i = 0; i < kPiecesPerLoader; ++i) {
+        const int pc = wave + i * kLoaders;                          // (meaningless for a wave that loads nothing)
+        const uint32_t off = 1024u * pc + 16u * lane;
+        const uint32_t r = off / kRowBytes, c = (off - r * kRowBytes) >> 4;
+        const uint32_t cs = (c & ~7u) | ((c & 7u) ^ ((r >> 1) & 7u));
+        const uint32_t wrow = r < 32 ? r : (uint32_t)inner + (r - 32);
+        p_voff[i] = wrow * kRowBytes + 16u * cs;
+    }
+    const char* const wbase = reinterpret_cast<const char*>(w);
+    const int n_steps = inner / kStep;
+    auto issue_tile = [&](int step) __attribute__((always_inline)) {
+        // steps past the end re-load the last tile (never read): every step issues the same number of pieces, the counted wait stays valid
+        const int st = step < n_steps ? step : n_steps - 1;
+        const uint32_t slot_off = (uint32_t)((step % kRing) * kTileBytes);
+        const char* const base = wbase + (int64_t)st * (kStep * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < kPiecesPerLoader; ++i) dma_piece(base, p_voff[i], lds0 + slot_off + 1024u * (wave + i * kLoaders));
+    };
+
+    // ---- LDS read addressing: A operand = W rows; lane (col, hh), k-step s reads row col (+32 for the gate block), chunk 2 s + hh
+    uint32_t ka[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ka[q] = (uint32_t)(col * kRowBytes + ((((2 * q + hh) & 7) ^ ((col >> 1) & 7)) << 4));
+    auto wfrag = [&](uint32_t slot_base, int blk, int s) __attribute__((always_inline)) {
+        if (kX == 4) return u32x4{0x3c003c00u, (uint32_t)s, 0, 0};
+        // chunk 2 s + hh = 8 (s >> 2) + (2 (s & 3) + hh): the swizzle touches the low three bits only
+        return *reinterpret_cast<MVI_AS3 const u32x4*>(lds + slot_base + ka[s & 3] + (s >> 2) * 128 + blk * (32 * kRowBytes));
+    };
+
+    // Output addressing. A operand = x rows, B operand = W rows, so the OUTPUT COLUMN sits on the lane (column step * 32 + col)
+    // and accumulator register r is x row (r & 3) + 8 (r >> 2) + 4 hh of the wave's 32: one bias pair per lane, and a store
+    // instruction writes two runs of 32 consecutive outputs (64 bytes). (With W as the A operand a lane held 4 consecutive columns
+    // of ONE row and every 8-byte store of a wave went to 64 different rows.) Stores are not predicated: the caller provides an
+    // output with room for the rows of whole blocks (include/mvi_unet_ops.h).
+    const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
+    char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
+    const uint32_t lane_off = (uint32_t)((4 * hh * o_rs + col) * 2);             // + row (r & 3) + 8 (r >> 2): scalar arithmetic on the base
+    const int64_t orow_bytes = o_rs * 2;
+
+    // One step = the 40 MFMAs of this step's 32 outputs (value block and gate block: two accumulator chains, W fragments requested
+    // kAhead k-steps ahead) with the EPILOGUE OF THE PREVIOUS STEP cut into 16 slices between them: k-step s carries output register
+    // s of the previous step (bias is already in the accumulator: its chain starts from it), and every second slice packs and stores
+    // a pair. Scheduling fences keep the slices where they are — left alone, the scheduler issues the 40 MFMAs back to back and
+    // the ~300 VALU instructions of the epilogue behind them, and the step takes the sum of both (measured: 637 us per call).
+    constexpr int kAhead = 2;
+    auto step_fn = [&](auto with_prev_c, uint32_t slot_base, int step, f32x16& av, f32x16& ag, const f32x16& pv, const f32x16& pg)
+                       __attribute__((always_inline)) {
+        constexpr bool kPrev = decltype(with_prev_c)::value;
+        const int n = step * kStep + col;
+        const float bv = lbias[n], bg = lbias[inner + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { av[i] = bv; ag[i] = bg; }
+        char* const op = obase + (step - 1) * (kStep * 2);           // the previous step's output columns
+        u32x4 fv[kAhead + 1], fg[kAhead + 1];
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) { fv[s] = wfrag(slot_base, 0, s); fg[s] = wfrag(slot_base, 1, s); }
+        float held = 0.f;
+#pragma unroll
+        for (int s = 0; s < kKS; ++s) {
+            if (s + kAhead < kKS) {
+                fv[(s + kAhead) % (kAhead + 1)] = wfrag(slot_base, 0, s + kAhead);
+                fg[(s + kAhead) % (kAhead + 1)] = wfrag(slot_base, 1, s + kAhead);
+            }
+            av = M::mfma(xf[s], as_frag<frag>(fv[s % (kAhead + 1)]), av);
+            ag = M::mfma(xf[s], as_frag<frag>(fg[s % (kAhead + 1)]), ag);
+            if (kPrev && s < 16) {
+                const float o = kX == 1 ? pv[s] + pg[s] : geglu1(pv[s], pg[s]);
+                if ((s & 1) == 0) {
+                    held = o;
+                } else {
+                    const uint32_t pk = M::pack2(held, o);
+                    const int m = ((s - 1) & 3) + 8 * ((s - 1) >> 2);
+                    if (kX != 2 || pk == 0x12345678u) {
+                        *reinterpret_cast<uint16_t*>(op + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
+                        *reinterpret_cast<uint16_t*>(op + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // the last step's outputs, with nothing left to hide behind
+    auto drain = [&](int step, const f32x16& pv, const f32x16& pg) __attribute__((always_inline)) {
+        char* const op = obase + step * (kStep * 2);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t pk = M::pack2(geglu1(pv[r], pg[r]), geglu1(pv[r + 1], pg[r + 1]));
+            const int m = (r & 3) + 8 * (r >> 2);
+            *reinterpret_cast<uint16_t*>(op + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
+            *reinterpret_cast<uint16_t*>(op + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+        }
+    };
+#ifdef MVI_FFG_STAMPS
+    uint64_t t_close = 0, t_issue = 0, t_all0 = __builtin_amdgcn_s_memtime();
+#endif
+    auto close_step = [&](int step) __attribute__((always_inline)) {
+#ifdef MVI_FFG_STAMPS
+        const uint64_t c0 = __builtin_amdgcn_s_memtime();
+        if (loader) issue_tile(step + 2);
+        const uint64_t c1 = __builtin_amdgcn_s_memtime();
+        if (loader) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        else asm volatile("s_barrier" ::: "memory");
+        const uint64_t c2 = __builtin_amdgcn_s_memtime();
+        t_issue += c1 - c0; t_close += c2 - c1;
+        return;
+#endif
+        // loaders: issue the tile two steps ahead (its slot held step - 1, which nobody reads any more), then wait for everything
+        // older than those pieces — this wave's pieces of tile step + 1 among them; then the block meets
+        if (loader && kX != 3) {
+            issue_tile(step + 2);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        } else {
+            asm volatile("s_barrier" ::: "memory");
+        }
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed
+    if (loader) {
+        issue_tile(0);
+        issue_tile(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerLoader) : "memory");
+    }
+    __syncthreads();                                             // tile 0 and the bias vector are in LDS
+
+    f32x16 va, ga, vb, gb;                                       // accumulator sets A (even steps) and B (odd steps)
+    auto next_slot = [&](uint32_t s) __attribute__((always_inline)) { return s + kTileBytes == (uint32_t)(kRing * kTileBytes) ? 0u : s + kTileBytes; };
+    int j = 0;
+    uint32_t slot = 0;                                           // byte offset of step j's ring slot
+    step_fn(std::false_type{}, slot, 0, va, ga, va, ga);
+    close_step(0);
+    slot = next_slot(slot);
+    for (j = 1; j + 1 < n_steps; j += 2) {
+        step_fn(std::true_type{}, slot, j, vb, gb, va, ga);
+        close_step(j);
+        slot = next_slot(slot);
+        step_fn(std::true_type{}, slot, j + 1, va, ga, vb, gb);
+        close_step(j + 1);
+        slot = next_slot(slot);
+    }
+    if (j < n_steps) {                                           // one step left (n_steps even): it is an odd step
+        step_fn(std::true_type{}, slot, j, vb, gb, va, ga);
+        drain(j, vb, gb);
+    } else {
+        drain(j - 1, va, ga);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // trailing (unused) pieces land before the block releases its LDS
+#ifdef MVI_FFG_STAMPS
+    if (lane == 0 && blockIdx.x == 300 && (wave == 0 || wave == 7)) {
+        const uint64_t tot = __builtin_amdgcn_s_memtime() - t_all0;
+        printf("block 300 wave %d: %d steps, cycles per step: total %llu, DMA issue %llu, wait+barrier %llu\n", wave, n_steps,
+               (unsigned long long)(tot / n_steps), (unsigned long long)(t_issue / n_steps), (unsigned long long)(t_close / n_steps));
+    }
+#endif
+}
+
+}  // namespace ffg
+
+template <typename T>
+static int ff_geglu_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int inner, int64_t x_rs,
+                           int64_t o_rs, hipStream_t st) {
+    using namespace ffg;
+    const int64_t n_blocks = (rows + kRows - 1) / kRows;
+    if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+    const int lds_bytes = kRing * kTileBytes + 2 * inner * (int)sizeof(float);
+    static unsigned long long attr_set = 0;                      // per device: the opt-in for > 64 KiB of dynamic LDS
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
+    auto kern = &ff_geglu_k320_kernel<T>;
+#ifdef MVI_FFG_EXPERIMENTS
+    static const int xp = getenv("MVI_FFG_EXPERIMENT") ? atoi(getenv("MVI_FFG_EXPERIMENT")) : 0;
+    if (xp == 1) kern = &ff_geglu_k320_kernel<T, 1>;
+    if (xp == 2) kern = &ff_geglu_k320_kernel<T, 2>;
+    if (xp == 3) kern = &ff_geglu_k320_kernel<T, 3>;
+    if (xp == 4) kern = &ff_geglu_k320_kernel<T, 4>;
+    if (xp) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    if (!(attr_set >> dev & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return MVI_EHIP;
+        attr_set |= 1ull << dev;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), lds_bytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, inner,
+                       x_rs, o_rs, (int)n_blocks);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+}  // namespace mvi
+
+extern "C" int mvi_ff_geglu_supported(int32_t K, int32_t inner, int32_t dtype) {
+    return K == mvi::ffg::kK && inner > 0 && inner % mvi::ffg::kStep == 0 && inner >= 2 * mvi::ffg::kStep &&
+           mvi::ffg::kRing * mvi::ffg::kTileBytes + 2 * (int64_t)inner * 4 <= 160 * 1024 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+extern "C" int64_t mvi_ff_geglu_out_rows(int64_t rows) { return (rows + mvi::ffg::kRows - 1) / mvi::ffg::kRows * mvi::ffg::kRows; }
+
+extern "C" int mvi_ff_geglu(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
+                            int32_t K, int32_t inner, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream) {
+    if (rows < 0 || !mvi_ff_geglu_supported(K, inner, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "ff_geglu: needs K = 320, inner a multiple of 32 (64 ... 4864), bf16 or f16");
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "ff_geglu: NULL pointer");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return mvi::unet_fail(MVI_EINVAL, "ff_geglu: out needs room for mvi_ff_geglu_out_rows(rows) rows (whole 256-row blocks are stored)");
+    if (x_row_stride < K || out_row_stride < inner || x_row_stride % 8 || out_row_stride % 4 ||
+        ((uintptr_t)x | (uintptr_t)weight) % 16 || (uintptr_t)out % 8)
+        return mvi::unet_fail(MVI_EINVAL, "ff_geglu: rows must be 16-byte aligned (x, weight) / 8-byte aligned (out)");
+    if ((int64_t)2 * inner * K * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "ff_geglu: weight exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::ff_geglu_launch<__hip_bfloat16>(x, weight, bias, out, rows, inner, x_row_stride, out_row_stride, st)
+                       : mvi::ff_geglu_launch<__half>(x, weight, bias, out, rows, inner, x_row_stride, out_row_stride, st);
+    return rc ? mvi::unet_fail(rc, "ff_geglu: kernel launch failed") : MVI_OK;
+}

@@ -278,6 +278,30 @@ def geglu(h):
     return out
 
 
+def ff_geglu_supported(K, inner, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_ff_geglu_supported(int(K), int(inner), _DT[dtype]))
+
+
+def ff_geglu(x, weight, bias):
+    """GEGLU(x) = (x W_v^T + b_v) * gelu(x W_g^T + b_g) in one kernel: x [..., K], weight [2 inner, K], bias [2 inner] or None."""
+    L = _lib.lib()
+    K, inner = x.shape[-1], weight.shape[0] // 2
+    xc = x.reshape(-1, K)
+    if xc.stride(1) != 1 or xc.stride(0) % 8:
+        xc = xc.contiguous()
+    wc = weight if weight.is_contiguous() else weight.contiguous()
+    rows = xc.shape[0]
+    cap = int(L.mvi_ff_geglu_out_rows(rows))                     # whole 256-row blocks are stored
+    full = torch.empty(cap, inner, dtype=x.dtype, device=x.device)
+    out = full[:rows]
+    b = None if bias is None else _f32(bias)
+    # algorithmic bytes: x once, W once, out once; flops priced separately by the caller
+    with torch.cuda.device(x.device), _Timed("ff_geglu", 4.0 * rows * K * inner, x.device):
+        _check(L.mvi_ff_geglu(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), rows, cap, K, inner,
+                              xc.stride(0), full.stride(0), _DT[x.dtype], _stream(x.device)), "ff_geglu")
+    return out.reshape(*x.shape[:-1], inner)
+
+
 def bias_residual_add(h, bias, x):
     L = _lib.lib()
     if h.dtype not in _DT:

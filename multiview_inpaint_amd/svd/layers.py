@@ -322,16 +322,43 @@ def temporal_conv3_stacked(x3, conv: nn.Conv3d, with_bias=True):
     return F.conv2d(x3, wt.reshape(conv.out_channels, ci3, 1, 1), conv.bias if with_bias else None)
 
 
+def _f32_param(p):
+    """fp32 copy of a small parameter: cached per parameter on the GPU (hip_ops._f32), a plain cast elsewhere."""
+    if p.is_cuda:
+        from . import hip_ops
+        return hip_ops._f32(p)
+    return p.float()
+
+
+_silu_emb_cache = []          # [(weakref(emb), version, silu(emb))], newest first: UNet and ControlNet each have one embedding per step
+
+
+def _emb_projection(emb_layers, emb):
+    """emb_layers(emb) = Linear(SiLU(emb)) with SiLU(emb) computed once per embedding tensor instead of once per ResBlock
+    (44 ResBlocks of a step share two embeddings); same values, same kernels."""
+    import weakref
+    if not (isinstance(emb_layers, nn.Sequential) and len(emb_layers) == 2 and isinstance(emb_layers[0], nn.SiLU)) \
+            or emb.requires_grad or torch.is_grad_enabled() and any(p.requires_grad for p in emb_layers.parameters()):
+        return emb_layers(emb)
+    for ref, ver, act in _silu_emb_cache:
+        if ref() is emb and ver == emb._version:
+            return emb_layers[1](act)
+    act = F.silu(emb)
+    _silu_emb_cache.insert(0, (weakref.ref(emb), emb._version, act))
+    del _silu_emb_cache[2:]
+    return emb_layers[1](act)
+
+
 def _resblock_forward_fused(self, x, emb):
     """The common ResBlock configuration (no up/down-sampling, additive embedding) with every bias and
     broadcast add folded into a neighbouring kernel: conv1's bias rides with the embedding bias inside the
     second GroupNorm, conv2's bias is added together with the skip tensor in one pass."""
     conv1, conv2 = self.in_layers[2], self.out_layers[3]
     h = conv_no_bias(conv1, norm_act(self.in_layers, x))
-    e = self.emb_layers(emb)
-    e = e.reshape(e.shape[0], e.shape[1]).float()
-    if conv1.bias is not None:
-        e = e + conv1.bias.float()
+    e = _emb_projection(self.emb_layers, emb)
+    e = e.reshape(e.shape[0], e.shape[1])
+    # fp32 [N, C] for the norm's chan_bias: the mixed-dtype add promotes inside one kernel (same values as cast-then-add)
+    e = e + _f32_param(conv1.bias) if conv1.bias is not None else e.float()
     h = self.out_layers[0](h, silu=True, chan_bias=e)
     h = conv_no_bias(conv2, self.out_layers[2](h))
     if isinstance(self.skip_connection, nn.Identity):
@@ -379,9 +406,8 @@ class VideoResBlock(ResBlock):
         c1, c2 = ts.in_layers[2], ts.out_layers[3]
         h3 = ops.group_norm_frames(x, T, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, stack3=True)
         h = temporal_conv3_stacked(h3, c1, with_bias=False)
-        e = ts.emb_layers(emb).float()                             # [(b T), c]: already per frame, fused into the norm
-        if c1.bias is not None:
-            e = e + c1.bias.float()
+        e = _emb_projection(ts.emb_layers, emb)                    # [(b T), c]: already per frame, fused into the norm
+        e = e + _f32_param(c1.bias) if c1.bias is not None else e.float()
         h3 = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, stack3=True)
         h = temporal_conv3_stacked(ts.out_layers[2](h3), c2, with_bias=False)
         if blend is not None:                                      # AlphaBlender folded into the skip add

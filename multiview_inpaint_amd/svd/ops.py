@@ -186,6 +186,22 @@ def geglu(h):
     return a * F.gelu(gate)
 
 
+FF_GEGLU_MIN_ROWS = 32768       # below, the fused kernel's 256-row blocks do not fill the chip: library GEMM + geglu
+
+
+def linear_geglu(x, weight, bias=None):
+    """GEGLU of the reference (sgm/modules/attention.py:87-95): `x, gate = F.linear(x, weight, bias).chunk(2, -1); x * F.gelu(gate)`.
+    On the GPU, for the shapes csrc/ff_geglu.hip covers (K = 320 in bf16 / f16: the level-0 FeedForward layers) and enough rows,
+    projection and gating run as ONE kernel and the [rows, 2 inner] intermediate never exists; everything else is the library
+    GEMM followed by geglu()."""
+    if x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
+            and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
+        from . import hip_ops
+        if hip_ops.ff_geglu_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
+            return hip_ops.ff_geglu(x, weight, bias)
+    return geglu(F.linear(x, weight, bias))
+
+
 def bias_residual_add(h, bias=None, x=None):
     """h [N, C, *spatial] + bias[c] + x in one pass (conv bias and ResBlock skip add, openaimodel.py:354)."""
     if h.is_cuda and not _needs_autograd(h, bias, x):

@@ -26,7 +26,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        return ops.geglu(self.proj(x))
+        return ops.linear_geglu(x, self.proj.weight, self.proj.bias)
 
 
 class FeedForward(nn.Module):

@@ -338,6 +338,44 @@ def test_groupnorm_one_launch_cluster_form(ops, dtype, tol):
     assert all(int(buf.view(torch.int32).abs().sum()) == 0 for buf in ops._gn_sync.values())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_ff_geglu_fused_projection(ops, dtype, tol):
+    """(x W_v^T + b_v) * gelu(x W_g^T + b_g) in one MFMA kernel (csrc/ff_geglu.hip, K = 320) against fp64 on the rounded
+    inputs: rows that are multiples of nothing (the kernel stores whole 256-row blocks into a padded buffer), 2 ... 150 output
+    steps (odd and even: the two accumulator sets swap every step), no bias, x as a strided view, gate values deep in both
+    tails of the GELU; and never less accurate than library GEMM + geglu, which rounds the [rows, 2 inner] intermediate."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(41)
+    for rows, inner, with_bias, strided in [(1000, 1280, True, False), (777, 64, False, False), (70001, 1280, True, True),
+                                            (256, 4800, True, False), (33, 96, True, False)]:
+        K = 320
+        wide = (torch.randn(rows, 2 * K if strided else K, generator=g) * 1.2).to(dtype)
+        x = wide[:, :K]
+        w = (torch.randn(2 * inner, K, generator=g) * K ** -0.5).to(dtype)
+        w[inner:inner + 4] *= 6.0                                    # gates of +-10 and beyond: gelu(g) -> g and -> -0
+        b = (torch.randn(2 * inner, generator=g) * 0.3).to(dtype) if with_bias else None
+        h = F.linear(x.double(), w.double(), None if b is None else b.double())
+        ref = h[:, :inner] * F.gelu(h[:, inner:])
+        xs = wide.cuda()[:, :K]                                      # a view with row stride 640 when `strided`
+        assert ops.ff_geglu_supported(K, inner, dtype) and xs.is_contiguous() != strided
+        y = ops.ff_geglu(xs, w.cuda(), None if b is None else b.cuda())
+        assert y.shape == (rows, inner) and y.dtype == dtype and torch.isfinite(y).all()
+        e_fused = rel(y, ref)
+        e_lib = rel(ops.geglu(F.linear(xs, w.cuda(), None if b is None else b.cuda())), ref)
+        assert e_fused < tol and e_fused <= 1.05 * e_lib + 1e-4, (rows, inner, e_fused, e_lib)
+    # dispatch: enough rows -> the fused kernel (op log), few rows or another K -> library GEMM + geglu; same numbers either way
+    x = (torch.randn(2, dev_ops.FF_GEGLU_MIN_ROWS // 2, 320, generator=g)).to(dtype).cuda()
+    w = (torch.randn(256, 320, generator=g) * 320 ** -0.5).to(dtype).cuda()
+    ops.PROFILE = []
+    big = dev_ops.linear_geglu(x, w, None)
+    small = dev_ops.linear_geglu(x[:, :100], w, None)
+    kinds = [e[0] for e in ops.PROFILE]
+    ops.PROFILE = None
+    assert big.shape == (2, dev_ops.FF_GEGLU_MIN_ROWS // 2, 128) and kinds == ["ff_geglu", "geglu"], kinds
+    assert rel(big[:, :100], small.double()) < 2 * tol
+    assert not ops.ff_geglu_supported(640, 1280, dtype) and not ops.ff_geglu_supported(320, 1280, torch.float32)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_bias_residual_add(ops, dtype, tol):
     g = torch.Generator().manual_seed(11)

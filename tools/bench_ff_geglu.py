@@ -1,0 +1,42 @@
+"""Fused GEGLU projection (csrc/ff_geglu.hip) against library GEMM + geglu kernel at the level-0 FeedForward shape of the
+14 x 576x1024 step ([258048, 320] x [320, 2 x 1280], bf16): results vs fp64 on a row sample, time of both forms.
+Run on the GPU box:  python tools/bench_ff_geglu.py"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from multiview_inpaint_amd.svd import hip_ops  # noqa: E402
+
+dev = torch.device("cuda")
+g = torch.Generator(device="cuda").manual_seed(0)
+for rows, K, inner, dtype in [(258048, 320, 1280, torch.bfloat16), (1000, 320, 1280, torch.bfloat16), (258048, 320, 1280, torch.float16)]:
+    x = (torch.randn(rows, K, device=dev, generator=g) * 1.2).to(dtype)
+    w = (torch.randn(2 * inner, K, device=dev, generator=g) * K ** -0.5).to(dtype)
+    b = (torch.randn(2 * inner, device=dev, generator=g) * 0.3).to(dtype)
+    y = hip_ops.ff_geglu(x, w, b)
+    unf = hip_ops.geglu(F.linear(x, w, b))
+    idx = torch.randint(0, rows, (512,), device=dev, generator=g)
+    idx[0], idx[1] = 0, rows - 1
+    h = F.linear(x[idx].double(), w.double(), b.double())
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    sc = float(ref.abs().max())
+    e_f = float((y[idx].double() - ref).abs().max()) / sc
+    e_u = float((unf[idx].double() - ref).abs().max()) / sc
+    ts = []
+    for fn in (lambda: hip_ops.ff_geglu(x, w, b), lambda: hip_ops.geglu(F.linear(x, w, b))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(e) / 10)
+    fl = 4.0 * rows * K * inner
+    print(f"rows {rows} K {K} inner {inner} {str(dtype)[6:]}: fused {ts[0] * 1e3:7.1f} us ({fl / ts[0] * 1e-9:6.1f} TFLOP/s)  GEMM + geglu {ts[1] * 1e3:7.1f} us;"
+          f"  max err / max |ref|: fused {e_f:.2e}  unfused {e_u:.2e}", flush=True)
