@@ -341,13 +341,13 @@ def test_groupnorm_one_launch_cluster_form(ops, dtype, tol):
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_ff_geglu_fused_projection(ops, dtype, tol):
     """(x W_v^T + b_v) * gelu(x W_g^T + b_g) in one MFMA kernel (csrc/ff_geglu.hip, K = 320) against fp64 on the rounded
-    inputs: rows that are multiples of nothing (the kernel stores whole 256-row blocks into a padded buffer), 2 ... 150 output
+    inputs: rows that are multiples of nothing (the kernel stores whole 256-row blocks into a padded buffer), 2 ... 95 output
     steps (odd and even: the two accumulator sets swap every step), no bias, x as a strided view, gate values deep in both
     tails of the GELU; and never less accurate than library GEMM + geglu, which rounds the [rows, 2 inner] intermediate."""
     from multiview_inpaint_amd.svd import ops as dev_ops
     g = torch.Generator().manual_seed(41)
     for rows, inner, with_bias, strided in [(1000, 1280, True, False), (777, 64, False, False), (70001, 1280, True, True),
-                                            (256, 4800, True, False), (33, 96, True, False)]:
+                                            (256, 3040, True, False), (33, 96, True, False)]:
         K = 320
         wide = (torch.randn(rows, 2 * K if strided else K, generator=g) * 1.2).to(dtype)
         x = wide[:, :K]
