@@ -112,6 +112,14 @@ int64_t mvi_ff_geglu_out_rows(int64_t rows);
 int mvi_ff_geglu(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
                  int32_t inner, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
 
+/* The same kernel with a plain epilogue: out[r, j] = x[r, :] . weight[j, :] + bias[j] — nn.Linear for K = 320 (bf16 / f16,
+ * out_features a multiple of 64): the bias-only projections of the level-0 transformer blocks (packed q/k/v, to_out, proj_in,
+ * proj_out; sgm/modules/attention.py:281-344, :690-712), which are short-K, output-bound GEMMs the library runs at 2 TB/s. Same
+ * padded-output contract as mvi_ff_geglu. */
+int mvi_linear_k320_supported(int32_t K, int32_t out_features, int32_t dtype);
+int mvi_linear_k320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
+                    int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
+
 /* out[n, c, p] = h[n, c, p] + bias[c] + x[n, c, p] over [N, C, spatial] activations in one pass; x and bias are
  * optional (NULL). Folds a convolution's bias (PyTorch-ROCm adds it in a separate kernel) and the ResBlock skip
  * add `self.skip_connection(x) + h` (svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:354). out may alias h. */

@@ -96,10 +96,15 @@ __device__ __forceinline__ float geglu1(float v, float g) {
     return v * __builtin_fmaf(__builtin_fabsf(hg), erf_abs, hg);
 }
 
-template <typename T, int kX = 0>                            // kX != 0: timing experiments that drop one kind of work (wrong results on purpose)
+// kGeglu = true : out[r, j] = (x . W[j] + b[j]) * gelu(x . W[inner + j] + b[inner + j]), j < inner; a step = 32 outputs
+// kGeglu = false: out[r, j] = x . W[j] + b[j], j < inner (= the Linear's out_features); a step = 64 outputs (the same two 32-row
+//                 blocks of a W tile, both plain) — the bias-only projections of level 0 (packed q/k/v, to_out, proj_in / proj_out),
+//                 which the library runs at 0.36 - 0.5 PFLOP/s because at K = 320 they are short loops around a lot of output
+template <typename T, int kX = 0, bool kGeglu = true>        // kX != 0: timing experiments that drop one kind of work (wrong results on purpose)
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                           int64_t rows, int inner, int64_t x_rs, int64_t o_rs, int n_blocks) {
+    constexpr int kOutStep = kGeglu ? kStep : 2 * kStep;         // outputs (and W rows of the first block) a step advances by
     using M = Mma<T>;
     using frag = typename M::frag;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -116,7 +121,8 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     const bool row_ok = row < rows;
 
     // ---- bias -> LDS (visible after the first barrier of the loop prologue)
-    for (int i = tid; i < 2 * inner; i += 64 * kWaves) lbias[i] = bias ? bias[i] : 0.f;
+    const int n_bias = kGeglu ? 2 * inner : inner;
+    for (int i = tid; i < n_bias; i += 64 * kWaves) lbias[i] = bias ? bias[i] : 0.f;
 
     // ---- x rows: B operand, element j of lane (col, hh), k-step s: x[row][16 s + 8 hh + j]
     frag xf[kKS];
@@ -136,16 +142,16 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
         const uint32_t off = 1024u * pc + 16u * lane;
         const uint32_t r = off / kRowBytes, c = (off - r * kRowBytes) >> 4;
         const uint32_t cs = (c & ~7u) | ((c & 7u) ^ ((r >> 1) & 7u));
-        const uint32_t wrow = r < 32 ? r : (uint32_t)inner + (r - 32);
+        const uint32_t wrow = r < 32 ? r : (kGeglu ? (uint32_t)inner + (r - 32) : r);
         p_voff[i] = wrow * kRowBytes + 16u * cs;
     }
     const char* const wbase = reinterpret_cast<const char*>(w);
-    const int n_steps = inner / kStep;
+    const int n_steps = inner / kOutStep;
     auto issue_tile = [&](int step) __attribute__((always_inline)) {
         // steps past the end re-load the last tile (never read): every step issues the same number of pieces, the counted wait stays valid
         const int st = step < n_steps ? step : n_steps - 1;
         const uint32_t slot_off = (uint32_t)((step % kRing) * kTileBytes);
-        const char* const base = wbase + (int64_t)st * (kStep * kRowBytes);
+        const char* const base = wbase + (int64_t)st * (kOutStep * kRowBytes);
 #pragma unroll
         for (int i = 0; i < kPiecesPerLoader; ++i) dma_piece(base, p_voff[i], lds0 + slot_off + 1024u * (wave + i * kLoaders));
     };
@@ -176,14 +182,22 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     // a pair. Scheduling fences keep the slices where they are — left alone, the scheduler issues the 40 MFMAs back to back and
     // the ~300 VALU instructions of the epilogue behind them, and the step takes the sum of both (measured: 637 us per call).
     constexpr int kAhead = 2;
+    // stores rows m, m + 1 (registers r, r + 1) of one 32-column block at byte offset `cb` of the step's output columns
+    auto store_pair = [&](char* op, int cb, int r, uint32_t pk) __attribute__((always_inline)) {
+        const int m = (r & 3) + 8 * (r >> 2);
+        if (kX != 2 || pk == 0x12345678u) {
+            *reinterpret_cast<uint16_t*>(op + cb + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
+            *reinterpret_cast<uint16_t*>(op + cb + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+        }
+    };
     auto step_fn = [&](auto with_prev_c, uint32_t slot_base, int step, f32x16& av, f32x16& ag, const f32x16& pv, const f32x16& pg)
                        __attribute__((always_inline)) {
         constexpr bool kPrev = decltype(with_prev_c)::value;
-        const int n = step * kStep + col;
-        const float bv = lbias[n], bg = lbias[inner + n];
+        const int n = step * kOutStep + col;
+        const float bv = lbias[n], bg = lbias[(kGeglu ? inner : kStep) + n];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { av[i] = bv; ag[i] = bg; }
-        char* const op = obase + (step - 1) * (kStep * 2);           // the previous step's output columns
+        char* const op = obase + (step - 1) * (kOutStep * 2);        // the previous step's output columns
         u32x4 fv[kAhead + 1], fg[kAhead + 1];
 #pragma unroll
         for (int s = 0; s < kAhead; ++s) { fv[s] = wfrag(slot_base, 0, s); fg[s] = wfrag(slot_base, 1, s); }
@@ -197,16 +211,13 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
             av = M::mfma(xf[s], as_frag<frag>(fv[s % (kAhead + 1)]), av);
             ag = M::mfma(xf[s], as_frag<frag>(fg[s % (kAhead + 1)]), ag);
             if (kPrev && s < 16) {
-                const float o = kX == 1 ? pv[s] + pg[s] : geglu1(pv[s], pg[s]);
-                if ((s & 1) == 0) {
-                    held = o;
-                } else {
-                    const uint32_t pk = M::pack2(held, o);
-                    const int m = ((s - 1) & 3) + 8 * ((s - 1) >> 2);
-                    if (kX != 2 || pk == 0x12345678u) {
-                        *reinterpret_cast<uint16_t*>(op + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
-                        *reinterpret_cast<uint16_t*>(op + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
-                    }
+                if (kGeglu) {
+                    const float o = kX == 1 ? pv[s] + pg[s] : geglu1(pv[s], pg[s]);
+                    if ((s & 1) == 0) held = o;
+                    else store_pair(op, 0, s - 1, M::pack2(held, o));
+                } else if ((s & 1) == 1) {                           // plain: both blocks are outputs (bias already inside)
+                    store_pair(op, 0, s - 1, M::pack2(pv[s - 1], pv[s]));
+                    store_pair(op, kStep * 2, s - 1, M::pack2(pg[s - 1], pg[s]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -214,13 +225,15 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     };
     // the last step's outputs, with nothing left to hide behind
     auto drain = [&](int step, const f32x16& pv, const f32x16& pg) __attribute__((always_inline)) {
-        char* const op = obase + step * (kStep * 2);
+        char* const op = obase + step * (kOutStep * 2);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const uint32_t pk = M::pack2(geglu1(pv[r], pg[r]), geglu1(pv[r + 1], pg[r + 1]));
-            const int m = (r & 3) + 8 * (r >> 2);
-            *reinterpret_cast<uint16_t*>(op + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
-            *reinterpret_cast<uint16_t*>(op + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+            if (kGeglu) {
+                store_pair(op, 0, r, M::pack2(geglu1(pv[r], pg[r]), geglu1(pv[r + 1], pg[r + 1])));
+            } else {
+                store_pair(op, 0, r, M::pack2(pv[r], pv[r + 1]));
+                store_pair(op, kStep * 2, r, M::pack2(pg[r], pg[r + 1]));
+            }
         }
     };
 #ifdef MVI_FFG_STAMPS
@@ -288,23 +301,23 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
 
 }  // namespace ffg
 
-template <typename T>
-static int ff_geglu_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int inner, int64_t x_rs,
-                           int64_t o_rs, hipStream_t st) {
+template <typename T, bool kGeglu>
+static int ff_k320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int inner, int64_t x_rs,
+                          int64_t o_rs, hipStream_t st) {
     using namespace ffg;
     const int64_t n_blocks = (rows + kRows - 1) / kRows;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
-    const int lds_bytes = kRing * kTileBytes + 2 * inner * (int)sizeof(float);
-    static unsigned long long attr_set = 0;                      // per device: the opt-in for > 64 KiB of dynamic LDS
+    const int lds_bytes = kRing * kTileBytes + (kGeglu ? 2 : 1) * inner * (int)sizeof(float);
+    static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &ff_geglu_k320_kernel<T>;
+    auto kern = &ff_geglu_k320_kernel<T, 0, kGeglu>;
 #ifdef MVI_FFG_EXPERIMENTS
     static const int xp = getenv("MVI_FFG_EXPERIMENT") ? atoi(getenv("MVI_FFG_EXPERIMENT")) : 0;
-    if (xp == 1) kern = &ff_geglu_k320_kernel<T, 1>;
-    if (xp == 2) kern = &ff_geglu_k320_kernel<T, 2>;
-    if (xp == 3) kern = &ff_geglu_k320_kernel<T, 3>;
-    if (xp == 4) kern = &ff_geglu_k320_kernel<T, 4>;
+    if (xp == 1) kern = &ff_geglu_k320_kernel<T, 1, kGeglu>;
+    if (xp == 2) kern = &ff_geglu_k320_kernel<T, 2, kGeglu>;
+    if (xp == 3) kern = &ff_geglu_k320_kernel<T, 3, kGeglu>;
+    if (xp == 4) kern = &ff_geglu_k320_kernel<T, 4, kGeglu>;
     if (xp) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     if (!(attr_set >> dev & 1ull)) {
@@ -340,7 +353,32 @@ extern "C" int mvi_ff_geglu(const void* x, const void* weight, const float* bias
     if ((int64_t)2 * inner * K * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "ff_geglu: weight exceeds 32-bit byte offsets");
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == MVI_DT_BF16
-                       ? mvi::ff_geglu_launch<__hip_bfloat16>(x, weight, bias, out, rows, inner, x_row_stride, out_row_stride, st)
-                       : mvi::ff_geglu_launch<__half>(x, weight, bias, out, rows, inner, x_row_stride, out_row_stride, st);
+                       ? mvi::ff_k320_launch<__hip_bfloat16, true>(x, weight, bias, out, rows, inner, x_row_stride, out_row_stride, st)
+                       : mvi::ff_k320_launch<__half, true>(x, weight, bias, out, rows, inner, x_row_stride, out_row_stride, st);
     return rc ? mvi::unet_fail(rc, "ff_geglu: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_linear_k320_supported(int32_t K, int32_t out_features, int32_t dtype) {
+    return K == mvi::ffg::kK && out_features >= 4 * mvi::ffg::kStep && out_features % (2 * mvi::ffg::kStep) == 0 &&
+           mvi::ffg::kRing * mvi::ffg::kTileBytes + (int64_t)out_features * 4 <= 160 * 1024 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+extern "C" int mvi_linear_k320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
+                               int32_t K, int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                               void* stream) {
+    if (rows < 0 || !mvi_linear_k320_supported(K, out_features, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "linear_k320: needs K = 320, out_features a multiple of 64 (128 ... 10240), bf16 or f16");
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "linear_k320: NULL pointer");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return mvi::unet_fail(MVI_EINVAL, "linear_k320: out needs room for mvi_ff_geglu_out_rows(rows) rows (whole 256-row blocks are stored)");
+    if (x_row_stride < K || out_row_stride < out_features || x_row_stride % 8 || out_row_stride % 4 ||
+        ((uintptr_t)x | (uintptr_t)weight) % 16 || (uintptr_t)out % 8)
+        return mvi::unet_fail(MVI_EINVAL, "linear_k320: rows must be 16-byte aligned (x, weight) / 8-byte aligned (out)");
+    if ((int64_t)out_features * K * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "linear_k320: weight exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::ff_k320_launch<__hip_bfloat16, false>(x, weight, bias, out, rows, out_features, x_row_stride, out_row_stride, st)
+                       : mvi::ff_k320_launch<__half, false>(x, weight, bias, out, rows, out_features, x_row_stride, out_row_stride, st);
+    return rc ? mvi::unet_fail(rc, "linear_k320: kernel launch failed") : MVI_OK;
 }

@@ -302,6 +302,28 @@ def ff_geglu(x, weight, bias):
     return out.reshape(*x.shape[:-1], inner)
 
 
+def linear_k320_supported(K, out_features, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_linear_k320_supported(int(K), int(out_features), _DT[dtype]))
+
+
+def linear_k320(x, weight, bias):
+    """F.linear(x, weight, bias) for K = 320 on the MFMA kernel of ff_geglu (plain epilogue): x [..., 320], weight [N, 320]."""
+    L = _lib.lib()
+    K, N = x.shape[-1], weight.shape[0]
+    xc = x.reshape(-1, K)
+    if xc.stride(1) != 1 or xc.stride(0) % 8:
+        xc = xc.contiguous()
+    wc = weight if weight.is_contiguous() else weight.contiguous()
+    rows = xc.shape[0]
+    cap = int(L.mvi_ff_geglu_out_rows(rows))
+    full = torch.empty(cap, N, dtype=x.dtype, device=x.device)
+    b = None if bias is None else _f32(bias)
+    with torch.cuda.device(x.device), _Timed("linear_k320", float(rows) * (K + N) * x.element_size(), x.device):
+        _check(L.mvi_linear_k320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), rows, cap, K, N,
+                                 xc.stride(0), full.stride(0), _DT[x.dtype], _stream(x.device)), "linear_k320")
+    return full[:rows].reshape(*x.shape[:-1], N)
+
+
 def bias_residual_add(h, bias, x):
     L = _lib.lib()
     if h.dtype not in _DT:

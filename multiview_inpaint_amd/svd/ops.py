@@ -202,6 +202,28 @@ def linear_geglu(x, weight, bias=None):
     return geglu(F.linear(x, weight, bias))
 
 
+def linear(x, weight, bias=None):
+    """F.linear(x, weight, bias). On the GPU, the K = 320 projections of the level-0 transformer blocks (packed q/k/v, to_out,
+    proj_in / proj_out: output-bound GEMMs around a 20-step loop) take csrc/ff_geglu.hip's plain-epilogue kernel
+    (mvi_linear_k320); everything else is the library GEMM."""
+    if x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
+            and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
+        from . import hip_ops
+        if hip_ops.linear_k320_supported(x.shape[-1], weight.shape[0], x.dtype):
+            return hip_ops.linear_k320(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+def linear_module(mod, x):
+    """`mod(x)` for an nn.Linear (or Sequential(Linear, Dropout) at inference) through linear()."""
+    if isinstance(mod, torch.nn.Sequential) and len(mod) == 2 and isinstance(mod[0], torch.nn.Linear) \
+            and isinstance(mod[1], torch.nn.Dropout) and not (mod[1].training and mod[1].p > 0):
+        return linear(x, mod[0].weight, mod[0].bias)
+    if type(mod) is torch.nn.Linear:
+        return linear(x, mod.weight, mod.bias)
+    return mod(x)
+
+
 def bias_residual_add(h, bias=None, x=None):
     """h [N, C, *spatial] + bias[c] + x in one pass (conv bias and ResBlock skip add, openaimodel.py:354)."""
     if h.is_cuda and not _needs_autograd(h, bias, x):

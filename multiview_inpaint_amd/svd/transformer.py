@@ -70,7 +70,7 @@ class CrossAttention(nn.Module):
         if context is None and not n_times_crossframe_attn_in_self and not n_extra and ops.packed_ok(x, self.heads, self.dim_head):
             # self-attention at inference: one GEMM [.., C] x [C, 3 H D] instead of three passes over the activations;
             # the attention kernel reads q, k, v out of the packed result in place
-            return self.to_out(ops.attention_packed(F.linear(x, self._packed_qkv_weight()), self.heads))
+            return ops.linear_module(self.to_out, ops.attention_packed(ops.linear(x, self._packed_qkv_weight()), self.heads))
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if n_times_crossframe_attn_in_self:
             n = n_times_crossframe_attn_in_self
@@ -97,7 +97,7 @@ class CrossAttention(nn.Module):
     def forward_temporal(self, x, T):
         """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back."""
         if ops.packed_ok(x, self.heads, self.dim_head) and self.to_k.in_features == self.to_q.in_features:
-            return self.to_out(ops.attention_temporal_packed(F.linear(x, self._packed_qkv_weight()), self.heads, T))
+            return ops.linear_module(self.to_out, ops.attention_temporal_packed(ops.linear(x, self._packed_qkv_weight()), self.heads, T))
         return self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
 
     def single_token(self, ctx):
@@ -190,14 +190,14 @@ class SpatialTransformer(nn.Module):
 
     def _tokens_in(self, x):
         if self.use_linear:
-            return self.proj_in(self.norm.forward_tokens(x))  # the norm writes b (h w) c directly
+            return ops.linear_module(self.proj_in, self.norm.forward_tokens(x))  # the norm writes b (h w) c directly
         h = self.proj_in(self.norm(x))
         return h.flatten(2).transpose(1, 2).contiguous()      # b c h w -> b (h w) c
 
     def _tokens_out(self, t, x_in):
         b, c, h, w = x_in.shape
         if self.use_linear:
-            return ops.tokens_to_planes_add(self.proj_out(t), x_in)   # b (h w) c -> b c h w, + x_in, one pass
+            return ops.tokens_to_planes_add(ops.linear_module(self.proj_out, t), x_in)   # b (h w) c -> b c h w, + x_in, one pass
         t = t.transpose(1, 2).reshape(b, -1, h, w)
         return self.proj_out(t) + x_in
 

@@ -376,6 +376,41 @@ def test_ff_geglu_fused_projection(ops, dtype, tol):
     assert not ops.ff_geglu_supported(640, 1280, dtype) and not ops.ff_geglu_supported(320, 1280, torch.float32)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_linear_k320_kernel(ops, dtype, tol):
+    """nn.Linear with K = 320 on the MFMA kernel of ff_geglu (plain epilogue, 64 outputs per step): against fp64 and against the
+    library GEMM (same inputs, fp32 accumulation either way: equal to the order of summation), ragged rows, 2 ... 15 steps, with
+    and without bias, a strided x; the dispatcher takes it only for enough rows."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(43)
+    for rows, N, with_bias, strided in [(1000, 960, False, False), (70001, 320, True, True), (300, 128, True, False), (513, 704, True, False)]:
+        K = 320
+        wide = (torch.randn(rows, 2 * K if strided else K, generator=g) * 1.2).to(dtype)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+        b = (torch.randn(N, generator=g) * 0.3).to(dtype) if with_bias else None
+        ref = F.linear(wide[:, :K].double(), w.double(), None if b is None else b.double())
+        xs = wide.cuda()[:, :K]
+        assert ops.linear_k320_supported(K, N, dtype)
+        y = ops.linear_k320(xs, w.cuda(), None if b is None else b.cuda())
+        lib = F.linear(xs, w.cuda(), None if b is None else b.cuda())
+        assert y.shape == (rows, N) and y.dtype == dtype
+        assert rel(y, ref) < tol and rel(y, lib.double()) < tol
+    x = torch.randn(dev_ops.FF_GEGLU_MIN_ROWS, 320, generator=g).to(dtype).cuda()
+    w = (torch.randn(320, 320, generator=g) * 320 ** -0.5).to(dtype).cuda()
+    lin = torch.nn.Linear(320, 320).to(dtype).cuda()
+    ops.PROFILE = []
+    big = dev_ops.linear(x, w)
+    small = dev_ops.linear(x[:100], w)
+    with torch.no_grad():
+        viamod = dev_ops.linear_module(torch.nn.Sequential(lin, torch.nn.Dropout(0.0)).eval(), x)
+    with_grad = dev_ops.linear_module(lin, x)                        # parameters that require grad under autograd: library GEMM
+    kinds = [e[0] for e in ops.PROFILE]
+    ops.PROFILE = None
+    assert kinds == ["linear_k320", "linear_k320"] and with_grad.requires_grad
+    assert rel(big[:100], small.double()) < tol and rel(viamod, with_grad.detach().double()) < tol
+    assert not ops.linear_k320_supported(320, 96, dtype) and not ops.linear_k320_supported(640, 640, dtype)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_bias_residual_add(ops, dtype, tol):
     g = torch.Generator().manual_seed(11)
