@@ -187,6 +187,7 @@ def geglu(h):
 
 
 FF_GEGLU_MIN_ROWS = 32768       # below, the fused kernel's 256-row blocks do not fill the chip: library GEMM + geglu
+K320_KERNELS = os.environ.get("MVI_K320", "1") != "0"      # MVI_K320=0: library GEMMs everywhere (same-box A/B runs)
 
 
 def linear_geglu(x, weight, bias=None):
@@ -194,7 +195,7 @@ def linear_geglu(x, weight, bias=None):
     On the GPU, for the shapes csrc/ff_geglu.hip covers (K = 320 in bf16 / f16: the level-0 FeedForward layers) and enough rows,
     projection and gating run as ONE kernel and the [rows, 2 inner] intermediate never exists; everything else is the library
     GEMM followed by geglu()."""
-    if x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
+    if K320_KERNELS and x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
         if hip_ops.ff_geglu_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
@@ -206,7 +207,7 @@ def linear(x, weight, bias=None):
     """F.linear(x, weight, bias). On the GPU, the K = 320 projections of the level-0 transformer blocks (packed q/k/v, to_out,
     proj_in / proj_out: output-bound GEMMs around a 20-step loop) take csrc/ff_geglu.hip's plain-epilogue kernel
     (mvi_linear_k320); everything else is the library GEMM."""
-    if x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
+    if K320_KERNELS and x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
         if hip_ops.linear_k320_supported(x.shape[-1], weight.shape[0], x.dtype):
