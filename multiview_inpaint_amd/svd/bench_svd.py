@@ -179,15 +179,20 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
     per_step = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
-    # separate instrumented pass of the same steps: every HIP op bracketed by events on its launch stream -> per-op table
+    # separate instrumented pass of the same steps: every HIP op bracketed by events on its launch stream -> per-op table.
+    # The ControlNet runs on the main stream here: with the two networks sharing the chip (engine.TWO_STREAMS, the timed
+    # region above) an op's events would time its kernel PLUS whatever ran beside it.
+    from . import engine as _engine
+    two_streams, _engine.TWO_STREAMS = _engine.TWO_STREAMS, False
     hip_ops.PROFILE = []
     for i in range(steps):
         step(i)
     torch.cuda.synchronize(device)
     prof = hip_ops.profile_summary()
     hip_ops.PROFILE = None
+    _engine.TWO_STREAMS = two_streams
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
-               step_ms=per_step, controlnet=with_control, gemm_tuning=bool(tuned),
+               step_ms=per_step, controlnet=with_control, gemm_tuning=bool(tuned), two_streams=bool(two_streams and with_control),
                dtype=("bf16 weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights == "bf16"
                       else "bf16 autocast over fp32 weights, fp32 GroupNorm statistics / softmax"),
                finite=bool(torch.isfinite(out).all()))

@@ -8,6 +8,7 @@ harness owns exactly the per-step hot path: ControlNet -> scaled residuals -> Co
 wrapped by Denoiser and driven by the sampler.
 """
 import contextlib
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -16,6 +17,19 @@ import torch.nn as nn
 from .schedule import Denoiser, instantiate_from_config
 
 OPENAIUNETWRAPPER = "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper"
+# ControlNet beside the UNet encoder (apply_model). OPT-IN: same-box A/B 181.3 -> 173.2 ms per step, but with the default on the
+# full-size property test stopped making progress once (killed after 7 minutes of silence; the bench runs had been fine): the
+# library's stream-K GEMMs (hipBLASLt "SK3" kernels) spin on flags of peer workgroups, and two such kernels on concurrent
+# streams can keep each other's peers off the chip. Not something to leave on for a caller who has not checked their GEMM set.
+TWO_STREAMS = os.environ.get("MVI_SVD_TWO_STREAMS", "0") == "1"
+_side = {}
+
+
+def _side_stream(device):
+    s = _side.get(device.index)
+    if s is None:
+        s = _side[device.index] = torch.cuda.Stream(device)
+    return s
 
 
 class IdentityWrapper(nn.Module):
@@ -87,12 +101,35 @@ class SVDInpaintEngine(nn.Module):
             hint = [hint, cond["palette"]]
         controls = None
         if hint is not None and self.control_model is not None:
-            controls = self.control_model(x=xin, hint=hint, timesteps=timesteps, context=context, y=y,
-                                          time_context=time_context, num_video_frames=num_video_frames,
-                                          image_only_indicator=image_only_indicator)
-            controls = [c if s == 1.0 else c * s for c, s in zip(controls, self.control_scales)]   # x * 1.0 is x: skip the pass
-            if self.global_average_pooling:
-                controls = [c.mean(dim=(2, 3), keepdim=True) for c in controls]
+            def run_control():
+                cs = self.control_model(x=xin, hint=hint, timesteps=timesteps, context=context, y=y,
+                                        time_context=time_context, num_video_frames=num_video_frames,
+                                        image_only_indicator=image_only_indicator)
+                cs = [c if s == 1.0 else c * s for c, s in zip(cs, self.control_scales)]   # x * 1.0 is x: skip the pass
+                if self.global_average_pooling:
+                    cs = [c.mean(dim=(2, 3), keepdim=True) for c in cs]
+                return cs
+            if TWO_STREAMS and xin.is_cuda and not torch.is_grad_enabled():
+                # The ControlNet and the UNet's encoder + middle block are independent until the first residual is added
+                # (csvd.py:79): the ControlNet runs on a side stream while the main stream runs the encoder, so that the
+                # low-resolution halves of both — whose kernels fill a quarter of the chip each (80 tiles per 3x3 convolution
+                # at 9 x 16) — share it. The UNet joins the side stream where it pops the first residual.
+                main = torch.cuda.current_stream(xin.device)
+                side = _side_stream(xin.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    produced = run_control()
+                for t in (xin, context, y, timesteps, *(hint if isinstance(hint, list) else [hint])):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(side)
+
+                def controls():
+                    main.wait_stream(side)
+                    for c in produced:
+                        c.record_stream(main)
+                    return produced
+            else:
+                controls = run_control()
         return self.model.diffusion_model(x=xin, timesteps=timesteps, context=context, y=y, time_context=time_context,
                                           control=controls, num_video_frames=num_video_frames,
                                           image_only_indicator=image_only_indicator)

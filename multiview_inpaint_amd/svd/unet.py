@@ -170,6 +170,8 @@ class VideoUNet(_Encoder):
             h = blk(h, emb, **kw)
             hs.append(h)
         h = self.middle_block(h, emb, **kw)
+        if callable(control):
+            control = control()                            # residuals produced on another stream: joined here (engine.py)
         if control is not None:
             h = h + control.pop()                          # consumes the caller's list (csvd.py:79-91)
         for blk in self.output_blocks:

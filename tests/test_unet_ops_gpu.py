@@ -812,3 +812,44 @@ def test_full_size_svd_step_properties(strict):
             c2 = eng.denoise(x, sig * 0.5, cond, **kw)
         d2 = eng.denoise(x, sig * 0.5, cond, **kw)
     assert rel_(c1, out) < tol and rel_(c2, d2) < tol
+
+
+def test_controlnet_on_a_side_stream_gives_the_same_step():
+    """SVDInpaintEngine.apply_model runs the ControlNet on a side stream beside the UNet's encoder (engine.TWO_STREAMS) and
+    joins it where the first residual is popped: same kernels, same inputs — the step must equal the one-stream step (fp32
+    small networks: bit for bit up to the vendor GEMMs' own run-to-run noise, bound 1e-6), repeatedly (the streams' buffers
+    and caches are reused), and with the hint-stem cache of sample()."""
+    from multiview_inpaint_amd.svd import engine as E
+    from multiview_inpaint_amd.svd.schedule import Denoiser
+    from multiview_inpaint_amd.svd.unet import ControlNet, ControlledVideoUNet
+    cunet = ControlledVideoUNet(**H.SMALL_UNET).eval()
+    cunet.load_state_dict(H.seeded_state_dict(cunet, 11))
+    cnet = ControlNet(**H.SMALL_CTRL).eval()
+    sd = H.seeded_state_dict(cnet, 12)
+    for k in sd:                                                     # zero convolutions would hide the ControlNet entirely
+        if "zero_convs" in k or "middle_block_out" in k:
+            sd[k] = torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(len(k))) * 0.05
+    cnet.load_state_dict(sd)
+    den = Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"})
+    eng = E.SVDInpaintEngine(cunet, cnet, den).cuda()
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(21).items()}
+    cond = {"concat": inp["concat"], "crossattn": inp["crossattn"], "vector": inp["vector"], "control_hint": inp["control_hint"]}
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    outs = {}
+    old = E.TWO_STREAMS
+    try:
+        with torch.no_grad():
+            for mode in (False, True, True, False):
+                E.TWO_STREAMS = mode
+                outs.setdefault(mode, []).append(eng.denoise(inp["x"], inp["sigma"], cond, **kw))
+            E.TWO_STREAMS = True
+            with cnet.hint_cache():
+                cached = [eng.denoise(inp["x"], inp["sigma"], cond, **kw) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        E.TWO_STREAMS = old
+    ref = outs[False][0].double()
+    assert float(ref.abs().max()) > 0 and rel(outs[False][1], ref) < 1e-6
+    for o in outs[True] + cached:
+        assert rel(o, ref) < 1e-6
+
