@@ -76,6 +76,16 @@ int mvi_groupnorm_silu_tokens(const void* x, void* y, const float* weight, const
                               int64_t N, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
                               int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* GroupNorm(+SiLU) with TOKEN-MAJOR input and output: x, y [N, spatial, C] (C contiguous = NHWC). The norm between the two
+ * 3x3 convolutions of a ResBlock (openaimodel.py:292-305, :341-352) when the convolutions run on channels-last tensors —
+ * MIOpen's kernels are NHWC and wrap NCHW tensors in transposes (csrc/groupnorm_tokens.hip). chan_bias: optional fp32 [N, C]
+ * added to x before the statistics (the timestep-embedding bias). workspace: mvi_groupnorm_tok2tok_workspace_bytes(...)
+ * (0 = shape not supported: C must be a multiple of groups <= 64 and of the 16-byte vector width). */
+size_t mvi_groupnorm_tok2tok_workspace_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups, int32_t dtype);
+int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int64_t N,
+                               int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t dtype,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* out = softmax(q k^T * scale) v per (batch, head). Token-major layout, as the Linear projections
  * produce it: q/out [B, Sq, H, D], k/v [B, Sk, H, D], contiguous. No mask (none is used on the
  * denoise path). dtype selects the I/O type; fp32 I/O computes in fp32 (validation mode, 1e-4
@@ -168,6 +178,9 @@ int mvi_add_lerp(const void* x, const void* h, const void* base, const float* al
  * C and spatial must be multiples of the 16-byte vector width (4 fp32 / 8 bf16, f16). */
 int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64_t N, int32_t C, int64_t spatial,
                              int32_t dtype, void* stream);
+/* ... + bias[c] (fp32 [C]): the bias of the convolution that produced the tokens rides on the same pass. */
+int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, const float* bias, void* out, int64_t N, int32_t C,
+                                  int64_t spatial, int32_t dtype, void* stream);
 
 /* out = silu(h + bias[c]) for h [N, C, spatial]: convolution bias + SiLU of the ControlNet hint stem
  * (svd_inpaint1/models/csvd.py:234-250: eight convolutions with SiLU between, at up to 576x1024) in one pass instead of

@@ -1,0 +1,222 @@
+// GroupNorm(+SiLU) on TOKEN-MAJOR activations: x [N, S, C] -> y [N, S, C] (C contiguous = NHWC), bf16 / f16 / f32.
+// Why it exists: MIOpen runs the 3x3 convolutions of the SVD step with NHWC kernels and, for NCHW tensors, wraps them in
+// transposes (9.3 ms per step in `batched_transpose_*`; tools/experiments/conv_layout_probe.py: 817 -> 649 us for one level-0
+// convolution, bit-identical output). Inside a ResBlock (openaimodel.py:328-354) the first norm can already write tokens
+// (mvi_groupnorm_silu_tokens) and the last add can read them (mvi_tokens_to_planes_add); this is the norm BETWEEN the two
+// convolutions, whose input and output are both NHWC. The timestep-embedding bias is fused as in the NCHW kernels (chan_bias).
+//
+// Three launches, x read twice, y written once (the two-launch NCHW form's traffic):
+//   stats : block = VPR x RP threads (VPR = C / vec 16-byte vectors per token, RP rows per pass), 8 passes = a chunk of 8 RP
+//           tokens held in registers; a thread owns the SAME vec channels in every pass. Chunk moments per group are exact
+//           (mean first, then the centred second moment from the registers), written as (count, mean, M2);
+//   merge : one block per sample: Chan-merges the chunks of every group, then writes per-channel scale / shift
+//           (weight * rstd, bias + (chan_bias - mean) * weight * rstd) — 2 C floats per sample;
+//   apply : same thread layout as stats, y = act(x * scale[c] + shift[c]).
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+#include "unet_io.h"
+
+namespace mvi {
+int unet_fail(int code, const char* msg);
+
+constexpr int kGtPasses = 8;          // token rows per thread and chunk
+constexpr int kGtMaxGroups = 64;
+
+__host__ __device__ inline int gt_rows_per_pass(int vpr) { int rp = 512 / vpr; return rp < 1 ? 1 : (rp > 8 ? 8 : rp); }
+
+template <typename T>
+__global__ __launch_bounds__(1024) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
+                                                        int C, int64_t S, int G, int vpr, int rp, int chunks) {
+    constexpr int V = Io<T>::kVec;
+    extern __shared__ float s_mem[];
+    float* s_ch = s_mem;                       // [rp][C] per-channel partials of the block's row groups
+    float* s_grp = s_mem + (size_t)rp * C;     // [G] group sums, then group means
+    const int tid = threadIdx.x, v = tid % vpr, r0 = tid / vpr;
+    const int64_t n = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t row0 = (int64_t)chunk * (kGtPasses * rp);
+    const int Cg = C / G;
+    const T* xb = x + (n * S) * C + (int64_t)v * V;
+    const float* cb = chan_bias ? chan_bias + n * C + v * V : nullptr;
+    float vals[kGtPasses][V];
+    float add[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) add[k] = cb ? cb[k] : 0.f;
+    int rows_here = 0;
+    float csum[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) csum[k] = 0.f;
+#pragma unroll
+    for (int p = 0; p < kGtPasses; ++p) {
+        const int64_t row = row0 + p * rp + r0;
+        if (row < S) {
+            Io<T>::load(xb + row * C, vals[p]);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { vals[p][k] += add[k]; csum[k] += vals[p][k]; }
+            ++rows_here;
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) vals[p][k] = 0.f;
+        }
+    }
+    const int64_t rows_chunk = (S - row0) < (int64_t)(kGtPasses * rp) ? (S - row0) : (int64_t)(kGtPasses * rp);
+    // per-channel sums of the chunk -> group means
+#pragma unroll
+    for (int k = 0; k < V; ++k) s_ch[(size_t)r0 * C + v * V + k] = csum[k];
+    __syncthreads();
+    if (tid < G) {
+        float s = 0.f;
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c)
+            for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
+        s_grp[tid] = s / (float)(rows_chunk * Cg);
+    }
+    __syncthreads();
+    // centred second moments from the registers
+    float m2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float mean = s_grp[(v * V + k) / Cg];
+        float a = 0.f;
+#pragma unroll
+        for (int p = 0; p < kGtPasses; ++p) {
+            const float d = vals[p][k] - mean;
+            a += (row0 + p * rp + r0 < S) ? d * d : 0.f;
+        }
+        m2[k] = a;
+    }
+    __syncthreads();                           // s_ch is reused
+#pragma unroll
+    for (int k = 0; k < V; ++k) s_ch[(size_t)r0 * C + v * V + k] = m2[k];
+    __syncthreads();
+    if (tid < G) {
+        float s = 0.f;
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c)
+            for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
+        float* p = part + ((n * chunks + chunk) * G + tid) * 3;
+        p[0] = (float)(rows_chunk * Cg); p[1] = s_grp[tid]; p[2] = s;
+    }
+}
+
+// one block per sample: Chan merge per group, then per-channel scale / shift
+__global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__ part, const float* __restrict__ weight, const float* __restrict__ bias,
+                                                       const float* __restrict__ chan_bias, float* __restrict__ scale_shift, int C, int G,
+                                                       int chunks, float eps) {
+    __shared__ float s_mean[kGtMaxGroups], s_rstd[kGtMaxGroups];
+    const int64_t n = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < G) {
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = part + ((n * chunks + c) * G + tid) * 3;
+            const float nb = p[0], mb = p[1], qb = p[2];
+            const float nt = cnt + nb, d = mb - mean;
+            mean += d * (nb / nt);
+            m2 += qb + d * d * (cnt * nb / nt);
+            cnt = nt;
+        }
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(m2 / cnt + eps);
+    }
+    __syncthreads();
+    const int Cg = C / G;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / Cg;
+        const float w = weight[c] * s_rstd[g];
+        const float add = chan_bias ? chan_bias[n * C + c] : 0.f;
+        scale_shift[(n * C + c) * 2 + 0] = w;
+        scale_shift[(n * C + c) * 2 + 1] = bias[c] + (add - s_mean[g]) * w;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void gt_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale_shift, int C,
+                                                        int64_t S, int vpr, int rp, int silu) {
+    constexpr int V = Io<T>::kVec;
+    const int tid = threadIdx.x, v = tid % vpr, r0 = tid / vpr;
+    const int64_t n = blockIdx.y;
+    const int64_t row0 = (int64_t)blockIdx.x * (kGtPasses * rp);
+    const float* ss = scale_shift + (n * C + v * V) * 2;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = ss[2 * k]; sh[k] = ss[2 * k + 1]; }
+    const T* xb = x + (n * S) * C + (int64_t)v * V;
+    T* yb = y + (n * S) * C + (int64_t)v * V;
+    float vals[kGtPasses][V];
+#pragma unroll
+    for (int p = 0; p < kGtPasses; ++p) {
+        const int64_t row = row0 + p * rp + r0;
+        if (row < S) Io<T>::load(xb + row * C, vals[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < kGtPasses; ++p) {
+        const int64_t row = row0 + p * rp + r0;
+        if (row < S) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float t = vals[p][k] * sc[k] + sh[k];
+                vals[p][k] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+            }
+            Io<T>::store(yb + row * C, vals[p]);
+        }
+    }
+}
+
+template <typename T>
+static int gt_launch(const void* x, void* y, const float* w, const float* b, const float* cb, int64_t N, int C, int64_t S, int G, float eps,
+                     int silu, float* ws, hipStream_t st) {
+    constexpr int V = Io<T>::kVec;
+    const int vpr = C / V, rp = gt_rows_per_pass(vpr);
+    const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
+    float* part = ws;
+    float* ss = ws + (size_t)N * chunks * G * 3;
+    const dim3 grid((unsigned)chunks, (unsigned)N), block((unsigned)(vpr * rp));
+    const size_t lds = ((size_t)rp * C + G) * sizeof(float);
+    hipLaunchKernelGGL((gt_stats_kernel<T>), grid, block, lds, st, (const T*)x, cb, part, C, S, G, vpr, rp, chunks);
+    hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)N), dim3(256), 0, st, part, w, b, cb, ss, C, G, chunks, eps);
+    hipLaunchKernelGGL((gt_apply_kernel<T>), grid, block, 0, st, (const T*)x, (T*)y, ss, C, S, vpr, rp, silu);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+}  // namespace mvi
+
+static int gt_geometry_ok(int64_t N, int32_t C, int64_t S, int32_t G, int32_t dtype) {
+    const int V = dtype == MVI_DT_F32 ? 4 : 8;
+    if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || G > mvi::kGtMaxGroups || C % G || C % V) return 0;
+    const int vpr = C / V;
+    if (vpr > 1024 || N > 65535) return 0;
+    const int rp = mvi::gt_rows_per_pass(vpr);
+    return ((size_t)rp * C + G) * sizeof(float) <= 64 * 1024;
+}
+
+extern "C" size_t mvi_groupnorm_tok2tok_workspace_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups, int32_t dtype) {
+    if (!gt_geometry_ok(N, C, spatial, groups, dtype)) return 0;
+    const int V = dtype == MVI_DT_F32 ? 4 : 8;
+    const int rp = mvi::gt_rows_per_pass(C / V);
+    const int64_t chunks = (spatial + mvi::kGtPasses * rp - 1) / (mvi::kGtPasses * rp);
+    return (size_t)(N * chunks * groups * 3 + N * C * 2) * sizeof(float);
+}
+
+extern "C" int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                          int64_t N, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!gt_geometry_ok(N, C, spatial, groups, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: C must be a multiple of groups (<= 64) and of the 16-byte vector width");
+    if (!x || !y || !weight || !bias || !workspace) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: NULL pointer");
+    if (((uintptr_t)x | (uintptr_t)y) % 16) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: x / y must be 16-byte aligned");
+    if (workspace_bytes < mvi_groupnorm_tok2tok_workspace_bytes(N, C, spatial, groups, dtype))
+        return mvi::unet_fail(MVI_ENOMEM, "groupnorm_tok2tok: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::gt_launch<float>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st); break;
+        case MVI_DT_BF16: rc = mvi::gt_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st); break;
+        case MVI_DT_F16: rc = mvi::gt_launch<__half>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: unknown dtype");
+    }
+    return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok: kernel launch failed") : MVI_OK;
+}

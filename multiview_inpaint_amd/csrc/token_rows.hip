@@ -142,7 +142,7 @@ constexpr int kTpTile = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __restrict__ tok, const T* __restrict__ x_in,
                                                                    T* __restrict__ out, int C, int64_t S, int p_tiles,
-                                                                   int c_tiles) {
+                                                                   int c_tiles, const float* __restrict__ bias) {
     constexpr int V = Io<T>::kVec;
     constexpr int VPR = kTpTile / V;            // 16-B vectors per tile row
     __shared__ float s_t[kTpTile][kTpTile + 1];
@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __re
             const int64_t o = (n * C + c0 + cr) * S + p0 + pv * V;
             float t[V], xi[V];
             Io<T>::load(x_in + o, xi);
+            const float bc = bias ? bias[c0 + cr] : 0.f;          // per-channel bias of the convolution that produced the tokens
 #pragma unroll
-            for (int k = 0; k < V; ++k) t[k] = s_t[pv * V + k][cr] + xi[k];
+            for (int k = 0; k < V; ++k) t[k] = s_t[pv * V + k][cr] + bc + xi[k];
             Io<T>::store(out + o, t);
         }
     }
@@ -241,14 +242,15 @@ extern "C" int mvi_add_lerp(const void* x, const void* h, const void* base, cons
 }
 
 template <typename T>
-static int tokens_to_planes_launch(const void* tok, const void* x_in, void* out, int64_t N, int C, int64_t S, hipStream_t st) {
+static int tokens_to_planes_launch(const void* tok, const void* x_in, void* out, int64_t N, int C, int64_t S, hipStream_t st,
+                                   const float* bias = nullptr) {
     constexpr int V = Io<T>::kVec;
     if (C % V || S % V) return MVI_EINVAL;
     const int p_tiles = (int)((S + kTpTile - 1) / kTpTile), c_tiles = (C + kTpTile - 1) / kTpTile;
     const int64_t blocks = N * p_tiles * c_tiles;
     if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     hipLaunchKernelGGL((tokens_to_planes_add_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)tok,
-                       (const T*)x_in, (T*)out, C, S, p_tiles, c_tiles);
+                       (const T*)x_in, (T*)out, C, S, p_tiles, c_tiles, bias);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -266,4 +268,20 @@ extern "C" int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void*
     }
     if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: C and spatial must be multiples of the 16-byte vector width");
     return rc ? unet_fail(MVI_EHIP, "tokens_to_planes_add: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial,
+                                        int32_t dtype, void* stream) {
+    if (N < 0 || C <= 0 || spatial < 0) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: bad shape");
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!tok || !x_in || !out) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: NULL pointer");
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = tokens_to_planes_launch<float>(tok, x_in, out, N, C, spatial, (hipStream_t)stream, bias); break;
+        case MVI_DT_BF16: rc = tokens_to_planes_launch<__hip_bfloat16>(tok, x_in, out, N, C, spatial, (hipStream_t)stream, bias); break;
+        case MVI_DT_F16: rc = tokens_to_planes_launch<__half>(tok, x_in, out, N, C, spatial, (hipStream_t)stream, bias); break;
+        default: return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: C and spatial must be multiples of the 16-byte vector width");
+    return rc ? unet_fail(MVI_EHIP, "tokens_to_planes_add_bias: kernel launch failed") : MVI_OK;
 }

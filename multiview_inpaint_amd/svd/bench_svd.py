@@ -150,7 +150,10 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     from .schedule import EDMDiscretization
     ops.STRICT = True               # every op of the timed step runs its HIP kernel or the run fails (svd/ops.py)
     # let MIOpen time its convolution solvers during warm-up (+10 % on the 3x3 convolutions; with the shipped find-db a look-up)
-    torch.backends.cudnn.benchmark = True
+    # MIOpen solver choice: the shipped find-db is consulted in immediate mode too — same kernels, same step time as with
+    # cudnn.benchmark (174.97 vs 174.14 ms same-box) — while benchmark mode re-runs its search for every channels-last
+    # problem in every process (first step 164 s). MVI_SVD_MIOPEN_FIND=1 turns the search back on (e.g. to record a new db).
+    torch.backends.cudnn.benchmark = os.environ.get("MVI_SVD_MIOPEN_FIND", "0") == "1"
     use_shipped_miopen_db()
     tuned = enable_gemm_tuning()
     eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)

@@ -467,8 +467,8 @@ def add_lerp(x, h, base, alpha):
     return out
 
 
-def tokens_to_planes_add(tok, x_in):
-    """tok [N, S, C] + x_in [N, C, *spatial] -> [N, C, *spatial]."""
+def tokens_to_planes_add(tok, x_in, bias=None):
+    """tok [N, S, C] (+ bias[c]) + x_in [N, C, *spatial] -> [N, C, *spatial]."""
     L = _lib.lib()
     if tok.dtype not in _DT or x_in.dtype != tok.dtype:
         raise TypeError("tokens_to_planes_add: tok and x_in must share a supported dtype")
@@ -479,9 +479,38 @@ def tokens_to_planes_add(tok, x_in):
     xc = x_in if x_in.is_contiguous() else x_in.contiguous()
     out = torch.empty_like(xc)
     with torch.cuda.device(tok.device), _Timed("tokens_to_planes_add", 3.0 * tc.numel() * tc.element_size(), tok.device):
-        _check(L.mvi_tokens_to_planes_add(tc.data_ptr(), xc.data_ptr(), out.data_ptr(), N, Cc, S, _DT[tok.dtype],
-                                          _stream(tok.device)), "tokens_to_planes_add")
+        if bias is None:
+            _check(L.mvi_tokens_to_planes_add(tc.data_ptr(), xc.data_ptr(), out.data_ptr(), N, Cc, S, _DT[tok.dtype],
+                                              _stream(tok.device)), "tokens_to_planes_add")
+        else:
+            _check(L.mvi_tokens_to_planes_add_bias(tc.data_ptr(), xc.data_ptr(), _f32(bias).data_ptr(), out.data_ptr(), N, Cc, S,
+                                                   _DT[tok.dtype], _stream(tok.device)), "tokens_to_planes_add")
     return out
+
+
+def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=None):
+    """GroupNorm(+SiLU) of token-major t [N, S, C] -> [N, S, C] (csrc/groupnorm_tokens.hip)."""
+    L = _lib.lib()
+    if t.dtype not in _DT:
+        raise TypeError(f"group_norm_tok2tok: unsupported dtype {t.dtype}")
+    tc = t if t.is_contiguous() else t.contiguous()
+    N, S, Cc = tc.shape
+    nbytes = L.mvi_groupnorm_tok2tok_workspace_bytes(N, Cc, S, num_groups, _DT[t.dtype])
+    if nbytes == 0:
+        raise ValueError(f"group_norm_tok2tok: unsupported shape {tuple(t.shape)} / {num_groups} groups")
+    cb = None
+    if chan_bias is not None:
+        cb = chan_bias.detach().float().contiguous()
+        if cb.shape != (N, Cc):
+            raise ValueError(f"group_norm_tok2tok: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
+    y = torch.empty_like(tc)
+    ws = _workspace(tc.device, nbytes)
+    with torch.cuda.device(tc.device), _Timed("groupnorm", 2.0 * tc.numel() * tc.element_size(), tc.device):
+        _check(L.mvi_groupnorm_silu_tok2tok(tc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
+                                            None if cb is None else cb.data_ptr(), N, Cc, S, num_groups, float(eps),
+                                            int(bool(silu)), _DT[t.dtype], ws.data_ptr(), ws.numel(), _stream(tc.device)),
+               "group_norm_tok2tok")
+    return y
 
 
 def attention_kernel_kind(Sq, Sk, D, dtype):

@@ -84,6 +84,17 @@ def group_norm_tokens(x, num_groups, weight, bias, eps, silu=False, chan_bias=No
     return group_norm(x, num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
 
 
+def group_norm_tok2tok(t, num_groups, weight, bias, eps, silu=False, chan_bias=None):
+    """GroupNorm(+SiLU) of token-major t [N, S, C] with token-major output (statistics per sample and group over (S, C/G));
+    chan_bias [N, C] is added first. The norm between two convolutions that run on channels-last tensors."""
+    if t.is_cuda and not _needs_autograd(t, weight, bias, chan_bias):
+        from . import hip_ops
+        return hip_ops.group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+    _fallback(t, "group_norm_tok2tok", _why(t, weight, bias, chan_bias))
+    y = group_norm(t.transpose(1, 2), num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias)
+    return y.transpose(1, 2).contiguous()
+
+
 def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False, chan_bias=None, stack3=False):
     """GroupNorm of the temporal layers — statistics over (C/G, T, H, W) per video — evaluated on the
     frame-major tensor x [(b T), C, H, W] the spatial layers produce (the reference permutes to
@@ -308,11 +319,13 @@ def add_lerp(x, h, base, alpha):
     return torch.lerp(t.reshape(G, -1, C_), base.reshape(G, -1, C_), a).reshape(x.shape)
 
 
-def tokens_to_planes_add(tok, x_in):
-    """tok [B, (h w), C] -> [B, C, h, w] plus x_in, one pass (SpatialTransformer's exit)."""
-    if tok.is_cuda and not _needs_autograd(tok, x_in):
+def tokens_to_planes_add(tok, x_in, bias=None):
+    """tok [B, (h w), C] (+ bias[c]) -> [B, C, h, w] plus x_in, one pass (SpatialTransformer's exit; ResBlock's exit when its
+    convolutions ran channels-last)."""
+    if tok.is_cuda and not _needs_autograd(tok, x_in, bias):
         from . import hip_ops
         if tok.shape[-1] % 8 == 0 and tok.shape[1] % 8 == 0:
-            return hip_ops.tokens_to_planes_add(tok, x_in)
+            return hip_ops.tokens_to_planes_add(tok, x_in, bias)
     _fallback(tok, "tokens_to_planes_add", _why(tok, x_in))
-    return tok.transpose(1, 2).reshape(x_in.shape) + x_in
+    t = tok if bias is None else tok + bias.to(tok.dtype)
+    return t.transpose(1, 2).reshape(x_in.shape) + x_in

@@ -853,3 +853,56 @@ def test_controlnet_on_a_side_stream_gives_the_same_step():
     for o in outs[True] + cached:
         assert rel(o, ref) < 1e-6
 
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_groupnorm_token_major_in_and_out(ops, dtype, tol):
+    """GroupNorm(+SiLU) with tokens on both sides (the norm between two channels-last convolutions): against fp64 GroupNorm of the
+    transposed tensor, with the fused timestep bias, a group whose mean is 30 standard deviations away, token counts that are not
+    multiples of the chunk (64 / 48 / 24 rows), 320 ... 2560 channels."""
+    g = torch.Generator().manual_seed(51)
+    for N, S, C, G, with_bias, silu in [(3, 1000, 320, 32, True, True), (2, 577, 640, 32, False, True), (2, 144, 1280, 32, True, False),
+                                        (1, 40, 2560, 32, True, True), (5, 64, 64, 8, False, True)]:
+        t = (torch.randn(N, S, C, generator=g) * 1.4 + 0.2).to(dtype)
+        t[0, :, :5] += 40.0
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        cb = torch.randn(N, C, generator=g) if with_bias else None
+        xf = t.double().transpose(1, 2) + (0 if cb is None else cb.double()[:, :, None])
+        ref = F.group_norm(xf, G, w.double(), b.double(), 1e-5)
+        ref = (F.silu(ref) if silu else ref).transpose(1, 2)
+        y = ops.group_norm_silu_tok2tok(t.cuda(), G, w.cuda(), b.cuda(), 1e-5, silu, chan_bias=None if cb is None else cb.cuda())
+        assert y.shape == t.shape and y.dtype == dtype and rel(y, ref) < tol, (N, S, C)
+    with pytest.raises(ValueError):
+        ops.group_norm_silu_tok2tok(torch.zeros(1, 8, 36, device="cuda", dtype=torch.bfloat16), 6, torch.ones(36).cuda(),
+                                    torch.zeros(36).cuda(), 1e-5, False)                         # 36 channels: not a multiple of the vector
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 3.0 / 128), (torch.float16, 3.0 / 1024)])
+def test_resblock_with_channels_last_convolutions_equals_the_nchw_path(dtype, tol):
+    """ResBlock._forward_fused in reduced precision hands its two 3x3 convolutions channels-last tensors (tokens from the first norm,
+    token-major norm in between, tokens into the last add): same block, same input through both routes (layers.NHWC_CONVS),
+    identity skip and 1x1 skip convolution, against the fp32 NCHW evaluation of the same weights."""
+    from multiview_inpaint_amd.svd import layers as LY
+    g = torch.Generator().manual_seed(8)
+    for cin, cout, hw in [(64, 64, (24, 40)), (128, 64, (16, 24))]:
+        blk = LY.ResBlock(cin, 256, 0.0, out_channels=cout, dims=2).eval()
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.3))
+        x = torch.randn(4, cin, *hw, generator=g)
+        emb = torch.randn(4, 256, generator=g)
+        with torch.no_grad():
+            ref = blk.double()(x.double(), emb.double())
+            blk = blk.to(dtype).cuda()
+            xs, es = x.to(dtype).cuda(), emb.to(dtype).cuda()
+            outs = {}
+            old = LY.NHWC_CONVS
+            try:
+                for mode in (False, True):
+                    LY.NHWC_CONVS = mode
+                    outs[mode] = blk(xs, es)
+            finally:
+                LY.NHWC_CONVS = old
+        assert outs[True].shape == ref.shape and outs[True].is_contiguous()
+        assert rel(outs[True], ref) < tol and rel(outs[False], ref) < tol
+        assert rel(outs[True], outs[False].double()) < tol
