@@ -331,6 +331,24 @@ def _f32_param(p):
     return p.float()
 
 
+_bias_sums = {}
+
+
+def _sum_param(a, b):
+    """a + b (fp32) for two small parameters, computed once per version of either (two bias vectors met by one fused add).
+    Entries hold weak references to both parameters: ids and addresses recur after a model is freed."""
+    import weakref
+    key = (id(a), id(b))
+    ver = (a.data_ptr(), a._version, b.data_ptr(), b._version, a.dtype, a.device)
+    hit = _bias_sums.get(key)
+    if hit is None or hit[0] != ver or hit[2]() is not a or hit[3]() is not b:
+        hit = (ver, a.detach().float() + b.detach().float(), weakref.ref(a), weakref.ref(b))
+        if len(_bias_sums) > 4096:
+            _bias_sums.clear()
+        _bias_sums[key] = hit
+    return hit[1]
+
+
 _silu_emb_cache = []          # [(weakref(emb), version, silu(emb))], newest first: UNet and ControlNet each have one embedding per step
 
 
@@ -407,8 +425,8 @@ def _resblock_forward_fused(self, x, emb):
         if isinstance(self.skip_connection, nn.Identity):
             return ops.tokens_to_planes_add(t, x, conv2.bias)
         sk = self.skip_connection
-        sb = sk.bias if conv2.bias is None else (conv2.bias if sk.bias is None else sk.bias + conv2.bias)
-        return ops.tokens_to_planes_add(t, conv_no_bias(sk, x, sb))
+        sb = sk.bias if conv2.bias is None else (conv2.bias if sk.bias is None else _sum_param(sk.bias, conv2.bias))
+        return ops.tokens_to_planes_add(t, conv_no_bias(sk, x, None), sb)      # both biases ride on the transposing add
     h = conv_no_bias(conv1, norm_act(self.in_layers, x))
     e = _emb_projection(self.emb_layers, emb)
     e = e.reshape(e.shape[0], e.shape[1])
