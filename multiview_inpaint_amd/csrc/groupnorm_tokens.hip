@@ -68,10 +68,16 @@ __global__ __launch_bounds__(1024) void gt_stats_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < V; ++k) s_ch[(size_t)r0 * C + v * V + k] = csum[k];
     __syncthreads();
+    // two short steps instead of one walk of Cg * rp values by G threads: channel sums over the rp row groups, then group sums
+    for (int c = tid; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
+        s_ch[c] = s;
+    }
+    __syncthreads();
     if (tid < G) {
         float s = 0.f;
-        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c)
-            for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) s += s_ch[c];
         s_grp[tid] = s / (float)(rows_chunk * Cg);
     }
     __syncthreads();
@@ -92,10 +98,15 @@ __global__ __launch_bounds__(1024) void gt_stats_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < V; ++k) s_ch[(size_t)r0 * C + v * V + k] = m2[k];
     __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
+        s_ch[c] = s;
+    }
+    __syncthreads();
     if (tid < G) {
         float s = 0.f;
-        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c)
-            for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) s += s_ch[c];
         float* p = part + ((n * chunks + chunk) * G + tid) * 3;
         p[0] = (float)(rows_chunk * Cg); p[1] = s_grp[tid]; p[2] = s;
     }
@@ -106,17 +117,35 @@ __global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__
                                                        const float* __restrict__ chan_bias, float* __restrict__ scale_shift, int C, int G,
                                                        int chunks, float eps) {
     __shared__ float s_mean[kGtMaxGroups], s_rstd[kGtMaxGroups];
+    __shared__ float s_p[256][3];
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid < G) {
-        float cnt = 0.f, mean = 0.f, m2 = 0.f;
-        for (int c = 0; c < chunks; ++c) {
-            const float* p = part + ((n * chunks + c) * G + tid) * 3;
+    // 256 / G threads per group take the chunks round-robin (a serial walk over 144 chunks by one thread cost 20 us per call),
+    // then one thread per group merges their partials in a fixed order
+    const int per = 256 / G, g = tid % G, sub = tid / G;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    if (sub < per) {
+        for (int c = sub; c < chunks; c += per) {
+            const float* p = part + ((n * chunks + c) * G + g) * 3;
             const float nb = p[0], mb = p[1], qb = p[2];
             const float nt = cnt + nb, d = mb - mean;
             mean += d * (nb / nt);
             m2 += qb + d * d * (cnt * nb / nt);
             cnt = nt;
+        }
+    }
+    s_p[tid][0] = cnt; s_p[tid][1] = mean; s_p[tid][2] = m2;
+    __syncthreads();
+    if (tid < G) {
+        cnt = 0.f; mean = 0.f; m2 = 0.f;
+        for (int k = 0; k < per; ++k) {
+            const float nb = s_p[k * G + tid][0], mb = s_p[k * G + tid][1], qb = s_p[k * G + tid][2];
+            if (nb > 0.f) {
+                const float nt = cnt + nb, d = mb - mean;
+                mean += d * (nb / nt);
+                m2 += qb + d * d * (cnt * nb / nt);
+                cnt = nt;
+            }
         }
         s_mean[tid] = mean;
         s_rstd[tid] = rsqrtf(m2 / cnt + eps);

@@ -505,7 +505,7 @@ def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=No
             raise ValueError(f"group_norm_tok2tok: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
     y = torch.empty_like(tc)
     ws = _workspace(tc.device, nbytes)
-    with torch.cuda.device(tc.device), _Timed("groupnorm", 2.0 * tc.numel() * tc.element_size(), tc.device):
+    with torch.cuda.device(tc.device), _Timed("groupnorm_tok2tok", 2.0 * tc.numel() * tc.element_size(), tc.device):
         _check(L.mvi_groupnorm_silu_tok2tok(tc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
                                             None if cb is None else cb.data_ptr(), N, Cc, S, num_groups, float(eps),
                                             int(bool(silu)), _DT[t.dtype], ws.data_ptr(), ws.numel(), _stream(tc.device)),
