@@ -17,12 +17,21 @@ import torch.nn as nn
 from .schedule import Denoiser, instantiate_from_config
 
 OPENAIUNETWRAPPER = "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper"
-# ControlNet beside the UNet encoder (apply_model). OPT-IN: same-box A/B 181.3 -> 173.2 ms per step, but with the default on the
-# full-size property test stopped making progress once (killed after 7 minutes of silence; the bench runs had been fine): the
-# library's stream-K GEMMs (hipBLASLt "SK3" kernels) spin on flags of peer workgroups, and two such kernels on concurrent
-# streams can keep each other's peers off the chip. Not something to leave on for a caller who has not checked their GEMM set.
+# ControlNet beside the UNet encoder (apply_model). OPT-IN: same-box A/B 181.3 -> 173.2 ms per step. What stands in the way of
+# making it the default (tools/experiments/two_stream_probe.py, every run under `timeout`): with hipBLASLt choosing its GEMM
+# kernels by its own heuristic, one of the first steps of a process stops making progress (twice out of two runs; some of its
+# stream-K kernels spin on flags of peer workgroups, and two of them on concurrent streams can keep each other's peers off
+# the chip); with the GEMM set pinned by the shipped TunableOp file (svd/tunableop_gfx950.csv, what bench_svd uses) the same
+# sequence and ~150 bench steps completed. A property of the library build, not of this code: left to the caller.
 TWO_STREAMS = os.environ.get("MVI_SVD_TWO_STREAMS", "0") == "1"
 _side = {}
+
+
+def _events_off():
+    """The per-op timing of hip_ops (two timing events per op, hip_ops.PROFILE) and a second stream do not go together: with
+    both on, the second step of tools/experiments/two_stream_probe.py never completed. Timed passes run on one stream."""
+    from . import hip_ops
+    return hip_ops.PROFILE is None
 
 
 def _side_stream(device):
@@ -109,7 +118,7 @@ class SVDInpaintEngine(nn.Module):
                 if self.global_average_pooling:
                     cs = [c.mean(dim=(2, 3), keepdim=True) for c in cs]
                 return cs
-            if TWO_STREAMS and xin.is_cuda and not torch.is_grad_enabled():
+            if TWO_STREAMS and xin.is_cuda and not torch.is_grad_enabled() and _events_off():
                 # The ControlNet and the UNet's encoder + middle block are independent until the first residual is added
                 # (csvd.py:79): the ControlNet runs on a side stream while the main stream runs the encoder, so that the
                 # low-resolution halves of both — whose kernels fill a quarter of the chip each (80 tiles per 3x3 convolution
