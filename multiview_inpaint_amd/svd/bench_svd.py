@@ -241,3 +241,18 @@ def run_cpu_baseline(threads=None):
                 sample=f"2 x Denoiser.forward(VideoUNet 1.52B params), 1 frame 256x256 (latent 32x32), fp32, "
                        f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; first call {times[0]:.1f} s, "
                        f"second {times[1]:.1f} s, model build {t_build:.1f} s")
+
+
+if __name__ == "__main__":
+    # one JSON line with run_gpu()'s result: the SVD leg of bench.py runs in a child process of its own (bench.py says why)
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sample-steps", type=int, default=25)
+    a = ap.parse_args()
+    use_shipped_miopen_db()
+    res = run_gpu(torch.device("cuda", 0), steps=a.steps, warmup=a.warmup, sample_steps=a.sample_steps)
+    print(json.dumps(res), flush=True)
+
