@@ -348,7 +348,11 @@ def main():
             from multiview_inpaint_amd.svd import bench_svd
             svd = svd_result                                  # measured in child processes at the start (svd_leg)
             if svd is None:
-                raise RuntimeError("the SVD benchmark child process failed (python -m multiview_inpaint_amd.svd.bench_svd)")
+                # no child could run (e.g. this process was started under a profiler that had already initialised the GPU, so
+                # the exec of a child is refused): the same measurement in this process, one stream
+                bench_svd.use_shipped_miopen_db()
+                svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=2)
+                svd["execution"] = "one stream (in-process: the child process could not run)"
             svd["metric"] = "SVD 14-frame 576x1024 denoise steps/s (ControlNet + ControlledVideoUNet, CFG batch 28)"
             if not args.no_cpu_baseline:
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
