@@ -148,8 +148,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     svd_result = None
-    if world == 1 and args.gpus == 1 and args.path in ("both", "svd"):
-        # child processes, started BEFORE this process loads the HIP library or touches the GPU in any way
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+    if world == 1 and args.gpus == 1 and args.path in ("both", "svd") and not under_profiler:
+        # child processes, started BEFORE this process loads the HIP library or touches the GPU in any way (under rocprofv3 the
+        # preloaded tool has already initialised the GPU: no children then, the SVD leg runs in this process further down)
         svd_result = svd_leg(args.svd_steps)
     if args.gpus > 1 and world == 1:
         # convenience: re-launch under torch.distributed.run as a child (never exec after GPU init)
