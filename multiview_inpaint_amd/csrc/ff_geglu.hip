@@ -183,6 +183,26 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     // the ~300 VALU instructions of the epilogue behind them, and the step takes the sum of both (measured: 637 us per call).
     constexpr int kAhead = 2;
     // stores rows m, m + 1 (registers r, r + 1) of one 32-column block at byte offset `cb` of the step's output columns
+    // Plain form: a step is 64 output columns = one full 128-byte line per row. The two 32 x 32 tiles go through a wave-private
+    // 4 KiB LDS tile [32 rows][64 columns] and leave as four 16-byte stores per lane, each instruction covering 8 rows x 128
+    // contiguous bytes — with 32 two-byte store instructions per step the stores, not the MFMAs, set the step time (6600
+    // cycles per step against 5700 for the GEGLU form, which stores half as much and computes an erf per output on top).
+    const uint32_t otile = (uint32_t)(kRing * kTileBytes + n_bias * (int)sizeof(float) + wave * 4096);
+    const uint32_t ot_w = otile + (uint32_t)(4 * hh * 128 + col * 2);              // + 128 * row of the register (+ 64 for the second tile)
+    const uint32_t ot_r = otile + (uint32_t)((lane >> 3) * 128 + (lane & 7) * 16);  // + 1024 i: rows 8 i + lane / 8
+    const uint32_t st_off = (uint32_t)((lane >> 3) * orow_bytes + (lane & 7) * 16);
+    auto put_pair = [&](int cb, int r, uint32_t pk) __attribute__((always_inline)) {
+        const int m = (r & 3) + 8 * (r >> 2);
+        *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + cb + m * 128) = (uint16_t)(pk & 0xFFFFu);
+        *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + cb + (m + 1) * 128) = (uint16_t)(pk >> 16);
+    };
+    auto flush_tile = [&](char* op) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 v = *reinterpret_cast<MVI_AS3 const u32x4*>(lds + ot_r + 1024 * i);
+            if (kX != 2 || v[0] == 0x12345678u) *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
+        }
+    };
     auto store_pair = [&](char* op, int cb, int r, uint32_t pk) __attribute__((always_inline)) {
         const int m = (r & 3) + 8 * (r >> 2);
         if (kX != 2 || pk == 0x12345678u) {
@@ -216,10 +236,11 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
                     if ((s & 1) == 0) held = o;
                     else store_pair(op, 0, s - 1, M::pack2(held, o));
                 } else if ((s & 1) == 1) {                           // plain: both blocks are outputs (bias already inside)
-                    store_pair(op, 0, s - 1, M::pack2(pv[s - 1], pv[s]));
-                    store_pair(op, kStep * 2, s - 1, M::pack2(pg[s - 1], pg[s]));
+                    put_pair(0, s - 1, M::pack2(pv[s - 1], pv[s]));
+                    put_pair(kStep * 2, s - 1, M::pack2(pg[s - 1], pg[s]));
                 }
             }
+            if (kPrev && !kGeglu && s == 18) flush_tile(op);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -231,10 +252,11 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
             if (kGeglu) {
                 store_pair(op, 0, r, M::pack2(geglu1(pv[r], pg[r]), geglu1(pv[r + 1], pg[r + 1])));
             } else {
-                store_pair(op, 0, r, M::pack2(pv[r], pv[r + 1]));
-                store_pair(op, kStep * 2, r, M::pack2(pg[r], pg[r + 1]));
+                put_pair(0, r, M::pack2(pv[r], pv[r + 1]));
+                put_pair(kStep * 2, r, M::pack2(pg[r], pg[r + 1]));
             }
         }
+        if (!kGeglu) flush_tile(op);
     };
 #ifdef MVI_FFG_STAMPS
     uint64_t t_close = 0, t_issue = 0, t_all0 = __builtin_amdgcn_s_memtime();
@@ -307,7 +329,7 @@ static int ff_k320_launch(const void* x, const void* w, const float* bias, void*
     using namespace ffg;
     const int64_t n_blocks = (rows + kRows - 1) / kRows;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
-    const int lds_bytes = kRing * kTileBytes + (kGeglu ? 2 : 1) * inner * (int)sizeof(float);
+    const int lds_bytes = kRing * kTileBytes + (kGeglu ? 2 : 1) * inner * (int)sizeof(float) + (kGeglu ? 0 : kWaves * 4096);
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
@@ -360,14 +382,15 @@ extern "C" int mvi_ff_geglu(const void* x, const void* weight, const float* bias
 
 extern "C" int mvi_linear_k320_supported(int32_t K, int32_t out_features, int32_t dtype) {
     return K == mvi::ffg::kK && out_features >= 4 * mvi::ffg::kStep && out_features % (2 * mvi::ffg::kStep) == 0 &&
-           mvi::ffg::kRing * mvi::ffg::kTileBytes + (int64_t)out_features * 4 <= 160 * 1024 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+           mvi::ffg::kRing * mvi::ffg::kTileBytes + (int64_t)out_features * 4 + mvi::ffg::kWaves * 4096 <= 160 * 1024 &&
+           (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
 }
 
 extern "C" int mvi_linear_k320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
                                int32_t K, int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                                void* stream) {
     if (rows < 0 || !mvi_linear_k320_supported(K, out_features, dtype))
-        return mvi::unet_fail(MVI_EINVAL, "linear_k320: needs K = 320, out_features a multiple of 64 (128 ... 10240), bf16 or f16");
+        return mvi::unet_fail(MVI_EINVAL, "linear_k320: needs K = 320, out_features a multiple of 64 (128 ... 2048), bf16 or f16");
     if (rows == 0) return MVI_OK;
     if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "linear_k320: NULL pointer");
     if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
