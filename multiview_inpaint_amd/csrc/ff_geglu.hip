@@ -120,6 +120,7 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     const int64_t row = (int64_t)bid * kRows + wave * 32 + col;
     const bool row_ok = row < rows;
 
+    if (kX == 6 && wave >= kWaves / 2) return;                    // (experiment: one wave per SIMD; s_barrier then counts the live waves only)
     // ---- bias -> LDS (visible after the first barrier of the loop prologue)
     const int n_bias = kGeglu ? 2 * inner : inner;
     for (int i = tid; i < n_bias; i += 64 * kWaves) lbias[i] = bias ? bias[i] : 0.f;
@@ -276,8 +277,9 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
         // older than those pieces — this wave's pieces of tile step + 1 among them; then the block meets
         if (loader && kX != 3) {
             issue_tile(step + 2);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
-        } else {
+            if (kX == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerLoader) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        } else if (kX != 5) {
             asm volatile("s_barrier" ::: "memory");
         }
     };
@@ -340,6 +342,8 @@ static int ff_k320_launch(const void* x, const void* w, const float* bias, void*
     if (xp == 2) kern = &ff_geglu_k320_kernel<T, 2, kGeglu>;
     if (xp == 3) kern = &ff_geglu_k320_kernel<T, 3, kGeglu>;
     if (xp == 4) kern = &ff_geglu_k320_kernel<T, 4, kGeglu>;
+    if (xp == 5) kern = &ff_geglu_k320_kernel<T, 5, kGeglu>;
+    if (xp == 6) kern = &ff_geglu_k320_kernel<T, 6, kGeglu>;
     if (xp) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     if (!(attr_set >> dev & 1ull)) {
