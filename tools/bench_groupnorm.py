@@ -4,10 +4,14 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from multiview_inpaint_amd.svd import hip_ops
 import torch.nn.functional as F
+only = os.environ.get("GN_SHAPE")            # e.g. GN_SHAPE=28,320,72,128: that shape only (per-kernel times under rocprofv3 --stats)
+only = tuple(int(v) for v in only.split(",")) if only else None
 shapes = [(28, 320, 72, 128), (28, 640, 72, 128), (28, 640, 36, 64), (28, 1280, 36, 64), (28, 1920, 36, 64), (28, 1280, 18, 32),
           (28, 2560, 18, 32), (28, 1280, 9, 16)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for shp in shapes:
+    if only and shp != only:
+        continue
     x = (torch.randn(shp, device="cuda", generator=g) * 1.5 + 0.3).bfloat16()
     w, b = torch.randn(shp[1], device="cuda", generator=g), torch.randn(shp[1], device="cuda", generator=g)
     cb = torch.randn(shp[0], shp[1], device="cuda", generator=g)
@@ -30,6 +34,8 @@ for shp in shapes:
 # token-major forms used inside the ResBlocks when their convolutions run channels-last (planes -> tokens, tokens -> tokens)
 print("planes -> tokens (mvi_groupnorm_silu_tokens) | tokens -> tokens (mvi_groupnorm_silu_tok2tok), fused bias + SiLU")
 for shp in [(28, 320, 72, 128), (28, 640, 72, 128), (28, 640, 36, 64), (28, 1280, 18, 32), (28, 1280, 9, 16)]:
+    if only and shp != only:
+        continue
     x = (torch.randn(shp, device="cuda", generator=g) * 1.5 + 0.3).bfloat16()
     t = x.flatten(2).transpose(1, 2).contiguous()
     w, b = torch.randn(shp[1], device="cuda", generator=g), torch.randn(shp[1], device="cuda", generator=g)
