@@ -362,7 +362,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     //     against the first block's own maximum (P = 1) as against the true one. Dropping the per-block max takes 14 v_max3
     //     + a half swap + a compare-and-branch per tile off the issue port that bounds this kernel.
     //   kSafe = true: the usual online softmax (max per 32-key block, rescale when it grows by more than 2^8). Run only if
-    //     the fast form's row sum left [0, 2^100] (or became NaN) for any query of the block — i.e. some score exceeded the
+    //     the fast form's row sum left [0, 2^100] ([0, 2^15] in f16, where P must fit the type; or became NaN) for any query of the block — i.e. some score exceeded the
     //     first block's maximum by ~100 / log2(e) = 69 — everything is then recomputed from scratch with this form.
     auto run = [&](auto safe_c) __attribute__((always_inline)) {
         constexpr bool kSafe = decltype(safe_c)::value;
@@ -501,7 +501,9 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     if (tid == 0) *redo_flag = 0u;                               // ordered before any read by the barriers of run()
     run(std::false_type{});
     // block-wide vote (the waves share the K / V ring and its barriers, so they repeat together or not at all)
-    const bool out_of_range = !(l <= 0x1p100f);                  // also true for NaN
+    // (f16: P itself is packed to f16, which ends at 65504 — a row sum of at most 2^15 proves that no P of the row was larger)
+    const float l_limit = std::is_same<T, __half>::value ? 0x1p15f : 0x1p100f;
+    const bool out_of_range = !(l <= l_limit);                   // also true for NaN
     if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull && lane == 0) *redo_flag = 1u;
     __syncthreads();
     if (*redo_flag != 0u) {
@@ -565,7 +567,10 @@ static int flash8_launch_w(const void* q, const void* k, const void* v, void* ou
     static unsigned long long attr_set = 0ull;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    static const bool fold = getenv("MVI_ATTN_FOLD_SCALE") && atoi(getenv("MVI_ATTN_FOLD_SCALE")) != 0;   // see kExact
+    // see kExact. Default: exact for bf16; folded for f16, whose 11-bit mantissa makes the second rounding of Q eight times smaller
+    // (below the exact bf16 form's own error) — f16 is the reference's precision recipe and the fold is worth 7 % of the kernel
+    static const int fold_env = getenv("MVI_ATTN_FOLD_SCALE") ? atoi(getenv("MVI_ATTN_FOLD_SCALE")) : -1;
+    const bool fold = fold_env >= 0 ? fold_env != 0 : std::is_same<T, __half>::value;
     if (!((attr_set >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, kWaves, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes + 16) != hipSuccess ||

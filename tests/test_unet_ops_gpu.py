@@ -125,6 +125,21 @@ def test_attention_8wave_kernel_ragged_shapes(ops, dtype, tol, B, Hh, Sq, Sk):
         assert torch.equal(ops.attention_packed(qkv, Hh), out)
 
 
+def test_attention_8wave_kernel_f16_folded_scale_on_peaked_rows(ops):
+    """f16 inputs take the 8-wave kernel with softmax scale x log2(e) folded into Q (csrc/attn_flash8.hip, kExact = false: Q is
+    rounded a second time, to f16's 11 bits). Peaked rows are where that shows: logits of +-20 nats with the top keys competing.
+    The bar is the one the exact bf16 form is held to on the same construction (attn_check 'peaky': 5e-3) — not the random-data bar."""
+    B, Hh, S, D = 1, 2, 1536, 64
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(B, S, Hh * D, generator=g) for _ in range(3))
+    q *= 6.0
+    qh, kh, vh = (t.to(torch.float16) for t in (q, k, v))
+    out = ops.attention(qh.cuda(), kh.cuda(), vh.cuda(), Hh)
+    assert ops.attention_kernel_kind(S, S, D, torch.float16) == 1
+    assert torch.isfinite(out).all()
+    assert rel(out, _attn_ref(qh, kh, vh, Hh)) < 5e-3
+
+
 def test_attention_8wave_kernel_repeats_safely_when_the_fixed_exponent_overflows(ops):
     """The fast path keeps the first tile's row maximum as the exponent reference for the whole row; here the logits climb
     by ~115 (in log2 units) along the key axis, far past what fp32 holds relative to that reference: the row sums
