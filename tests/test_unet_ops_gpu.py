@@ -255,21 +255,24 @@ def test_sample_loop_on_gpu_matches_reference_golden_with_and_without_hint_cache
     assert rel(plain, torch.tensor(G["sample_final"])) < 5e-4 and rel(cached, torch.tensor(G["sample_final"])) < 5e-4
 
 
-def test_small_unet_bf16_autocast_error_is_reported(G):
-    """Production precision: bf16 autocast (the reference runs fp16 autocast, csvd.py:27-31). Not a
-    1e-4 claim — the measured error against the fp32 reference golden is bounded loosely and printed."""
+@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 8e-2), (torch.float16, 1e-2)])
+def test_small_unet_reduced_precision_autocast_error_is_reported(G, dtype, bound):
+    """Reduced precision: bf16 autocast (what bench.py runs) and fp16 autocast (the reference's own recipe, csvd.py:27-31:
+    the half-precision HIP ops — MFMA attention with the scale folded into Q, the K = 320 kernels, the norms — on f16 data).
+    Not a 1e-4 claim — the measured error against the fp32 reference golden is bounded loosely and printed."""
     from sgm.modules.diffusionmodules.video_model import VideoUNet
     unet = VideoUNet(**H.SMALL_UNET).eval()
     unet.load_state_dict(H.seeded_state_dict(unet, 11))
     unet = unet.cuda()
     inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(21).items()}
     xin = torch.cat([inp["x"], inp["concat"]], 1)
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
         y = unet(xin, 0.25 * inp["sigma"].log(), inp["crossattn"], inp["vector"], num_video_frames=H.T_FRAMES,
                  image_only_indicator=inp["image_only_indicator"])
+    assert torch.isfinite(y).all()
     e = rel(y.float(), torch.tensor(G["unet_out"]))
-    print(f"bf16-autocast small-UNet relative error vs fp32 reference: {e:.3e}")
-    assert e < 8e-2
+    print(f"{dtype}-autocast small-UNet relative error vs fp32 reference: {e:.3e}")
+    assert e < bound
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1.0 / 128)])
