@@ -93,7 +93,9 @@ def _svd_child(two_streams, steps, timeout):
     import subprocess
     env = dict(os.environ, MVI_SVD_TWO_STREAMS="1" if two_streams else "0")
     try:
-        p = subprocess.run([sys.executable, "-m", "multiview_inpaint_amd.svd.bench_svd", "--steps", str(steps), "--warmup", "2"],
+        # MVI_BENCH_SVD_WEIGHTS=f16: the reference's own precision (fp16), +1.5 % step time on this chip; default bf16
+        p = subprocess.run([sys.executable, "-m", "multiview_inpaint_amd.svd.bench_svd", "--steps", str(steps), "--warmup", "2",
+                            "--weights", os.environ.get("MVI_BENCH_SVD_WEIGHTS", "bf16")],
                            cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
     except subprocess.TimeoutExpired:
         return None

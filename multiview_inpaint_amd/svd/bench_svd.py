@@ -120,8 +120,8 @@ def run_sample_loop(eng, device, num_steps=25, T=14, h=72, w=128, weights="bf16"
     done once per sample (ControlNet hint stem, doubled conditioning), which the per-step metric never skips."""
     from .schedule import EulerEDMSampler
     _, c, ind = inputs(device, T, h, w, cfg_doubled=False)
-    if weights == "bf16":
-        c = {k: v.bfloat16() for k, v in c.items()}
+    if weights in _HALF:
+        c = {k: v.to(_HALF[weights]) for k, v in c.items()}
     uc = {k: (v if k == "control_hint" else torch.zeros_like(v)) for k, v in c.items()}
     sch = "multiview_inpaint_amd.svd.schedule."
     eng.sampler = EulerEDMSampler(num_steps=num_steps, device=device,
@@ -131,7 +131,7 @@ def run_sample_loop(eng, device, num_steps=25, T=14, h=72, w=128, weights="bf16"
                                                             "additional_cond_keys": ["control_hint"]}})
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(weights != "bf16")):
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(weights not in _HALF)):
         out = eng.sample(None, c, uc=uc, batch_size=T, shape=(4, h, w), num_video_frames=T, image_only_indicator=ind)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
@@ -141,9 +141,12 @@ def run_sample_loop(eng, device, num_steps=25, T=14, h=72, w=128, weights="bf16"
                 finite=bool(torch.isfinite(out).all()))
 
 
+_HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
 def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, weights="bf16", sample_steps=25):
-    """weights="bf16": parameters stored in bf16, no autocast (nothing is re-cast per step; GroupNorm
-    statistics, softmax and LayerNorm still accumulate in fp32 inside their kernels).
+    """weights="bf16" (bench.py) / "f16" (the reference's precision): parameters stored in that type, no autocast (nothing is
+    re-cast per step; GroupNorm statistics, softmax and LayerNorm still accumulate in fp32 inside their kernels).
     weights="fp32": fp32 parameters under torch.autocast(bf16), the reference's mixed-precision recipe
     (it uses fp16 autocast, models/csvd.py:27-31)."""
     from . import hip_ops, ops
@@ -156,10 +159,10 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     torch.backends.cudnn.benchmark = os.environ.get("MVI_SVD_MIOPEN_FIND", "0") == "1"
     use_shipped_miopen_db()
     tuned = enable_gemm_tuning()
-    eng = build(device, with_control=with_control, dtype=torch.bfloat16 if weights == "bf16" else torch.float32)
+    eng = build(device, with_control=with_control, dtype=_HALF.get(weights, torch.float32))
     x, cond, ind = inputs(device, T, h, w)
-    if weights == "bf16":
-        cond = {k: v.bfloat16() for k, v in cond.items()}      # conditioning is computed once per sample
+    if weights in _HALF:
+        cond = {k: v.to(_HALF[weights]) for k, v in cond.items()}      # conditioning is computed once per sample
     if not with_control:
         cond.pop("control_hint")
     sig = EDMDiscretization(sigma_max=700.0)(25, device=device)
@@ -167,7 +170,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
 
     def step(i):
         s = sig[i % 25].expand(x.shape[0])
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=(weights != "bf16")):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=(weights not in _HALF)):
             return eng.denoise(x, s, cond, **kw)
     for i in range(warmup):
         step(i)
@@ -196,7 +199,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     _engine.TWO_STREAMS = two_streams
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
                step_ms=per_step, controlnet=with_control, gemm_tuning=bool(tuned), two_streams=bool(two_streams and with_control),
-               dtype=("bf16 weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights == "bf16"
+               dtype=(f"{weights} weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights in _HALF
                       else "bf16 autocast over fp32 weights, fp32 GroupNorm statistics / softmax"),
                finite=bool(torch.isfinite(out).all()))
     ops = {}
@@ -251,8 +254,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sample-steps", type=int, default=25)
+    ap.add_argument("--weights", choices=["bf16", "f16", "fp32"], default="bf16")
     a = ap.parse_args()
     use_shipped_miopen_db()
-    res = run_gpu(torch.device("cuda", 0), steps=a.steps, warmup=a.warmup, sample_steps=a.sample_steps)
+    res = run_gpu(torch.device("cuda", 0), steps=a.steps, warmup=a.warmup, sample_steps=a.sample_steps, weights=a.weights)
     print(json.dumps(res), flush=True)
 
