@@ -1,0 +1,290 @@
+// Linear with 320 outputs and a long contraction (K = 1280: the second projection of the 21 level-0 FeedForward layers and their
+// temporal twins, svd_inpaint1/sgm/modules/attention.py:98-115 `net[2]`) for gfx950, bf16 / f16 MFMA:
+//     out[r, n] = x[r, :] . W[n, :] + b[n],   r < rows, n < 320, K a multiple of 64
+// Why it exists: at [258048, 1280] x [1280, 320] the library's 256 x 256 macro-tile covers 320 columns with two column tiles, 37 % of
+// the second one empty, and runs at 0.60 PFLOP/s (0.35 ms per call, 42 calls = 14.9 ms of a 168 ms step). Here a block's 256 rows
+// keep ALL 320 outputs in accumulators (a wave: 32 rows x 10 column tiles = 160 registers), so nothing is padded and x is read once.
+//
+// Structure (csrc/ff_geglu.hip with the roles turned: there x is stationary and the outputs stream, here the outputs are stationary
+// and K streams):
+//   * block = 8 waves x 32 rows; K advances in chunks of 64; per chunk and wave 4 k-steps x 10 column tiles = 40 MFMAs
+//     (v_mfma_f32_32x32x16, A = x rows, B = W rows: the output column sits on the lane);
+//   * W chunk [320 rows][64 k] = 40 KiB streams through a 3-slot LDS ring by LDS-DMA (128-byte rows, 16-byte chunk c of row r at
+//     slot c ^ ((r >> 1) & 7), swizzled on the source side: the K image of attn_flash8.hip, conflict-free ds_read_b128); all 8 waves
+//     read the same chunk; 4 loader waves issue the chunk two ahead at the END of a chunk and wait with a counted vmcnt;
+//   * a wave's own x rows go HBM -> registers directly (4 x global_load_dwordx4 per chunk, one chunk ahead, double-buffered;
+//     the 4 loads of a chunk touch the same 32 lines). They are inline assembly like the DMA: a load the compiler knows about
+//     makes it wait for vmcnt(0) at the first use — the DMA pieces just issued included;
+//   * the bias is the accumulators' initial value; outputs leave through a wave-private 4 KiB LDS tile as 16-byte stores
+//     (two column tiles = one 128-byte line per row per flush) into a buffer padded to whole 256-row blocks.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+
+namespace mvi {
+int unet_fail(int code, const char* msg);
+namespace ln3 {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#define MVI_AS3 __attribute__((address_space(3)))
+
+constexpr int kN = 320;                              // outputs
+constexpr int kNT = kN / 32;                         // column tiles per wave
+constexpr int kWaves = 8;
+constexpr int kRows = 32 * kWaves;                   // x rows per block
+constexpr int kKC = 64;                              // contraction elements per chunk
+constexpr int kChunkBytes = kN * kKC * 2;            // 40960
+constexpr int kPieces = kChunkBytes / 1024;          // 40 LDS-DMA pieces of 1 KiB (8 W rows each)
+constexpr int kRing = 3;
+#ifndef LN3_LOADERS
+#define LN3_LOADERS 4
+#endif
+#ifndef LN3_AHEAD
+#define LN3_AHEAD 3
+#endif
+constexpr int kLoaders = LN3_LOADERS;
+constexpr int kPiecesPerLoader = kPieces / kLoaders; // 10
+constexpr int kLdsBytes = kRing * kChunkBytes + kWaves * 4096;
+
+template <typename T> struct Mma;
+template <> struct Mma<__hip_bfloat16> {
+    using frag = bf16x8;
+    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        f32x2 f = {lo, hi};
+        bf16x2 r = __builtin_convertvector(f, bf16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
+    }
+};
+template <> struct Mma<__half> {
+    using frag = f16x8;
+    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        f32x2 f = {lo, hi};
+        f16x2 r = __builtin_convertvector(f, f16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
+    }
+};
+template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
+
+__device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
+// 16 bytes per lane, invisible to the compiler's wait-count bookkeeping (see the header): whoever reads the result waits first
+__device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
+    const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
+    const int64_t row = row0 + col;
+    const int n_chunks = K / kKC;
+
+    // ---- accumulators start from the bias: column 32 j + col of every row this lane holds
+    f32x16 acc[kNT];
+#pragma unroll
+    for (int j = 0; j < kNT; ++j) {
+        const float b = bias ? bias[32 * j + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = b;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the compiler's own loads are done before the hand-counted ones start
+
+    // ---- x: A operand, element e of lane (col, hh), k-step s of chunk c: x[row][64 c + 16 s + 8 hh + e]; rows past the end read the last row
+    const char* const xbase = reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
+    const int64_t rclamp = row < rows ? (row - (row0 < rows ? row0 : rows - 1)) : 0;                       // (a block never starts past the end)
+    const uint32_t x_voff = (uint32_t)(rclamp * x_rs * 2 + 16 * hh);
+    auto load_x = [&](int c, u32x4 (&xr)[4]) __attribute__((always_inline)) {
+        const char* const base = xbase + (int64_t)c * (kKC * 2);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, x_voff);
+    };
+
+    // ---- LDS-DMA source addressing: piece p = W rows 8 p .. 8 p + 7 of the chunk (128 bytes each); lane i fills (row 8 p + i / 8,
+    // slot i % 8) with source chunk slot ^ ((row >> 1) & 7)
+    const bool loader = wave < kLoaders;
+    uint32_t p_voff[kPiecesPerLoader];
+    const uint32_t w_row_bytes = (uint32_t)K * 2u;
+#pragma unroll
+    for (int i = 0; i < kPiecesPerLoader; ++i) {
+        const uint32_t pc = (uint32_t)(wave + i * kLoaders);         // (meaningless for a wave that loads nothing)
+        const uint32_t r = 8u * pc + (uint32_t)(lane >> 3), slot = (uint32_t)(lane & 7);
+        p_voff[i] = r * w_row_bytes + 16u * (slot ^ ((r >> 1) & 7u));
+    }
+    const char* const wbase = reinterpret_cast<const char*>(w);
+    auto issue_chunk = [&](int c) __attribute__((always_inline)) {
+        // chunks past the end re-load the last one (never read): every call issues the same number of pieces, the counted wait stays valid
+        const int cc = c < n_chunks ? c : n_chunks - 1;
+        const uint32_t slot_off = (uint32_t)((c % kRing) * kChunkBytes);
+        const char* const base = wbase + (int64_t)cc * (kKC * 2);
+#pragma unroll
+        for (int i = 0; i < kPiecesPerLoader; ++i) dma_piece(base, p_voff[i], lds0 + slot_off + 1024u * (uint32_t)(wave + i * kLoaders));
+    };
+
+    // ---- LDS read addressing: B operand = W rows; lane (col, hh), column tile j, k-step s reads row 32 j + col, chunk 2 s + hh
+    uint32_t ka[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = (uint32_t)(col * 128 + (((2 * s + hh) ^ ((col >> 1) & 7)) << 4));
+    auto wfrag = [&](uint32_t slot_base, int q) __attribute__((always_inline)) {      // q = 10 s + j
+        const int s = q / kNT, j = q % kNT;
+        return *reinterpret_cast<MVI_AS3 const u32x4*>(lds + slot_base + ka[s] + j * 4096);
+    };
+
+    // One chunk: 40 MFMAs, W fragments requested kAhead ahead. Ten independent accumulator chains: no MFMA waits for the one before it.
+    constexpr int kAhead = LN3_AHEAD;
+    auto chunk_fn = [&](uint32_t slot_base, const u32x4 (&xr)[4]) __attribute__((always_inline)) {
+        u32x4 wf[kAhead + 1];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) wf[q] = wfrag(slot_base, q);
+#pragma unroll
+        for (int q = 0; q < 4 * kNT; ++q) {
+            if (q + kAhead < 4 * kNT) wf[(q + kAhead) % (kAhead + 1)] = wfrag(slot_base, q + kAhead);
+            acc[q % kNT] = M::mfma(as_frag<frag>(xr[q / kNT]), as_frag<frag>(wf[q % (kAhead + 1)]), acc[q % kNT]);
+        }
+    };
+    // Loaders issue the chunk two ahead (its slot held chunk c - 1, which nobody reads any more), then every wave waits for
+    // everything older than those pieces — the next chunk's W pieces and its own next x rows among them — and the block meets.
+    // (The x registers are NOT operands of the wait: tied operands made the allocator copy them in front of it, i.e. before the
+    // loads had landed. Nothing that uses them can move above the wait anyway: every MFMA also takes a W fragment read from LDS
+    // after it, and LDS reads do not cross a statement that clobbers memory.)
+    auto close_chunk = [&](int c) __attribute__((always_inline)) {
+        if (loader) {
+            issue_chunk(c + 2);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: W chunks 0 and 1 in flight, x of chunk 0; chunk 0 landed
+    u32x4 xa[4], xb[4];
+    load_x(0, xa);
+    if (loader) {
+        issue_chunk(0);
+        issue_chunk(1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto next_slot = [&](uint32_t s) __attribute__((always_inline)) { return s + kChunkBytes == (uint32_t)(kRing * kChunkBytes) ? 0u : s + kChunkBytes; };
+    uint32_t slot = 0;
+    int c = 0;
+    for (; c + 1 < n_chunks; c += 2) {
+        load_x(c + 1, xb);                                           // (c + 1 < n_chunks)
+        chunk_fn(slot, xa);
+        close_chunk(c);
+        slot = next_slot(slot);
+        load_x(c + 2 < n_chunks ? c + 2 : n_chunks - 1, xa);         // past the end: re-read the last chunk's rows (never used)
+        chunk_fn(slot, xb);
+        close_chunk(c + 1);
+        slot = next_slot(slot);
+    }
+    if (c < n_chunks) chunk_fn(slot, xa);                            // K / 64 odd: one chunk left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // trailing (unused) pieces and rows land before the block ends
+
+    // ---- outputs: two column tiles at a time through the wave's LDS tile [32 rows][64 columns], then four 16-byte stores per lane
+    char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
+    const int64_t orow_bytes = o_rs * 2;
+    const uint32_t otile = (uint32_t)(kRing * kChunkBytes + wave * 4096);
+    const uint32_t ot_w = otile + (uint32_t)(4 * hh * 128 + col * 2);              // + 128 * row of the register (+ 64 for the second tile)
+    const uint32_t ot_r = otile + (uint32_t)((lane >> 3) * 128 + (lane & 7) * 16);  // + 1024 i: rows 8 i + lane / 8
+    const int64_t st_off = (int64_t)(lane >> 3) * orow_bytes + (lane & 7) * 16;
+#pragma unroll
+    for (int j = 0; j < kNT; j += 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t pk = M::pack2(acc[j + t][r], acc[j + t][r + 1]);
+                const int m = (r & 3) + 8 * (r >> 2);
+                *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + 64 * t + m * 128) = (uint16_t)(pk & 0xFFFFu);
+                *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + 64 * t + (m + 1) * 128) = (uint16_t)(pk >> 16);
+            }
+        }
+        char* const op = obase + (j / 2) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 v = *reinterpret_cast<MVI_AS3 const u32x4*>(lds + ot_r + 1024 * i);
+            *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
+        }
+    }
+}
+
+}  // namespace ln3
+
+template <typename T>
+static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
+                              hipStream_t st) {
+    using namespace ln3;
+    const int64_t n_blocks = (rows + kRows - 1) / kRows;
+    if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+    static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
+    auto kern = &linear_n320_kernel<T>;
+    if (!(attr_set >> dev & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return MVI_EHIP;
+        attr_set |= 1ull << dev;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
+                       o_rs, (int)n_blocks);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+}  // namespace mvi
+
+extern "C" int mvi_linear_n320_supported(int32_t K, int32_t out_features, int32_t dtype) {
+    return out_features == mvi::ln3::kN && K >= 2 * mvi::ln3::kKC && K % mvi::ln3::kKC == 0 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
+                               int32_t K, int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
+                               void* stream) {
+    if (rows < 0 || !mvi_linear_n320_supported(K, out_features, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320: needs out_features = 320, K a multiple of 64 (>= 128), bf16 or f16");
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "linear_n320: NULL pointer");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320: out needs room for mvi_ff_geglu_out_rows(rows) rows (whole 256-row blocks are stored)");
+    if (x_row_stride < K || out_row_stride < out_features || x_row_stride % 8 || out_row_stride % 8 ||
+        ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320: x, weight and out rows must be 16-byte aligned");
+    if ((int64_t)out_features * K * 2 > 0xFFFFFFFFll || 256 * x_row_stride * 2 > 0xFFFFFFFFll)
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320: weight / row block exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st)
+                                        : mvi::linear_n320_launch<__half>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st);
+    return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
+}

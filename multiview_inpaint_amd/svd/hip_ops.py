@@ -324,6 +324,28 @@ def linear_k320(x, weight, bias):
     return full[:rows].reshape(*x.shape[:-1], N)
 
 
+def linear_n320_supported(K, out_features, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_linear_n320_supported(int(K), int(out_features), _DT[dtype]))
+
+
+def linear_n320(x, weight, bias):
+    """F.linear(x, weight, bias) for 320 outputs and K a multiple of 64 (csrc/linear_n320.hip): x [..., K], weight [320, K]."""
+    L = _lib.lib()
+    K, N = x.shape[-1], weight.shape[0]
+    xc = x.reshape(-1, K)
+    if xc.stride(1) != 1 or xc.stride(0) % 8 or xc.data_ptr() % 16:
+        xc = xc.contiguous()
+    wc = weight if weight.is_contiguous() else weight.contiguous()
+    rows = xc.shape[0]
+    cap = int(L.mvi_ff_geglu_out_rows(rows))
+    full = torch.empty(cap, N, dtype=x.dtype, device=x.device)
+    b = None if bias is None else _f32(bias)
+    with torch.cuda.device(x.device), _Timed("linear_n320", 2.0 * rows * K * N, x.device):
+        _check(L.mvi_linear_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), rows, cap, K, N,
+                                 xc.stride(0), full.stride(0), _DT[x.dtype], _stream(x.device)), "linear_n320")
+    return full[:rows].reshape(*x.shape[:-1], N)
+
+
 def bias_residual_add(h, bias, x):
     L = _lib.lib()
     if h.dtype not in _DT:

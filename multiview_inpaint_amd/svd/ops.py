@@ -214,15 +214,21 @@ def linear_geglu(x, weight, bias=None):
     return geglu(F.linear(x, weight, bias))
 
 
+N320_KERNEL = os.environ.get("MVI_N320", "1") != "0"          # csrc/linear_n320.hip for [rows, K] x [K, 320] with rows >= FF_GEGLU_MIN_ROWS
+
+
 def linear(x, weight, bias=None):
     """F.linear(x, weight, bias). On the GPU, the K = 320 projections of the level-0 transformer blocks (packed q/k/v, to_out,
     proj_in / proj_out: output-bound GEMMs around a 20-step loop) take csrc/ff_geglu.hip's plain-epilogue kernel
-    (mvi_linear_k320); everything else is the library GEMM."""
+    (mvi_linear_k320), and the level-0 projections INTO 320 channels with a long contraction (FeedForward.net[2], K = 1280) take
+    csrc/linear_n320.hip (mvi_linear_n320); everything else is the library GEMM."""
     if K320_KERNELS and x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
         if hip_ops.linear_k320_supported(x.shape[-1], weight.shape[0], x.dtype):
             return hip_ops.linear_k320(x, weight, bias)
+        if N320_KERNEL and hip_ops.linear_n320_supported(x.shape[-1], weight.shape[0], x.dtype):
+            return hip_ops.linear_n320(x, weight, bias)
     return F.linear(x, weight, bias)
 
 

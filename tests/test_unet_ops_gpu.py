@@ -395,6 +395,39 @@ def test_ff_geglu_fused_projection(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_linear_n320_kernel(ops, dtype, tol):
+    """nn.Linear INTO 320 channels with a long contraction (csrc/linear_n320.hip: outputs stationary in accumulators, K streamed
+    in chunks of 64 through an LDS ring): against fp64 and against the library GEMM, ragged rows (a last block of 232 / 1 / 44
+    rows, waves that start past the end), an even and an odd number of chunks (K = 1280, 128, 192, 704), with and without bias, a
+    strided x; the dispatcher takes it only for enough rows; the library keeps every other shape."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(47)
+    for rows, K, with_bias, strided in [(1000, 1280, True, False), (70001, 128, False, True), (300, 192, True, False), (2561, 704, True, True)]:
+        N = 320
+        wide = (torch.randn(rows, K + 64 if strided else K, generator=g) * 1.2).to(dtype)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+        b = (torch.randn(N, generator=g) * 0.3).to(dtype) if with_bias else None
+        ref = F.linear(wide[:, :K].double(), w.double(), None if b is None else b.double())
+        xs = wide.cuda()[:, :K]
+        assert ops.linear_n320_supported(K, N, dtype)
+        y = ops.linear_n320(xs, w.cuda(), None if b is None else b.cuda())
+        lib = F.linear(xs, w.cuda(), None if b is None else b.cuda())
+        assert y.shape == (rows, N) and y.dtype == dtype
+        assert rel(y, ref) < tol and rel(y, lib.double()) < tol
+    x = torch.randn(dev_ops.FF_GEGLU_MIN_ROWS, 1280, generator=g).to(dtype).cuda()
+    w = (torch.randn(320, 1280, generator=g) * 1280 ** -0.5).to(dtype).cuda()
+    ops.PROFILE = []
+    big = dev_ops.linear(x, w)
+    small = dev_ops.linear(x[:100], w)                               # too few rows: library
+    other = dev_ops.linear(x, torch.cat([w, w]))                     # 640 outputs: library
+    kinds = [e[0] for e in ops.PROFILE]
+    ops.PROFILE = None
+    assert kinds == ["linear_n320"] and other.shape[-1] == 640
+    assert rel(big[:100], small.double()) < tol
+    assert not ops.linear_n320_supported(1280, 640, dtype) and not ops.linear_n320_supported(1000, 320, dtype) and not ops.linear_n320_supported(64, 320, dtype)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_linear_k320_kernel(ops, dtype, tol):
     """nn.Linear with K = 320 on the MFMA kernel of ff_geglu (plain epilogue, 64 outputs per step): against fp64 and against the
     library GEMM (same inputs, fp32 accumulation either way: equal to the order of summation), ragged rows, 2 ... 15 steps, with

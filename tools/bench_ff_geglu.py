@@ -68,3 +68,32 @@ for rows, K, N, with_bias in [(258048, 320, 960, False), (258048, 320, 320, True
     byt = rows * (K + N) * 2
     print(f"linear rows {rows} {K} -> {N} bias {int(with_bias)}: k320 kernel {ts[0] * 1e3:7.1f} us ({byt / ts[0] * 1e-6:6.0f} GB/s)  library {ts[1] * 1e3:7.1f} us;"
           f"  max err / max |ref|: {e_k:.2e} vs {e_l:.2e}", flush=True)
+
+# the projection INTO 320 channels with a long contraction (csrc/linear_n320.hip): FeedForward.net[2] at level 0
+for rows, K, with_bias in [(258048, 1280, True), (64512, 1280, True)]:
+    N = 320
+    dtype = torch.bfloat16
+    x = (torch.randn(rows, K, device=dev, generator=g) * 1.2).to(dtype)
+    w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(dtype)
+    b = (torch.randn(N, device=dev, generator=g) * 0.3).to(dtype) if with_bias else None
+    y = hip_ops.linear_n320(x, w, b)
+    lib = F.linear(x, w, b)
+    idx = torch.randint(0, rows, (512,), device=dev, generator=g)
+    ref = F.linear(x[idx].double(), w.double(), None if b is None else b.double())
+    sc = float(ref.abs().max())
+    e_k, e_l = float((y[idx].double() - ref).abs().max()) / sc, float((lib[idx].double() - ref).abs().max()) / sc
+    ts = []
+    for fn in (lambda: hip_ops.linear_n320(x, w, b), lambda: F.linear(x, w, b)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(e) / 10)
+    fl = 2.0 * rows * K * N
+    print(f"linear rows {rows} {K} -> {N} bias {int(with_bias)}: n320 kernel {ts[0] * 1e3:7.1f} us ({fl / ts[0] * 1e-9:6.1f} TFLOP/s)  library {ts[1] * 1e3:7.1f} us "
+          f"({fl / ts[1] * 1e-9:6.1f} TFLOP/s);  max err / max |ref|: {e_k:.2e} vs {e_l:.2e}", flush=True)
