@@ -368,6 +368,91 @@ def _emb_projection(emb_layers, emb):
     return emb_layers[1](act)
 
 
+BATCHED_EMB = os.environ.get("MVI_SVD_BATCHED_EMB", "1") != "0"
+_emb_plans = {}               # id(root) -> (weakref(root), signature, groups)
+_emb_tables = []              # [(weakref(emb), version, {id(linear): fp32 [N, C]})], newest first (UNet + ControlNet)
+
+
+def _emb_plan(root):
+    """Every (VideoRes)ResBlock under `root` that projects the step's embedding through Linear(SiLU(emb)) in its fused forward, grouped
+    by output width: per group the concatenated weight / bias of the projections and the concatenated bias of the convolution
+    each projection is added behind (conv1: it rides with the embedding inside the second GroupNorm). Cached per root and
+    rebuilt when any of those parameters changes."""
+    import weakref
+    blocks = [m for m in root.modules() if isinstance(m, ResBlock) and isinstance(m.emb_layers, nn.Sequential) and len(m.emb_layers) == 2
+              and isinstance(m.emb_layers[0], nn.SiLU) and type(m.emb_layers[1]) is nn.Linear and not m.use_scale_shift_norm
+              and isinstance(m.in_layers[2], (nn.Conv2d, nn.Conv3d))]
+    if len(blocks) < 4:
+        return None
+    params = []
+    for b in blocks:
+        lin, conv = b.emb_layers[1], b.in_layers[2]
+        params += [lin.weight, lin.bias, conv.bias]
+    if any(p is not None and p.requires_grad and torch.is_grad_enabled() for p in params):
+        return None
+    sig = tuple((id(p), p._version, p.data_ptr()) if p is not None else None for p in params)
+    hit = _emb_plans.get(id(root))
+    if hit is not None and hit[0]() is root and hit[1] == sig:
+        return hit[2]
+    by_width = {}
+    for b in blocks:
+        lin = b.emb_layers[1]
+        if lin.bias is None or lin.out_features != b.in_layers[2].out_channels:
+            continue
+        by_width.setdefault((lin.out_features, lin.in_features, lin.weight.dtype, lin.weight.device), []).append(b)
+    groups = []
+    with torch.no_grad():
+        for (C, _, _, dev), bs in by_width.items():
+            W = torch.cat([b.emb_layers[1].weight for b in bs], 0).contiguous()
+            bl = torch.cat([b.emb_layers[1].bias for b in bs], 0).contiguous()
+            cb = torch.cat([(b.in_layers[2].bias.float() if b.in_layers[2].bias is not None else torch.zeros(C, device=dev)) for b in bs], 0)
+            groups.append((C, W, bl, cb.contiguous(), [id(b.emb_layers[1]) for b in bs]))
+    key = id(root)
+    _emb_plans[key] = (weakref.ref(root, lambda _r, k=key: _emb_plans.pop(k, None)), sig, groups)
+    return groups
+
+
+def prepare_emb_projections(root, emb):
+    """One GEMM per output width for ALL embedding projections of a network's ResBlocks (44 in the UNet, 25 in the ControlNet:
+    each was a 28-row GEMM + a bias add of a few microseconds, ~130 launches per network and step), with the bias of the
+    convolution in front folded in as the per-block path does (fp32 add behind the GEMM's rounding: the same values). The
+    blocks pick their [N, C] fp32 slice up in _emb_chan_bias; anything not prepared here takes the per-block path."""
+    import weakref
+    if not (BATCHED_EMB and emb.is_cuda) or torch.is_grad_enabled() or emb.requires_grad or emb.dim() != 2:
+        return
+    groups = _emb_plan(root)
+    if not groups:
+        return
+    act = F.silu(emb)
+    N = emb.shape[0]
+    table = {}
+    for C, W, bl, cb, ids in groups:
+        if W.dtype != act.dtype:
+            return
+        out = F.linear(act, W, bl).float() + cb                      # [N, n C] fp32
+        out = out.view(N, len(ids), C).permute(1, 0, 2).contiguous()  # [n, N, C]: a block's slice is contiguous
+        for k, i in enumerate(ids):
+            table[i] = out[k]
+    _emb_tables.insert(0, (weakref.ref(emb), emb._version, table))
+    del _emb_tables[2:]
+
+
+def _emb_chan_bias(emb_layers, emb, conv):
+    """fp32 [N, C]: emb_layers(emb) + conv.bias — what the second GroupNorm of a ResBlock adds per (sample, channel). From the
+    batched projection of this step when the network prepared one (prepare_emb_projections), else computed here."""
+    if isinstance(emb_layers, nn.Sequential) and len(emb_layers) == 2:
+        for ref, ver, table in _emb_tables:
+            if ref() is emb and ver == emb._version:
+                hit = table.get(id(emb_layers[1]))
+                if hit is not None:
+                    return hit
+                break
+    e = _emb_projection(emb_layers, emb)
+    e = e.reshape(e.shape[0], e.shape[1])
+    # fp32 [N, C] for the norm's chan_bias: the mixed-dtype add promotes inside one kernel (same values as cast-then-add)
+    return e + _f32_param(conv.bias) if conv.bias is not None else e.float()
+
+
 NHWC_CONVS = os.environ.get("MVI_SVD_NHWC_CONVS", "1") != "0"
 _cl_weights = {}
 
@@ -417,9 +502,7 @@ def _resblock_forward_fused(self, x, emb):
         H, W = x.shape[2], x.shape[3]
         t = ops.group_norm_tokens(x, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True)
         t = _conv_tokens(conv1, t, H, W)
-        e = _emb_projection(self.emb_layers, emb)
-        e = e.reshape(e.shape[0], e.shape[1])
-        e = e + _f32_param(conv1.bias) if conv1.bias is not None else e.float()
+        e = _emb_chan_bias(self.emb_layers, emb, conv1)
         t = ops.group_norm_tok2tok(t, g2.num_groups, g2.weight, g2.bias, g2.eps, silu=True, chan_bias=e)
         t = _conv_tokens(conv2, self.out_layers[2](t), H, W)
         if isinstance(self.skip_connection, nn.Identity):
@@ -428,10 +511,7 @@ def _resblock_forward_fused(self, x, emb):
         sb = sk.bias if conv2.bias is None else (conv2.bias if sk.bias is None else _sum_param(sk.bias, conv2.bias))
         return ops.tokens_to_planes_add(t, conv_no_bias(sk, x, None), sb)      # both biases ride on the transposing add
     h = conv_no_bias(conv1, norm_act(self.in_layers, x))
-    e = _emb_projection(self.emb_layers, emb)
-    e = e.reshape(e.shape[0], e.shape[1])
-    # fp32 [N, C] for the norm's chan_bias: the mixed-dtype add promotes inside one kernel (same values as cast-then-add)
-    e = e + _f32_param(conv1.bias) if conv1.bias is not None else e.float()
+    e = _emb_chan_bias(self.emb_layers, emb, conv1)
     h = self.out_layers[0](h, silu=True, chan_bias=e)
     h = conv_no_bias(conv2, self.out_layers[2](h))
     if isinstance(self.skip_connection, nn.Identity):
@@ -479,8 +559,7 @@ class VideoResBlock(ResBlock):
         c1, c2 = ts.in_layers[2], ts.out_layers[3]
         h3 = ops.group_norm_frames(x, T, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, stack3=True)
         h = temporal_conv3_stacked(h3, c1, with_bias=False)
-        e = _emb_projection(ts.emb_layers, emb)                    # [(b T), c]: already per frame, fused into the norm
-        e = e + _f32_param(c1.bias) if c1.bias is not None else e.float()
+        e = _emb_chan_bias(ts.emb_layers, emb, c1)                 # [(b T), c] fp32: already per frame, fused into the norm
         h3 = ops.group_norm_frames(h, T, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, stack3=True)
         h = temporal_conv3_stacked(ts.out_layers[2](h3), c2, with_bias=False)
         if blend is not None:                                      # AlphaBlender folded into the skip add

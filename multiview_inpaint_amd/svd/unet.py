@@ -16,7 +16,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .layers import (Downsample, TimestepEmbedSequential, Timestep, Upsample, VideoResBlock, conv_nd, linear,
+from .layers import (Downsample, TimestepEmbedSequential, Timestep, Upsample, VideoResBlock, conv_nd, linear, prepare_emb_projections,
                      norm_act, normalization, timestep_embedding, zero_module)
 from .transformer import SpatialVideoTransformer
 from . import ops
@@ -163,6 +163,7 @@ class VideoUNet(_Encoder):
     def forward(self, x, timesteps, context=None, y=None, time_context=None, num_video_frames=None,
                 image_only_indicator=None, control: Optional[List[torch.Tensor]] = None):
         emb = self._embed(x, timesteps, y)
+        prepare_emb_projections(self, emb)                # all ResBlock embedding projections of this step as one GEMM per width
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
         hs, h = [], x
@@ -268,6 +269,7 @@ class ControlNet(_Encoder):
     def forward(self, x, hint, timesteps, context=None, y=None, time_context=None, num_video_frames=None,
                 image_only_indicator=None):
         emb = self._embed(x, timesteps, y)
+        prepare_emb_projections(self, emb)
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
         guided = self._hint_stem_cached(hint, emb, context)

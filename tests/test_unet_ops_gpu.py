@@ -255,6 +255,50 @@ def test_sample_loop_on_gpu_matches_reference_golden_with_and_without_hint_cache
     assert rel(plain, torch.tensor(G["sample_final"])) < 5e-4 and rel(cached, torch.tensor(G["sample_final"])) < 5e-4
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-6), (torch.bfloat16, 2e-2)])
+def test_batched_embedding_projections_equal_the_per_block_ones(dtype, tol):
+    """svd/layers.py prepare_emb_projections: one GEMM per output width for every ResBlock's Linear(SiLU(emb)) (+ the bias of
+    the convolution in front) against the per-block path, on the small UNet and ControlNet: the table is filled and used, the
+    outputs agree (fp32: to the order of summation of two GEMM kernels; bf16: a few roundings of the projection flip), and
+    changing a projection's weights rebuilds the plan."""
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    from multiview_inpaint_amd.svd import layers
+    unet = VideoUNet(**H.SMALL_UNET).eval()
+    unet.load_state_dict(H.seeded_state_dict(unet, 11))
+    unet = unet.cuda().to(dtype)
+    inp = {k: (v.cuda().to(dtype) if torch.is_tensor(v) and v.is_floating_point() else (v.cuda() if torch.is_tensor(v) else v))
+           for k, v in H.seeded_inputs(21).items()}
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    tt = 0.25 * inp["sigma"].float().log()
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+
+    def run():
+        with torch.no_grad():
+            return unet(xin, tt, inp["crossattn"], inp["vector"], **kw).float()
+    layers._emb_tables.clear()
+    layers.BATCHED_EMB = True
+    try:
+        on = run()
+        assert layers._emb_tables and len(layers._emb_tables[0][2]) >= 8       # every (Video)ResBlock's projection is in the table
+        n_plans = len(layers._emb_plans)
+        layers.BATCHED_EMB = False
+        layers._emb_tables.clear()
+        off = run()
+        assert not layers._emb_tables
+        assert rel(on, off.double()) < tol
+        layers.BATCHED_EMB = True
+        # (a block with more than one channel per GroupNorm group: with one, the norm removes a per-channel offset entirely)
+        blk = max((m for m in unet.modules() if isinstance(m, layers.ResBlock)), key=lambda m: m.out_channels)
+        with torch.no_grad():                                                   # a new parameter version: the plan must follow
+            blk.emb_layers[1].bias.add_(torch.randn(blk.emb_layers[1].bias.shape, generator=torch.Generator().manual_seed(5)).cuda().to(dtype) * 2.0)
+        on2 = run()
+        layers.BATCHED_EMB = False
+        off2 = run()
+        assert rel(on2, off2.double()) < tol and rel(on2, on.double()) > 20 * max(rel(on2, off2.double()), 1e-7) and len(layers._emb_plans) == n_plans
+    finally:
+        layers.BATCHED_EMB = True
+
+
 @pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 8e-2), (torch.float16, 1e-2)])
 def test_small_unet_reduced_precision_autocast_error_is_reported(G, dtype, bound):
     """Reduced precision: bf16 autocast (what bench.py runs) and fp16 autocast (the reference's own recipe, csvd.py:27-31:
