@@ -29,7 +29,7 @@ constexpr int kGtMaxGroups = 64;
 __host__ __device__ inline int gt_rows_per_pass(int vpr) { int rp = 512 / vpr; return rp < 1 ? 1 : (rp > 8 ? 8 : rp); }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
                                                         int C, int64_t S, int G, int vpr, int rp, int chunks) {
     constexpr int V = Io<T>::kVec;
     extern __shared__ float s_mem[];
@@ -42,25 +42,27 @@ __global__ __launch_bounds__(1024) void gt_stats_kernel(const T* __restrict__ x,
     const int Cg = C / G;
     const T* xb = x + (n * S) * C + (int64_t)v * V;
     const float* cb = chan_bias ? chan_bias + n * C + v * V : nullptr;
-    float vals[kGtPasses][V];
+    // The chunk is kept as loaded (16 bytes per row: 4 registers instead of 8 floats) and decoded once per pass: 32 registers
+    // of payload instead of 64, so more waves — and more loads in flight — fit a CU (the pass runs at a read-only 2.5 TB/s).
+    uint4 raw[kGtPasses];
     float add[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) add[k] = cb ? cb[k] : 0.f;
-    int rows_here = 0;
+#pragma unroll
+    for (int p = 0; p < kGtPasses; ++p) {
+        const int64_t row = row0 + p * rp + r0;
+        raw[p] = row < S ? *reinterpret_cast<const uint4*>(xb + row * C) : make_uint4(0, 0, 0, 0);
+    }
     float csum[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) csum[k] = 0.f;
 #pragma unroll
     for (int p = 0; p < kGtPasses; ++p) {
-        const int64_t row = row0 + p * rp + r0;
-        if (row < S) {
-            Io<T>::load(xb + row * C, vals[p]);
+        if (row0 + p * rp + r0 < S) {
+            float t[V];
+            Io<T>::load(reinterpret_cast<const T*>(&raw[p]), t);
 #pragma unroll
-            for (int k = 0; k < V; ++k) { vals[p][k] += add[k]; csum[k] += vals[p][k]; }
-            ++rows_here;
-        } else {
-#pragma unroll
-            for (int k = 0; k < V; ++k) vals[p][k] = 0.f;
+            for (int k = 0; k < V; ++k) csum[k] += t[k] + add[k];
         }
     }
     const int64_t rows_chunk = (S - row0) < (int64_t)(kGtPasses * rp) ? (S - row0) : (int64_t)(kGtPasses * rp);
@@ -82,17 +84,17 @@ __global__ __launch_bounds__(1024) void gt_stats_kernel(const T* __restrict__ x,
     }
     __syncthreads();
     // centred second moments from the registers
-    float m2[V];
+    float m2[V], gmean[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const float mean = s_grp[(v * V + k) / Cg];
-        float a = 0.f;
+    for (int k = 0; k < V; ++k) { m2[k] = 0.f; gmean[k] = s_grp[(v * V + k) / Cg] - add[k]; }
 #pragma unroll
-        for (int p = 0; p < kGtPasses; ++p) {
-            const float d = vals[p][k] - mean;
-            a += (row0 + p * rp + r0 < S) ? d * d : 0.f;
+    for (int p = 0; p < kGtPasses; ++p) {
+        if (row0 + p * rp + r0 < S) {
+            float t[V];
+            Io<T>::load(reinterpret_cast<const T*>(&raw[p]), t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float dd = t[k] - gmean[k]; m2[k] += dd * dd; }
         }
-        m2[k] = a;
     }
     __syncthreads();                           // s_ch is reused
 #pragma unroll
@@ -174,22 +176,24 @@ __global__ __launch_bounds__(1024) void gt_apply_kernel(const T* __restrict__ x,
     for (int k = 0; k < V; ++k) { sc[k] = ss[2 * k]; sh[k] = ss[2 * k + 1]; }
     const T* xb = x + (n * S) * C + (int64_t)v * V;
     T* yb = y + (n * S) * C + (int64_t)v * V;
-    float vals[kGtPasses][V];
+    uint4 raw[kGtPasses];                       // as loaded (4 registers per row, decoded one row at a time): see gt_stats_kernel
 #pragma unroll
     for (int p = 0; p < kGtPasses; ++p) {
         const int64_t row = row0 + p * rp + r0;
-        if (row < S) Io<T>::load(xb + row * C, vals[p]);
+        if (row < S) raw[p] = *reinterpret_cast<const uint4*>(xb + row * C);
     }
 #pragma unroll
     for (int p = 0; p < kGtPasses; ++p) {
         const int64_t row = row0 + p * rp + r0;
         if (row < S) {
+            float t[V];
+            Io<T>::load(reinterpret_cast<const T*>(&raw[p]), t);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                const float t = vals[p][k] * sc[k] + sh[k];
-                vals[p][k] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+                const float u = t[k] * sc[k] + sh[k];
+                t[k] = silu ? u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f)) : u;
             }
-            Io<T>::store(yb + row * C, vals[p]);
+            Io<T>::store(yb + row * C, t);
         }
     }
 }
