@@ -271,7 +271,11 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
 // consumers that contract over channels (the transformer's proj_in Linear, attention.py:700-707; the channels-last
 // 3x3 convolution of ResBlock). One block = a 64 (channels) x 64 (positions) tile through LDS; the tile's channels
 // merge their groups' partials themselves (a handful per group), so no extra finalise launch exists.
-constexpr int kGnTok = 64;
+constexpr int kGnTok = 64;                                // channels per tile
+constexpr int kGnTokS = 128;                              // positions per tile
+// The tile sits in LDS in the OUTPUT type (the rounding of the final store, done before the transpose instead of after it:
+// same values) — 17 KB for bf16 / f16 instead of 33 KB of floats, so the 8 blocks a CU's wave slots allow are resident and a
+// thread has four 16-byte loads in flight instead of two (the 64 x 64 float tile ran at 4.2 TB/s of read + write).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_tokens_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                               const float* __restrict__ weight,
@@ -279,8 +283,10 @@ __global__ __launch_bounds__(256) void gn_apply_tokens_kernel(const T* __restric
                                                               const float* __restrict__ part, GnGeom q, float eps, int silu,
                                                               int s_tiles, int c_tiles) {
     constexpr int V = Io<T>::kVec;
-    constexpr int VPR = kGnTok / V;
-    __shared__ float s_t[kGnTok][kGnTok + 1];
+    constexpr int VPRS = kGnTokS / V;                     // vectors per channel row of the tile (load side)
+    constexpr int VPRC = kGnTok / V;                      // vectors per token row of the tile (store side)
+    constexpr int kPad = 16 / (int)sizeof(T);             // row pitch 128 + 16 bytes' worth: 16-byte aligned rows, transposed reads conflict-free
+    __shared__ __attribute__((aligned(16))) T s_t[kGnTok][kGnTokS + kPad];
     __shared__ float s_sc[kGnTok], s_sh[kGnTok];
     int bid = blockIdx.x;
     const int stile = bid % s_tiles; bid /= s_tiles;
@@ -288,14 +294,14 @@ __global__ __launch_bounds__(256) void gn_apply_tokens_kernel(const T* __restric
     const int64_t n = bid / c_tiles;
     const int C = q.Cg * q.G;
     const int c0 = ctile * kGnTok;
-    const int64_t s0 = (int64_t)stile * kGnTok, S = q.S;
+    const int64_t s0 = (int64_t)stile * kGnTokS, S = q.S;
     if (threadIdx.x < kGnTok) {
         const int c = c0 + threadIdx.x;
         if (c < C) {
             const int64_t g = n * q.G + c / q.Cg;
             float cnt = 0.f, mean = 0.f, m2 = 0.f;
             // the partials four at a time, loads first: one at a time this walk was a chain of 6 ... 12 dependent L2 round trips in
-            // front of every 16 KB tile (a block's data phase is shorter than that)
+            // front of every tile (a block's data phase is shorter than that)
             for (int k0 = 0; k0 < q.cps; k0 += 4) {
                 float nb[4], mb[4], qb[4];
 #pragma unroll
@@ -320,28 +326,38 @@ __global__ __launch_bounds__(256) void gn_apply_tokens_kernel(const T* __restric
             s_sh[threadIdx.x] = bias[c] + (add - mean) * w;
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kGnTok * VPR; i += 256) {
-        const int cr = i / VPR, sv = i % VPR;
-        if (c0 + cr < C && s0 + sv * V < S) {
-            float v[V];
-            Io<T>::load(x + ((n * C + c0 + cr) * S + s0 + sv * V), v);
-            const float w = s_sc[cr], b = s_sh[cr];
+    // the tile's loads do not depend on the scale / shift: issue them before the barrier
+    constexpr int kLoads = kGnTok * VPRS / 256;
+    uint4 raw[kLoads];
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                const float t = v[k] * w + b;
-                s_t[cr][sv * V + k] = silu ? t / (1.0f + __expf(-t)) : t;
-            }
-        }
+    for (int j = 0; j < kLoads; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int cr = i / VPRS, sv = i % VPRS;
+        raw[j] = (c0 + cr < C && s0 + sv * V < S) ? *reinterpret_cast<const uint4*>(x + ((n * C + c0 + cr) * S + s0 + sv * V)) : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kGnTok * VPR; i += 256) {
-        const int sr = i / VPR, cv = i % VPR;
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int cr = i / VPRS, sv = i % VPRS;
+        float v[V];
+        Io<T>::load(reinterpret_cast<const T*>(&raw[j]), v);
+        const float w = s_sc[cr], b = s_sh[cr];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float t = v[k] * w + b;
+            v[k] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+        }
+        Io<T>::store(&s_t[cr][sv * V], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGnTokS * VPRC; i += 256) {
+        const int sr = i / VPRC, cv = i % VPRC;
         if (s0 + sr < S && c0 + cv * V < C) {
-            float o[V];
+            T o[V];
 #pragma unroll
             for (int k = 0; k < V; ++k) o[k] = s_t[cv * V + k][sr];
-            Io<T>::store(y + ((n * S + s0 + sr) * C + c0 + cv * V), o);
+            *reinterpret_cast<uint4*>(y + ((n * S + s0 + sr) * C + c0 + cv * V)) = *reinterpret_cast<const uint4*>(o);
         }
     }
 }
@@ -715,7 +731,7 @@ static int gn_launch(const void* x, void* y, const float* w, const float* b, con
     dim3 grid((unsigned)(q.cps * slices), (unsigned)(N * G));
     if (tokens) {
         if (!vec || C % KV != 0 || slices != 1 || stack3) return MVI_EINVAL;
-        const int s_tiles = (int)((S + kGnTok - 1) / kGnTok), c_tiles = (C + kGnTok - 1) / kGnTok;
+        const int s_tiles = (int)((S + kGnTokS - 1) / kGnTokS), c_tiles = (C + kGnTok - 1) / kGnTok;
         const int64_t blocks = N * s_tiles * c_tiles;
         if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
         hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(kGnBlock), 0, st, (const T*)x, part, q);
