@@ -216,13 +216,23 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
     }
     T* y_zero2 = (q.stack3 && slice == q.slices - 1) ? y + row * (3 * (int64_t)C * S) + 2 * (int64_t)C * S + (int64_t)c0 * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    // VEC: all of the thread's loads first, as loaded (4 registers each) — with a load, its arithmetic and its stores per turn of
+    // the loop a thread had one load in flight at a time (23 registers: the occupancy was there, the loads were not)
+    uint4 raw[VEC ? kGnVecPerThread : 1];
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < kGnVecPerThread; ++i) {
+            const int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
+            raw[i] = e < E ? *reinterpret_cast<const uint4*>(xb + e) : make_uint4(0, 0, 0, 0);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < kGnVecPerThread; ++i) {
         int64_t e = e0 + ((int64_t)i * kGnBlock + threadIdx.x) * KV;
         if (e >= E) continue;
         float v[KV];
         if (VEC) {
-            Io<T>::load(xb + e, v);
+            Io<T>::load(reinterpret_cast<const T*>(&raw[i]), v);
             const int cl = E < (1 << 24) ? div_small((uint32_t)e, (uint32_t)S, inv_S) : (int)(e / S);   // S % KV == 0 on this path: one channel per vector
             const int c = c0 + cl;
             const float add = cb ? cb[c] : 0.f;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_apply_kernel(const T* __restrict_
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
                 float t = v[k] * w + b;
-                v[k] = silu ? t / (1.0f + __expf(-t)) : t;
+                v[k] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
             }
             if (!q.stack3) {
                 Io<T>::store(yb + e, v);
