@@ -1,0 +1,186 @@
+// 3x3 convolution (stride 1, padding 1) with 16 output channels and at most 16 input channels, + bias + SiLU, NCHW bf16 / f16, for
+// gfx950 — the first two layers of ControlNet.input_hint_block (svd_inpaint1/models/csvd.py:234-250: conv(7 -> 16), SiLU,
+// conv(16 -> 16), SiLU at the 576 x 1024 hint resolution, once per ControlNet call). The library runs them at 1.16 + 1.09 ms for
+// 28 frames (its kernels are built for wide channels) plus a pass for bias + SiLU over each 528 MB output; they move 0.76 / 1.06 GB,
+// i.e. ~0.2 ms of HBM time each.
+//
+// Implicit GEMM on v_mfma_f32_16x16x32: M = 16 pixels of an output row, N = the 16 output channels, K = (tap, input channel) —
+// 9 x 16 = 144 padded to 160 (five k-steps; CINP = 8 for the 7-channel hint: 9 x 8 = 72 padded to 96, three k-steps).
+//   * block = 4 waves = a tile of 4 output rows x 64 pixels; its input patch (6 x 66 pixels, all input channels) is brought from
+//     the NCHW planes with 16-byte loads and laid out in LDS pixel-major ([row][pixel][channel], 16 or 32 bytes per pixel), so the
+//     A fragment of a k-step is ONE ds_read_b128 per lane: 8 consecutive channels of pixel (p + dx, row + dy);
+//   * the weights are the B operand, built once per wave in registers (20 or 12 registers);
+//   * the accumulator starts from the bias; a lane ends with 4 consecutive pixels of one output channel: SiLU, pack, one 8-byte store.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/mvi_raster.h"
+#include "../../include/mvi_unet_ops.h"
+
+namespace mvi {
+int unet_fail(int code, const char* msg);
+namespace sc {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int kTW = 64;                // tile width in pixels
+constexpr int kTH = 8;                 // tile rows = waves
+constexpr int kCout = 16;
+constexpr int kPW = kTW + 2, kPH = kTH + 2;
+
+template <typename T> struct Mma;
+template <> struct Mma<__hip_bfloat16> {
+    using frag = bf16x8;
+    __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        f32x2 f = {lo, hi};
+        bf16x2 r = __builtin_convertvector(f, bf16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
+    }
+};
+template <> struct Mma<__half> {
+    using frag = f16x8;
+    __device__ static f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    __device__ static uint32_t pack2(float lo, float hi) {
+        f32x2 f = {lo, hi};
+        f16x2 r = __builtin_convertvector(f, f16x2);
+        return *reinterpret_cast<uint32_t*>(&r);
+    }
+};
+template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
+
+template <typename T, int CINP>
+__global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                                T* __restrict__ y, int Cin, int H, int W, int silu) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    constexpr int kTapsPerStep = 32 / CINP;                       // 2 (16 channels) or 4 (8 channels)
+    constexpr int kSteps = (9 + kTapsPerStep - 1) / kTapsPerStep; // 5 or 3
+    // LDS patch, pixel-major with 16 bytes of padding after every 8 pixels (keeps the 16-byte alignment of the fragment reads and
+    // spreads the 8-pixel pieces a wave writes at once over the banks)
+    constexpr int kPixB = CINP * 2;                                             // bytes per pixel
+    constexpr int kRowB = kPW * kPixB + 16 * ((kPW + 7) / 8);                   // bytes per patch row
+    __shared__ __attribute__((aligned(16))) char s_in[kPH * kRowB];
+    auto pix_off = [](int q) { return q * kPixB + (q >> 3) * 16; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int64_t img = blockIdx.z;
+    const uint16_t* xin = reinterpret_cast<const uint16_t*>(x) + img * Cin * (int64_t)H * W;
+
+    // ---- input patch -> LDS. An item = 8 pixels of a channel PAIR (two 16-byte loads from two planes, eight 4-byte LDS writes);
+    // consecutive lanes take consecutive pairs of the same pixels, i.e. consecutive LDS words. The two halo columns one element at a
+    // time; everything outside the image, and the padding channels, is zero
+    constexpr int kPairs = CINP / 2;
+    for (int i = tid; i < kPairs * (kTW / 8) * kPH; i += 64 * kTH) {
+        const int cp = i % kPairs, ch8 = (i / kPairs) % (kTW / 8), r = i / (kPairs * (kTW / 8));
+        const int gy = y0 + r - 1, gx = x0 + 8 * ch8;
+        u32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+        if (gy >= 0 && gy < H && gx < W) {
+            if (2 * cp < Cin) v0 = *reinterpret_cast<const u32x4*>(xin + ((int64_t)(2 * cp) * H + gy) * W + gx);
+            if (2 * cp + 1 < Cin) v1 = *reinterpret_cast<const u32x4*>(xin + ((int64_t)(2 * cp + 1) * H + gy) * W + gx);
+        }
+        char* const dst = s_in + r * kRowB + 4 * cp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            *reinterpret_cast<uint32_t*>(dst + pix_off(1 + 8 * ch8 + 2 * k)) = (v0[k] & 0xFFFFu) | (v1[k] << 16);
+            *reinterpret_cast<uint32_t*>(dst + pix_off(1 + 8 * ch8 + 2 * k + 1)) = (v0[k] >> 16) | (v1[k] & 0xFFFF0000u);
+        }
+    }
+    for (int i = tid; i < CINP * kPH * 2; i += 64 * kTH) {
+        const int c = i % CINP, side = (i / CINP) & 1, r = i / (2 * CINP);
+        const int gy = y0 + r - 1, gx = side ? x0 + kTW : x0 - 1;
+        uint16_t v = 0;
+        if (c < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xin[((int64_t)c * H + gy) * W + gx];
+        *reinterpret_cast<uint16_t*>(s_in + r * kRowB + pix_off(side ? kTW + 1 : 0) + 2 * c) = v;
+    }
+
+    // ---- weights: B operand. Lane (n = lane & 15, g = lane >> 4), k-step s, element j: tap = kTapsPerStep s + g / (CINP / 8),
+    // channel = 8 (g % (CINP / 8)) + j; zero past tap 8 and past the real input channels
+    // The weights reach LDS as they are (16 C_in 9 elements, 16-byte loads by the whole block) and every lane picks its fragments from
+    // there: gathered straight from memory they were 24 - 40 two-byte loads per lane, and a vector-memory instruction costs the issuing
+    // wave 100+ cycles whatever it moves — that, not the convolution, set the kernel's time (1.1 ms for the 16-channel layer)
+    __shared__ __attribute__((aligned(16))) uint16_t s_w[kCout * 16 * 9];
+    {
+        const int n_vec = (kCout * Cin * 9 * 2) / 16;                // 18 C_in: the tensor is a whole number of 16-byte pieces
+        for (int i = tid; i < n_vec; i += 64 * kTH) reinterpret_cast<u32x4*>(s_w)[i] = reinterpret_cast<const u32x4*>(w)[i];
+    }
+    const int n = lane & 15, g = lane >> 4;
+    const float b = bias ? bias[n] : 0.f;
+    __syncthreads();
+    const uint16_t* wp = s_w + n * Cin * 9;
+    u32x4 wf[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+        const int tap = kTapsPerStep * s + g / (CINP / 8), c0 = 8 * (g % (CINP / 8));
+        uint32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (tap < 9 && c0 + j < Cin) ? (uint32_t)wp[(c0 + j) * 9 + tap] : 0u;
+        wf[s] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+    }
+
+    // ---- one output row per wave: four M-tiles of 16 pixels
+    const int row = wave;                                         // tile row; input rows row .. row + 2 of the patch
+    const int gy = y0 + row;
+    const int m = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < kTW / 16; ++mt) {
+        f32x4 acc = {b, b, b, b};
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+            int tap = kTapsPerStep * s + g / (CINP / 8);
+            tap = tap < 9 ? tap : 0;                              // (its weights are zero: any finite operand will do)
+            const int dy = tap / 3, dx = tap % 3;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + (row + dy) * kRowB + pix_off(16 * mt + m + dx) + 16 * (g % (CINP / 8)));
+            acc = M::mfma(as_frag<frag>(a), as_frag<frag>(wf[s]), acc);
+        }
+        // lane: output channel n, pixels 16 mt + 4 g + 0..3 of the row
+        const int gx = x0 + 16 * mt + 4 * g;
+        if (gy < H && gx < W) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = acc[i];
+                o[i] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+            }
+            const u32x2 pk = {M::pack2(o[0], o[1]), M::pack2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(y + ((img * kCout + n) * H + gy) * (int64_t)W + gx) = pk;
+        }
+    }
+}
+
+}  // namespace sc
+}  // namespace mvi
+
+extern "C" int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t dtype) {
+    return Cout == mvi::sc::kCout && Cin >= 1 && Cin <= 16 && W % 8 == 0 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+extern "C" int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout,
+                                     int32_t H, int32_t W, int32_t fuse_silu, int32_t dtype, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || !mvi_stem_conv3x3_supported(Cin, Cout, W, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs C_out = 16, C_in <= 16, W a multiple of 8, bf16 or f16");
+    if (N == 0) return MVI_OK;
+    if (!x || !weight || !y) return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: NULL pointer");
+    if (((uintptr_t)x | (uintptr_t)y) % 16 || N > 65535 || (H + mvi::sc::kTH - 1) / mvi::sc::kTH > 65535)
+        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: x / y must be 16-byte aligned, N and H / 8 at most 65535");
+    using namespace mvi::sc;
+    const dim3 grid((unsigned)((W + kTW - 1) / kTW), (unsigned)((H + kTH - 1) / kTH), (unsigned)N), block(64 * kTH);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MVI_DT_BF16) {
+        if (Cin <= 8) hipLaunchKernelGGL((stem_conv3x3_kernel<__hip_bfloat16, 8>), grid, block, 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)weight, bias, (__hip_bfloat16*)y, Cin, H, W, fuse_silu);
+        else hipLaunchKernelGGL((stem_conv3x3_kernel<__hip_bfloat16, 16>), grid, block, 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)weight, bias, (__hip_bfloat16*)y, Cin, H, W, fuse_silu);
+    } else {
+        if (Cin <= 8) hipLaunchKernelGGL((stem_conv3x3_kernel<__half, 8>), grid, block, 0, st, (const __half*)x, (const __half*)weight, bias, (__half*)y, Cin, H, W, fuse_silu);
+        else hipLaunchKernelGGL((stem_conv3x3_kernel<__half, 16>), grid, block, 0, st, (const __half*)x, (const __half*)weight, bias, (__half*)y, Cin, H, W, fuse_silu);
+    }
+    return hipGetLastError() == hipSuccess ? MVI_OK : mvi::unet_fail(MVI_EHIP, "stem_conv3x3: kernel launch failed");
+}

@@ -21,6 +21,8 @@ from .layers import (Downsample, TimestepEmbedSequential, Timestep, Upsample, Vi
 from .transformer import SpatialVideoTransformer
 from . import ops
 
+STEM_CONV = os.environ.get("MVI_SVD_STEM_CONV", "1") != "0"     # csrc/stem_conv.hip for the 16-channel layers of the hint stem
+
 
 class _Encoder(nn.Module):
     """Everything VideoUNet and ControlNet have in common up to and including the middle block."""
@@ -223,13 +225,16 @@ class ControlNet(_Encoder):
         plain = all(isinstance(m, (nn.Conv2d, nn.SiLU)) for m in layers_)
         if not (plain and hint.is_cuda and not torch.is_grad_enabled()):
             return self.input_hint_block(hint, emb, context)
-        from . import ops
+        from . import hip_ops, ops
         from .layers import conv_no_bias
         h, i = hint, 0
         while i < len(layers_):
             conv = layers_[i]
             if i + 1 < len(layers_) and isinstance(layers_[i + 1], nn.SiLU):
-                h = ops.bias_silu(conv_no_bias(conv, h), conv.bias)
+                if STEM_CONV and hip_ops.stem_conv3x3_supported(conv, h):
+                    h = hip_ops.stem_conv3x3_silu(h, conv.weight, conv.bias)      # the two 16-channel layers at the hint's resolution
+                else:
+                    h = ops.bias_silu(conv_no_bias(conv, h), conv.bias)
                 i += 2
             else:
                 h = conv(h)
