@@ -33,9 +33,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 constexpr int kTW = 64;                // tile width in pixels
-constexpr int kTH = 8;                 // tile rows = waves
-constexpr int kCout = 16;
-constexpr int kPW = kTW + 2, kPH = kTH + 2;
+constexpr int kTHMax = 8;              // tile rows = waves: 8 for the 16-output forms, 4 for the 32-output form (registers, LDS)
+constexpr int kPW = kTW + 2;
 
 template <typename T> struct Mma;
 template <> struct Mma<__hip_bfloat16> {
@@ -58,13 +57,15 @@ template <> struct Mma<__half> {
 };
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
-template <typename T, int CINP>
+template <typename T, int CINP, int COUT, int kTH>
 __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                                 T* __restrict__ y, int Cin, int H, int W, int silu) {
     using M = Mma<T>;
     using frag = typename M::frag;
-    constexpr int kTapsPerStep = 32 / CINP;                       // 2 (16 channels) or 4 (8 channels)
-    constexpr int kSteps = (9 + kTapsPerStep - 1) / kTapsPerStep; // 5 or 3
+    constexpr int kTapsPerStep = 32 / CINP;                       // 1 (32 channels), 2 (16) or 4 (8)
+    constexpr int kSteps = (9 + kTapsPerStep - 1) / kTapsPerStep; // 9, 5 or 3
+    constexpr int NT = COUT / 16;                                 // output-channel tiles of 16
+    constexpr int kPH = kTH + 2;
     // LDS patch, pixel-major with 16 bytes of padding after every 8 pixels (keeps the 16-byte alignment of the fragment reads and
     // spreads the 8-pixel pieces a wave writes at once over the banks)
     constexpr int kPixB = CINP * 2;                                             // bytes per pixel
@@ -108,23 +109,28 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     // The weights reach LDS as they are (16 C_in 9 elements, 16-byte loads by the whole block) and every lane picks its fragments from
     // there: gathered straight from memory they were 24 - 40 two-byte loads per lane, and a vector-memory instruction costs the issuing
     // wave 100+ cycles whatever it moves — that, not the convolution, set the kernel's time (1.1 ms for the 16-channel layer)
-    __shared__ __attribute__((aligned(16))) uint16_t s_w[kCout * 16 * 9];
+    __shared__ __attribute__((aligned(16))) uint16_t s_w[COUT * CINP * 9];
     {
-        const int n_vec = (kCout * Cin * 9 * 2) / 16;                // 18 C_in: the tensor is a whole number of 16-byte pieces
+        const int n_vec = (COUT * Cin * 9 * 2) / 16;                 // 18 or 36 C_in: the tensor is a whole number of 16-byte pieces
         for (int i = tid; i < n_vec; i += 64 * kTH) reinterpret_cast<u32x4*>(s_w)[i] = reinterpret_cast<const u32x4*>(w)[i];
     }
     const int n = lane & 15, g = lane >> 4;
-    const float b = bias ? bias[n] : 0.f;
+    float b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bias ? bias[16 * nt + n] : 0.f;
     __syncthreads();
-    const uint16_t* wp = s_w + n * Cin * 9;
-    u32x4 wf[kSteps];
+    u32x4 wf[NT][kSteps];
 #pragma unroll
-    for (int s = 0; s < kSteps; ++s) {
-        const int tap = kTapsPerStep * s + g / (CINP / 8), c0 = 8 * (g % (CINP / 8));
-        uint32_t e[8];
+    for (int nt = 0; nt < NT; ++nt) {
+        const uint16_t* wp = s_w + (16 * nt + n) * Cin * 9;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (tap < 9 && c0 + j < Cin) ? (uint32_t)wp[(c0 + j) * 9 + tap] : 0u;
-        wf[s] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        for (int s = 0; s < kSteps; ++s) {
+            const int tap = kTapsPerStep * s + g / (CINP / 8), c0 = 8 * (g % (CINP / 8));
+            uint32_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (tap < 9 && c0 + j < Cin) ? (uint32_t)wp[(c0 + j) * 9 + tap] : 0u;
+            wf[nt][s] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        }
     }
 
     // ---- one output row per wave: four M-tiles of 16 pixels
@@ -133,26 +139,32 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     const int m = lane & 15;
 #pragma unroll
     for (int mt = 0; mt < kTW / 16; ++mt) {
-        f32x4 acc = {b, b, b, b};
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{b[nt], b[nt], b[nt], b[nt]};
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) {
             int tap = kTapsPerStep * s + g / (CINP / 8);
             tap = tap < 9 ? tap : 0;                              // (its weights are zero: any finite operand will do)
             const int dy = tap / 3, dx = tap % 3;
             const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + (row + dy) * kRowB + pix_off(16 * mt + m + dx) + 16 * (g % (CINP / 8)));
-            acc = M::mfma(as_frag<frag>(a), as_frag<frag>(wf[s]), acc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = M::mfma(as_frag<frag>(a), as_frag<frag>(wf[nt][s]), acc[nt]);
         }
-        // lane: output channel n, pixels 16 mt + 4 g + 0..3 of the row
+        // lane: output channel 16 nt + n, pixels 16 mt + 4 g + 0..3 of the row
         const int gx = x0 + 16 * mt + 4 * g;
         if (gy < H && gx < W) {
-            float o[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float t = acc[i];
-                o[i] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+            for (int nt = 0; nt < NT; ++nt) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = acc[nt][i];
+                    o[i] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+                }
+                const u32x2 pk = {M::pack2(o[0], o[1]), M::pack2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(y + ((img * COUT + 16 * nt + n) * H + gy) * (int64_t)W + gx) = pk;
             }
-            const u32x2 pk = {M::pack2(o[0], o[1]), M::pack2(o[2], o[3])};
-            *reinterpret_cast<u32x2*>(y + ((img * kCout + n) * H + gy) * (int64_t)W + gx) = pk;
         }
     }
 }
@@ -161,26 +173,36 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
 }  // namespace mvi
 
 extern "C" int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t dtype) {
-    return Cout == mvi::sc::kCout && Cin >= 1 && Cin <= 16 && W % 8 == 0 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+    return ((Cout == 16 && Cin >= 1 && Cin <= 16) || (Cout == 32 && Cin >= 1 && Cin <= 32)) && W % 8 == 0 &&
+           (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+template <typename T>
+static void stem_conv_launch(const void* x, const void* w, const float* bias, void* y, int64_t N, int Cin, int Cout, int H, int W, int silu,
+                             hipStream_t st) {
+    using namespace mvi::sc;
+    const unsigned gx = (unsigned)((W + kTW - 1) / kTW);
+    if (Cout == 32)
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 32, 32, 4>), dim3(gx, (unsigned)((H + 3) / 4), (unsigned)N), dim3(256), 0, st, (const T*)x, (const T*)w, bias,
+                           (T*)y, Cin, H, W, silu);
+    else if (Cin <= 8)
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 8, 16, 8>), dim3(gx, (unsigned)((H + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w, bias,
+                           (T*)y, Cin, H, W, silu);
+    else
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 16, 16, 8>), dim3(gx, (unsigned)((H + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w, bias,
+                           (T*)y, Cin, H, W, silu);
 }
 
 extern "C" int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout,
                                      int32_t H, int32_t W, int32_t fuse_silu, int32_t dtype, void* stream) {
     if (N < 0 || H <= 0 || W <= 0 || !mvi_stem_conv3x3_supported(Cin, Cout, W, dtype))
-        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs C_out = 16, C_in <= 16, W a multiple of 8, bf16 or f16");
+        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs (C_out = 16, C_in <= 16) or (C_out = 32, C_in <= 32), W a multiple of 8, bf16 or f16");
     if (N == 0) return MVI_OK;
     if (!x || !weight || !y) return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: NULL pointer");
-    if (((uintptr_t)x | (uintptr_t)y) % 16 || N > 65535 || (H + mvi::sc::kTH - 1) / mvi::sc::kTH > 65535)
-        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: x / y must be 16-byte aligned, N and H / 8 at most 65535");
-    using namespace mvi::sc;
-    const dim3 grid((unsigned)((W + kTW - 1) / kTW), (unsigned)((H + kTH - 1) / kTH), (unsigned)N), block(64 * kTH);
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight) % 16 || N > 65535 || (H + 3) / 4 > 65535)
+        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: x / y / weight must be 16-byte aligned, N and H / 4 at most 65535");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MVI_DT_BF16) {
-        if (Cin <= 8) hipLaunchKernelGGL((stem_conv3x3_kernel<__hip_bfloat16, 8>), grid, block, 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)weight, bias, (__hip_bfloat16*)y, Cin, H, W, fuse_silu);
-        else hipLaunchKernelGGL((stem_conv3x3_kernel<__hip_bfloat16, 16>), grid, block, 0, st, (const __hip_bfloat16*)x, (const __hip_bfloat16*)weight, bias, (__hip_bfloat16*)y, Cin, H, W, fuse_silu);
-    } else {
-        if (Cin <= 8) hipLaunchKernelGGL((stem_conv3x3_kernel<__half, 8>), grid, block, 0, st, (const __half*)x, (const __half*)weight, bias, (__half*)y, Cin, H, W, fuse_silu);
-        else hipLaunchKernelGGL((stem_conv3x3_kernel<__half, 16>), grid, block, 0, st, (const __half*)x, (const __half*)weight, bias, (__half*)y, Cin, H, W, fuse_silu);
-    }
+    if (dtype == MVI_DT_BF16) stem_conv_launch<__hip_bfloat16>(x, weight, bias, y, N, Cin, Cout, H, W, fuse_silu, st);
+    else stem_conv_launch<__half>(x, weight, bias, y, N, Cin, Cout, H, W, fuse_silu, st);
     return hipGetLastError() == hipSuccess ? MVI_OK : mvi::unet_fail(MVI_EHIP, "stem_conv3x3: kernel launch failed");
 }

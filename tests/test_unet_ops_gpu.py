@@ -441,15 +441,16 @@ def test_ff_geglu_fused_projection(ops, dtype, tol):
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
     """silu(conv2d(x, w, b, padding=1)) for 16 output channels and <= 16 input channels on the MFMA kernel of csrc/stem_conv.hip
-    (the first two layers of the ControlNet hint stem): against fp64 on the rounded inputs, 7 / 16 / 3 / 9 input channels (the
-    padded-channel forms of both instantiations), images whose height and width are not multiples of the 4 x 64 tile (borders,
+    (the stride-1 layers of the ControlNet hint stem at its two finest resolutions): against fp64 on the rounded inputs, 7 / 16 / 3 / 9
+    input channels into 16 and 32 / 20 into 32 (the padded-channel forms of the three instantiations), images whose height and width are not multiples of the 4 x 64 tile (borders,
     ragged last tiles), with and without bias / SiLU; the dispatcher's conditions."""
     g = torch.Generator().manual_seed(53)
-    for N, Cin, Hh, Ww, with_bias, silu in [(2, 7, 20, 128, True, True), (1, 16, 37, 72, True, True), (3, 3, 4, 64, False, True),
-                                            (1, 9, 9, 200, True, False), (2, 16, 64, 64, True, True)]:
+    for N, Cin, Cout, Hh, Ww, with_bias, silu in [(2, 7, 16, 20, 128, True, True), (1, 16, 16, 37, 72, True, True), (3, 3, 16, 4, 64, False, True),
+                                                  (1, 9, 16, 9, 200, True, False), (2, 16, 16, 64, 64, True, True), (2, 32, 32, 19, 136, True, True),
+                                                  (1, 20, 32, 8, 64, False, True)]:
         x = torch.randn(N, Cin, Hh, Ww, generator=g).to(dtype)
-        w = (torch.randn(16, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dtype)
-        b = (torch.randn(16, generator=g) * 0.3).to(dtype) if with_bias else None
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dtype)
+        b = (torch.randn(Cout, generator=g) * 0.3).to(dtype) if with_bias else None
         ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
         ref = F.silu(ref) if silu else ref
         y = ops.stem_conv3x3_silu(x.cuda(), w.cuda(), None if b is None else b.cuda(), silu=silu)
@@ -459,7 +460,8 @@ def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
     xs = torch.randn(1, 7, 8, 64, generator=g).to(dtype).cuda()
     assert ops.stem_conv3x3_supported(conv, xs)
     assert not ops.stem_conv3x3_supported(conv, xs[:, :, :, :60].contiguous())           # width not a multiple of 8
-    assert not ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 32, 3, padding=1).to(dtype).cuda(), xs)
+    assert ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 32, 3, padding=1).to(dtype).cuda(), xs)
+    assert not ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 48, 3, padding=1).to(dtype).cuda(), xs)
     assert not ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 16, 3, padding=1, stride=2).to(dtype).cuda(), xs)
     assert not ops.stem_conv3x3_supported(conv, xs.float())
 
