@@ -144,10 +144,11 @@ int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* 
  * at its two finest resolutions
  * (models/csvd.py:234-250: conv(7 -> 16) SiLU conv(16 -> 16) SiLU at the hint's 576 x 1024), which the library's wide-channel
  * kernels run 5x off their memory time. x [N, C_in, H, W], weight [C_out, C_in, 3, 3] in the activation type, bias fp32 [C_out] or
- * NULL, y [N, C_out, H, W]; W a multiple of 8, x / y 16-byte aligned; fuse_silu != 0 applies SiLU. */
-int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t dtype);
+ * NULL, y [N, C_out, H_out, W_out]; W a multiple of 8, x / y 16-byte aligned; fuse_silu != 0 applies SiLU. stride 2 (H_out =
+ * (H - 1) / 2 + 1, likewise W_out; W a multiple of 16) is built for the 16 -> 32 layer that halves the hint's resolution. */
+int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t stride, int32_t dtype);
 int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout, int32_t H,
-                          int32_t W, int32_t fuse_silu, int32_t dtype, void* stream);
+                          int32_t W, int32_t stride, int32_t fuse_silu, int32_t dtype, void* stream);
 
 /* out[n, c, p] = h[n, c, p] + bias[c] + x[n, c, p] over [N, C, spatial] activations in one pass; x and bias are
  * optional (NULL). Folds a convolution's bias (PyTorch-ROCm adds it in a separate kernel) and the ResBlock skip

@@ -34,7 +34,6 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 constexpr int kTW = 64;                // tile width in pixels
 constexpr int kTHMax = 8;              // tile rows = waves: 8 for the 16-output forms, 4 for the 32-output form (registers, LDS)
-constexpr int kPW = kTW + 2;
 
 template <typename T> struct Mma;
 template <> struct Mma<__hip_bfloat16> {
@@ -57,15 +56,17 @@ template <> struct Mma<__half> {
 };
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
-template <typename T, int CINP, int COUT, int kTH>
+template <typename T, int CINP, int COUT, int kTH, int STRIDE>
 __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
-                                                                T* __restrict__ y, int Cin, int H, int W, int silu) {
+                                                                T* __restrict__ y, int Cin, int H, int W, int Ho, int Wo, int silu) {
     using M = Mma<T>;
     using frag = typename M::frag;
     constexpr int kTapsPerStep = 32 / CINP;                       // 1 (32 channels), 2 (16) or 4 (8)
     constexpr int kSteps = (9 + kTapsPerStep - 1) / kTapsPerStep; // 9, 5 or 3
     constexpr int NT = COUT / 16;                                 // output-channel tiles of 16
-    constexpr int kPH = kTH + 2;
+    constexpr int kPH = STRIDE * (kTH - 1) + 3;                   // input rows / columns a tile of kTH x kTW outputs reads
+    constexpr int kPW = STRIDE * kTW + 2;                         // (stride 2: 129 used, the interior is filled in whole 8-pixel pieces)
+    constexpr int kInt = STRIDE * kTW / 8;                        // 8-pixel pieces of the patch interior per row
     // LDS patch, pixel-major with 16 bytes of padding after every 8 pixels (keeps the 16-byte alignment of the fragment reads and
     // spreads the 8-pixel pieces a wave writes at once over the banks)
     constexpr int kPixB = CINP * 2;                                             // bytes per pixel
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     __shared__ __attribute__((aligned(16))) char s_in[kPH * kRowB];
     auto pix_off = [](int q) { return q * kPixB + (q >> 3) * 16; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;      // output coordinates of the tile
+    const int ix0 = STRIDE * x0, iy0 = STRIDE * y0 - 1;           // input column of patch column 1, input row of patch row 0
     const int64_t img = blockIdx.z;
     const uint16_t* xin = reinterpret_cast<const uint16_t*>(x) + img * Cin * (int64_t)H * W;
 
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     // consecutive lanes take consecutive pairs of the same pixels, i.e. consecutive LDS words. The two halo columns one element at a
     // time; everything outside the image, and the padding channels, is zero
     constexpr int kPairs = CINP / 2;
-    for (int i = tid; i < kPairs * (kTW / 8) * kPH; i += 64 * kTH) {
-        const int cp = i % kPairs, ch8 = (i / kPairs) % (kTW / 8), r = i / (kPairs * (kTW / 8));
-        const int gy = y0 + r - 1, gx = x0 + 8 * ch8;
+    for (int i = tid; i < kPairs * kInt * kPH; i += 64 * kTH) {
+        const int cp = i % kPairs, ch8 = (i / kPairs) % kInt, r = i / (kPairs * kInt);
+        const int gy = iy0 + r, gx = ix0 + 8 * ch8;
         u32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
         if (gy >= 0 && gy < H && gx < W) {
             if (2 * cp < Cin) v0 = *reinterpret_cast<const u32x4*>(xin + ((int64_t)(2 * cp) * H + gy) * W + gx);
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     }
     for (int i = tid; i < CINP * kPH * 2; i += 64 * kTH) {
         const int c = i % CINP, side = (i / CINP) & 1, r = i / (2 * CINP);
-        const int gy = y0 + r - 1, gx = side ? x0 + kTW : x0 - 1;
+        const int gy = iy0 + r, gx = side ? ix0 + STRIDE * kTW : ix0 - 1;
         uint16_t v = 0;
         if (c < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xin[((int64_t)c * H + gy) * W + gx];
-        *reinterpret_cast<uint16_t*>(s_in + r * kRowB + pix_off(side ? kTW + 1 : 0) + 2 * c) = v;
+        *reinterpret_cast<uint16_t*>(s_in + r * kRowB + pix_off(side ? STRIDE * kTW + 1 : 0) + 2 * c) = v;
     }
 
     // ---- weights: B operand. Lane (n = lane & 15, g = lane >> 4), k-step s, element j: tap = kTapsPerStep s + g / (CINP / 8),
@@ -147,13 +149,13 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
             int tap = kTapsPerStep * s + g / (CINP / 8);
             tap = tap < 9 ? tap : 0;                              // (its weights are zero: any finite operand will do)
             const int dy = tap / 3, dx = tap % 3;
-            const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + (row + dy) * kRowB + pix_off(16 * mt + m + dx) + 16 * (g % (CINP / 8)));
+            const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + (STRIDE * row + dy) * kRowB + pix_off(STRIDE * (16 * mt + m) + dx) + 16 * (g % (CINP / 8)));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = M::mfma(as_frag<frag>(a), as_frag<frag>(wf[nt][s]), acc[nt]);
         }
         // lane: output channel 16 nt + n, pixels 16 mt + 4 g + 0..3 of the row
         const int gx = x0 + 16 * mt + 4 * g;
-        if (gy < H && gx < W) {
+        if (gy < Ho && gx < Wo) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float o[4];
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
                     o[i] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
                 }
                 const u32x2 pk = {M::pack2(o[0], o[1]), M::pack2(o[2], o[3])};
-                *reinterpret_cast<u32x2*>(y + ((img * COUT + 16 * nt + n) * H + gy) * (int64_t)W + gx) = pk;
+                *reinterpret_cast<u32x2*>(y + ((img * COUT + 16 * nt + n) * Ho + gy) * (int64_t)Wo + gx) = pk;
             }
         }
     }
@@ -172,37 +174,44 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
 }  // namespace sc
 }  // namespace mvi
 
-extern "C" int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t dtype) {
-    return ((Cout == 16 && Cin >= 1 && Cin <= 16) || (Cout == 32 && Cin >= 1 && Cin <= 32)) && W % 8 == 0 &&
-           (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+extern "C" int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t stride, int32_t dtype) {
+    if (!(dtype == MVI_DT_BF16 || dtype == MVI_DT_F16) || Cin < 1) return 0;
+    if (stride == 1) return ((Cout == 16 && Cin <= 16) || (Cout == 32 && Cin <= 32)) && W % 8 == 0;
+    if (stride == 2) return Cout == 32 && Cin <= 16 && W % 16 == 0;             // (the output rows are stored in 8-byte pieces too)
+    return 0;
 }
 
 template <typename T>
-static void stem_conv_launch(const void* x, const void* w, const float* bias, void* y, int64_t N, int Cin, int Cout, int H, int W, int silu,
-                             hipStream_t st) {
+static void stem_conv_launch(const void* x, const void* w, const float* bias, void* y, int64_t N, int Cin, int Cout, int H, int W, int stride,
+                             int silu, hipStream_t st) {
     using namespace mvi::sc;
-    const unsigned gx = (unsigned)((W + kTW - 1) / kTW);
-    if (Cout == 32)
-        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 32, 32, 4>), dim3(gx, (unsigned)((H + 3) / 4), (unsigned)N), dim3(256), 0, st, (const T*)x, (const T*)w, bias,
-                           (T*)y, Cin, H, W, silu);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const unsigned gx = (unsigned)((Wo + kTW - 1) / kTW);
+    if (stride == 2)
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 16, 32, 4, 2>), dim3(gx, (unsigned)((Ho + 3) / 4), (unsigned)N), dim3(256), 0, st, (const T*)x, (const T*)w,
+                           bias, (T*)y, Cin, H, W, Ho, Wo, silu);
+    else if (Cout == 32)
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 32, 32, 4, 1>), dim3(gx, (unsigned)((Ho + 3) / 4), (unsigned)N), dim3(256), 0, st, (const T*)x, (const T*)w,
+                           bias, (T*)y, Cin, H, W, Ho, Wo, silu);
     else if (Cin <= 8)
-        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 8, 16, 8>), dim3(gx, (unsigned)((H + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w, bias,
-                           (T*)y, Cin, H, W, silu);
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 8, 16, 8, 1>), dim3(gx, (unsigned)((Ho + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w,
+                           bias, (T*)y, Cin, H, W, Ho, Wo, silu);
     else
-        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 16, 16, 8>), dim3(gx, (unsigned)((H + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w, bias,
-                           (T*)y, Cin, H, W, silu);
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 16, 16, 8, 1>), dim3(gx, (unsigned)((Ho + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w,
+                           bias, (T*)y, Cin, H, W, Ho, Wo, silu);
 }
 
 extern "C" int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout,
-                                     int32_t H, int32_t W, int32_t fuse_silu, int32_t dtype, void* stream) {
-    if (N < 0 || H <= 0 || W <= 0 || !mvi_stem_conv3x3_supported(Cin, Cout, W, dtype))
-        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs (C_out = 16, C_in <= 16) or (C_out = 32, C_in <= 32), W a multiple of 8, bf16 or f16");
+                                     int32_t H, int32_t W, int32_t stride, int32_t fuse_silu, int32_t dtype, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || !mvi_stem_conv3x3_supported(Cin, Cout, W, stride, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs stride 1 with (C_out 16, C_in <= 16) or (C_out 32, C_in <= 32) and W % 8 == 0, or stride 2 with "
+                                          "C_out 32, C_in <= 16 and W % 16 == 0; bf16 or f16");
     if (N == 0) return MVI_OK;
     if (!x || !weight || !y) return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: NULL pointer");
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight) % 16 || N > 65535 || (H + 3) / 4 > 65535)
         return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: x / y / weight must be 16-byte aligned, N and H / 4 at most 65535");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MVI_DT_BF16) stem_conv_launch<__hip_bfloat16>(x, weight, bias, y, N, Cin, Cout, H, W, fuse_silu, st);
-    else stem_conv_launch<__half>(x, weight, bias, y, N, Cin, Cout, H, W, fuse_silu, st);
+    if (dtype == MVI_DT_BF16) stem_conv_launch<__hip_bfloat16>(x, weight, bias, y, N, Cin, Cout, H, W, stride, fuse_silu, st);
+    else stem_conv_launch<__half>(x, weight, bias, y, N, Cin, Cout, H, W, stride, fuse_silu, st);
     return hipGetLastError() == hipSuccess ? MVI_OK : mvi::unet_fail(MVI_EHIP, "stem_conv3x3: kernel launch failed");
 }

@@ -347,23 +347,25 @@ def linear_n320(x, weight, bias):
 
 
 def stem_conv3x3_supported(conv, x):
-    """A 3x3 / stride 1 / padding 1 Conv2d with 16 outputs and <= 16 inputs on a contiguous NCHW half tensor (csrc/stem_conv.hip)."""
+    """A 3x3 / padding 1 Conv2d of the shapes csrc/stem_conv.hip builds (stride 1: <= 16 -> 16, <= 32 -> 32; stride 2: <= 16 -> 32) on a
+    contiguous NCHW half tensor."""
     return (x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous() and conv.weight.dtype == x.dtype
-            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) in ((1, 1), (2, 2)) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
-            and bool(_lib.lib().mvi_stem_conv3x3_supported(int(conv.in_channels), int(conv.out_channels), int(x.shape[3]), _DT[x.dtype])))
+            and bool(_lib.lib().mvi_stem_conv3x3_supported(int(conv.in_channels), int(conv.out_channels), int(x.shape[3]), int(conv.stride[0]),
+                                                           _DT[x.dtype])))
 
 
-def stem_conv3x3_silu(x, weight, bias, silu=True):
-    """silu(conv2d(x, weight, bias, padding=1)) in one kernel; x [N, C_in <= 16, H, W], weight [16, C_in, 3, 3]."""
+def stem_conv3x3_silu(x, weight, bias, silu=True, stride=1):
+    """silu(conv2d(x, weight, bias, stride, padding=1)) in one kernel; x [N, C_in, H, W], weight [C_out, C_in, 3, 3]."""
     L = _lib.lib()
     N, Cin, H, W = x.shape
     wc = weight if weight.is_contiguous() else weight.contiguous()
     b = None if bias is None else _f32(bias)
-    y = torch.empty(N, weight.shape[0], H, W, dtype=x.dtype, device=x.device)
+    y = torch.empty(N, weight.shape[0], (H - 1) // stride + 1, (W - 1) // stride + 1, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device), _Timed("stem_conv", float(x.numel() + y.numel()) * x.element_size(), x.device):
         _check(L.mvi_stem_conv3x3_silu(x.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), N, Cin,
-                                       weight.shape[0], H, W, int(bool(silu)), _DT[x.dtype], _stream(x.device)), "stem_conv3x3_silu")
+                                       weight.shape[0], H, W, int(stride), int(bool(silu)), _DT[x.dtype], _stream(x.device)), "stem_conv3x3_silu")
     return y
 
 

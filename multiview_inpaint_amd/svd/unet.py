@@ -232,7 +232,7 @@ class ControlNet(_Encoder):
             conv = layers_[i]
             if i + 1 < len(layers_) and isinstance(layers_[i + 1], nn.SiLU):
                 if STEM_CONV and hip_ops.stem_conv3x3_supported(conv, h):
-                    h = hip_ops.stem_conv3x3_silu(h, conv.weight, conv.bias)      # the two 16-channel layers at the hint's resolution
+                    h = hip_ops.stem_conv3x3_silu(h, conv.weight, conv.bias, stride=conv.stride[0])   # the 16- / 32-channel layers of the stem
                 else:
                     h = ops.bias_silu(conv_no_bias(conv, h), conv.bias)
                 i += 2

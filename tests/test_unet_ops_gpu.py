@@ -456,6 +456,14 @@ def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
         y = ops.stem_conv3x3_silu(x.cuda(), w.cuda(), None if b is None else b.cuda(), silu=silu)
         assert y.shape == ref.shape and y.dtype == dtype
         assert rel(y, ref) < tol
+    for N, Cin, Hh, Ww in [(2, 16, 20, 128), (1, 5, 37, 80), (1, 16, 7, 16), (2, 12, 64, 256)]:          # stride 2, <= 16 -> 32: odd heights, ragged tiles
+        x = torch.randn(N, Cin, Hh, Ww, generator=g).to(dtype)
+        w = (torch.randn(32, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dtype)
+        b = (torch.randn(32, generator=g) * 0.3).to(dtype)
+        ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+        y = ops.stem_conv3x3_silu(x.cuda(), w.cuda(), b.cuda(), silu=True, stride=2)
+        assert y.shape == ref.shape and y.dtype == dtype
+        assert rel(y, ref) < tol
     conv = torch.nn.Conv2d(7, 16, 3, padding=1).to(dtype).cuda()
     xs = torch.randn(1, 7, 8, 64, generator=g).to(dtype).cuda()
     assert ops.stem_conv3x3_supported(conv, xs)
@@ -463,6 +471,7 @@ def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
     assert ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 32, 3, padding=1).to(dtype).cuda(), xs)
     assert not ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 48, 3, padding=1).to(dtype).cuda(), xs)
     assert not ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 16, 3, padding=1, stride=2).to(dtype).cuda(), xs)
+    assert ops.stem_conv3x3_supported(torch.nn.Conv2d(7, 32, 3, padding=1, stride=2).to(dtype).cuda(), xs)
     assert not ops.stem_conv3x3_supported(conv, xs.float())
 
 

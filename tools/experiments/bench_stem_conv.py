@@ -13,14 +13,14 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / n
-for Cin, Cout, Hh, Ww in ((7, 16, 576, 1024), (16, 16, 576, 1024), (32, 32, 288, 512)):
+for Cin, Cout, Hh, Ww, st in ((7, 16, 576, 1024, 1), (16, 16, 576, 1024, 1), (16, 32, 576, 1024, 2), (32, 32, 288, 512, 1)):
     x = torch.randn(28, Cin, Hh, Ww, device="cuda", generator=g).bfloat16()
     w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * (9 * Cin) ** -0.5).bfloat16()
     b = (torch.randn(Cout, device="cuda", generator=g) * 0.3).bfloat16()
-    y = hip_ops.stem_conv3x3_silu(x, w, b)
-    ref = F.silu(F.conv2d(x, w, b, padding=1))
+    y = hip_ops.stem_conv3x3_silu(x, w, b, stride=st)
+    ref = F.silu(F.conv2d(x, w, b, stride=st, padding=1))
     err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
-    ms_k = t(lambda: hip_ops.stem_conv3x3_silu(x, w, b))
-    ms_l = t(lambda: hip_ops.bias_silu(F.conv2d(x, w, None, padding=1), b))
+    ms_k = t(lambda: hip_ops.stem_conv3x3_silu(x, w, b, stride=st))
+    ms_l = t(lambda: hip_ops.bias_silu(F.conv2d(x, w, None, stride=st, padding=1), b))
     gb = (x.numel() + y.numel()) * 2 / 1e9
-    print(f"C_in {Cin:2d} -> {Cout} @ 28 x {Hh} x {Ww}: kernel {ms_k * 1e3:7.1f} us ({gb / ms_k * 1e3:5.0f} GB/s)   library conv + bias_silu {ms_l * 1e3:7.1f} us   max |diff| / max {err:.2e}", flush=True)
+    print(f"C_in {Cin:2d} -> {Cout} stride {st} @ 28 x {Hh} x {Ww}: kernel {ms_k * 1e3:7.1f} us ({gb / ms_k * 1e3:5.0f} GB/s)   library conv + bias_silu {ms_l * 1e3:7.1f} us   max |diff| / max {err:.2e}", flush=True)
