@@ -124,12 +124,25 @@ class AlphaBlender(nn.Module):
         else:
             self.register_parameter("mix_factor", nn.Parameter(torch.tensor([float(alpha)])))
 
-    def get_alpha(self, image_only_indicator):
+    def get_alpha(self, image_only_indicator, rows=None):
+        """`rows`: the batch the blend is applied to (videos, i.e. leading size of the arranged alpha). When the indicator was built
+        before the batch was doubled for classifier-free guidance the reference repeats alpha (util.py:365-367); with `rows` given
+        that repeat happens here, once per indicator, instead of as a small concatenation in every block of every step."""
         if self.merge_strategy == "fixed":
             return self.mix_factor
         if self.merge_strategy == "learned":
             return torch.sigmoid(self.mix_factor)
         assert image_only_indicator is not None, "need image_only_indicator ..."
+        if rows is not None:
+            a = self.get_alpha(image_only_indicator)
+            if a.size(0) == rows or torch.is_grad_enabled():
+                return a if a.size(0) == rows else torch.cat([a] * 2)
+            hit = self.__dict__.get("_alpha2_cache")
+            if hit is not None and hit[0] is a:
+                return hit[1]
+            a2 = torch.cat([a] * 2)
+            self.__dict__["_alpha2_cache"] = (a, a2)                 # keyed on the cached single-batch alpha object itself
+            return a2
         # five tiny kernels per call and ~55 calls per denoise step: without a graph being recorded the result is kept until
         # the indicator or the mix factor changes (storage address + in-place version counters; the cache holds the
         # indicator it was computed from, so that address cannot be handed to another tensor meanwhile)
@@ -157,8 +170,8 @@ class AlphaBlender(nn.Module):
 
     def forward(self, x_spatial, x_temporal, image_only_indicator=None):
         a = self.get_alpha(image_only_indicator)
-        if a.size(0) != x_spatial.size(0):
-            a = torch.cat([a] * 2)
+        if a.numel() > 1 and a.size(0) != x_spatial.size(0):
+            a = self.get_alpha(image_only_indicator, rows=x_spatial.size(0))
         # alpha * spatial + (1 - alpha) * temporal as ONE pass: temporal + alpha * (spatial - temporal)
         return torch.lerp(x_temporal, x_spatial, a.to(x_spatial.dtype))
 
@@ -574,7 +587,7 @@ class VideoResBlock(ResBlock):
             a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)
             if a.ndim == 5:
                 if a.size(0) != bt // t:
-                    a = torch.cat([a] * 2)                                 # CFG-doubled batch (util.py:365-367)
+                    a = self.time_mixer.get_alpha(image_only_indicator, rows=bt // t)   # CFG-doubled batch (util.py:365-367)
                 return self._time_stack_frames(x, emb, t, blend=a.reshape(bt))    # (b, t) order = frame-major rows
             xt = self._time_stack_frames(x, emb, t)
             return torch.lerp(xt, x, a.to(x.dtype))

@@ -371,7 +371,7 @@ class SpatialVideoTransformer(SpatialTransformer):
                 if alpha is None:
                     alpha = self.time_mixer.get_alpha(image_only_indicator)
                     if alpha.numel() > 1 and alpha.size(0) != t.size(0):
-                        alpha = torch.cat([alpha] * 2)                      # the reference's CFG patch (util.py:365-367)
+                        alpha = self.time_mixer.get_alpha(image_only_indicator, rows=t.size(0))   # the reference's CFG patch (util.py:365-367)
                     alpha = alpha.reshape(-1).to(t.dtype)
                 # alpha * spatial + (1 - alpha) * (f + x_t), with the temporal block's last residual add inside
                 t = ops.add_lerp(f if x_t is None else x_t, None if x_t is None else f, x_spatial, alpha)
