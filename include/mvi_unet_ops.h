@@ -140,7 +140,7 @@ int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* 
                     int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
 
 /* y = act(conv2d(x, weight, padding = 1) + bias) for a 3x3, stride-1 convolution with 16 output channels and at most 16 input
- * channels, or 32 and at most 32, on NCHW bf16 / f16 tensors (csrc/stem_conv.hip) — the stride-1 layers of ControlNet.input_hint_block
+ * channels, 32 and at most 32, or 320 and at most 8 (the networks' input convolution), on NCHW bf16 / f16 tensors (csrc/stem_conv.hip) — the stride-1 layers of ControlNet.input_hint_block
  * at its two finest resolutions
  * (models/csvd.py:234-250: conv(7 -> 16) SiLU conv(16 -> 16) SiLU at the hint's 576 x 1024), which the library's wide-channel
  * kernels run 5x off their memory time. x [N, C_in, H, W], weight [C_out, C_in, 3, 3] in the activation type, bias fp32 [C_out] or

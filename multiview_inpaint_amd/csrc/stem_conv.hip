@@ -117,55 +117,60 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
         for (int i = tid; i < n_vec; i += 64 * kTH) reinterpret_cast<u32x4*>(s_w)[i] = reinterpret_cast<const u32x4*>(w)[i];
     }
     const int n = lane & 15, g = lane >> 4;
-    float b[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = bias ? bias[16 * nt + n] : 0.f;
     __syncthreads();
-    u32x4 wf[NT][kSteps];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const uint16_t* wp = s_w + (16 * nt + n) * Cin * 9;
-#pragma unroll
-        for (int s = 0; s < kSteps; ++s) {
-            const int tap = kTapsPerStep * s + g / (CINP / 8), c0 = 8 * (g % (CINP / 8));
-            uint32_t e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = (tap < 9 && c0 + j < Cin) ? (uint32_t)wp[(c0 + j) * 9 + tap] : 0u;
-            wf[nt][s] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-        }
-    }
-
-    // ---- one output row per wave: four M-tiles of 16 pixels
-    const int row = wave;                                         // tile row; input rows row .. row + 2 of the patch
+    const int row = wave;                                         // tile row; input rows STRIDE row .. + 2 of the patch
     const int gy = y0 + row;
     const int m = lane & 15;
+    // The output channels in chunks of NTC tiles of 16 (all of them at once for 16 / 32 outputs; four at a time for the 320 outputs of
+    // the UNet / ControlNet input convolution, whose fragments would not fit the registers): per chunk the weight fragments are picked
+    // from LDS, then the wave's row is walked in four M-tiles of 16 pixels (the A fragments are re-read from LDS per chunk)
+    constexpr int NTC = NT < 4 ? NT : 4;
+    static_assert(NT % NTC == 0, "output tiles must divide into chunks");
+#pragma unroll 1
+    for (int nc = 0; nc < NT; nc += NTC) {
+        float b[NTC];
+        u32x4 wf[NTC][kSteps];
 #pragma unroll
-    for (int mt = 0; mt < kTW / 16; ++mt) {
-        f32x4 acc[NT];
+        for (int nt = 0; nt < NTC; ++nt) {
+            b[nt] = bias ? bias[16 * (nc + nt) + n] : 0.f;
+            const uint16_t* wp = s_w + (16 * (nc + nt) + n) * Cin * 9;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{b[nt], b[nt], b[nt], b[nt]};
+            for (int s = 0; s < kSteps; ++s) {
+                const int tap = kTapsPerStep * s + g / (CINP / 8), c0 = 8 * (g % (CINP / 8));
+                uint32_t e[8];
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) {
-            int tap = kTapsPerStep * s + g / (CINP / 8);
-            tap = tap < 9 ? tap : 0;                              // (its weights are zero: any finite operand will do)
-            const int dy = tap / 3, dx = tap % 3;
-            const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + (STRIDE * row + dy) * kRowB + pix_off(STRIDE * (16 * mt + m) + dx) + 16 * (g % (CINP / 8)));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = M::mfma(as_frag<frag>(a), as_frag<frag>(wf[nt][s]), acc[nt]);
+                for (int j = 0; j < 8; ++j) e[j] = (tap < 9 && c0 + j < Cin) ? (uint32_t)wp[(c0 + j) * 9 + tap] : 0u;
+                wf[nt][s] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+            }
         }
-        // lane: output channel 16 nt + n, pixels 16 mt + 4 g + 0..3 of the row
-        const int gx = x0 + 16 * mt + 4 * g;
-        if (gy < Ho && gx < Wo) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float o[4];
+        for (int mt = 0; mt < kTW / 16; ++mt) {
+            f32x4 acc[NTC];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = acc[nt][i];
-                    o[i] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+            for (int nt = 0; nt < NTC; ++nt) acc[nt] = f32x4{b[nt], b[nt], b[nt], b[nt]};
+#pragma unroll
+            for (int s = 0; s < kSteps; ++s) {
+                int tap = kTapsPerStep * s + g / (CINP / 8);
+                tap = tap < 9 ? tap : 0;                          // (its weights are zero: any finite operand will do)
+                const int dy = tap / 3, dx = tap % 3;
+                const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + (STRIDE * row + dy) * kRowB + pix_off(STRIDE * (16 * mt + m) + dx) + 16 * (g % (CINP / 8)));
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) acc[nt] = M::mfma(as_frag<frag>(a), as_frag<frag>(wf[nt][s]), acc[nt]);
+            }
+            // lane: output channel 16 (nc + nt) + n, pixels 16 mt + 4 g + 0..3 of the row
+            const int gx = x0 + 16 * mt + 4 * g;
+            if (gy < Ho && gx < Wo) {
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = acc[nt][i];
+                        o[i] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)) : t;
+                    }
+                    const u32x2 pk = {M::pack2(o[0], o[1]), M::pack2(o[2], o[3])};
+                    *reinterpret_cast<u32x2*>(y + ((img * COUT + 16 * (nc + nt) + n) * Ho + gy) * (int64_t)Wo + gx) = pk;
                 }
-                const u32x2 pk = {M::pack2(o[0], o[1]), M::pack2(o[2], o[3])};
-                *reinterpret_cast<u32x2*>(y + ((img * COUT + 16 * nt + n) * Ho + gy) * (int64_t)Wo + gx) = pk;
             }
         }
     }
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
 
 extern "C" int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t stride, int32_t dtype) {
     if (!(dtype == MVI_DT_BF16 || dtype == MVI_DT_F16) || Cin < 1) return 0;
-    if (stride == 1) return ((Cout == 16 && Cin <= 16) || (Cout == 32 && Cin <= 32)) && W % 8 == 0;
+    if (stride == 1) return ((Cout == 16 && Cin <= 16) || (Cout == 32 && Cin <= 32) || (Cout == 320 && Cin <= 8)) && W % 8 == 0;
     if (stride == 2) return Cout == 32 && Cin <= 16 && W % 16 == 0;             // (the output rows are stored in 8-byte pieces too)
     return 0;
 }
@@ -187,7 +192,10 @@ static void stem_conv_launch(const void* x, const void* w, const float* bias, vo
     using namespace mvi::sc;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const unsigned gx = (unsigned)((Wo + kTW - 1) / kTW);
-    if (stride == 2)
+    if (Cout == 320)
+        hipLaunchKernelGGL((stem_conv3x3_kernel<T, 8, 320, 8, 1>), dim3(gx, (unsigned)((Ho + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w,
+                           bias, (T*)y, Cin, H, W, Ho, Wo, silu);
+    else if (stride == 2)
         hipLaunchKernelGGL((stem_conv3x3_kernel<T, 16, 32, 4, 2>), dim3(gx, (unsigned)((Ho + 3) / 4), (unsigned)N), dim3(256), 0, st, (const T*)x, (const T*)w,
                            bias, (T*)y, Cin, H, W, Ho, Wo, silu);
     else if (Cout == 32)
@@ -204,7 +212,7 @@ static void stem_conv_launch(const void* x, const void* w, const float* bias, vo
 extern "C" int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout,
                                      int32_t H, int32_t W, int32_t stride, int32_t fuse_silu, int32_t dtype, void* stream) {
     if (N < 0 || H <= 0 || W <= 0 || !mvi_stem_conv3x3_supported(Cin, Cout, W, stride, dtype))
-        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs stride 1 with (C_out 16, C_in <= 16) or (C_out 32, C_in <= 32) and W % 8 == 0, or stride 2 with "
+        return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: needs stride 1 with (C_out 16, C_in <= 16), (C_out 32, C_in <= 32) or (C_out 320, C_in <= 8) and W % 8 == 0, or stride 2 with "
                                           "C_out 32, C_in <= 16 and W % 16 == 0; bf16 or f16");
     if (N == 0) return MVI_OK;
     if (!x || !weight || !y) return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3: NULL pointer");

@@ -24,6 +24,18 @@ from . import ops
 STEM_CONV = os.environ.get("MVI_SVD_STEM_CONV", "1") != "0"     # csrc/stem_conv.hip for the 16-channel layers of the hint stem
 
 
+def _input_conv(blk, x):
+    """input_blocks[0] = TimestepEmbedSequential(conv 3x3, in_channels -> model_channels) (openaimodel.py / video_model.py): with
+    8 input channels and 320 outputs in reduced precision on the GPU it is the small-channel MFMA kernel of csrc/stem_conv.hip with
+    the bias fused (the library needs 0.18 ms + a 0.11 ms bias pass for a 165 MB output); anything else is the module as it is."""
+    if STEM_CONV and len(blk) == 1 and type(blk[0]) is nn.Conv2d and x.is_cuda and not torch.is_grad_enabled():
+        from . import hip_ops
+        conv = blk[0]
+        if hip_ops.stem_conv3x3_supported(conv, x):
+            return hip_ops.stem_conv3x3_silu(x, conv.weight, conv.bias, silu=False, stride=conv.stride[0])
+    return blk(x, None)
+
+
 class _Encoder(nn.Module):
     """Everything VideoUNet and ControlNet have in common up to and including the middle block."""
 
@@ -170,7 +182,7 @@ class VideoUNet(_Encoder):
                   num_video_frames=num_video_frames)
         hs, h = [], x
         for blk in self.input_blocks:
-            h = blk(h, emb, **kw)
+            h = _input_conv(blk, h) if blk is self.input_blocks[0] else blk(h, emb, **kw)
             hs.append(h)
         h = self.middle_block(h, emb, **kw)
         if callable(control):
@@ -280,7 +292,7 @@ class ControlNet(_Encoder):
         guided = self._hint_stem_cached(hint, emb, context)
         outs, h = [], x
         for blk, zc in zip(self.input_blocks, self.zero_convs):
-            h = blk(h, emb, **kw)
+            h = _input_conv(blk, h) if blk is self.input_blocks[0] else blk(h, emb, **kw)
             if guided is not None:
                 h = h + guided                              # added once, after the first input block (:471-473)
                 guided = None

@@ -446,7 +446,7 @@ def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
     ragged last tiles), with and without bias / SiLU; the dispatcher's conditions."""
     g = torch.Generator().manual_seed(53)
     for N, Cin, Cout, Hh, Ww, with_bias, silu in [(2, 7, 16, 20, 128, True, True), (1, 16, 16, 37, 72, True, True), (3, 3, 16, 4, 64, False, True),
-                                                  (1, 9, 16, 9, 200, True, False), (2, 16, 16, 64, 64, True, True), (2, 32, 32, 19, 136, True, True),
+                                                  (1, 9, 16, 9, 200, True, False), (2, 16, 16, 64, 64, True, True), (2, 32, 32, 19, 136, True, True), (2, 8, 320, 18, 72, True, False), (1, 4, 320, 9, 64, False, False),
                                                   (1, 20, 32, 8, 64, False, True)]:
         x = torch.randn(N, Cin, Hh, Ww, generator=g).to(dtype)
         w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dtype)

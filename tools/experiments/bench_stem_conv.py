@@ -13,7 +13,7 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / n
-for Cin, Cout, Hh, Ww, st in ((7, 16, 576, 1024, 1), (16, 16, 576, 1024, 1), (16, 32, 576, 1024, 2), (32, 32, 288, 512, 1)):
+for Cin, Cout, Hh, Ww, st in ((7, 16, 576, 1024, 1), (16, 16, 576, 1024, 1), (16, 32, 576, 1024, 2), (32, 32, 288, 512, 1), (8, 320, 72, 128, 1)):
     x = torch.randn(28, Cin, Hh, Ww, device="cuda", generator=g).bfloat16()
     w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * (9 * Cin) ** -0.5).bfloat16()
     b = (torch.randn(Cout, device="cuda", generator=g) * 0.3).bfloat16()
