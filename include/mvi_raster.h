@@ -205,6 +205,17 @@ int mvi_raster_timing_enable_stages(uint32_t stage_mask);
 int mvi_raster_timing_read(float* ms_sum_host, int32_t* calls_host);
 const char* mvi_raster_stage_name(int stage);
 
+/* Binning implementation: 2 (default) = the rectangle-expanding partition of csrc/raster_binning2.hip, used for tile grids of
+ * at most 256 x 256 tiles; 1 = the pair-emitting radix partition of csrc/raster_binning.hip (always used above that size,
+ * or when MVI_BINNING_LEGACY=1). Both produce the same point list, tile ids and ranges bit for bit; the switch exists for
+ * the A/B parity test and A/B timing. Pass 1 or 2 to select, anything else to query; returns the previous selection. Must
+ * not change between a forward and its backward (the scratch layouts differ). Not thread-safe. */
+int mvi_raster_binning_version(int version);
+/* Diagnostics for kernel work (tools/expand_stamps.py), inert unless set: while device_buffer is non-NULL, every block of the
+ * binning partition kernel of `pass` (1 | 2) writes 8 shader-clock stamps (uint64) at its phase boundaries into
+ * device_buffer[block][8]. The caller sizes the buffer for the launch grid (mvi_raster_binning_bytes / 8 is ample). */
+int mvi_raster_dev_stamps(int pass, void* device_buffer);
+
 const char* mvi_raster_last_error(void);
 const char* mvi_version(void);
 

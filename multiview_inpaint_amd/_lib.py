@@ -120,6 +120,10 @@ def lib():
     L.mvi_raster_timing_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.mvi_raster_stage_name.restype = C.c_char_p
     L.mvi_raster_stage_name.argtypes = [C.c_int]
+    L.mvi_raster_binning_version.restype = C.c_int
+    L.mvi_raster_binning_version.argtypes = [C.c_int]
+    L.mvi_raster_dev_stamps.restype = C.c_int
+    L.mvi_raster_dev_stamps.argtypes = [C.c_int, vp]
     _bind_unet_ops(L)
     _bind_train_ops(L)
     _lib = L

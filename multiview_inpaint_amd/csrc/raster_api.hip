@@ -14,6 +14,9 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 }
 
 static thread_local char g_err[512] = "";
+// column segments of the last forward_geom of this thread (binning version 2): a sizing hint for the launches of the
+// forward_render that follows on the same scratch; any other forward_render falls back to the bound num_rendered
+static thread_local struct { const void* geom = nullptr; int32_t P = 0; int64_t segments = 0; } g_last_segments;
 
 // ---- stage timing ------------------------------------------------------------------------------
 #include <vector>
@@ -66,6 +69,7 @@ static int make_frame(const mvi_raster_settings* s, int P, int M, mvi::Frame& f)
     f.fy = (float)f.H / (2.0f * s->tanfovy);
     f.scale_modifier = s->scale_modifier;
     f.view = s->viewmatrix; f.proj = s->projmatrix; f.campos = s->campos; f.bg = s->bg;
+    f.bin_v2 = mvi::binning_v2_ok(f.gx, f.gy) ? 1 : 0;
     return MVI_OK;
 }
 
@@ -95,6 +99,8 @@ const char* mvi_raster_stage_name(int i) {
                                                 "tile_ranges", "render_forward", "render_backward", "preprocess_backward"};
     return (i >= 0 && i < MVI_RASTER_NSTAGES) ? n[i] : "";
 }
+int mvi_raster_dev_stamps(int pass, void* device_buffer) { mvi::set_dev_stamps(pass, device_buffer); return MVI_OK; }
+int mvi_raster_binning_version(int version) { return mvi::set_binning_version(version); }
 const char* mvi_version(void) { return "multiview_inpaint_amd 0.1.0 (gfx950)"; }
 
 size_t mvi_raster_geom_bytes(int32_t P) { return mvi::carve_geom(nullptr, P).bytes; }
@@ -172,7 +178,7 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     Readback& rb = readbacks[device];
     if (!rb.host) {
         unsigned long long* h = nullptr;
-        if ((e = hipHostMalloc((void**)&h, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess) return hip_fail("hipHostMalloc", e);
+        if ((e = hipHostMalloc((void**)&h, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess) return hip_fail("hipHostMalloc", e);
         if ((e = hipHostGetDevicePointer((void**)&rb.dev, h, 0)) != hipSuccess) { (void)hipHostFree(h); return hip_fail("hipHostGetDevicePointer", e); }
         if ((e = hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming)) != hipSuccess) { (void)hipHostFree(h); return hip_fail("hipEventCreate", e); }
         rb.host = h;
@@ -182,10 +188,13 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     const hipEvent_t ev = rb.ev;
     {
         mvi::StageTimer tm(mvi::kStScan, st);
-        if (mvi::launch_scan_block_sums(g, P, pinned_dev, st)) return hip_fail("scan_block_sums", hipGetLastError());
+        // binning version 2 also totals the column segments (pinned[1]): they size the grids of its second pass
+        if (f.bin_v2 ? mvi::launch_binning2_totals(g, P, pinned_dev, st) : mvi::launch_scan_block_sums(g, P, pinned_dev, st))
+            return hip_fail("scan_block_sums", hipGetLastError());
     }
     if ((e = hipEventRecord(ev, st)) != hipSuccess) return hip_fail("event record", e);
-    if (mvi::launch_binning_level1(f, g, st)) return hip_fail("binning level 1", hipGetLastError());
+    if (f.bin_v2 ? mvi::launch_binning2_level1(f, g, st) : mvi::launch_binning_level1(f, g, st))
+        return hip_fail("binning level 1", hipGetLastError());
     e = hipEventSynchronize(ev);
     if (e != hipSuccess) return hip_fail("forward_geom sync", e);
     const unsigned long long total = *pinned;
@@ -193,6 +202,7 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     if (total > 0xFFFFFFFFull)
         return fail(MVI_EINVAL, "num_rendered exceeds the 32-bit pair offsets%s: %lld pairs", "", (long long)total);
     *num_rendered_host = (int64_t)total;
+    if (f.bin_v2) { g_last_segments.geom = geom; g_last_segments.P = P; g_last_segments.segments = (int64_t)pinned[1]; }
     return MVI_OK;
 }
 
@@ -211,7 +221,9 @@ static int forward_render_impl(const mvi_raster_settings* s, int32_t P, int64_t 
     if (D > 0 && binning_bytes < b.bytes) return fail(MVI_ENOMEM, "binning scratch too small%s: %lld < %lld", "", (long long)binning_bytes, (long long)b.bytes);
     if (D > 0 && geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s", "");
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = mvi::launch_binning(f, g, radii, b, im, D, st)) return hip_fail("binning", hipGetLastError());
+    const int64_t segments = (g_last_segments.geom == geom && g_last_segments.P == P) ? g_last_segments.segments : 0;
+    if (f.bin_v2 ? mvi::launch_binning2(f, g, b, im, D, segments, st) : mvi::launch_binning(f, g, radii, b, im, D, st))
+        return hip_fail("binning", hipGetLastError());
     {
         mvi::StageTimer tm(mvi::kStRenderFwd, st);
         if (mvi::launch_render_forward(f, g, b, im, D, out_color, out_depth, st, grad_rows_to_zero))

@@ -47,7 +47,21 @@ struct Frame {
     // opacities / scales / rotations are the un-activated parameters (sigmoid / exp / normalize happen in the kernels)
     const float* shs_rest = nullptr;
     int raw = 0;
+    int bin_v2 = 0;      // binning version 2 (rectangle-expanding partition, raster_binning2.hip): set by make_frame
 };
+
+// ---- binning version 2 (raster_binning2.hip): tile grids of at most 256 x 256 tiles (images up to 4096 x 4096) ------------
+constexpr int kDsThreads = 256;                     // depth sort: 256 threads x 8 keys = 2048-key tiles
+constexpr int kDsItems = 8;
+constexpr int kDsTile = kDsThreads * kDsItems;
+constexpr int kDsSuper = 16;                        // count-table rows per super row (two-level predecessor sums)
+constexpr int kExThreads = 512;                     // expanding partition passes: 512 threads x 4 items
+constexpr int kExItems = 4;
+constexpr int kExChunk = kExThreads * kExItems;     // items (Gaussians in pass 1, column segments in pass 2) per block
+bool binning_v2_enabled();                          // false when MVI_BINNING_LEGACY=1 or after set_binning_version(1)
+void set_dev_stamps(int pass, void* buf);            // diagnostics: shader-clock stamps of the partition kernel's phases
+int set_binning_version(int v);                     // 1 | 2 (anything else: query only); returns the previous version
+inline bool binning_v2_ok(int gx, int gy) { return gx <= 256 && gy <= 256 && binning_v2_enabled(); }
 
 // ---- scratch layouts (all offsets 256-B aligned) ---------------------------------------------
 struct GeomView {
@@ -70,6 +84,17 @@ struct GeomView {
     uint32_t* dtot;           // [256]
     uint32_t* perm_sums;      // [nblk]   tiles touched per 256 depth-ordered Gaussians
     uint32_t* perm_offsets;   // [nblk+1]
+    // binning version 2
+    uint2* rect_sorted;       // [P] the tile rectangles in depth order (written by the column count, read by pass 1)
+    uint32_t* col_table;      // [256][nblk1] column-major: column segments per (column, block of kExChunk Gaussians)
+    uint32_t* col_tot;        // [256] column segments per tile column
+    uint32_t* seg_sums;       // [npre] column segments (sum of rectangle widths) per preprocess block
+    uint32_t* chunk_first;    // [257] first pass-2 chunk of tile column x; [gx] = number of chunks
+    uint32_t* col_start;      // [257] first column segment of tile column x; [gx] = number of segments
+    uint32_t* ds_table;       // [nds][256] depth-sort digit counts per 4096-key tile (aliases dhist)
+    uint32_t* ds_super[2];    // [nsuper][256] sums over kDsSuper tiles, one region per pass parity (inside dhist)
+    int nds, nsuper;
+    int nblk1;                // blocks of pass 1
     int nsortP;
     size_t bytes;
 };
@@ -80,6 +105,10 @@ struct ImageView {
     size_t bytes;
 };
 struct BinningView {
+    // Version 2 (v2 != 0, grids up to 256 x 256 tiles): keys[0] = (first row | rows - 1 << 8) of each column segment,
+    // vals[0] = its Gaussian (pass 1 output, in column order); keys[1] = tile id of each sorted pair, vals[1] = the sorted
+    // point list (pass 2 output); passes = 1 so that keys / vals[passes & 1] is the result in both versions.
+    // block_hist = [256][nsort] rows-per-chunk table, digit_tot = pairs per tile row, col_rel = [gy][gx + 1].
     void* keys[2];        // ping-pong [D] tile ids, key_bytes each (the 64-bit (tile|depth) key is implicit: pairs are
                           // emitted in depth order and stably partitioned by tile)
     int key_bytes;        // 2 while the image has at most 65536 tiles, else 4
@@ -89,6 +118,8 @@ struct BinningView {
     int nsort;            // blocks per radix pass
     int passes;           // 8-bit passes over the tile bits; sorted pairs end in keys/vals[passes & 1]
     int key_bits;         // tile bits
+    int v2;               // binning version 2 layout
+    uint32_t* col_rel;    // v2: [gy][gx + 1] pairs of tile row y in front of column x (row-relative)
     size_t bytes;
 };
 
@@ -119,6 +150,18 @@ inline GeomView carve_geom(void* base, int P) {
     g.dtot = (uint32_t*)take(4 * 256);
     g.perm_sums = (uint32_t*)take(4 * (size_t)nblk);
     g.perm_offsets = (uint32_t*)take(4 * (size_t)(nblk + 1));
+    g.rect_sorted = (uint2*)take(8 * n);
+    g.nblk1 = (int)((n + kExChunk - 1) / kExChunk);
+    g.col_table = (uint32_t*)take(4 * 256 * (size_t)g.nblk1);
+    g.col_tot = (uint32_t*)take(4 * 256);
+    g.seg_sums = (uint32_t*)take(4 * npre);
+    g.chunk_first = (uint32_t*)take(4 * 257);
+    g.col_start = (uint32_t*)take(4 * 257);
+    g.nds = (int)((n + kDsTile - 1) / kDsTile);
+    g.nsuper = (g.nds + kDsSuper - 1) / kDsSuper;
+    g.ds_table = (uint32_t*)take(4 * 256 * (size_t)g.nds);
+    g.ds_super[0] = (uint32_t*)take(4 * 256 * (size_t)g.nsuper);
+    g.ds_super[1] = (uint32_t*)take(4 * 256 * (size_t)g.nsuper);
     g.bytes = o;
     return g;
 }
@@ -152,12 +195,23 @@ inline BinningView carve_binning(void* base, int64_t D, int W, int H) {
     auto take = [&](size_t b) { char* r = p ? p + o : nullptr; o += align256(b); return r; };
     const unsigned tiles = (unsigned)(((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile));
     v.key_bytes = tiles <= 65536u ? 2 : 4;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    v.v2 = binning_v2_ok(gx, gy) ? 1 : 0;
+    v.col_rel = nullptr;
+    if (v.v2) {
+        // chunks of pass 2: every tile column owns at least one, so at most D / kExChunk + gx (column segments <= pairs);
+        // the launches use the exact segment count when the forward knows it
+        v.nsort = (int)((n / kExChunk + (size_t)gx + 1 + 3) / 4 * 4);
+        v.passes = 1;
+        v.key_bytes = 2;
+    }
     v.keys[0] = take((size_t)v.key_bytes * n);
     v.keys[1] = take((size_t)v.key_bytes * n);
     v.vals[0] = (uint32_t*)take(4 * n);
     v.vals[1] = (uint32_t*)take(4 * n);
     v.block_hist = (uint32_t*)take(4 * 256 * (size_t)v.nsort);
     v.digit_tot = (uint32_t*)take(4 * 256);
+    if (v.v2) v.col_rel = (uint32_t*)take(4 * (size_t)gy * (size_t)(gx + 1));
     v.bytes = o;
     return v;
 }
@@ -236,6 +290,11 @@ int launch_preprocess_backward(const Frame& f, const float* means3D, const float
                                RawBackwardExtra raw = RawBackwardExtra());
 int launch_binning(const Frame& f, GeomView g, const int32_t* radii, BinningView b, ImageView im,
                    int64_t D, hipStream_t st);
+int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
+int launch_binning2_totals(GeomView g, int P, unsigned long long* totals_host_devptr, hipStream_t st);   // [0] = D, [1] = segments
+int launch_binning2_level1(const Frame& f, GeomView g, hipStream_t st);
+// segments: the exact number of column segments if known (> 0), else the bound D is used to size the pass-2 grids
+int launch_binning2(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D, int64_t segments, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                           float* out_color, float* out_depth, hipStream_t st, float* zero_rows = nullptr);
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,

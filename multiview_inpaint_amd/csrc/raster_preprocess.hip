@@ -328,10 +328,15 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
         g.rect[i] = rect;
         // level-1 sort input (binning): depth bits (monotonic for depth > 0.2), culled Gaussians last
         g.dkeys[0][i] = touched ? __float_as_uint(depth_key) : 0xFFFFFFFFu;
-        g.dvals[0][i] = (uint32_t)i;
+        if (!f.bin_v2) g.dvals[0][i] = (uint32_t)i;          // version 2's first sort pass takes the index itself
     }
     uint32_t wsum = wave_sum_u32(touched);
     if ((tid & 63) == 0 && wsum) atomicAdd(&s_sum, wsum);
+    if (f.bin_v2) {   // column segments (rectangle widths) of the block: sizes the grids of binning version 2's second pass
+        const uint32_t segs = wave_sum_u32(touched ? (rect.y & 0xFFFFu) : 0u);
+        static_assert(kPB == 64, "one wave per block");
+        if (tid == 0) g.seg_sums[blockIdx.x] = segs;
+    }
     __syncthreads();
     if (tid == 0) g.block_sums[blockIdx.x] = s_sum;
 }

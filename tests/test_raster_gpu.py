@@ -352,6 +352,64 @@ def test_binning_properties_at_mid_sizes(R, N, W, H):
 
 
 
+def _binning_outputs(R, cam, t, deg, version):
+    from multiview_inpaint_amd import _lib
+    L = _lib.lib()
+    prev = L.mvi_raster_binning_version(version)
+    try:
+        W, H = cam["W"], cam["H"]
+        _, radii, _, st = R.rasterize_forward(_settings(R, cam, np.zeros(3, np.float32), deg), t["means3D"], t["opacities"],
+                                              shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        out = dict(D=st.D, radii=radii.clone(), plist=st.tensor("point_list", (st.D,), torch.int32),
+                   tids=st.tensor("tile_ids_sorted", (st.D,), torch.int32),
+                   ranges=st.tensor("ranges", (tiles, 2), torch.int32), id_bytes=st.views().tile_id_bytes)
+        torch.cuda.synchronize()
+        return out, st
+    finally:
+        L.mvi_raster_binning_version(prev)
+
+
+@pytest.mark.parametrize("N,W,H,deg,log_scale", [
+    (1_500_000, 1920, 1080, 3, None),          # the headline scene: 128-bin kernels, one image group per block
+    (400_000, 3840, 2160, 0, None),            # 240 x 135 tiles: the 256-bin instantiation
+    (200_000, 4096, 4096, 0, np.log(0.03)),    # 256 x 256 tiles: every bin index in use
+    (9_000, 1920, 1080, 0, np.log(0.5)),       # huge footprints: a block's entries exceed the LDS image (several groups)
+    (70_000, 800, 800, 1, np.log(0.08)),       # large footprints at the bring-up image size
+    (5, 64, 48, 0, np.log(0.3)), (2049, 176, 112, 1, np.log(0.2))])
+def test_binning_version_2_equals_version_1_bit_for_bit(R, N, W, H, deg, log_scale):
+    """The rectangle-expanding partition (csrc/raster_binning2.hip: depth sort with in-kernel table sums, column pass, row
+    pass + tile ranges) against the pair-emitting radix partition (csrc/raster_binning.hip, the round-1 / round-2 path that
+    the oracle tests pinned): num_rendered, point list, tile ids and ranges identical, and version 2's output passes the
+    size-independent binning properties on its own."""
+    cam = syn.make_camera(W, H, 50.0)
+    kw = {} if log_scale is None else dict(log_scale_mean=log_scale)
+    sc = syn.make_scene(N, cam, deg, seed=5, **kw)
+    t = _to_dev(sc)
+    a, st2 = _binning_outputs(R, cam, t, deg, 2)
+    b, _ = _binning_outputs(R, cam, t, deg, 1)
+    assert a["D"] == b["D"] and a["D"] > 0
+    assert torch.equal(a["radii"], b["radii"])
+    assert torch.equal(a["plist"], b["plist"]), "point lists differ"
+    assert torch.equal(a["tids"], b["tids"]), "tile ids differ"
+    assert torch.equal(a["ranges"], b["ranges"]), "tile ranges differ"
+    _assert_binning_properties(st2, a["radii"], W, H)
+
+
+@pytest.mark.parametrize("seed,deg,pose,N,W,H", [(0, 3, True, 400, 100, 70), (3, 2, True, 5000, 320, 240)])
+def test_forward_parity_small_with_binning_version_1(R, ro, seed, deg, pose, N, W, H):
+    """The oracle comparison of test_forward_parity_small on the version-1 binning (still the path of grids above 256 x 256
+    tiles)."""
+    from multiview_inpaint_amd import _lib
+    L = _lib.lib()
+    prev = L.mvi_raster_binning_version(1)
+    try:
+        cam, sc, bg = small_scene(seed, N=N, W=W, H=H, deg=deg, pose=pose, log_scale=np.log(0.04))
+        _check_forward(R, ro, cam, sc, bg)
+    finally:
+        L.mvi_raster_binning_version(prev)
+
+
 def test_partial_sh_degree_scale_modifier_and_background_gradient(R, ro):
     """sh_degree below the stored coefficient count (the reference raises the active degree during training,
     gs-simp/scene/gaussian_model.py:119-121), scale_modifier != 1 and a non-zero background: forward + backward."""
