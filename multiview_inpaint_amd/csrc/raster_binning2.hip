@@ -60,10 +60,12 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, int tid, uint
 __global__ __launch_bounds__(1024) void totals2_kernel(const uint32_t* __restrict__ pair_sums,
                                                        const uint32_t* __restrict__ seg_sums, int n,
                                                        uint32_t* __restrict__ super0, int super_words,
+                                                       uint32_t* __restrict__ arrivals,
                                                        unsigned long long* __restrict__ totals_host) {
     __shared__ unsigned long long s_wave[2][16];
     const int tid = threadIdx.x;
     for (int i = tid; i < super_words; i += 1024) super0[i] = 0u;
+    if (tid == 0) *arrivals = 0u;                 // scratch is uninitialised memory: the column scan counts its blocks here
     unsigned long long a = 0, b = 0;
     const int n4 = n >> 2;
     const uint4* p4 = reinterpret_cast<const uint4*>(pair_sums);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(1024) void totals2_kernel(const uint32_t* __restric
 int launch_binning2_totals(GeomView g, int P, unsigned long long* totals_host_devptr, hipStream_t st) {
     const int npre = (P + kPB - 1) / kPB;
     hipLaunchKernelGGL(totals2_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.seg_sums, npre, g.ds_super[0],
-                       256 * g.nsuper, totals_host_devptr);
+                       256 * g.nsuper, g.arrivals, totals_host_devptr);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -327,11 +329,30 @@ __global__ __launch_bounds__(kExThreads) void column_count_kernel(int P, int gx,
 }
 
 // =================================================================================================== row scans
-// block b turns row b of table ([rows][stride], n used entries per row) into exclusive offsets; tot[b] = row sum
-__global__ __launch_bounds__(1024) void rows_scan_kernel(uint32_t* __restrict__ table, int stride, int n,
-                                                         uint32_t* __restrict__ tot) {
+// Chunk table of pass 2 from the column totals: chunk_first[x] = first chunk of tile column x, chunk_first[gx] = number of
+// chunks; col_start[x] = first segment of column x, col_start[gx] = number of segments. Every column owns at least one chunk
+// (an empty one writes the column's empty ranges). Built by the block of columns_scan_kernel whose arrival is last.
+__device__ __forceinline__ void build_chunk_table(const uint32_t* col_tot, int gx, int tid, uint32_t* __restrict__ chunk_first,
+                                                  uint32_t* __restrict__ col_start, uint32_t* s_w4) {
+    // the totals were stored by other blocks with agent-scope stores, each drained before that block's arrival: L2 loads
+    const uint32_t v = tid < gx ? __hip_atomic_load(col_tot + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t c = tid < gx ? max(1u, (v + (uint32_t)kExChunk - 1u) / (uint32_t)kExChunk) : 0u;
+    uint32_t tv, tc;
+    const uint32_t ev = block_excl_scan256(v, tid, s_w4, &tv);
+    const uint32_t ec = block_excl_scan256(c, tid, s_w4, &tc);
+    if (tid < gx) { col_start[tid] = ev; chunk_first[tid] = ec; }
+    if (tid == 0) { col_start[gx] = tv; chunk_first[gx] = tc; }
+}
+// pass 1 scan: block x turns row x of the column table into exclusive offsets and stores the column total; the block that
+// arrives last (a counter, reset by that block for the next call) builds the chunk table — one launch instead of two. No
+// block waits for another.
+__global__ __launch_bounds__(1024) void columns_scan_kernel(uint32_t* __restrict__ table, int stride, int n,
+                                                            uint32_t* __restrict__ tot, int gx, uint32_t* __restrict__ arrivals,
+                                                            uint32_t* __restrict__ chunk_first,
+                                                            uint32_t* __restrict__ col_start) {
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_carry, s_last;
+    __shared__ uint32_t s_w4[4];
     uint32_t* row = table + (size_t)blockIdx.x * stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
@@ -355,25 +376,16 @@ __global__ __launch_bounds__(1024) void rows_scan_kernel(uint32_t* __restrict__ 
         if (tid == 1023) s_carry = carry + wave_off + inc;
         __syncthreads();
     }
-    if (tid == 0) tot[blockIdx.x] = s_carry;
-}
-
-// Chunk table of pass 2 from the column totals (one small block, queued with the depth sort before the host reads
-// num_rendered): chunk_first[x] = first chunk of tile column x, chunk_first[gx] = number of chunks; col_start[x] = first
-// segment of column x, col_start[gx] = number of segments. Every column owns at least one chunk (an empty one writes the
-// column's empty ranges).
-__global__ __launch_bounds__(256) void chunk_table_kernel(const uint32_t* __restrict__ col_tot, int gx,
-                                                          uint32_t* __restrict__ chunk_first,
-                                                          uint32_t* __restrict__ col_start) {
-    __shared__ uint32_t s_w4[4];
-    const int tid = threadIdx.x;
-    const uint32_t v = tid < gx ? col_tot[tid] : 0u;
-    const uint32_t c = tid < gx ? max(1u, (v + (uint32_t)kExChunk - 1u) / (uint32_t)kExChunk) : 0u;
-    uint32_t tv, tc;
-    const uint32_t ev = block_excl_scan256(v, tid, s_w4, &tv);
-    const uint32_t ec = block_excl_scan256(c, tid, s_w4, &tc);
-    if (tid < gx) { col_start[tid] = ev; chunk_first[tid] = ec; }
-    if (tid == 0) { col_start[gx] = tv; chunk_first[gx] = tc; }
+    if (tid == 0) {
+        __hip_atomic_store(tot + blockIdx.x, s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the total has left before the arrival
+        const uint32_t prev = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == (uint32_t)gridDim.x - 1u;
+        if (s_last) __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    build_chunk_table(tot, gx, tid, chunk_first, col_start, s_w4);
 }
 // the block's chunk: false when blockIdx.x is not a chunk. Loads the 2 x 257-entry table into LDS (one round trip).
 struct Chunk { int x; uint32_t seg0, seg1; bool first; };
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(kExThreads) void expand_scatter_kernel(ExpandArgs A
     __shared__ uint32_t s_pay[kExChunk];
     __shared__ uint16_t s_aux[PASS == 1 ? kExChunk : 1];
     __shared__ uint32_t s_img[kCap];                 // item | bin << 16
-    __shared__ uint32_t s_base[NB], s_lstart[NB + 1], s_goff[NB];
+    __shared__ uint32_t s_lstart[NB + 1], s_delta[NB];
     __shared__ uint32_t s_rtot[kRounds];
     __shared__ uint32_t s_w[2][8];
     __shared__ uint32_t s_first[PASS == 2 ? 257 : 1], s_col[PASS == 2 ? 257 : 1];
@@ -578,13 +590,21 @@ __global__ __launch_bounds__(kExThreads) void expand_scatter_kernel(ExpandArgs A
         if (PASS == 1) s_aux[li] = (uint16_t)aux;
     }
     const int nb = A.nbins;
-    // totals of the bins and this block's offset inside each (thread = bin): scanned below, together with the entry counts
-    const uint32_t bin_tot = tid < nb ? A.tot[tid] : 0u;
-    const uint32_t bin_off = tid < nb ? A.table[(size_t)tid * A.stride + blk] : 0u;
+    // worker thread = (bin b, part q of the rounds), BIN-MAJOR: as many parts as 512 threads allow for the bins in use (68 tile
+    // rows -> 7 parts of 4 - 5 rounds, 120 tile columns -> 4 parts of 8). An exclusive scan of the workers' entry counts in
+    // thread order is then the image layout itself (bin runs, inside a bin the parts in round order): one barrier.
+    const int parts = min(kExThreads / nb, 16);
+    const bool worker = tid < parts * nb;
+    const int b = worker ? tid / parts : 0, q = worker ? tid % parts : 0;
+    const int r_lo = worker ? q * kRounds / parts : 0, r_hi = worker ? (q + 1) * kRounds / parts : 0;
+    // total of the bin and this block's offset inside it, held by the bin's first worker: scanned below together with the
+    // entry counts (the scan of the totals over the threads in order = over the bins in order)
+    const bool bin_head = worker && q == 0;
+    const uint32_t bin_tot = bin_head ? A.tot[b] : 0u;
+    const uint32_t bin_off = bin_head ? A.table[(size_t)b * A.stride + blk] : 0u;
     {
         uint4* m4 = reinterpret_cast<uint4*>(&s_mask[0]);
         for (int i = tid; i < (kRounds * kStride + 1) / 2; i += kExThreads) m4[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid < NB) s_goff[tid] = 0;
         if (tid < kRounds) s_rtot[tid] = 0;
     }
     __syncthreads();
@@ -600,14 +620,9 @@ __global__ __launch_bounds__(kExThreads) void expand_scatter_kernel(ExpandArgs A
     __syncthreads();
     MVI_STAMP(2);
 
-    // worker thread = (bin b, part q of the rounds), BIN-MAJOR: as many parts as 512 threads allow for the bins in use (68 tile
-    // rows -> 7 parts of 4 - 5 rounds, 120 tile columns -> 4 parts of 8). An exclusive scan of the workers' entry counts in
-    // thread order is then the image layout itself (bin runs, inside a bin the parts in round order): one barrier.
-    const int parts = min(kExThreads / nb, 16);
-    const bool worker = tid < parts * nb;
-    const int b = worker ? tid / parts : 0, q = worker ? tid % parts : 0;
-    const int r_lo = worker ? q * kRounds / parts : 0, r_hi = worker ? (q + 1) * kRounds / parts : 0;
     const unsigned long long* mcol = s_mask + b;
+    uint32_t my_base = 0, my_goff = 0;                         // bin heads: global start of the block's run in the bin, entries
+                                                               // of the bin placed by earlier groups
 
     int g0 = 0, g1 = kRounds;
     bool first = true, have_rtot = false;
@@ -618,14 +633,13 @@ __global__ __launch_bounds__(kExThreads) void expand_scatter_kernel(ExpandArgs A
         block_excl_scan512x2(cnt, first ? bin_tot : 0u, tid, s_w, pos0, total, bin_start);
         if (first) {
             first = false;
-            if (tid < nb) s_base[tid] = bin_start + bin_off;
-            if (PASS == 2 && ck.first && tid < nb) {
-                // tile (row tid, column ck.x): its pairs start where this chunk's run of row tid starts
-                const uint32_t* cr = A.col_rel + (size_t)tid * (A.gx + 1);
+            my_base = bin_start + bin_off;
+            if (PASS == 2 && ck.first && bin_head) {
+                // tile (row b, column ck.x): its pairs start where this chunk's run of row b starts
+                const uint32_t* cr = A.col_rel + (size_t)b * (A.gx + 1);
                 const uint32_t c = cr[ck.x + 1] - cr[ck.x];
-                const uint32_t start = bin_start + bin_off;
-                uint2* rg = reinterpret_cast<uint2*>(A.ranges) + ((size_t)tid * A.gx + ck.x);
-                *rg = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
+                uint2* rg = reinterpret_cast<uint2*>(A.ranges) + ((size_t)b * A.gx + ck.x);
+                *rg = c ? make_uint2(my_base, my_base + c) : make_uint2(0u, 0u);
             }
             if (total == 0) return;                            // nothing to place (culled tail of the depth order, empty column)
         }
@@ -645,7 +659,10 @@ __global__ __launch_bounds__(kExThreads) void expand_scatter_kernel(ExpandArgs A
             while (g1 < kRounds && acc + s_rtot[g1] <= (uint32_t)kCap) { acc += s_rtot[g1]; ++g1; }   // >= 1 round: <= 64 * NB each
             continue;
         }
-        if (worker && q == 0) s_lstart[b] = pos0;              // start of bin b's run in the image
+        if (bin_head) {
+            s_lstart[b] = pos0;                                // start of bin b's run in the image
+            s_delta[b] = my_base + my_goff - pos0;             // + place in the image = place in the output
+        }
         if (tid == 0) s_lstart[nb] = total;
         MVI_STAMP(4);
         // C: walk the set bits (32 at a time: one find-first-bit, one clear per entry)
@@ -674,16 +691,15 @@ __global__ __launch_bounds__(kExThreads) void expand_scatter_kernel(ExpandArgs A
         for (uint32_t p = tid; p < total; p += kExThreads) {
             const uint32_t e = s_img[p];
             const uint32_t eb = e >> 16, item = e & 0xFFFFu;
-            const uint32_t dst = s_base[eb] + s_goff[eb] + (p - s_lstart[eb]);
+            const uint32_t dst = p + s_delta[eb];
             A.out_idx[dst] = s_pay[item];
             if (PASS == 1) A.out_aux[dst] = s_aux[item];
-            else if (A.out_aux) A.out_aux[dst] = (uint16_t)(eb * (uint32_t)A.gx + (uint32_t)ck.x);
+            else A.out_aux[dst] = (uint16_t)(eb * (uint32_t)A.gx + (uint32_t)ck.x);
         }
         MVI_STAMP(6);
         if (g1 >= kRounds) break;
-        __syncthreads();
-        if (tid < nb) s_goff[tid] += s_lstart[tid + 1] - s_lstart[tid];
-        __syncthreads();
+        if (bin_head) my_goff += s_lstart[b + 1] - pos0;       // written before the barrier in front of D
+        __syncthreads();                                       // D has read the image and the bin starts
         g0 = g1; g1 = kRounds;
     }
 }
@@ -709,8 +725,8 @@ int launch_binning2_level1(const Frame& f, GeomView g, hipStream_t st) {
     StageTimer tm(kStDup, st);
     hipLaunchKernelGGL(column_count_kernel, dim3(g.nblk1), dim3(kExThreads), 0, st, f.P, f.gx, g.rect_sorted, g.col_table,
                        g.nblk1);
-    hipLaunchKernelGGL(rows_scan_kernel, dim3(f.gx), dim3(1024), 0, st, g.col_table, g.nblk1, g.nblk1, g.col_tot);
-    hipLaunchKernelGGL(chunk_table_kernel, dim3(1), dim3(256), 0, st, g.col_tot, f.gx, g.chunk_first, g.col_start);
+    hipLaunchKernelGGL(columns_scan_kernel, dim3(f.gx), dim3(1024), 0, st, g.col_table, g.nblk1, g.nblk1, g.col_tot, f.gx,
+                       g.arrivals, g.chunk_first, g.col_start);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

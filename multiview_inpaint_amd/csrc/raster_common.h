@@ -91,6 +91,7 @@ struct GeomView {
     uint32_t* seg_sums;       // [npre] column segments (sum of rectangle widths) per preprocess block
     uint32_t* chunk_first;    // [257] first pass-2 chunk of tile column x; [gx] = number of chunks
     uint32_t* col_start;      // [257] first column segment of tile column x; [gx] = number of segments
+    uint32_t* arrivals;       // [1] blocks of the column scan that have finished (the last one builds the chunk table)
     uint32_t* ds_table;       // [nds][256] depth-sort digit counts per 4096-key tile (aliases dhist)
     uint32_t* ds_super[2];    // [nsuper][256] sums over kDsSuper tiles, one region per pass parity (inside dhist)
     int nds, nsuper;
@@ -157,6 +158,7 @@ inline GeomView carve_geom(void* base, int P) {
     g.seg_sums = (uint32_t*)take(4 * npre);
     g.chunk_first = (uint32_t*)take(4 * 257);
     g.col_start = (uint32_t*)take(4 * 257);
+    g.arrivals = (uint32_t*)take(4);
     g.nds = (int)((n + kDsTile - 1) / kDsTile);
     g.nsuper = (g.nds + kDsSuper - 1) / kDsSuper;
     g.ds_table = (uint32_t*)take(4 * 256 * (size_t)g.nds);
