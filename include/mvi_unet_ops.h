@@ -229,6 +229,10 @@ int mvi_softmax_rows(void* x, int64_t rows, int32_t cols, float scale, int32_t d
 
 /* Which kernel mvi_attention_forward would pick: 0 = rowtile fp32-math, 1 = MFMA flash. */
 int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);
+/* The kernel itself: 0 = rowtile, 4 = attn_flash_kernel (4 waves, 128-query blocks: short sequences), 8 =
+ * attn_flash8_kernel (8 waves, 256-query blocks, LDS-DMA ring: S_q >= 1024 and S_k >= 256 — every level-0 / level-1 spatial
+ * self-attention of the 576 x 1024 step). mvi_attention_forward* dispatch on exactly this function. */
+int mvi_attention_kernel_variant(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype);
 
 const char* mvi_unet_last_error(void);
 

@@ -396,6 +396,13 @@ int unet_fail(int code, const char* msg);
 extern "C" int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype) {
     return (dtype != MVI_DT_F32 && D == mvi::kFD && Sk > 32) ? 1 : 0;
 }
+// the ONE place that picks the kernel: mvi_attention_forward* and the tests' assertion read the same answer
+extern "C" int mvi_attention_kernel_variant(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype) {
+    if (mvi_attention_kernel_kind(Sq, Sk, D, dtype) != 1) return 0;
+    // 256-row blocks pay off once there are enough of them and the padding of the last block is small
+    static const int forced = getenv("MVI_ATTN_VARIANT") ? atoi(getenv("MVI_ATTN_VARIANT")) : 0;   // 4 / 8: force a kernel (A/B runs)
+    return (forced == 8 || (forced != 4 && Sq >= 1024 && Sk >= 256)) ? 8 : 4;
+}
 
 static int attention_forward_impl(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Sq,
                                   int32_t Sk, int32_t D, float scale, int32_t dtype, int64_t q_ts, int64_t kv_ts, int64_t o_ts,
@@ -412,11 +419,9 @@ static int attention_forward_impl(const void* q, const void* k, const void* v, v
         return mvi::unet_fail(MVI_EINVAL, "attention: token strides must be 0 or >= H*D elements and 16-byte multiples");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (mvi_attention_kernel_kind(Sq, Sk, D, dtype) == 1) {
-        // 256-row blocks pay off once there are enough of them and the padding of the last block is small
-        static const int variant = getenv("MVI_ATTN_VARIANT") ? atoi(getenv("MVI_ATTN_VARIANT")) : 0;   // 4 / 8: force a kernel (A/B runs)
-        const bool long_seq = variant == 8 || (variant != 4 && Sq >= 1024 && Sk >= 256);
-        if (long_seq)
+    const int variant = mvi_attention_kernel_variant(Sq, Sk, D, dtype);
+    if (variant != 0) {
+        if (variant == 8)
             rc = dtype == MVI_DT_BF16 ? mvi::attn_flash8_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
                                       : mvi::attn_flash8_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
         else

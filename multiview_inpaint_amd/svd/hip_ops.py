@@ -13,6 +13,10 @@ _ws = {}
 # Optional per-op timing for bench.py: when PROFILE is a list, every op appends
 # (kind, start_event, end_event, work) with events recorded on the stream the kernel runs on.
 PROFILE = None
+# When a list: every attention call appends (kernel variant, Sq, Sk) — 0 rowtile, 4 / 8 = the 4- / 8-wave MFMA kernel
+# (mvi_attention_kernel_variant, the function the C dispatch itself uses). The parity tests assert from it WHICH kernel ran
+# inside a module graph.
+ATTN_VARIANTS = None
 
 
 class _Timed:
@@ -174,6 +178,8 @@ def attention(q, k, v, heads):
     q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
     out = torch.empty_like(q)
     kind = "attention_mfma" if L.mvi_attention_kernel_kind(Sq, Sk, D, _DT[q.dtype]) == 1 else "attention_rowtile"
+    if ATTN_VARIANTS is not None:
+        ATTN_VARIANTS.append((int(L.mvi_attention_kernel_variant(Sq, Sk, D, _DT[q.dtype])), Sq, Sk))
     with torch.cuda.device(q.device), _Timed(kind, 4.0 * B * heads * Sq * Sk * D, q.device):
         _check(L.mvi_attention_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, Sq, Sk, D,
                                        float(D) ** -0.5, _DT[q.dtype], _stream(q.device)), "attention")
@@ -192,6 +198,8 @@ def attention_packed(qkv, heads):
     out = torch.empty(B, S, HD, dtype=qkv.dtype, device=qkv.device)
     es = qkv.element_size()
     kind = "attention_mfma" if L.mvi_attention_kernel_kind(S, S, D, _DT[qkv.dtype]) == 1 else "attention_rowtile"
+    if ATTN_VARIANTS is not None:
+        ATTN_VARIANTS.append((int(L.mvi_attention_kernel_variant(S, S, D, _DT[qkv.dtype])), S, S))
     p = qkv.data_ptr()
     with torch.cuda.device(qkv.device), _Timed(kind, 4.0 * B * heads * S * S * D, qkv.device):
         _check(L.mvi_attention_forward_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), B, heads, S, S, D,

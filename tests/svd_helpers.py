@@ -21,6 +21,9 @@ SMALL_UNET64 = dict(SMALL_UNET, model_channels=64, num_head_channels=64)
 SMALL_CTRL64 = {k: v for k, v in SMALL_UNET64.items() if k != "out_channels"}
 SMALL_CTRL64["hint_channels"] = 7
 LATENT_HW64 = (16, 16)
+# the same networks on a 32x32 latent: the level-0 spatial self-attention has S_q = S_k = 1024, the range of the PRODUCTION
+# 8-wave kernel (csrc/attn_flash8.hip: S_q >= 1024 and S_k >= 256); level 1 (S = 256) stays on the 4-wave kernel
+LATENT_HW64_L = (32, 32)
 
 
 def seeded_state_dict(module, seed):

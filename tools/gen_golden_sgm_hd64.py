@@ -55,9 +55,35 @@ with torch.no_grad():
     with torch.autocast("cpu", dtype=torch.bfloat16):
         run("bf16ac")
 out["n_ctrl"] = np.array(n)
+
+# ---- the same three networks on a 32x32 latent (S = 1024 at level 0: the production 8-wave attention kernel's range).
+# Only the two network outputs and the last control residual are kept (the others are 1.5 MB each); budgets for bf16 AND
+# fp16 autocast (fp16 is the reference's own recipe on the GPU, configs/test/svd_f_est_ctrl_simp1.yaml:214).
+inpL = H.seeded_inputs(43, hw=H.LATENT_HW64_L, cfg=H.SMALL_UNET64)
+kwL = dict(num_video_frames=T, image_only_indicator=inpL["image_only_indicator"])
+xinL = torch.cat([inpL["x"], inpL["concat"]], 1)
+ttL = 0.25 * inpL["sigma"].log()
+
+
+def runL(tag):
+    y = unet(xinL, ttL, inpL["crossattn"], inpL["vector"], **kwL)
+    ctrls = cnet(xinL, inpL["control_hint"], ttL, inpL["crossattn"], inpL["vector"], **kwL)
+    yc = cunet(xinL, ttL, inpL["crossattn"], inpL["vector"], control=[c.clone() for c in ctrls], **kwL)
+    out["L_unet_out_" + tag] = y.float().numpy()
+    out["L_cunet_out_" + tag] = yc.float().numpy()
+    out["L_ctrl_last_" + tag] = ctrls[-1].float().numpy()
+
+
+with torch.no_grad():
+    runL("f32")
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        runL("bf16ac")
+    with torch.autocast("cpu", dtype=torch.float16):
+        runL("f16ac")
 path = os.path.join(HERE, "..", "tests", "golden", "sgm_hd64.npz")
 np.savez_compressed(path, **out)
 e = lambda a, b: float(np.abs(out[a] - out[b]).max() / np.abs(out[b]).max())
 print("wrote", os.path.normpath(path), f"{os.path.getsize(path) / 1e6:.2f} MB; unet params",
       sum(p.numel() for p in unet.parameters()), "autocast-vs-fp32 rel: unet", e("unet_out_bf16ac", "unet_out_f32"),
-      "cunet", e("cunet_out_bf16ac", "cunet_out_f32"), "mean|unet_out|", float(np.abs(out["unet_out_f32"]).mean()))
+      "cunet", e("cunet_out_bf16ac", "cunet_out_f32"), "mean|unet_out|", float(np.abs(out["unet_out_f32"]).mean()),
+      "| 32x32: bf16ac", e("L_cunet_out_bf16ac", "L_cunet_out_f32"), "f16ac", e("L_cunet_out_f16ac", "L_cunet_out_f32"))
