@@ -29,6 +29,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+# useful fp32 operations per evaluated (pixel, Gaussian) pair, counted from the kernels' arithmetic (csrc/raster_render.hip):
+# forward: dx, dy 2, power 7, exp 1, alpha 2, test_T 2, colour + depth weights 8 = 22; backward: the forward's alpha / T replay
+# 14, dL/dalpha incl. the background term 14, nine raw moments 18, colour accumulation 12, T / accumulators 6 = 64
+PAIR_FLOPS = {"render_forward": 22, "render_backward": 64}
 
 
 def algorithmic_bytes(N, V, D, M, P, T, n_pass=1):
@@ -62,8 +67,9 @@ def view_camera(rank, W, H):
 
 
 def cpu_baseline():
-    """The oracle (a port: the reference has no CPU rasterizer) on a bounded sample: fwd+bwd of one
-    800x800 view at N=100k (BASELINE.json configs[1]), one host core."""
+    """The oracle (a port: the reference has no CPU rasterizer) on a bounded sample: fwd+bwd of one 800x800 view at N=100k
+    (BASELINE.json configs[1]) on the host cores this process may use (at most 32: the per-Gaussian and per-pixel loops of
+    oracle/raster_oracle.c are split over threads for this measurement only; the binning stays on one thread)."""
     from multiview_inpaint_amd import synthetic as syn
     from oracle import raster_oracle as ro
     W = H = 800
@@ -74,17 +80,27 @@ def cpu_baseline():
                        cam["campos"], np.zeros(3, np.float32))
     kw = dict(shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
     g_img = np.random.default_rng(0).normal(size=(3, H, W)).astype(np.float32)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        f = ro.forward(p, sc["means3D"], sc["opacities"], **kw)
-        ro.backward(p, f, g_img, sc["means3D"], **kw)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 20:
-            break
-    return dict(value=round(reps * W * H / dt / 1e6, 4), unit="Mpix/s", cores=1, kind="port",
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
+    ro.set_threads(cores)
+    try:
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            f = ro.forward(p, sc["means3D"], sc["opacities"], **kw)
+            ro.backward(p, f, g_img, sc["means3D"], **kw)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or reps >= 40:
+                break
+    finally:
+        ro.set_threads(1)
+    return dict(value=round(reps * W * H / dt / 1e6, 4), unit="Mpix/s", cores=cores, kind="port",
                 sample=f"{reps} x (fwd+bwd, N=100k Gaussians, 800x800, sh_degree 3, D={f['num_rendered']}) "
-                       f"with oracle/raster_oracle.c on 1 of {os.cpu_count()} host cores, {dt:.1f} s")
+                       f"with oracle/raster_oracle.c on {cores} OpenMP threads ({avail} of {os.cpu_count()} host cores available "
+                       f"to this process), {dt:.1f} s")
 
 
 def _svd_child(two_streams, steps, timeout):
@@ -112,23 +128,18 @@ def _svd_child(two_streams, steps, timeout):
 
 def svd_leg(steps):
     """Second half of the BASELINE.json metric, measured in child processes started before this process initialises the GPU (a
-    child may not be exec'd from a process that has): first the step on ONE stream; then with the ControlNet on a side stream
-    beside the UNet encoder (svd/engine.py TWO_STREAMS), which is 4 - 5 % faster but depends on the GEMM library's kernels not
-    waiting on each other across streams — fine with the GEMM set this benchmark pins (svd/tunableop_gfx950.csv), and bounded
-    here by a time-out all the same. The faster completed variant is reported, the other one next to it."""
+    child may not be exec'd from a process that has). The HEADLINE is the step on ONE stream — the library's default
+    (engine.TWO_STREAMS off). The opt-in mode with the ControlNet on a side stream beside the UNet encoder
+    (MVI_SVD_TWO_STREAMS=1; 4 - 5 % faster, but only safe when the GEMM set is pinned: DESIGN.md) is measured as well, under a
+    time-out, and reported NEXT to the headline as `two_streams`. MVI_BENCH_TWO_STREAMS=0 skips it."""
     one = _svd_child(False, steps, 900)
-    two = _svd_child(True, steps, 240) if one is not None and os.environ.get("MVI_BENCH_TWO_STREAMS", "1") != "0" else None
     if one is None:
         return None
-    one["execution"] = "one stream"
-    if two is not None and two.get("finite") and two["steps_per_s"] > one["steps_per_s"]:
-        two["execution"] = "two streams: ControlNet beside the UNet encoder (MVI_SVD_TWO_STREAMS=1); per-op table from a one-stream pass"
-        two["one_stream"] = {k: one[k] for k in ("steps_per_s", "ms_per_step", "step_ms") if k in one}
-        if "sample_loop" in one:
-            two["one_stream"]["sample_loop_ms_per_step"] = one["sample_loop"]["ms_per_step"]
-        return two
-    if two is None and os.environ.get("MVI_BENCH_TWO_STREAMS", "1") != "0":
-        one["two_streams"] = "did not complete"
+    one["execution"] = "one stream (the library default)"
+    if os.environ.get("MVI_BENCH_TWO_STREAMS", "1") != "0":
+        two = _svd_child(True, steps, 240)
+        one["two_streams"] = ({k: two[k] for k in ("steps_per_s", "ms_per_step", "step_ms", "finite") if k in two}
+                              if two is not None else "did not complete")
     return one
 
 
@@ -254,8 +265,12 @@ def main():
     ms = (C.c_float * 8)()
     calls = (C.c_int32 * 8)()
     _lib.check(L.mvi_raster_timing_read(ms, calls), "timing_read")
+    per_rank_ms = [round(dt / args.steps * 1e3, 4)]
     if world > 1 or force_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(td.get_world_size())]
+        td.all_gather(every, tt)                            # every rank's own wall time around the K steps
+        per_rank_ms = [round(float(x.item()) / args.steps * 1e3, 4) for x in every]
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -287,10 +302,6 @@ def main():
                 issue = next((v for k, v in tj.get("issue_per_kernel", {}).items() if k.startswith(dom + "_kernel")), None)
         except (OSError, KeyError, ValueError):
             pass
-        # The two render kernels move a fraction of their algorithmic bytes (the tile lists are served from L2) and are
-        # bound by the SIMDs' vector issue port: for them the roofline is VALU issue (PMC: SQ_INSTS_VALU x 4 cycles over
-        # SIMDs x cycles of the launch); every other stage — and the step as a whole — is priced against HBM.
-        valu_bound = dom in ("render_backward", "render_forward") and issue is not None
         ms_step = dt / args.steps * 1e3
         total_bytes = sum(stage_bytes.values())
         ranges = st.tensor("ranges", (T, 2), torch.int32).long()
@@ -306,6 +317,8 @@ def main():
             "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
+            # one process per GPU; `value` uses the slowest rank's time. rccl_ranks = size of the RCCL group the exchange ran in
+            "rccl_ranks": (td.get_world_size() if distributed else 0), "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rasterizer-with-depth fwd+bwd, one {W}x{H} view per GPU per step, "
@@ -318,21 +331,32 @@ def main():
                                                              + (f" in {n_ranges} ranges overlapped with the chain rule" if ranged else "")
                                                             if factored else " + RCCL all-reduce of the gradient bucket")
                                                            if distributed else "")},
-            "roofline": {"bound": "valu" if valu_bound else "hbm", "kernel": dom,
-                         **({"achieved": round(issue["SQ_INSTS_VALU"] * 4.0 / issue["cycles"], 1), "peak": 1024.0,
-                             "unit": "SIMD issue cycles per clock (SQ_INSTS_VALU x 4 / launch cycles, 1024 SIMDs)",
-                             "frac": issue["valu_issue_frac"],
-                             "hbm": {"achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(dom_gbs / HBM_PEAK_GBS, 5)}} if valu_bound else
-                            {"achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(dom_gbs / HBM_PEAK_GBS, 5)}),
+            # achieved = algorithmic bytes of the dominant kernel's launch / its launch time, against the HBM peak.
+            # The render kernels are not HBM-bound (most of their list gathers are L2 hits: `traffic` is BELOW the algorithmic
+            # bytes), which is exactly what a low fraction says; what they ARE bound by rides along as information only:
+            # `issue` (vector instructions issued per launch from the PMC passes, as a share of the launch's SIMD cycles — a
+            # utilisation, not a roof: it rewards wasted instructions) and `compute` (useful fp32 work: evaluated (pixel,
+            # Gaussian) pairs x FLOPs per pair against the 157.3 TFLOP/s vector peak).
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
-                         "counters_build": _lib.raster_source_digest(),
                          "launch_ms": round(dom_ms, 4),
                          "algorithmic_bytes_per_launch": int(stage_bytes[dom]),
+                         "counters_build": _lib.raster_source_digest(),
                          "whole_step": {"algorithmic_bytes": int(total_bytes),
                                         "GBs": round(total_bytes / ms_step / 1e6, 1),
-                                        "frac": round(total_bytes / ms_step / 1e6 / HBM_PEAK_GBS, 5)}},
+                                        "frac": round(total_bytes / ms_step / 1e6 / HBM_PEAK_GBS, 5)},
+                         "compute": {"evaluated_pairs": int(nc.double().sum().item()),
+                                     "flops_per_pair": PAIR_FLOPS.get(dom),
+                                     "TFLOPs": (round(float(nc.double().sum().item()) * PAIR_FLOPS[dom] / dom_ms / 1e9, 2)
+                                                if dom in PAIR_FLOPS else None),
+                                     "peak": FP32_VECTOR_PEAK_TFLOPS,
+                                     "frac": (round(float(nc.double().sum().item()) * PAIR_FLOPS[dom] / dom_ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS, 4)
+                                              if dom in PAIR_FLOPS else None),
+                                     "note": "pairs = sum of n_contrib (list entries each pixel walks); FLOPs per pair counted "
+                                             "from the kernel's arithmetic (DESIGN.md §4)"},
+                         **({"issue": {"valu_wave_instructions_per_launch": int(issue["SQ_INSTS_VALU"]),
+                                       "share_of_simd_cycles": issue["valu_issue_frac"]}} if issue else {})},
             "stages": stages,
             "stages_note": "per-stage times from a separate pass of K steps with every stage bracketed by hipEvents (each "
                            "bracketed boundary idles the GPU ~10 us); the timed region brackets only the roofline kernel",
@@ -361,6 +385,16 @@ def main():
             if not args.no_cpu_baseline:
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
             out["svd"] = svd
+            am = svd.get("hip_ops", {}).get("attention_mfma")
+            if am:
+                # the roofline of path B's hand-written contraction, flat at the top level (attention FLOPs /
+                # summed launch time of the attention kernels / 2.5 PFLOP/s dense bf16)
+                out["roofline_svd_attention"] = {
+                    "bound": "mfma", "kernel": "attn_flash8_kernel (+ attn_flash_kernel for S < 1024)",
+                    "achieved": am["TFLOPs"], "peak": bench_svd.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": am["frac_of_bf16_mfma_peak"], "calls_per_step": am["calls_per_step"], "ms_per_step": am["ms_per_step"],
+                    "traffic": None}
+            out["svd_steps_per_s"] = svd.get("steps_per_s")
     if world > 1 or force_dist:
         td.destroy_process_group()
     if rank == 0:

@@ -515,12 +515,18 @@ static int gn_resident_launch(const void* x, void* y, const float* w, const floa
 // block's wait and store phases run under the other's loads.
 //   * Exchange through memory: the triples and counters move with agent-scope relaxed atomics (the XCDs' L2s are not
 //     coherent with each other); each thread drains its stores before the block arrives.
-//   * Progress: the K blocks of a group are consecutive in ONE XCD's dispatch sequence (ids 8 s + xcd) and an XCD starts
-//     its workgroups in id order, so the oldest unfinished group of an XCD has all its K <= 8 blocks resident (32 CUs)
-//     and finishes; the spin is bounded anyway (kGnSpinLimit, then sync[2 * kGnSyncGroups] is set and the block goes on
-//     with what it has).
-//   * sync = 2 words per group [arrived, departed], zero before the launch and zero again after it: the last block to
-//     leave re-arms them. The caller provides one zeroed buffer per (device, stream) (mvi_groupnorm_sync_bytes()).
+//   * Progress, by construction (round 3; round 2 relied on the observed workgroup-id -> XCD dispatch order): a block's place
+//     (group, part) comes from a TICKET it draws when it starts (one atomic add), not from blockIdx. Tickets are handed out in
+//     start order, so at any time at most ONE group is incomplete — the one the next ticket belongs to — and every other
+//     waiting block belongs to a group whose K <= 8 blocks have all started: those groups finish without help, their slots
+//     free, and the blocks that start next draw exactly the missing tickets. No block ever waits for a block that cannot
+//     start, whatever the dispatcher does (other tenants, CU masks, partition modes). Blocks with consecutive tickets started
+//     together, so a group's blocks also meet quickly. The spin stays bounded as a defence against a wedged device
+//     (kGnSpinLimit, then sync[2 * kGnSyncGroups] is set); hip_ops.groupnorm_cluster_timeouts() reads that flag and the
+//     engine / benchmark raise on it at the end of every sample / run.
+//   * sync = 2 words per group [arrived, departed] + [timeout flag, ticket, departed blocks], zero before the launch and
+//     zero again after it: the last block of a group re-arms the group's words, the last block of the launch the ticket. The
+//     caller provides one zeroed buffer per (device, stream) (mvi_groupnorm_sync_bytes()).
 constexpr int kGnClusterBlock = 512;
 constexpr int kGnSyncGroups = 65536;
 constexpr uint32_t kGnSpinLimit = 1u << 22;
@@ -535,14 +541,11 @@ __global__ __launch_bounds__(kGnClusterBlock) __attribute__((amdgpu_waves_per_eu
     __shared__ float s_red[BS / 64];
     __shared__ float s_stat[2];
     const int K = q.slices * kps;
-    // workgroup id -> XCD is round-robin (id % 8) and each XCD dispatches its ids in order: the K blocks of a group are
-    // CONSECUTIVE IN ONE XCD's sequence, so they start within a few block-slots of each other (spread over the 8 XCDs their
-    // start times drift apart by up to a whole block and the early ones hold their registers idle: measured 268 us against
-    // 250 us for the two-launch form at (28, 640, 72, 128)), and the triples stay in that XCD's L2
-    const int xcd = blockIdx.x & 7;
-    const int64_t seq = blockIdx.x >> 3;
-    const int64_t g = (seq / K) * 8 + xcd;
-    if (g >= groups) return;
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(sync + 2 * kGnSyncGroups + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int64_t seq = s_ticket;                                        // place in START order (see above), not blockIdx
+    const int64_t g = seq / K;
     const int j = (int)(seq % K), slice = j / kps, piece = j % kps;
     const int Cg = q.Cg, G = q.G, C = Cg * G;
     const int64_t S = q.S;
@@ -689,6 +692,12 @@ __global__ __launch_bounds__(kGnClusterBlock) __attribute__((amdgpu_waves_per_eu
             __hip_atomic_store(gs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gs + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // ... and the last block of the launch the ticket counter (every block has drawn its ticket by then)
+        uint32_t* all = sync + 2 * kGnSyncGroups + 2;
+        if (__hip_atomic_fetch_add(all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 2 * kGnSyncGroups + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -713,7 +722,7 @@ static int gn_cluster_launch(const void* x, void* y, const float* w, const float
     const int vpb = (int)((nvec + kps - 1) / kps);
     if ((int64_t)vpb * (kps - 1) >= nvec) return 1;                      // every block must own at least one vector
     const int need = (vpb + BS - 1) / BS;
-    const unsigned blocks = (unsigned)(((groups + 7) / 8) * 8 * K);       // groups round-robin over the XCDs; surplus blocks exit
+    const unsigned blocks = (unsigned)(groups * K);                       // exactly the tickets 0 .. groups * K - 1
 #define MVI_GN_CL(NVV)                                                                                                        \
     hipLaunchKernelGGL((gn_cluster_kernel<T, NVV>), dim3(blocks), dim3(BS), 0, st, (const T*)x, (T*)y, w, b, q, kps, vpb, eps, silu, \
                        part, sync, groups)
@@ -845,7 +854,7 @@ extern "C" int mvi_groupnorm_silu_ex(const void* x, void* y, const float* weight
     return gn_dispatch(x, y, weight, bias, chan_bias, stack3 ? 1 : 0, videos, T, C, spatial, groups, eps, fuse_silu, dtype, workspace, workspace_bytes, stream);
 }
 
-extern "C" size_t mvi_groupnorm_sync_bytes(void) { return (2 * (size_t)mvi::kGnSyncGroups + 1) * sizeof(uint32_t); }
+extern "C" size_t mvi_groupnorm_sync_bytes(void) { return (2 * (size_t)mvi::kGnSyncGroups + 3) * sizeof(uint32_t); }
 
 extern "C" int mvi_groupnorm_silu_ex2(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
                                       int64_t videos, int32_t T, int32_t C, int64_t spatial, int32_t groups, float eps,

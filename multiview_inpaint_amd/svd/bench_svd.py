@@ -205,7 +205,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     ops = {}
     for kind, (calls, ms, work) in prof.items():
         per_step_ms = ms / steps
-        if kind.startswith("attention") or kind in ("ff_geglu", "linear_n320"):       # MFMA kernels: work = FLOPs
+        if kind in ("attention_mfma", "attention_rowtile", "ff_geglu", "linear_n320"):   # MFMA kernels: work = FLOPs
             tf = work / (ms * 1e-3) / 1e12
             ops[kind] = dict(calls_per_step=calls // steps, ms_per_step=round(per_step_ms, 3), TFLOPs=round(tf, 1),
                              frac_of_bf16_mfma_peak=round(tf / MFMA_BF16_PEAK_TFLOPS, 4))
@@ -214,6 +214,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
             ops[kind] = dict(calls_per_step=calls // steps, ms_per_step=round(per_step_ms, 3), GBs=round(gbs, 1),
                              frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
     res["hip_ops"] = ops
+    hip_ops.check_groupnorm_cluster(device)         # a benchmark number from a run with a timed-out GroupNorm wait is no number
     if sample_steps and with_control:
         res["sample_loop"] = run_sample_loop(eng, device, sample_steps, T, h, w, weights)
     return res

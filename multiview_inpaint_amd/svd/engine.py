@@ -164,4 +164,8 @@ class SVDInpaintEngine(nn.Module):
             if shared_hint:
                 uc["control_hint"] = cond["control_hint"]           # still ONE tensor in both halves, as the caller passed it
         with cache():                                               # the hint stem runs once per sample, not per step
-            return self.sampler(fn, randn, cond, uc=uc)             # (the sampler drops the guider's doubled conditioning)
+            out = self.sampler(fn, randn, cond, uc=uc)              # (the sampler drops the guider's doubled conditioning)
+        if out.is_cuda:
+            from . import hip_ops
+            hip_ops.check_groupnorm_cluster(out.device)             # one 4-byte read per sample: raises if a GroupNorm block
+        return out                                                  # ever gave up waiting for its group (never silently wrong)

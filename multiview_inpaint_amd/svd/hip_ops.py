@@ -85,8 +85,18 @@ def groupnorm_cluster_timeouts(dev=None):
     tot = 0
     for (di, _), b in _gn_sync.items():
         if dev is None or di == torch.device(dev).index:
-            tot += int(b[-4:].view(torch.int32).item())
+            tot += int(b.view(torch.int32)[2 * 65536].item())     # [arrived, departed] x 65536 groups, then the flag
     return tot
+
+
+def check_groupnorm_cluster(dev=None):
+    """Raises if a block of the one-launch cluster GroupNorm ever ran out of its bounded wait (the statistics of that call
+    were then merged from stale partners). Cannot happen while the device makes progress (csrc/groupnorm_silu.hip: places are
+    drawn as tickets in start order); called at the end of every SVDInpaintEngine.sample() and benchmark run."""
+    n = groupnorm_cluster_timeouts(dev)
+    if n:
+        raise RuntimeError("cluster GroupNorm: a block gave up waiting for its group (device wedged?); results of this run "
+                           "are not valid. MVI_GN_CLUSTER_KB=-1 selects the two-launch kernels.")
 
 
 _f32_cache = {}
@@ -219,7 +229,8 @@ def attention_temporal_packed(qkv, heads, T):
     out = torch.empty(BT, S, HD, dtype=qkv.dtype, device=qkv.device)
     es = qkv.element_size()
     p = qkv.data_ptr()
-    with torch.cuda.device(qkv.device), _Timed("attention_temporal", 4.0 * (BT // T) * S * heads * T * T * D, qkv.device):
+    # HBM-bound (T = 14 keys per query): work = algorithmic bytes, q + k + v read and the output written once
+    with torch.cuda.device(qkv.device), _Timed("attention_temporal", 4.0 * BT * S * HD * es, qkv.device):
         _check(L.mvi_attention_temporal_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), BT // T, T, S, heads, D,
                                                 float(D) ** -0.5, _DT[qkv.dtype], C3, HD, _stream(qkv.device)),
                "attention_temporal (packed)")
@@ -267,7 +278,7 @@ def attention_temporal(q, k, v, heads, T):
     D = HD // heads
     q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
     out = torch.empty_like(q)
-    with torch.cuda.device(q.device), _Timed("attention_temporal", 4.0 * (BT // T) * S * heads * T * T * D, q.device):
+    with torch.cuda.device(q.device), _Timed("attention_temporal", 4.0 * BT * S * HD * q.element_size(), q.device):
         _check(L.mvi_attention_temporal(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), BT // T, T, S, heads, D,
                                         float(D) ** -0.5, _DT[q.dtype], _stream(q.device)), "attention_temporal")
     return out

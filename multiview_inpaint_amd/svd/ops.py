@@ -16,10 +16,15 @@ import os
 import torch
 import torch.nn.functional as F
 
-# Strict mode (MVI_STRICT=1, or ops.STRICT = True): a GPU tensor that would leave the HIP path — a shape / contiguity
-# gate that fails, or a tensor that requires grad — raises instead of running PyTorch-ROCm's ops. The GPU tests and
-# bench_svd.run_gpu run with it, so "the full-size step took the HIP branch everywhere" is asserted, not assumed.
-STRICT = os.environ.get("MVI_STRICT", "0") == "1"
+# A GPU tensor leaves the HIP path for one of two reasons, treated differently:
+#   * it requires grad (ControlNet training, out of scope): PyTorch-ROCm's differentiable ops run — the documented path;
+#   * a shape / contiguity gate of a kernel fails under no_grad: that RAISES by default (STRICT_GATES; since round 3) — an
+#     inference call never silently runs PyTorch ops in place of the kernels. MVI_STRICT=0 allows the substitute again
+#     (recorded in FALLBACKS).
+# Strict mode proper (MVI_STRICT=1, or ops.STRICT = True) raises in BOTH cases. The GPU tests and bench_svd.run_gpu run with
+# it, so "the full-size step took the HIP branch everywhere" is asserted, not assumed.
+STRICT = os.environ.get("MVI_STRICT", "") == "1"
+STRICT_GATES = os.environ.get("MVI_STRICT", "") != "0"
 FALLBACKS = []          # (op, reason) of every GPU-tensor fallback taken when not strict (diagnostics)
 
 
@@ -31,8 +36,8 @@ def _fallback(t, op, reason):
     """Called right before a PyTorch substitute runs. CPU tensors: that IS the CPU path. GPU tensors: raise in strict
     mode, otherwise record."""
     if t is not None and t.is_cuda:
-        if STRICT:
-            raise HipPathError(f"{op}: GPU tensor left the HIP path ({reason}); MVI_STRICT forbids the PyTorch substitute")
+        if STRICT or (STRICT_GATES and reason != "requires grad"):
+            raise HipPathError(f"{op}: GPU tensor left the HIP path ({reason}); set MVI_STRICT=0 to allow the PyTorch substitute")
         if len(FALLBACKS) < 4096:
             FALLBACKS.append((op, reason))
 

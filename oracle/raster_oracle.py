@@ -44,7 +44,14 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_scan.restype = C.c_int64
         _lib.orc_key_bits.restype = C.c_int
+        _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_get_threads.restype = C.c_int
     return _lib
+
+
+def set_threads(n):
+    """Host threads of the per-Gaussian / per-pixel loops (bench.py's cpu_baseline only; the tests keep 1, see raster_oracle.c)."""
+    lib().orc_set_threads(int(n))
 
 
 def _p(a, ty=None):
