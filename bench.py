@@ -207,18 +207,27 @@ def main():
     # factored form (all-gather of 3 floats per view and Gaussian + local rebuild) and an all-reduce of the other 11
     mode = os.environ.get("MVI_BENCH_EXCHANGE", "auto")
     distributed = world > 1 or force_dist
-    factored = distributed and (mode == "factored" or (mode == "auto" and mdist.FactoredGradExchange.pays(M, world)))
+    factored = distributed and (mode in ("factored", "compacted") or (mode == "auto" and mdist.FactoredGradExchange.pays(M, world)))
     # MVI_BENCH_RANGES=4: the other 11 floats are all-reduced in four Gaussian ranges, each started behind its own
     # chain-rule kernel (dist.RangedGradExchange). Not the default: on one rank (RCCL group of 1) the four smaller kernels,
     # the four collective calls and the assembly copy cost 0.19 ms per step (1.60 vs 1.41 ms), about what hiding three
     # quarters of a 66 MB all-reduce can return at 8 ranks — to be decided on an 8-GPU node, which this round never had
     n_ranges = int(os.environ.get("MVI_BENCH_RANGES", "1"))
     ranged = factored and n_ranges > 1
-    bucket = (mdist.RangedGradExchange(N, M, deg, dev, n_ranges=n_ranges) if ranged else
+    # MVI_BENCH_EXCHANGE=compacted: only the rows visible on at least one rank travel (dist.CompactedGradExchange); it
+    # falls back to the full-size factored exchange when the union of the views is above 80 % of the Gaussians — which it is
+    # in this scene (94 % at 8 views), so "auto" does not take it
+    compacted = distributed and mode == "compacted" and M > 1
+    bucket = (mdist.CompactedGradExchange(N, M, deg, dev) if compacted else
+              mdist.RangedGradExchange(N, M, deg, dev, n_ranges=n_ranges) if ranged else
               mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev))
 
     def step():
         color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **kw)
+        if compacted:
+            R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, sh_grad="factor", **kw)
+            bucket.exchange_visible(t["means3D"], rs.campos, radii > 0)
+            return st, radii
         if ranged:
             R.rasterize_backward_ranged(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], bucket)
             return st, radii
@@ -330,6 +339,8 @@ def main():
                        "parallelism": f"views x{world}" + ((" + RCCL all-gather of SH colour factors + all-reduce of 11 floats/Gaussian"
                                                              + (f" in {n_ranges} ranges overlapped with the chain rule" if ranged else "")
                                                             if factored else " + RCCL all-reduce of the gradient bucket")
+                                                           + (f" (visibility-compacted: union {bucket.last_union_fraction:.3f}, "
+                                                              f"{'taken' if bucket.last_compacted else 'not taken'})" if compacted else "")
                                                            if distributed else "")},
             # achieved = algorithmic bytes of the dominant kernel's launch / its launch time, against the HBM peak.
             # The render kernels are not HBM-bound (most of their list gathers are L2 hits: `traffic` is BELOW the algorithmic

@@ -302,3 +302,53 @@ def test_sharded_adam_world2(tmp_path):
     a, b = (torch.load(tmp_path / f"s{r}.pt") for r in range(2))
     for n in a:
         assert torch.equal(a[n], b[n]), n                       # replicas stay bit-identical
+
+
+def _worker_compacted(rank, world, port, out_dir):
+    """World 4, ragged P (not a multiple of anything), rank 2's view sees NOTHING: the visibility-compacted exchange against
+    the plain sums, on the compacted path (views that overlap little) and on the full-size path it falls back to."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from multiview_inpaint_amd import dist as md
+    P, M, deg = 1237, 16, 3
+    means = torch.randn(P, 3, generator=torch.Generator().manual_seed(7)) * 2 + torch.tensor([0.0, 0.0, 5.0])
+    results = {}
+    for case, p_vis in (("sparse", 0.18), ("dense", 0.7)):
+        g = [torch.Generator().manual_seed(900 + 10 * r + (0 if case == "sparse" else 5)) for r in range(world)]
+        vis = [(torch.rand(P, generator=g[r]) < p_vis) if r != 2 else torch.zeros(P, dtype=torch.bool) for r in range(world)]
+        cams = [torch.randn(3, generator=g[r]) for r in range(world)]
+        fac = [torch.randn(P, 3, generator=g[r]) * vis[r][:, None] for r in range(world)]
+        small = [{n: torch.randn(P, w, generator=g[r]) * vis[r][:, None] for n, w in md.FactoredGradExchange.SMALL}
+                 for r in range(world)]
+        ex = md.CompactedGradExchange(P, M, deg, "cpu")
+        ex.views["sh_color_factor"].copy_(fac[rank])
+        for n, v in small[rank].items():
+            ex.views[n].copy_(v)
+        got = ex.exchange_visible(means, cams[rank], vis[rank])
+        union = torch.stack(vis).any(0)
+        assert ex.last_union_fraction == int(union.sum()) / P
+        assert ex.last_compacted == (case == "sparse"), (case, ex.last_union_fraction)
+        dense = torch.zeros(P, M, 3)
+        for r in range(world):
+            d = means - cams[r]
+            Y = md._sh_basis_cpu(deg, d / d.norm(dim=-1, keepdim=True))
+            dense += Y[:, :, None] * fac[r][:, None, :]
+        assert torch.allclose(got["shs"], dense, rtol=1e-5, atol=1e-6), case
+        assert float(got["shs"][~union].abs().max()) == 0.0
+        for n, _ in md.FactoredGradExchange.SMALL:
+            assert torch.allclose(got[n], sum(small[r][n] for r in range(world)), rtol=1e-5, atol=1e-6), (case, n)
+            assert float(got[n][~union].abs().max()) == 0.0
+        results[case] = {k: v.clone() for k, v in got.items()}
+    # view sharding with more views than ranks and an uneven remainder
+    assert md.shard_views(list(range(10)), rank, world) == [v for v in range(10) if v % world == rank]
+    torch.save(results, os.path.join(out_dir, f"c{rank}.pt"))
+    td.destroy_process_group()
+
+
+def test_visibility_compacted_exchange_world4_ragged_with_an_empty_view(tmp_path):
+    world = 4
+    mp.spawn(_worker_compacted, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"c{r}.pt") for r in range(world)]
+    for case in ("sparse", "dense"):
+        for k in res[0][case]:
+            assert all(torch.equal(res[0][case][k], res[r][case][k]) for r in range(1, world)), (case, k)   # ranks agree bit for bit
