@@ -369,7 +369,7 @@ static int backward_geom_range_impl(const mvi_raster_settings* s, int32_t P, int
     mvi::Frame f;
     if (int rc = make_frame(s, P, M, f)) return rc;
     if (first < 0 || count < 0 || (int64_t)first + count > P || (first % 64) != 0)
-        return fail(MVI_EINVAL, "backward range out of bounds or not 64-aligned%s: first %lld count %lld", "", first, count);
+        return fail(MVI_EINVAL, "backward range out of bounds or not 64-aligned%s: first %lld count %lld", "", (long long)first, (long long)count);
     if (P == 0 || count == 0) return MVI_OK;
     if ((shs == nullptr) == (colors_precomp == nullptr))
         return fail(MVI_EINVAL, "Please provide excatly one of either SHs or precomputed colors!%s");

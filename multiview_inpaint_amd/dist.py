@@ -272,13 +272,20 @@ class RangedGradExchange(FactoredGradExchange):
         per = -(-per // 64) * 64                               # range starts are multiples of 64 (the kernels' block of Gaussians)
         self.ranges = [(a, min(per, P - a)) for a in range(0, P, per)] if P else []
         self.width = sum(w for _, w in self.SMALL)             # 11
-        self._range_views = []
+        # Every sub-array of a range segment starts on a 16-byte boundary: the chain-rule kernel stores dL/drotations as
+        # float4. Range starts are multiples of 64 rows, so only the LAST range can have a row count that is not a multiple
+        # of 4; its sub-arrays are laid out for n rounded up to 4 rows (the pad rows stay zero and ride in the all-reduce).
+        pad = (-P) % 4
+        self.small = torch.zeros(self.width * (P + pad), dtype=torch.float32, device=device)
+        self._range_views, self._range_span = [], []
         for first, n in self.ranges:
-            seg, o, v = self.small[self.width * first:self.width * (first + n)], 0, {}
+            npad = -(-n // 4) * 4
+            seg, o, v = self.small[self.width * first:self.width * first + self.width * npad], 0, {}
             for name, w in self.SMALL:
                 v[name] = seg[o:o + n * w].view(n, w)
-                o += n * w
+                o += npad * w
             self._range_views.append(v)
+            self._range_span.append((self.width * first, self.width * npad))
         # the SoA views of the base class do not describe this layout: assembled by finish()
         for name, _ in self.SMALL:
             self.views[name] = None
@@ -290,9 +297,8 @@ class RangedGradExchange(FactoredGradExchange):
 
     def reduce_range(self, r: int):
         """Starts the all-reduce of range r (call right after its chain-rule kernel has been queued)."""
-        first, n = self.ranges[r]
-        self._works.append(td.all_reduce(self.small[self.width * first:self.width * (first + n)], op=td.ReduceOp.SUM,
-                                         group=self.group, async_op=True))
+        o, length = self._range_span[r]
+        self._works.append(td.all_reduce(self.small[o:o + length], op=td.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self, means3D: torch.Tensor):
         """Waits for the pieces and the gather begun earlier, rebuilds dL/dSH; returns {means3D, opacities, scales,

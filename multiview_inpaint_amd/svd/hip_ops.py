@@ -306,9 +306,9 @@ def ff_geglu(x, weight, bias):
     L = _lib.lib()
     K, inner = x.shape[-1], weight.shape[0] // 2
     xc = x.reshape(-1, K)
-    if xc.stride(1) != 1 or xc.stride(0) % 8:
+    if xc.stride(1) != 1 or xc.stride(0) % 8 or xc.data_ptr() % 16:      # the kernels read 16-byte vectors: a misaligned view is copied
         xc = xc.contiguous()
-    wc = weight if weight.is_contiguous() else weight.contiguous()
+    wc = weight if weight.is_contiguous() and weight.data_ptr() % 16 == 0 else weight.contiguous().clone()
     rows = xc.shape[0]
     cap = int(L.mvi_ff_geglu_out_rows(rows))                     # whole 256-row blocks are stored
     full = torch.empty(cap, inner, dtype=x.dtype, device=x.device)
@@ -330,9 +330,9 @@ def linear_k320(x, weight, bias):
     L = _lib.lib()
     K, N = x.shape[-1], weight.shape[0]
     xc = x.reshape(-1, K)
-    if xc.stride(1) != 1 or xc.stride(0) % 8:
+    if xc.stride(1) != 1 or xc.stride(0) % 8 or xc.data_ptr() % 16:
         xc = xc.contiguous()
-    wc = weight if weight.is_contiguous() else weight.contiguous()
+    wc = weight if weight.is_contiguous() and weight.data_ptr() % 16 == 0 else weight.contiguous().clone()
     rows = xc.shape[0]
     cap = int(L.mvi_ff_geglu_out_rows(rows))
     full = torch.empty(cap, N, dtype=x.dtype, device=x.device)

@@ -499,7 +499,15 @@ def _nhwc_path_ok(self, x):
             and isinstance(conv1, nn.Conv2d) and isinstance(conv2, nn.Conv2d) and conv1.weight.dtype == x.dtype
             and all(tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1) and c.groups == 1
                     for c in (conv1, conv2))
-            and x.shape[1] % 8 == 0 and conv1.out_channels % 8 == 0 and conv2.out_channels % 8 == 0 and (x.shape[2] * x.shape[3]) % 8 == 0)
+            and x.shape[1] % 8 == 0 and conv1.out_channels % 8 == 0 and conv2.out_channels % 8 == 0 and (x.shape[2] * x.shape[3]) % 8 == 0
+            and _tok2tok_ok(x.shape[0], conv1.out_channels, x.shape[2] * x.shape[3], self.out_layers[0].num_groups, x.dtype))
+
+
+def _tok2tok_ok(N, C, S, groups, dtype):
+    """The token-major GroupNorm between the two convolutions has geometry limits of its own (rows per launch, groups, its
+    row pass in LDS): a shape outside them keeps the whole block on the NCHW path instead of raising inside it."""
+    from . import hip_ops
+    return hip_ops._lib.lib().mvi_groupnorm_tok2tok_workspace_bytes(int(N), int(C), int(S), int(groups), hip_ops._DT[dtype]) != 0
 
 
 def _resblock_forward_fused(self, x, emb):

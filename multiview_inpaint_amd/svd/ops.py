@@ -211,7 +211,7 @@ def linear_geglu(x, weight, bias=None):
     On the GPU, for the shapes csrc/ff_geglu.hip covers (K = 320 in bf16 / f16: the level-0 FeedForward layers) and enough rows,
     projection and gating run as ONE kernel and the [rows, 2 inner] intermediate never exists; everything else is the library
     GEMM followed by geglu()."""
-    if K320_KERNELS and x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
+    if K320_KERNELS and x.is_cuda and not _needs_autograd(x, weight, bias) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
         if hip_ops.ff_geglu_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
@@ -227,7 +227,7 @@ def linear(x, weight, bias=None):
     proj_in / proj_out: output-bound GEMMs around a 20-step loop) take csrc/ff_geglu.hip's plain-epilogue kernel
     (mvi_linear_k320), and the level-0 projections INTO 320 channels with a long contraction (FeedForward.net[2], K = 1280) take
     csrc/linear_n320.hip (mvi_linear_n320); everything else is the library GEMM."""
-    if K320_KERNELS and x.is_cuda and not (_needs_autograd(x) or _needs_autograd(weight)) and x.dtype == weight.dtype \
+    if K320_KERNELS and x.is_cuda and not _needs_autograd(x, weight, bias) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
         if hip_ops.linear_k320_supported(x.shape[-1], weight.shape[0], x.dtype):

@@ -642,8 +642,10 @@ def test_edge_1080p_scale_image_not_a_multiple_of_the_tile(R, ro):
     _fwd_bwd_vs_oracle(R, ro, cam, sc, np.array([0.2, 0.1, 0.4], np.float32), 3)
 
 
-def test_ranged_backward_with_overlapped_exchange_equals_one_call(R):
-    """rasterize_backward_ranged (render backward, then the chain rule in four Gaussian ranges through
+@pytest.mark.parametrize("N", [3000, 3001, 3002, 3003])
+def test_ranged_backward_with_overlapped_exchange_equals_one_call(R, N):
+    """(P % 4 in {0, 1, 2, 3}: the last range's sub-arrays must still start on 16-byte boundaries — the chain-rule kernel
+    stores dL/drotations as float4.) rasterize_backward_ranged (render backward, then the chain rule in four Gaussian ranges through
     mvi_raster_backward_geom_range, each range's all-reduce started behind its kernel: dist.RangedGradExchange) on ONE rank
     over RCCL: the sums of one rank are the rank's own gradients, so everything must equal rasterize_backward to the order
     of the float atomics, dL/dSH included (rebuilt from the colour factor and the camera centre)."""
@@ -651,7 +653,7 @@ def test_ranged_backward_with_overlapped_exchange_equals_one_call(R):
     import socket
     import torch.distributed as td
     from multiview_inpaint_amd import dist as md
-    cam, sc, bg = small_scene(9, N=3000, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
+    cam, sc, bg = small_scene(9, N=N, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
     t = _to_dev(sc)
     rs = _settings(R, cam, bg, 3)
     kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
@@ -668,6 +670,7 @@ def test_ranged_backward_with_overlapped_exchange_equals_one_call(R):
         P, M = t["means3D"].shape[0], t["shs"].shape[1]
         ex = md.RangedGradExchange(P, M, 3, "cuda", n_ranges=4)
         assert len(ex.ranges) == 4 and all(a % 64 == 0 for a, _ in ex.ranges)
+        assert all(v.data_ptr() % 16 == 0 for r in range(4) for v in ex.range_views(r).values())
         two = R.rasterize_backward_ranged(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], ex)
         torch.cuda.synchronize()
     finally:
@@ -675,3 +678,43 @@ def test_ranged_backward_with_overlapped_exchange_equals_one_call(R):
     for k in ("means3D", "means2D", "opacities", "scales", "rotations", "shs"):
         assert two[k].shape == one[k].shape, k
         assert _same_to_summation_order(two[k].cpu().numpy(), one[k].cpu().numpy()), k
+
+
+def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backward(R):
+    """dist.CompactedGradExchange on ONE rank over RCCL with the compaction forced (THRESHOLD = 1): gather of the visible
+    rows, all-reduce / all-gather of the compacted buffers, rebuild of dL/dSH for those rows, scatter into zeroed outputs —
+    the sums of one rank are the rank's own gradients, so everything equals rasterize_backward to fp32 rounding, and every
+    invisible row is exactly zero."""
+    import os
+    import socket
+    import torch.distributed as td
+    from multiview_inpaint_amd import dist as md
+    cam, sc, bg = small_scene(19, N=5003, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
+    t = _to_dev(sc)
+    rs = _settings(R, cam, bg, 3)
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+    g_img = torch.randn(3, cam["H"], cam["W"], device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    one = R.rasterize_backward(rs, st, g_img, t["means3D"], **kw)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        P, M = t["means3D"].shape[0], t["shs"].shape[1]
+        ex = md.CompactedGradExchange(P, M, 3, "cuda")
+        ex.THRESHOLD = 1.0
+        R.rasterize_backward(rs, st, g_img, t["means3D"], out=ex.views, sh_grad="factor", **kw)
+        got = ex.exchange_visible(t["means3D"], rs.campos, radii > 0)
+        torch.cuda.synchronize()
+        assert ex.last_compacted and 0.3 < ex.last_union_fraction < 1.0
+    finally:
+        td.destroy_process_group()
+    vis = (radii > 0).cpu().numpy()
+    for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+        a, b = got[k].cpu().numpy(), one[k].cpu().numpy()
+        assert a.shape == b.shape, k
+        assert _same_to_summation_order(a, b), k
+        assert (a[~vis] == 0).all(), k
