@@ -188,6 +188,9 @@ typedef struct mvi_raster_views {
     const float* final_T;         /* [H,W] */
     const uint32_t* n_contrib;    /* [H,W] */
     int32_t tile_id_bytes;        /* 2 (uint16) while the image has at most 65536 tiles, else 4 (uint32) */
+    const uint8_t* grad_support;  /* [P] valid after a backward: 1 = the render backward added to this Gaussian's accumulation
+                                   * row; 0 = every gradient of the Gaussian is exactly zero in this view (occluded, culled or
+                                   * outside the image). View-parallel training exchanges only rows in the union of the supports. */
 } mvi_raster_views;
 int mvi_raster_get_views(int32_t P, int64_t num_rendered, int32_t image_width, int32_t image_height,
                          const void* geom, const void* binning, const void* image,
@@ -211,6 +214,12 @@ const char* mvi_raster_stage_name(int stage);
  * the A/B parity test and A/B timing. Pass 1 or 2 to select, anything else to query; returns the previous selection. Must
  * not change between a forward and its backward (the scratch layouts differ). Not thread-safe. */
 int mvi_raster_binning_version(int version);
+/* The per-Gaussian chain rule of mvi_raster_backward / _raw: 0 (default) = every output array is zeroed by the render backward
+ * on the side and only the Gaussians in the gradient support (mvi_raster_views.grad_support) are read, computed and written;
+ * 1 = the dense kernel that reads and writes every Gaussian (what the split / ranged entry points always use;
+ * MVI_RASTER_DENSE_BACKWARD=1 selects it at start-up). Same results: an untouched accumulation row is exactly zero. Pass 0 or 1
+ * to select, anything else to query; returns the previous selection. For the A/B parity test and A/B timing. */
+int mvi_raster_backward_mode(int dense);
 /* Diagnostics for kernel work (tools/expand_stamps.py), inert unless set: while device_buffer is non-NULL, every block of the
  * binning partition kernel of `pass` (1 | 2) writes 8 shader-clock stamps (uint64) at its phase boundaries into
  * device_buffer[block][8]. The caller sizes the buffer for the launch grid (mvi_raster_binning_bytes / 8 is ample). */

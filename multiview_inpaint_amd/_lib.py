@@ -25,7 +25,8 @@ class RasterViews(C.Structure):
     """struct mvi_raster_views"""
     _fields_ = [(n, C.c_void_p) for n in (
         "depths", "means2D", "cov3D_a", "cov3D_b", "conic_opacity", "rgbd", "tiles_touched", "clamped",
-        "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")] + [("tile_id_bytes", C.c_int32)]
+        "tile_ids_sorted", "point_list", "ranges", "final_T", "n_contrib")] + [("tile_id_bytes", C.c_int32),
+                                                                                   ("grad_support", C.c_void_p)]
 
 
 class AdamGroup(C.Structure):
@@ -122,6 +123,8 @@ def lib():
     L.mvi_raster_stage_name.argtypes = [C.c_int]
     L.mvi_raster_binning_version.restype = C.c_int
     L.mvi_raster_binning_version.argtypes = [C.c_int]
+    L.mvi_raster_backward_mode.restype = C.c_int
+    L.mvi_raster_backward_mode.argtypes = [C.c_int]
     L.mvi_raster_dev_stamps.restype = C.c_int
     L.mvi_raster_dev_stamps.argtypes = [C.c_int, vp]
     _bind_unet_ops(L)

@@ -3,6 +3,7 @@
 // reference imports (gs-simp/gaussian_renderer/__init__.py:14): argument-combination errors are
 // reported, never silently repaired.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "raster_common.h"
@@ -14,6 +15,8 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 }
 
 static thread_local char g_err[512] = "";
+// 0 (default): one-call backward with outputs zeroed on the side + sparse chain rule; 1: the dense chain-rule kernel
+static int g_dense_backward = [] { const char* e = getenv("MVI_RASTER_DENSE_BACKWARD"); return (e && e[0] == '1') ? 1 : 0; }();
 // column segments of the last forward_geom of this thread (binning version 2): a sizing hint for the launches of the
 // forward_render that follows on the same scratch; any other forward_render falls back to the bound num_rendered
 static thread_local struct { const void* geom = nullptr; int32_t P = 0; int64_t segments = 0; } g_last_segments;
@@ -100,6 +103,11 @@ const char* mvi_raster_stage_name(int i) {
     return (i >= 0 && i < MVI_RASTER_NSTAGES) ? n[i] : "";
 }
 int mvi_raster_dev_stamps(int pass, void* device_buffer) { mvi::set_dev_stamps(pass, device_buffer); return MVI_OK; }
+int mvi_raster_backward_mode(int dense) {
+    const int old = g_dense_backward;
+    if (dense == 0 || dense == 1) g_dense_backward = dense;
+    return old;
+}
 int mvi_raster_binning_version(int version) { return mvi::set_binning_version(version); }
 const char* mvi_version(void) { return "multiview_inpaint_amd 0.1.0 (gfx950)"; }
 
@@ -249,7 +257,7 @@ int mvi_raster_forward_render_prepare(const mvi_raster_settings* s, int32_t P, i
 
 static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32_t* radii, const void* geom, const void* binning,
                                 const void* image, const float* dL_dout_color, float* grad_rows, float* dL_dcolor_factor,
-                                int sh_input, int rows_prezeroed, void* stream);
+                                int sh_input, int rows_prezeroed, void* stream, const mvi::ZeroRegions* zero_outputs = nullptr);
 static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* scales, const float* rotations,
                          const float* cov3D_precomp, const int32_t* radii, const void* geom, const void* binning,
@@ -316,10 +324,35 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
     if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations))
         return fail(MVI_EINVAL, "missing covariance gradient output%s");
     if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
-    if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0,
-                                      rawx.rows_prezeroed, stream)) return rc;
+    // One-call backward: every gradient output is zeroed by the render backward on the side (it is bound by vector issue, its
+    // memory pipes are idle), and the per-Gaussian chain rule then touches only the rows that received a gradient — a few per
+    // cent of the Gaussians of a large scene (the others are occluded in this view). MVI_RASTER_DENSE_BACKWARD=1 keeps the
+    // dense kernel (A/B runs).
+    const bool dense_bwd = g_dense_backward != 0;
     mvi::GeomView g = mvi::carve_geom(const_cast<void*>(geom), P);
     hipStream_t st = (hipStream_t)stream;
+    if (!dense_bwd) {
+        mvi::ZeroRegions z;
+        const size_t n = (size_t)P, Mz = (size_t)f.M;
+        z.add(dL_dmeans3D, 3 * n);
+        z.add(dL_dmeans2D, 3 * n);
+        z.add(dL_dopacity, n);
+        if (dL_dcolors) z.add(dL_dcolors, 3 * n);
+        if (shs && dL_dshs) z.add(dL_dshs, f.raw ? 3 * n : 3 * Mz * n);
+        if (f.raw && rawx.dL_dshs_rest && Mz > 1) z.add(rawx.dL_dshs_rest, (3 * Mz - 3) * n);
+        if (cov3D_precomp) z.add(dL_dcov3D, 6 * n);
+        else { z.add(dL_dscales, 3 * n); z.add(dL_drotations, 4 * n); }
+        if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0,
+                                          rawx.rows_prezeroed, stream, &z)) return rc;
+        mvi::StageTimer tm(mvi::kStPreBwd, st);
+        if (mvi::launch_preprocess_backward_sparse(f, means3D, shs, scales, rotations, cov3D_precomp, g, dL_dconic_scratch,
+                                                   dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dshs, dL_dcov3D,
+                                                   dL_dscales, dL_drotations, st, rawx))
+            return hip_fail("preprocess_backward (sparse)", hipGetLastError());
+        return MVI_OK;
+    }
+    if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0,
+                                      rawx.rows_prezeroed, stream)) return rc;
     mvi::StageTimer tm(mvi::kStPreBwd, st);
     if (mvi::launch_preprocess_backward(f, means3D, shs, scales, rotations, cov3D_precomp, radii, g, dL_dconic_scratch,
                                         dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors,
@@ -331,7 +364,7 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
 // first half of the backward: zero the accumulation rows, render backward, optionally the colour factors
 static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32_t* radii, const void* geom, const void* binning,
                                 const void* image, const float* dL_dout_color, float* grad_rows, float* dL_dcolor_factor,
-                                int sh_input, int rows_prezeroed, void* stream) {
+                                int sh_input, int rows_prezeroed, void* stream, const mvi::ZeroRegions* zero_outputs) {
     if (P == 0) return MVI_OK;
     if (!radii || !geom || !image || !dL_dout_color || !grad_rows) return fail(MVI_EINVAL, "NULL required pointer in backward%s");
     if (D > 0 && !binning) return fail(MVI_EINVAL, "NULL binning with num_rendered > 0%s");
@@ -339,11 +372,16 @@ static int backward_render_impl(mvi::Frame& f, int32_t P, int64_t D, const int32
     mvi::ImageView im = mvi::carve_image(const_cast<void*>(image), f.W, f.H);
     mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, f.W, f.H);
     hipStream_t st = (hipStream_t)stream;
-    if (!rows_prezeroed && mvi::launch_zero_fill(grad_rows, sizeof(float) * mvi::kGradRow * (size_t)P, st))
-        return hip_fail("zero grad rows", hipGetLastError());
+    if (!rows_prezeroed) {      // accumulation rows + the touched flags (the forward zeroes both when asked to prepare a backward)
+        mvi::ZeroRegions z;
+        z.add(grad_rows, (size_t)mvi::kGradRow * (size_t)P);
+        z.add(g.touched, ((size_t)P + 15) / 16 * 4);
+        z.add(g.touched_count, 1);
+        if (mvi::launch_zero_regions(z, st)) return hip_fail("zero grad rows", hipGetLastError());
+    }
     {
         mvi::StageTimer tm(mvi::kStRenderBwd, st);
-        if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, grad_rows, st))
+        if (mvi::launch_render_backward(f, g, b, im, D, dL_dout_color, grad_rows, st, zero_outputs))
             return hip_fail("render_backward", hipGetLastError());
     }
     if (dL_dcolor_factor && mvi::launch_color_factors(P, radii, grad_rows, sh_input ? g.clamped : nullptr, dL_dcolor_factor, st))
@@ -453,6 +491,7 @@ int mvi_raster_get_views(int32_t P, int64_t D, int32_t W, int32_t H, const void*
         out->cov3D_a = reinterpret_cast<const float*>(g.cov_a); out->cov3D_b = reinterpret_cast<const float*>(g.cov_b);
         out->conic_opacity = reinterpret_cast<const float*>(g.conic_opacity); out->rgbd = reinterpret_cast<const float*>(g.rgbd);
         out->tiles_touched = g.tiles_touched; out->clamped = g.clamped;
+        out->grad_support = g.touched;
     }
     if (binning) {
         mvi::BinningView b = mvi::carve_binning(const_cast<void*>(binning), D, W, H);

@@ -75,6 +75,10 @@ struct GeomView {
     uint2* rect;              // [P] tile rectangle (x0 | y0 << 16, w | h << 16); w * h = tiles touched, 0 when culled:
                               //     pair emission gathers this one 8-byte record per depth-ordered Gaussian
     uint8_t* clamped;         // [P] bit c set = colour channel c was clamped at 0
+    uint32_t* touched_list;   // [P] the touched Gaussians, compacted (any order); touched_count[0] of them
+    uint32_t* touched_count;  // [1]
+    uint8_t* touched;         // [P] 1 = the render backward added something to this Gaussian's accumulation row (gradient
+                              //     support: ~3 % of the Gaussians of the bench scene; the others are occluded). Zeroed with the rows.
     uint32_t* block_sums;     // [npre]   tiles touched per preprocess block (kPB Gaussians)
     uint32_t* block_offsets;  // [npre+1] exclusive scan of block_sums; [npre] = D
     // depth sort of the Gaussians (binning level 1): ping-pong (depth bits, index) pairs
@@ -142,6 +146,9 @@ inline GeomView carve_geom(void* base, int P) {
     g.tiles_touched = (uint32_t*)take(4 * n);
     g.rect = (uint2*)take(8 * n);
     g.clamped = (uint8_t*)take(n);
+    g.touched = (uint8_t*)take(n);
+    g.touched_list = (uint32_t*)take(4 * n);
+    g.touched_count = (uint32_t*)take(4);
     const size_t npre = (n + kPB - 1) / kPB;
     g.block_sums = (uint32_t*)take(4 * npre);
     g.block_offsets = (uint32_t*)take(4 * (npre + 1));
@@ -277,6 +284,42 @@ struct StageTimer {
     ~StageTimer() { stage_end(stage, st); }
 };
 
+// Memory a kernel zeroes on the side while it runs (the render kernels are issue-bound with the memory pipes idle): up to
+// kMaxZero arrays of fp32 words, each cut into an unaligned head (< 4 words), a 16-byte-aligned body and a tail (< 4 words);
+// the bodies are shared out over the blocks of the launch, block 0 also writes heads and tails.
+constexpr int kMaxZero = 10;
+struct ZeroRegions {
+    float* head[kMaxZero];      // first word of the array
+    uint4* body[kMaxZero];
+    float* tail[kMaxZero];
+    uint32_t n_head[kMaxZero], n_body[kMaxZero], n_tail[kMaxZero];   // words, 16-byte units, words
+    int n = 0;
+    void add(void* ptr, size_t words) {
+        if (!ptr || !words || n >= kMaxZero) return;
+        float* p = (float*)ptr;
+        const size_t mis = ((uintptr_t)p & 15u) / 4u;
+        size_t h = mis ? 4 - mis : 0;
+        if (h > words) h = words;
+        const size_t b = (words - h) / 4, t = words - h - 4 * b;
+        head[n] = p; n_head[n] = (uint32_t)h;
+        body[n] = (uint4*)(p + h); n_body[n] = (uint32_t)b;
+        tail[n] = p + h + 4 * b; n_tail[n] = (uint32_t)t;
+        ++n;
+    }
+};
+__device__ __forceinline__ void zero_share(const ZeroRegions& z, int tid, int nthreads) {
+    for (int r = 0; r < z.n; ++r) {
+        const uint32_t per = (z.n_body[r] + gridDim.x - 1) / gridDim.x;
+        const size_t z0 = (size_t)blockIdx.x * per;
+        for (uint32_t i = tid; i < per && z0 + i < z.n_body[r]; i += nthreads) z.body[r][z0 + i] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0) {
+            if (tid < (int)z.n_head[r]) z.head[r][tid] = 0.f;
+            if (tid < (int)z.n_tail[r]) z.tail[r][tid] = 0.f;
+        }
+    }
+}
+int launch_zero_regions(const ZeroRegions& z, hipStream_t st);
+
 // launchers (defined in the .hip files; all enqueue on `st`, none synchronise)
 int launch_preprocess_forward(const Frame& f, const float* means3D, const float* shs,
                               const float* colors_precomp, const float* opacities, const float* scales,
@@ -284,6 +327,13 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               int32_t* radii, hipStream_t st);
 // raw mode only: raw_opacity [P] (chain rule of the sigmoid), dL_dshs_rest [P,M-1,3]
 struct RawBackwardExtra { const float* raw_opacity = nullptr; float* dL_dshs_rest = nullptr; int rows_prezeroed = 0; };
+// sparse form: the gradient outputs are already zero (the render backward zeroed them on the side) and only the Gaussians
+// whose accumulation row was touched are read, computed and written (per-lane accesses: ~3 % of the rows)
+int launch_preprocess_backward_sparse(const Frame& f, const float* means3D, const float* shs, const float* scales,
+                                      const float* rotations, const float* cov3D_precomp, GeomView g, const float* grad_rows,
+                                      float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors,
+                                      float* dL_dshs, float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st,
+                                      RawBackwardExtra raw);
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,
                                const float* scales, const float* rotations, const float* cov3D_precomp,
                                const int32_t* radii, GeomView g, const float* grad_rows, float* dL_dmeans3D,
@@ -300,7 +350,7 @@ int launch_binning2(const Frame& f, GeomView g, BinningView b, ImageView im, int
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                           float* out_color, float* out_depth, hipStream_t st, float* zero_rows = nullptr);
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
-                           const float* dL_dpix, float* grad_rows, hipStream_t st);
+                           const float* dL_dpix, float* grad_rows, hipStream_t st, const ZeroRegions* zero = nullptr);
 constexpr int kGradRow = 16;   // floats per Gaussian in the backward accumulation rows (64 B)
 int launch_sh_backward_views(int P, int M, int deg, int n_views, const float* means3D, const float* campos,
                              int64_t campos_stride, const float* gcol, int64_t gcol_stride, float* dL_dshs, hipStream_t st);

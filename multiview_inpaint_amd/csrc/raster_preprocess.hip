@@ -389,6 +389,120 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // One thread per Gaussian. Input: grad_rows [P][16] from render_backward (mean2D.xy NDC-scaled,
 // dL/dA, dL/dB, dL/dC of power = -0.5(A dx^2 + C dy^2) - B dx dy, dL/dopacity, dL/drgb).
 // Outputs are written for every Gaussian (zeros where radii == 0).
+// Chain rule from the 2-D gradients of one Gaussian (gr: dL/dmean2D (NDC-scaled) 2, dL/dconic 3, ...) to dL/dcov3D (g6)
+// and the covariance / projection part of dL/dmean3D (dm). Shared by the dense and the sparse backward kernel.
+__device__ __forceinline__ void backward_cov_and_mean(const Frame& f, float px, float py, float pz, const float* gr,
+                                                  float4 ca, float2 cb, float* dm, float* g6) {
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = f.view[k]; PM[k] = f.proj[k]; }
+    float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
+    float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
+    float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
+    float c6[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
+    Ewa e;
+    ewa_setup(f, V, vx, vy, vz, e);
+    float a, b, c;
+    cov2d_from_cov3d(e, c6, a, b, c);
+    float denom = a * c - b * b;
+    float d2inv = 1.0f / (denom * denom + 0.0000001f);
+    const float4 gc = make_float4(gr[2], gr[3], gr[4], gr[5]);
+    float da = 0, db = 0, dc = 0;
+    if (d2inv != 0.0f) {
+        da = d2inv * (-c * c * gc.x + b * c * gc.y + (denom - a * c) * gc.z);
+        dc = d2inv * (-a * a * gc.z + a * b * gc.y + (denom - a * c) * gc.x);
+        db = d2inv * (2.0f * b * c * gc.x - (denom + 2.0f * b * b) * gc.y + 2.0f * a * b * gc.z);
+        const float(*Tm)[3] = e.Tm;
+        g6[0] = Tm[0][0] * Tm[0][0] * da + Tm[0][0] * Tm[1][0] * db + Tm[1][0] * Tm[1][0] * dc;
+        g6[3] = Tm[0][1] * Tm[0][1] * da + Tm[0][1] * Tm[1][1] * db + Tm[1][1] * Tm[1][1] * dc;
+        g6[5] = Tm[0][2] * Tm[0][2] * da + Tm[0][2] * Tm[1][2] * db + Tm[1][2] * Tm[1][2] * dc;
+        g6[1] = 2 * Tm[0][0] * Tm[0][1] * da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * db +
+                2 * Tm[1][0] * Tm[1][1] * dc;
+        g6[2] = 2 * Tm[0][0] * Tm[0][2] * da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * db +
+                2 * Tm[1][0] * Tm[1][2] * dc;
+        g6[4] = 2 * Tm[0][2] * Tm[0][1] * da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * db +
+                2 * Tm[1][1] * Tm[1][2] * dc;
+    }
+    float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float st0 = S[k][0] * e.Tm[0][0] + S[k][1] * e.Tm[0][1] + S[k][2] * e.Tm[0][2];
+        float st1 = S[k][0] * e.Tm[1][0] + S[k][1] * e.Tm[1][1] + S[k][2] * e.Tm[1][2];
+        float dT0 = 2.0f * da * st0 + db * st1;
+        float dT1 = 2.0f * dc * st1 + db * st0;
+        dJ00 += dT0 * V[0 + 4 * k];
+        dJ02 += dT0 * V[2 + 4 * k];
+        dJ11 += dT1 * V[1 + 4 * k];
+        dJ12 += dT1 * V[2 + 4 * k];
+    }
+    float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    float dtx = e.xmul * -f.fx * tz2 * dJ02;
+    float dty = e.ymul * -f.fy * tz2 * dJ12;
+    float dtz = -f.fx * tz2 * dJ00 - f.fy * tz2 * dJ11 + (2 * f.fx * e.tx) * tz3 * dJ02 +
+                (2 * f.fy * e.ty) * tz3 * dJ12;
+    dm[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+    dm[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+    dm[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+
+    float hx = affine3(PM[0], PM[4], PM[8], PM[12], px, py, pz);
+    float hy = affine3(PM[1], PM[5], PM[9], PM[13], px, py, pz);
+    float hw = affine3(PM[3], PM[7], PM[11], PM[15], px, py, pz);
+    float mw = 1.0f / (hw + 0.0000001f);
+    float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+    float g2x = gr[0], g2y = gr[1];
+    dm[0] += (PM[0] * mw - PM[3] * mul1) * g2x + (PM[1] * mw - PM[3] * mul2) * g2y;
+    dm[1] += (PM[4] * mw - PM[7] * mul1) * g2x + (PM[5] * mw - PM[7] * mul2) * g2y;
+    dm[2] += (PM[8] * mw - PM[11] * mul1) * g2x + (PM[9] * mw - PM[11] * mul2) * g2y;
+
+}
+
+// dL/dcov3D (g6) -> dL/dscale (ds), dL/dquaternion (dq); raw mode: through exp and the normalisation as well
+__device__ __forceinline__ void backward_scale_rot(const Frame& f, const float* g6, float4 qrot, const float* sa_in, float* ds,
+                                                   float* dq) {
+    float4 q = qrot;
+    float nq = 1.0f;
+    if (f.raw) {
+        nq = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        q = make_float4(q.x / nq, q.y / nq, q.z / nq, q.w / nq);
+    }
+    float R[3][3];
+    quat_to_rot(q.x, q.y, q.z, q.w, R);
+    float sa[3] = {sa_in[0], sa_in[1], sa_in[2]};
+    if (f.raw) { sa[0] = expf(sa[0]); sa[1] = expf(sa[1]); sa[2] = expf(sa[2]); }
+    float s[3] = {f.scale_modifier * sa[0], f.scale_modifier * sa[1], f.scale_modifier * sa[2]};
+    float Gf[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
+                      {0.5f * g6[1], g6[3], 0.5f * g6[4]},
+                      {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
+    float dR[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float acc_s = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float dMrj = 2.0f * (Gf[r][0] * R[0][j] + Gf[r][1] * R[1][j] + Gf[r][2] * R[2][j]) * s[j];
+            acc_s += dMrj * R[r][j];
+            dR[r][j] = dMrj * s[j];
+        }
+        ds[j] = acc_s * f.scale_modifier;
+    }
+    float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+    dq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+    dq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2 * qx * dR[1][1] - qr * dR[1][2] +
+                    qz * dR[2][0] + qr * dR[2][1] - 2 * qx * dR[2][2]);
+    dq[2] = 2.0f * (-2 * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
+                    qr * dR[2][0] + qz * dR[2][1] - 2 * qy * dR[2][2]);
+    dq[3] = 2.0f * (-2 * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2 * qz * dR[1][1] +
+                    qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+    if (f.raw) {                                   // chain rule of exp and of y = q / |q|: (g - y (y . g)) / |q|
+        ds[0] *= sa[0]; ds[1] *= sa[1]; ds[2] *= sa[2];
+        const float dot = q.x * dq[0] + q.y * dq[1] + q.z * dq[2] + q.w * dq[3];
+        const float inq = 1.0f / nq;
+        dq[0] = (dq[0] - q.x * dot) * inq; dq[1] = (dq[1] - q.y * dot) * inq;
+        dq[2] = (dq[2] - q.z * dot) * inq; dq[3] = (dq[3] - q.w * dot) * inq;
+    }
+}
+
 __global__ __launch_bounds__(kPB) void preprocess_backward_kernel(
     Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -448,68 +562,8 @@ __global__ __launch_bounds__(kPB) void preprocess_backward_kernel(
     float g6[6] = {0, 0, 0, 0, 0, 0};
     const int nb = (f.deg + 1) * (f.deg + 1);
     if (live) {
-        float V[16], PM[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { V[k] = f.view[k]; PM[k] = f.proj[k]; }
-        float px = s_mean[3 * tid], py = s_mean[3 * tid + 1], pz = s_mean[3 * tid + 2];
-        float vx = affine3(V[0], V[4], V[8], V[12], px, py, pz);
-        float vy = affine3(V[1], V[5], V[9], V[13], px, py, pz);
-        float vz = affine3(V[2], V[6], V[10], V[14], px, py, pz);
-        float c6[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
-        Ewa e;
-        ewa_setup(f, V, vx, vy, vz, e);
-        float a, b, c;
-        cov2d_from_cov3d(e, c6, a, b, c);
-        float denom = a * c - b * b;
-        float d2inv = 1.0f / (denom * denom + 0.0000001f);
-        const float4 gc = make_float4(gr[2], gr[3], gr[4], gr[5]);
-        float da = 0, db = 0, dc = 0;
-        if (d2inv != 0.0f) {
-            da = d2inv * (-c * c * gc.x + b * c * gc.y + (denom - a * c) * gc.z);
-            dc = d2inv * (-a * a * gc.z + a * b * gc.y + (denom - a * c) * gc.x);
-            db = d2inv * (2.0f * b * c * gc.x - (denom + 2.0f * b * b) * gc.y + 2.0f * a * b * gc.z);
-            const float(*Tm)[3] = e.Tm;
-            g6[0] = Tm[0][0] * Tm[0][0] * da + Tm[0][0] * Tm[1][0] * db + Tm[1][0] * Tm[1][0] * dc;
-            g6[3] = Tm[0][1] * Tm[0][1] * da + Tm[0][1] * Tm[1][1] * db + Tm[1][1] * Tm[1][1] * dc;
-            g6[5] = Tm[0][2] * Tm[0][2] * da + Tm[0][2] * Tm[1][2] * db + Tm[1][2] * Tm[1][2] * dc;
-            g6[1] = 2 * Tm[0][0] * Tm[0][1] * da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * db +
-                    2 * Tm[1][0] * Tm[1][1] * dc;
-            g6[2] = 2 * Tm[0][0] * Tm[0][2] * da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * db +
-                    2 * Tm[1][0] * Tm[1][2] * dc;
-            g6[4] = 2 * Tm[0][2] * Tm[0][1] * da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * db +
-                    2 * Tm[1][1] * Tm[1][2] * dc;
-        }
-        float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
-        float dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float st0 = S[k][0] * e.Tm[0][0] + S[k][1] * e.Tm[0][1] + S[k][2] * e.Tm[0][2];
-            float st1 = S[k][0] * e.Tm[1][0] + S[k][1] * e.Tm[1][1] + S[k][2] * e.Tm[1][2];
-            float dT0 = 2.0f * da * st0 + db * st1;
-            float dT1 = 2.0f * dc * st1 + db * st0;
-            dJ00 += dT0 * V[0 + 4 * k];
-            dJ02 += dT0 * V[2 + 4 * k];
-            dJ11 += dT1 * V[1 + 4 * k];
-            dJ12 += dT1 * V[2 + 4 * k];
-        }
-        float tz = 1.0f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-        float dtx = e.xmul * -f.fx * tz2 * dJ02;
-        float dty = e.ymul * -f.fy * tz2 * dJ12;
-        float dtz = -f.fx * tz2 * dJ00 - f.fy * tz2 * dJ11 + (2 * f.fx * e.tx) * tz3 * dJ02 +
-                    (2 * f.fy * e.ty) * tz3 * dJ12;
-        dm[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
-        dm[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
-        dm[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
-
-        float hx = affine3(PM[0], PM[4], PM[8], PM[12], px, py, pz);
-        float hy = affine3(PM[1], PM[5], PM[9], PM[13], px, py, pz);
-        float hw = affine3(PM[3], PM[7], PM[11], PM[15], px, py, pz);
-        float mw = 1.0f / (hw + 0.0000001f);
-        float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-        float g2x = gr[0], g2y = gr[1];
-        dm[0] += (PM[0] * mw - PM[3] * mul1) * g2x + (PM[1] * mw - PM[3] * mul2) * g2y;
-        dm[1] += (PM[4] * mw - PM[7] * mul1) * g2x + (PM[5] * mw - PM[7] * mul2) * g2y;
-        dm[2] += (PM[8] * mw - PM[11] * mul1) * g2x + (PM[9] * mw - PM[11] * mul2) * g2y;
+        const float px = s_mean[3 * tid], py = s_mean[3 * tid + 1], pz = s_mean[3 * tid + 2];
+        backward_cov_and_mean(f, px, py, pz, gr, ca, cb, dm, g6);
 
         if (shs) {
             float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];
@@ -552,47 +606,8 @@ __global__ __launch_bounds__(kPB) void preprocess_backward_kernel(
     } else {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         if (live) {
-            float4 q = qrot;
-            float nq = 1.0f;
-            if (f.raw) {
-                nq = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-                q = make_float4(q.x / nq, q.y / nq, q.z / nq, q.w / nq);
-            }
-            float R[3][3];
-            quat_to_rot(q.x, q.y, q.z, q.w, R);
-            float sa[3] = {s_scale[3 * tid], s_scale[3 * tid + 1], s_scale[3 * tid + 2]};
-            if (f.raw) { sa[0] = expf(sa[0]); sa[1] = expf(sa[1]); sa[2] = expf(sa[2]); }
-            float s[3] = {f.scale_modifier * sa[0], f.scale_modifier * sa[1], f.scale_modifier * sa[2]};
-            float Gf[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]},
-                              {0.5f * g6[1], g6[3], 0.5f * g6[4]},
-                              {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
-            float dR[3][3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float acc_s = 0;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    float dMrj = 2.0f * (Gf[r][0] * R[0][j] + Gf[r][1] * R[1][j] + Gf[r][2] * R[2][j]) * s[j];
-                    acc_s += dMrj * R[r][j];
-                    dR[r][j] = dMrj * s[j];
-                }
-                ds[j] = acc_s * f.scale_modifier;
-            }
-            float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
-            dq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
-            dq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2 * qx * dR[1][1] - qr * dR[1][2] +
-                            qz * dR[2][0] + qr * dR[2][1] - 2 * qx * dR[2][2]);
-            dq[2] = 2.0f * (-2 * qy * dR[0][0] + qx * dR[0][1] + qr * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] -
-                            qr * dR[2][0] + qz * dR[2][1] - 2 * qy * dR[2][2]);
-            dq[3] = 2.0f * (-2 * qz * dR[0][0] - qr * dR[0][1] + qx * dR[0][2] + qr * dR[1][0] - 2 * qz * dR[1][1] +
-                            qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
-            if (f.raw) {                                   // chain rule of exp and of y = q / |q|: (g - y (y . g)) / |q|
-                ds[0] *= sa[0]; ds[1] *= sa[1]; ds[2] *= sa[2];
-                const float dot = q.x * dq[0] + q.y * dq[1] + q.z * dq[2] + q.w * dq[3];
-                const float inq = 1.0f / nq;
-                dq[0] = (dq[0] - q.x * dot) * inq; dq[1] = (dq[1] - q.y * dot) * inq;
-                dq[2] = (dq[2] - q.z * dot) * inq; dq[3] = (dq[3] - q.w * dot) * inq;
-            }
+            const float sa_in[3] = {s_scale[3 * tid], s_scale[3 * tid + 1], s_scale[3 * tid + 2]};
+            backward_scale_rot(f, g6, qrot, sa_in, ds, dq);
         }
         s_dscale[3 * tid] = ds[0]; s_dscale[3 * tid + 1] = ds[1]; s_dscale[3 * tid + 2] = ds[2];
         if (in_range) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
@@ -609,6 +624,173 @@ __global__ __launch_bounds__(kPB) void preprocess_backward_kernel(
             if (f.M > 1) stage_out_split(rawx.dL_dshs_rest + (size_t)blk0 * (3 * f.M - 3), s_sh + 3, n_rec, 3 * f.M - 3, shs_w);
         }
     }
+}
+
+// The per-Gaussian chain rule for the Gaussians whose accumulation row the render backward TOUCHED (g.touched), one lane per
+// Gaussian, no LDS: in the bench scene 3 % of the Gaussians receive a gradient (the rest are occluded), and an untouched row
+// is exactly zero, so its outputs are exactly zero — the caller zeroed every output array beforehand (the render backward does
+// it on the side) and this kernel reads and writes the touched rows only, with per-lane accesses. Same expressions as
+// preprocess_backward_kernel (shared helpers), which stays the form for dense outputs (split / ranged backward).
+__global__ __launch_bounds__(256) void preprocess_backward_sparse_kernel(
+    Frame f, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, GeomView g,
+    const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= *g.touched_count) return;                     // the grid covers P; the list is a few per cent of that
+    const int i = (int)g.touched_list[slot];
+    const size_t si = (size_t)i;
+    float gr[9];
+    {
+        const float4* row = reinterpret_cast<const float4*>(grad_rows + si * kGradRow);
+        const float4 a = row[0], b4 = row[1];
+        gr[0] = a.x; gr[1] = a.y; gr[2] = a.z; gr[3] = a.w; gr[4] = b4.x; gr[5] = b4.y; gr[6] = b4.z; gr[7] = b4.w;
+        gr[8] = grad_rows[si * kGradRow + 8];
+    }
+    const float4 ca = g.cov_a[i];
+    const float2 cb = g.cov_b[i];
+    const uint32_t cl = shs ? g.clamped[i] : 0u;
+    const float px = means3D[3 * si], py = means3D[3 * si + 1], pz = means3D[3 * si + 2];
+    dL_dmeans2D[3 * si] = gr[0];
+    dL_dmeans2D[3 * si + 1] = gr[1];
+    {
+        float go = gr[5];
+        if (f.raw) { const float o = sigmoidf_(rawx.raw_opacity[i]); go *= o * (1.0f - o); }    // d sigmoid
+        dL_dopacity[i] = go;
+    }
+    if (dL_dcolors) {
+        dL_dcolors[3 * si] = (cl & 1u) ? 0.0f : gr[6];
+        dL_dcolors[3 * si + 1] = (cl & 2u) ? 0.0f : gr[7];
+        dL_dcolors[3 * si + 2] = (cl & 4u) ? 0.0f : gr[8];
+    }
+    float dm[3] = {0, 0, 0};
+    float g6[6] = {0, 0, 0, 0, 0, 0};
+    backward_cov_and_mean(f, px, py, pz, gr, ca, cb, dm, g6);
+    if (shs) {
+        const int M = f.M, nb = (f.deg + 1) * (f.deg + 1);
+        float ox = px - f.campos[0], oy = py - f.campos[1], oz = pz - f.campos[2];
+        float len = sqrtf(ox * ox + oy * oy + oz * oz);
+        float dx = ox / len, dy = oy / len, dz = oz / len;
+        float bs[16], bx[16], by[16], bz[16];
+        sh_basis(f.deg, dx, dy, dz, bs);
+        sh_basis_grad(f.deg, dx, dy, dz, bx, by, bz);
+        float gcol[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) gcol[ch] = ((cl >> ch) & 1u) ? 0.0f : gr[6 + ch];
+        // coefficient k of this Gaussian: one [P,M,3] array, or (raw mode) features_dc [P,1,3] + features_rest [P,M-1,3]
+        const float* in0 = f.raw ? shs + 3 * si : shs + si * M * 3;
+        const float* in_rest = f.raw ? f.shs_rest + si * (3 * M - 3) - 3 : in0;          // + 3 k for k >= 1
+        float* out0 = dL_dshs ? (f.raw ? dL_dshs + 3 * si : dL_dshs + si * M * 3) : nullptr;
+        float* out_rest = dL_dshs ? (f.raw ? rawx.dL_dshs_rest + si * (3 * M - 3) - 3 : out0) : nullptr;
+        float ddx = 0, ddy = 0, ddz = 0;
+        if (!f.raw && M == 16) {
+            // the common case (sh_degree <= 3 stored with 16 coefficients): the 192-byte row moves as twelve 16-byte
+            // accesses per lane instead of 48 + 48 scattered words
+            float rowv[48];
+            const float4* in4 = reinterpret_cast<const float4*>(in0);
+#pragma unroll
+            for (int v = 0; v < 12; ++v) { const float4 t = in4[v]; rowv[4 * v] = t.x; rowv[4 * v + 1] = t.y; rowv[4 * v + 2] = t.z; rowv[4 * v + 3] = t.w; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float w = k < nb ? rowv[3 * k + ch] * gcol[ch] : 0.f;
+                    rowv[3 * k + ch] = k < nb ? bs[k] * gcol[ch] : 0.f;
+                    ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;      // bx / by / bz are zero above nb
+                }
+            }
+            if (out0) {
+                float4* out4 = reinterpret_cast<float4*>(out0);
+#pragma unroll
+                for (int v = 0; v < 12; ++v) out4[v] = make_float4(rowv[4 * v], rowv[4 * v + 1], rowv[4 * v + 2], rowv[4 * v + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < nb) {
+                    const float* in = k == 0 ? in0 : in_rest + 3 * k;
+                    float* out = k == 0 ? out0 : out_rest + 3 * k;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float w = in[ch] * gcol[ch];
+                        if (out0) out[ch] = bs[k] * gcol[ch];
+                        ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+                    }
+                }
+            }
+        }
+        float dotp = dx * ddx + dy * ddy + dz * ddz;
+        dm[0] += (ddx - dx * dotp) / len;
+        dm[1] += (ddy - dy * dotp) / len;
+        dm[2] += (ddz - dz * dotp) / len;
+    }
+    dL_dmeans3D[3 * si] = dm[0]; dL_dmeans3D[3 * si + 1] = dm[1]; dL_dmeans3D[3 * si + 2] = dm[2];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * si + k] = g6[k];
+    } else {
+        const float4 qrot = *reinterpret_cast<const float4*>(rotations + 4 * si);
+        const float sa_in[3] = {scales[3 * si], scales[3 * si + 1], scales[3 * si + 2]};
+        float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        backward_scale_rot(f, g6, qrot, sa_in, ds, dq);
+        dL_dscales[3 * si] = ds[0]; dL_dscales[3 * si + 1] = ds[1]; dL_dscales[3 * si + 2] = ds[2];
+        dL_drots[4 * si] = dq[0]; dL_drots[4 * si + 1] = dq[1]; dL_drots[4 * si + 2] = dq[2]; dL_drots[4 * si + 3] = dq[3];
+    }
+}
+
+// touched flags -> compact list of Gaussian indices (any order) + their number: the chain rule then runs full waves.
+// 16 flags per thread, 16384 per block, ONE returning atomic per block: a returning atomic on a single word completes at
+// ~88 per microsecond on this chip (MI355X_MICROARCH.md, dequeue), so one per wave of a 1.5 M-flag pass cost 67 us.
+constexpr int kCompactThreads = 1024, kCompactPer = 16;
+__global__ __launch_bounds__(kCompactThreads) void compact_touched_kernel(int P, const uint8_t* __restrict__ touched,
+                                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_wave[kCompactThreads / 64];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = (blockIdx.x * kCompactThreads + tid) * kCompactPer;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (i0 < P) w = *reinterpret_cast<const uint4*>(touched + i0);      // bytes past P are padding of the segment, never set
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        mine += ((ww[q] & 0xFFu) != 0) + ((ww[q] & 0xFF00u) != 0) + ((ww[q] & 0xFF0000u) != 0) + ((ww[q] >> 24) != 0);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactThreads / 64; ++k) { const uint32_t c = s_wave[k]; if (k < wave) off += c; total += c; }
+    if (total == 0) return;
+    if (tid == 0) s_base = atomicAdd(count, total);
+    __syncthreads();
+    uint32_t dst = s_base + off + inc - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (((ww[q] >> (8 * k)) & 0xFFu) && i0 + 4 * q + k < P) list[dst++] = (uint32_t)(i0 + 4 * q + k);
+}
+
+int launch_preprocess_backward_sparse(const Frame& f, const float* means3D, const float* shs, const float* scales,
+                                      const float* rotations, const float* cov3D_precomp, GeomView g, const float* grad_rows,
+                                      float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors,
+                                      float* dL_dshs, float* dL_dcov3D, float* dL_dscales, float* dL_drots, hipStream_t st,
+                                      RawBackwardExtra rawx) {
+    if (f.P <= 0) return 0;
+    constexpr int kPerBlock = kCompactThreads * kCompactPer;
+    hipLaunchKernelGGL(compact_touched_kernel, dim3((f.P + kPerBlock - 1) / kPerBlock), dim3(kCompactThreads), 0, st, f.P, g.touched,
+                       g.touched_list, g.touched_count);
+    hipLaunchKernelGGL(preprocess_backward_sparse_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, f, means3D, shs, scales,
+                       rotations, cov3D_precomp, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dshs,
+                       dL_dcov3D, dL_dscales, dL_drots, rawx);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
 int launch_preprocess_backward(const Frame& f, const float* means3D, const float* shs,

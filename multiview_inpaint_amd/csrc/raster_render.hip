@@ -87,19 +87,17 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth, uint4* __restrict__ zero_rows, uint32_t zero_per_block, size_t zero_n16) {
+    float* __restrict__ out_depth, ZeroRegions zero) {
     __shared__ float2 s_xy[kBlock];
     __shared__ float s_t2[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_cd[kBlock];                 // r, g, b, depth
     __shared__ float4 w_a[4][64], w_co[4][64], w_cd[4][64];   // per-wave compacted strip: (x, y, list position, -)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (zero_rows) {
-        // the backward's accumulation rows are zeroed HERE: this kernel is issue-bound with the memory pipes nearly idle, so
-        // the 64 bytes per Gaussian ride along for free instead of costing a 96 MB fill pass in front of the render backward
-        const size_t z0 = (size_t)blockIdx.x * zero_per_block;
-        for (uint32_t i = tid; i < zero_per_block && z0 + i < zero_n16; i += kBlock) zero_rows[z0 + i] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    // the backward's accumulation rows (and the touched flags) are zeroed HERE: this kernel is issue-bound with the memory
+    // pipes nearly idle, so the 65 bytes per Gaussian ride along for free instead of costing a 96 MB fill pass in front of
+    // the render backward
+    zero_share(zero, tid, kBlock);
     const int tile = xcd_band_tile(blockIdx.x, f.gx * f.gy);
     const int tile_y = tile / f.gx, tile_x = tile - tile_y * f.gx;
     const int qx0 = tile_x * kTile + 8 * (wave & 1), qy0 = tile_y * kTile + 8 * (wave >> 1);
@@ -184,13 +182,25 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
 int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                           float* out_color, float* out_depth, hipStream_t st, float* zero_rows) {
-    const size_t zero_n16 = zero_rows ? (size_t)f.P * kGradRow * sizeof(float) / 16 : 0;
-    if (f.W <= 0 || f.H <= 0) return zero_rows ? launch_zero_fill(zero_rows, zero_n16 * 16, st) : 0;
+    ZeroRegions z;
+    if (zero_rows) {
+        z.add(zero_rows, (size_t)f.P * kGradRow);
+        z.add(g.touched, ((size_t)f.P + 15) / 16 * 4);           // bytes, rounded up to the 16 the compaction reads at once
+                                                                  // (inside the scratch segment's 256-byte padding)
+        z.add(g.touched_count, 1);
+    }
+    if (f.W <= 0 || f.H <= 0) return launch_zero_regions(z, st);
     const uint32_t* plist = b.vals[b.passes & 1];
     const unsigned blocks = (unsigned)(f.gx * f.gy);
-    const uint32_t per = (uint32_t)((zero_n16 + blocks - 1) / blocks);
     hipLaunchKernelGGL(render_forward_kernel, dim3(blocks), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
-                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth, (uint4*)zero_rows, per, zero_n16);
+                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth, z);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroRegions z) { zero_share(z, threadIdx.x, 256); }
+int launch_zero_regions(const ZeroRegions& z, hipStream_t st) {
+    if (z.n == 0) return 0;
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(2048), dim3(256), 0, st, z);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -249,8 +259,11 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, float* __restrict__ grad_rows) {
+    const float* __restrict__ dL_dpix, float* __restrict__ grad_rows, uint8_t* __restrict__ touched, ZeroRegions zero) {
 #pragma clang fp contract(off)
+    // the dense gradient outputs of the per-Gaussian chain rule are zeroed HERE (this kernel is bound by vector issue, its
+    // memory pipes are idle): preprocess_backward then only writes the few per cent of rows that received a gradient
+    zero_share(zero, threadIdx.x, kB2);
     __shared__ uint32_t s_id[kB2];
     __shared__ float2 s_xy[kB2];
     __shared__ float s_t2[kB2];
@@ -415,16 +428,19 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 default: v = a[comp]; break;                                           // 6,7,8: rgb
             }
             atomicAdd(&grad_rows[(size_t)s_id[e] * kRow + comp], v);
+            if (comp == 0) touched[s_id[e]] = 1;              // gradient support (idempotent store)
         }
     }
 }
 
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
-                           const float* dL_dpix, float* grad_rows, hipStream_t st) {
-    if (f.W <= 0 || f.H <= 0 || D <= 0) return 0;
+                           const float* dL_dpix, float* grad_rows, hipStream_t st, const ZeroRegions* zero) {
+    ZeroRegions z;
+    if (zero) z = *zero;
+    if (f.W <= 0 || f.H <= 0 || D <= 0) return launch_zero_regions(z, st);
     const uint32_t* plist = b.vals[b.passes & 1];
     hipLaunchKernelGGL(render_backward_kernel, dim3(f.gx * f.gy), dim3(kB2), 0, st, f, im.ranges, plist, g.xy,
-                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, dL_dpix, grad_rows);
+                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, dL_dpix, grad_rows, g.touched, z);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

@@ -718,3 +718,45 @@ def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backwar
         assert a.shape == b.shape, k
         assert _same_to_summation_order(a, b), k
         assert (a[~vis] == 0).all(), k
+
+
+@pytest.mark.parametrize("N,W,H,deg,mode,log_scale", [(60_000, 640, 368, 3, "sh", None), (3001, 200, 120, 1, "sh", np.log(0.05)),
+                                                      (5000, 320, 240, 2, "precomp", np.log(0.04)), (400_000, 800, 448, 0, "sh", None)])
+def test_sparse_backward_equals_dense_backward_and_the_support_is_a_superset(R, N, W, H, deg, mode, log_scale):
+    """mvi_raster_backward's default form (outputs zeroed inside the render backward, chain rule only for the Gaussians whose
+    accumulation row was touched: csrc/raster_preprocess.hip preprocess_backward_sparse_kernel) against the dense kernel:
+    every gradient array equal to the order of the float atomics, every row outside the support exactly zero in both, and
+    the support flags cover every non-zero row. (The oracle comparisons of this file run the sparse form: it is the default.)"""
+    from multiview_inpaint_amd import _lib
+    L = _lib.lib()
+    cam = syn.make_camera(W, H, 50.0)
+    kw0 = {} if log_scale is None else dict(log_scale_mean=log_scale)
+    sc = syn.make_scene(N, cam, deg, seed=21, **kw0)
+    t = _to_dev(sc)
+    rs = _settings(R, cam, np.array([0.2, 0.1, 0.3], np.float32), deg)
+    if mode == "precomp":
+        cols = torch.rand(N, 3, device="cuda")
+        fkw = dict(colors_precomp=cols, scales=t["scales"], rotations=t["rotations"])
+        names = ("means3D", "means2D", "opacities", "colors_precomp", "scales", "rotations")
+    else:
+        fkw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        names = ("means3D", "means2D", "opacities", "shs", "scales", "rotations")
+    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **fkw)
+    g_img = torch.randn(3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    prev = L.mvi_raster_backward_mode(0)
+    try:
+        sparse = R.rasterize_backward(rs, st, g_img, t["means3D"], **fkw)
+        support = st.tensor("grad_support", (N,), torch.uint8).bool()
+        L.mvi_raster_backward_mode(1)
+        dense = R.rasterize_backward(rs, st, g_img, t["means3D"], **fkw)
+    finally:
+        L.mvi_raster_backward_mode(prev)
+    torch.cuda.synchronize()
+    assert 0 < int(support.sum()) <= int((radii > 0).sum())
+    for k in names:
+        a, b = sparse[k], dense[k]
+        assert a.shape == b.shape, k
+        assert _same_to_summation_order(a.cpu().numpy(), b.cpu().numpy()), k
+        flat_a, flat_b = a.reshape(N, -1), b.reshape(N, -1)
+        assert (flat_a[~support] == 0).all() and (flat_b[~support] == 0).all(), k
+    print(f"gradient support: {float(support.float().mean()):.4f} of the Gaussians (visible: {float((radii > 0).float().mean()):.3f})")
