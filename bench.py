@@ -206,18 +206,19 @@ def main():
     # exchange step: one flat all-reduce, or — when it moves fewer bytes (W < 2M) — the SH gradient in
     # factored form (all-gather of 3 floats per view and Gaussian + local rebuild) and an all-reduce of the other 11
     mode = os.environ.get("MVI_BENCH_EXCHANGE", "auto")
+    n_ranges = int(os.environ.get("MVI_BENCH_RANGES", "1"))
     distributed = world > 1 or force_dist
     factored = distributed and (mode in ("factored", "compacted") or (mode == "auto" and mdist.FactoredGradExchange.pays(M, world)))
     # MVI_BENCH_RANGES=4: the other 11 floats are all-reduced in four Gaussian ranges, each started behind its own
     # chain-rule kernel (dist.RangedGradExchange). Not the default: on one rank (RCCL group of 1) the four smaller kernels,
     # the four collective calls and the assembly copy cost 0.19 ms per step (1.60 vs 1.41 ms), about what hiding three
     # quarters of a 66 MB all-reduce can return at 8 ranks — to be decided on an 8-GPU node, which this round never had
-    n_ranges = int(os.environ.get("MVI_BENCH_RANGES", "1"))
     ranged = factored and n_ranges > 1
-    # MVI_BENCH_EXCHANGE=compacted: only the rows visible on at least one rank travel (dist.CompactedGradExchange); it
-    # falls back to the full-size factored exchange when the union of the views is above 80 % of the Gaussians — which it is
-    # in this scene (94 % at 8 views), so "auto" does not take it
-    compacted = distributed and mode == "compacted" and M > 1
+    # "auto" (and "compacted") with more than one rank: only the rows inside the gradient support of at least one rank travel
+    # (dist.CompactedGradExchange; the support of a view is 3 % of this scene's Gaussians, so the union over 8 views is a
+    # fraction of the rows); it falls back to the full-size factored exchange when the union is above 80 %.
+    # MVI_BENCH_EXCHANGE=factored / dense select the other forms.
+    compacted = distributed and M > 1 and (mode == "compacted" or (mode == "auto" and world > 1 and n_ranges <= 1))
     bucket = (mdist.CompactedGradExchange(N, M, deg, dev) if compacted else
               mdist.RangedGradExchange(N, M, deg, dev, n_ranges=n_ranges) if ranged else
               mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev))
@@ -226,7 +227,7 @@ def main():
         color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **kw)
         if compacted:
             R.rasterize_backward(rs, st, g_img, t["means3D"], out=bucket.views, sh_grad="factor", **kw)
-            bucket.exchange_visible(t["means3D"], rs.campos, radii > 0)
+            bucket.exchange_support(t["means3D"], rs.campos, st.tensor("grad_support", (N,), torch.uint8))
             return st, radii
         if ranged:
             R.rasterize_backward_ranged(rs, st, g_img, t["means3D"], t["shs"], t["scales"], t["rotations"], bucket)
@@ -339,7 +340,7 @@ def main():
                        "parallelism": f"views x{world}" + ((" + RCCL all-gather of SH colour factors + all-reduce of 11 floats/Gaussian"
                                                              + (f" in {n_ranges} ranges overlapped with the chain rule" if ranged else "")
                                                             if factored else " + RCCL all-reduce of the gradient bucket")
-                                                           + (f" (visibility-compacted: union {bucket.last_union_fraction:.3f}, "
+                                                           + (f" (support-compacted: union of the ranks' gradient supports {bucket.last_union_fraction:.3f} of the Gaussians, "
                                                               f"{'taken' if bucket.last_compacted else 'not taken'})" if compacted else "")
                                                            if distributed else "")},
             # achieved = algorithmic bytes of the dominant kernel's launch / its launch time, against the HBM peak.

@@ -311,7 +311,12 @@ __device__ __forceinline__ void zero_share(const ZeroRegions& z, int tid, int nt
     for (int r = 0; r < z.n; ++r) {
         const uint32_t per = (z.n_body[r] + gridDim.x - 1) / gridDim.x;
         const size_t z0 = (size_t)blockIdx.x * per;
-        for (uint32_t i = tid; i < per && z0 + i < z.n_body[r]; i += nthreads) z.body[r][z0 + i] = make_uint4(0u, 0u, 0u, 0u);
+        // write-through stores that do not stay in the XCD's L2 (MI355X_MICROARCH.md, stores of each flavour): the zeros are
+        // not read again by this kernel, and the lines they would occupy hold the tile lists the kernel gathers from
+        typedef uint32_t zero_u32x4 __attribute__((ext_vector_type(4)));
+        const zero_u32x4 zz = {0u, 0u, 0u, 0u};
+        for (uint32_t i = tid; i < per && z0 + i < z.n_body[r]; i += nthreads)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(z.body[r] + z0 + i), "v"(zz) : "memory");
         if (blockIdx.x == 0) {
             if (tid < (int)z.n_head[r]) z.head[r][tid] = 0.f;
             if (tid < (int)z.n_tail[r]) z.tail[r][tid] = 0.f;

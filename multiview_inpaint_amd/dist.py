@@ -200,21 +200,23 @@ class FactoredGradExchange:
 
 
 class CompactedGradExchange(FactoredGradExchange):
-    """FactoredGradExchange that moves only the rows (Gaussians) visible on AT LEAST ONE rank: a Gaussian no view saw has a
-    zero gradient on every rank, so neither its 11 floats nor its colour factors need the wire.
+    """FactoredGradExchange that moves only the rows (Gaussians) inside the GRADIENT SUPPORT of at least one rank. The render
+    backward marks every Gaussian whose accumulation row it touches (mvi_raster_views.grad_support; RasterState.tensor(
+    "grad_support")); a Gaussian outside that set — culled, outside the image, or simply occluded in that view — has an exactly
+    zero gradient there, so neither its 11 floats nor its colour factor need the wire. In the bench scene the support of one
+    1920 x 1080 view is 3 % of the 1.5 M Gaussians (87 % are "visible" in the radii > 0 sense, but the first ~240 entries of a
+    tile's list saturate its pixels), so the union over 8 views is at most a quarter of the rows.
 
-        1. all-reduce(MAX) of the per-rank visibility bytes [P] (1.5 MB at P = 1.5 M) -> the union, identical on all ranks
+        1. all-reduce(MAX) of the per-rank support bytes [P] (1.5 MB at P = 1.5 M) -> the union, identical on all ranks
         2. idx = union.nonzero() (one host read-back of its length), u = len(idx) / P
         3. u <= THRESHOLD: gather the union rows ([n, 11] and [n, 3]), all-reduce / all-gather those, rebuild dL/dSH for
            them, scatter back into zeroed full-size outputs; else the full-size exchange of the base class
 
-    Wire per GPU: u x the base class's 241 MB (W = 8, M = 16, P = 1.5 M), plus the mask. What it costs: the mask's
-    all-reduce (latency-bound, ~50 us over xGMI), one read-back, and two gather + scatter passes over the compacted rows
-    (~84 u P bytes each way in HBM). It therefore pays only when the views overlap little — inpaint_rec.py's camera ring
-    around an object, or a large scene of which every view sees a part. In bench.py's scene every view sees 75 - 87 % of
-    the Gaussians and the union of 8 views is 94 % (2 views: 91 %): there the compaction saves 6 % of the wire and is not
-    taken (THRESHOLD = 0.8). The sums are those of FactoredGradExchange (same elements; rows outside the union are exact
-    zeros on both paths)."""
+    Wire per GPU: u x the base class's 241 MB (W = 8, M = 16, P = 1.5 M), plus the mask: ~50 MB at u = 0.2. Costs: the mask's
+    all-reduce (latency-bound), one read-back, gather + scatter passes over the compacted rows. Passing a visibility filter
+    (radii > 0) instead of the support is valid too (any superset of the support is), but compacts little: the union of 8
+    views' visibility is 94 % of this scene. The sums are those of FactoredGradExchange (same elements; rows outside the
+    union are exact zeros on both paths)."""
 
     THRESHOLD = 0.8
 
@@ -222,9 +224,11 @@ class CompactedGradExchange(FactoredGradExchange):
         super().__init__(P, M, sh_degree, device, group=group)
         self.last_union_fraction = None
         self.last_compacted = None
+        self._shs_rows = None          # rows of self.shs that may be non-zero: None = none, "all", or an index tensor
 
     def exchange_visible(self, means3D: torch.Tensor, campos: torch.Tensor, visible: torch.Tensor):
-        """visible [P] bool / uint8: this rank's visibility filter (radii > 0, gaussian_renderer/__init__.py:100). Returns
+        """visible [P] bool / uint8: any superset of this rank's gradient support — RasterState.tensor("grad_support", ...)
+        after the backward (tight), or the visibility filter radii > 0 (gaussian_renderer/__init__.py:100; loose). Returns
         the same dict as exchange()."""
         P = self.P
         mask = visible.to(torch.uint8).contiguous().clone()
@@ -234,6 +238,7 @@ class CompactedGradExchange(FactoredGradExchange):
         self.last_union_fraction = n / P if P else 0.0
         self.last_compacted = bool(P) and n <= self.THRESHOLD * P
         if not self.last_compacted:
+            self._shs_rows = "all"
             return self.exchange(means3D, campos)
         widths = [w for _, w in self.SMALL]
         rows = torch.cat([self.views[name][idx] for name, _ in self.SMALL], 1).contiguous()          # [n, 11]
@@ -244,18 +249,25 @@ class CompactedGradExchange(FactoredGradExchange):
         h.wait()
         sh_c = sh_grad_from_factors(means3D[idx].contiguous(), recv[:, 3 * n:].contiguous(),
                                     recv[:, :3 * n].reshape(self.world, n, 3).contiguous(), self.M, self.deg)
-        self.shs.zero_()
+        # the full-size outputs are zero outside the rows written here: the small arrays are the backward's own outputs
+        # (zero outside this rank's support, which the union contains), self.shs is cleared where the last step wrote it
+        if isinstance(self._shs_rows, str):
+            self.shs.zero_()
+        elif self._shs_rows is not None:
+            self.shs[self._shs_rows] = 0
         self.shs[idx] = sh_c
+        self._shs_rows = idx
         g, o = {}, 0
         for (name, w) in self.SMALL:
             v = self.views[name]
-            v.zero_()
             v[idx] = rows[:, o:o + w]
             g[name] = v
             o += w
         assert o == sum(widths)
         g["shs"] = self.shs
         return g
+
+    exchange_support = exchange_visible
 
 
 class RangedGradExchange(FactoredGradExchange):

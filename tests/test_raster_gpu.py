@@ -681,8 +681,8 @@ def test_ranged_backward_with_overlapped_exchange_equals_one_call(R, N):
 
 
 def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backward(R):
-    """dist.CompactedGradExchange on ONE rank over RCCL with the compaction forced (THRESHOLD = 1): gather of the visible
-    rows, all-reduce / all-gather of the compacted buffers, rebuild of dL/dSH for those rows, scatter into zeroed outputs —
+    """dist.CompactedGradExchange on ONE rank over RCCL with the compaction forced (THRESHOLD = 1), keyed on the gradient
+    support the render backward recorded: gather of the support's rows, all-reduce / all-gather of the compacted buffers, rebuild of dL/dSH for those rows, scatter into zeroed outputs —
     the sums of one rank are the rank's own gradients, so everything equals rasterize_backward to fp32 rounding, and every
     invisible row is exactly zero."""
     import os
@@ -707,12 +707,13 @@ def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backwar
         ex = md.CompactedGradExchange(P, M, 3, "cuda")
         ex.THRESHOLD = 1.0
         R.rasterize_backward(rs, st, g_img, t["means3D"], out=ex.views, sh_grad="factor", **kw)
-        got = ex.exchange_visible(t["means3D"], rs.campos, radii > 0)
+        support = st.tensor("grad_support", (P,), torch.uint8)
+        got = ex.exchange_support(t["means3D"], rs.campos, support)
         torch.cuda.synchronize()
-        assert ex.last_compacted and 0.3 < ex.last_union_fraction < 1.0
+        assert ex.last_compacted and 0.0 < ex.last_union_fraction <= float((radii > 0).float().mean())
     finally:
         td.destroy_process_group()
-    vis = (radii > 0).cpu().numpy()
+    vis = support.bool().cpu().numpy()
     for k in ("means3D", "opacities", "scales", "rotations", "shs"):
         a, b = got[k].cpu().numpy(), one[k].cpu().numpy()
         assert a.shape == b.shape, k

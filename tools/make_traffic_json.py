@@ -14,7 +14,15 @@ STAGE = {"preprocess_forward_kernel": "preprocess_forward", "total_block_sums_ke
          "scan_block_sums_kernel": "duplicate_keys", "depth_keys_kernel": "radix_sort", "radix_count_kernel": "radix_sort", "radix_scan_rows_kernel": "radix_sort",
          "radix_scatter_kernel": "radix_sort", "perm_block_sums_kernel": "duplicate_keys", "emit_pairs_kernel": "duplicate_keys",
          "tile_ranges_kernel": "tile_ranges", "render_forward_kernel": "render_forward",
-         "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
+         "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward",
+         # binning version 2 (csrc/raster_binning2.hip) and the sparse backward, under the stage names of the bench line
+         "totals2_kernel": "scan_block_sums", "depth_count_kernel": "radix_sort", "depth_scatter_kernel": "radix_sort",
+         "column_count_kernel": "duplicate_keys", "columns_scan_kernel": "duplicate_keys",
+         "expand_scatter_kernel<1, 128>": "duplicate_keys", "expand_scatter_kernel<1, 256>": "duplicate_keys",
+         "row_count_kernel": "radix_sort", "row_scan_kernel": "radix_sort",
+         "expand_scatter_kernel<2, 128>": "radix_sort", "expand_scatter_kernel<2, 256>": "radix_sort",
+         "compact_touched_kernel": "preprocess_backward", "preprocess_backward_sparse_kernel": "preprocess_backward",
+         "zero_regions_kernel": "render_backward"}
 STEPS = None       # launches of a once-per-step kernel in the profiled run (bench.py --steps 5 --warmup 1: 1 warm-up + 5
                    # instrumented + 5 timed = 11), read from the render_backward_kernel entry
 
