@@ -114,6 +114,44 @@ def enable_gemm_tuning(tune_ms=int(os.environ.get("MVI_SVD_GEMM_TUNING_MS", "0")
         return False
 
 
+def library_selection_status(device):
+    """Did the shipped solver / solution tables actually take effect in THIS process? Both are keyed to library builds and a
+    mismatch is otherwise silent (the step just runs ~20 % slower on whatever the libraries pick):
+      * TunableOp: the csv's `Validator` lines against torch.cuda.tunable.get_validators() of the running stack;
+      * MIOpen: MIOpen names its user-db files after its own version — after a step, a db file in MIOPEN_USER_DB_PATH that is
+        not one of the shipped ones means the installed MIOpen looked its problems up under another name and missed.
+    Returns (dict for the bench line, list of warning strings); bench_svd prints the warnings to stderr."""
+    status, warns = {}, []
+    try:
+        import torch.cuda.tunable as tn
+        want = {}
+        with open(TUNED_GEMMS) as fh:
+            for line in fh:
+                if line.startswith("Validator,"):
+                    _, k, v = line.rstrip("\n").split(",", 2)
+                    want[k] = v
+        have = {str(k): str(v) for k, v in (tn.get_validators() or ())} if tn.is_enabled() else {}
+        bad = {k: (v, have.get(k)) for k, v in want.items() if have and have.get(k) != v}
+        status["tunableop_file_matches_stack"] = bool(have) and not bad
+        if bad:
+            warns.append(f"TunableOp file {os.path.basename(TUNED_GEMMS)} was recorded on another stack {bad}: PyTorch ignores it and "
+                         "the GEMMs run with the library's default solutions (re-record with tools/tune_svd_gemms.sh)")
+    except Exception as e:                                   # TunableOp absent: nothing selected, nothing to mismatch
+        status["tunableop_file_matches_stack"] = None
+        warns.append(f"TunableOp status unavailable ({e})")
+    d = os.environ.get("MIOPEN_USER_DB_PATH")
+    if d and os.path.isdir(d) and os.path.isdir(MIOPEN_USERDB):
+        shipped = set(os.listdir(MIOPEN_USERDB))
+        extra = sorted(f for f in os.listdir(d) if f not in shipped and f.endswith(("udb.txt", "ufdb.txt")))
+        status["miopen_db_matches_library"] = not extra
+        if extra:
+            warns.append(f"the shipped MIOpen find-db ({sorted(shipped)}) is keyed to another MIOpen build: this one wrote {extra}; "
+                         "its convolutions ran on immediate-mode fallbacks (re-record with tools/regen_miopen_db.sh)")
+    else:
+        status["miopen_db_matches_library"] = None
+    return status, warns
+
+
 def run_sample_loop(eng, device, num_steps=25, T=14, h=72, w=128, weights="bf16"):
     """One whole sample through SVDInpaintEngine.sample(): EulerEDMSampler (sampling.py:110-131) with per-frame linear
     guidance over c / uc (CFG batch 2T) — the loop the per-step metric is a slice of. Here the step-invariant work is
@@ -214,6 +252,9 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
             ops[kind] = dict(calls_per_step=calls // steps, ms_per_step=round(per_step_ms, 3), GBs=round(gbs, 1),
                              frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
     res["hip_ops"] = ops
+    res["library_selection"], warns = library_selection_status(device)
+    for w in warns:
+        print(f"[mvi] WARNING: {w}", file=sys.stderr, flush=True)
     hip_ops.check_groupnorm_cluster(device)         # a benchmark number from a run with a timed-out GroupNorm wait is no number
     if sample_steps and with_control:
         res["sample_loop"] = run_sample_loop(eng, device, sample_steps, T, h, w, weights)
