@@ -761,3 +761,36 @@ def test_sparse_backward_equals_dense_backward_and_the_support_is_a_superset(R, 
         flat_a, flat_b = a.reshape(N, -1), b.reshape(N, -1)
         assert (flat_a[~support] == 0).all() and (flat_b[~support] == 0).all(), k
     print(f"gradient support: {float(support.float().mean()):.4f} of the Gaussians (visible: {float((radii > 0).float().mean()):.3f})")
+
+
+@pytest.mark.parametrize("N,W,H,log_scale,squeeze", [
+    (1, 16, 16, np.log(0.3), None), (5, 15, 33, np.log(0.3), None), (70, 4096, 16, np.log(0.05), None),
+    (3000, 16, 4096, np.log(0.05), None), (3000, 33, 4090, np.log(0.02), None),
+    (60_000, 1920, 1080, None, "column"),      # every Gaussian in ONE tile column: one bin holds every entry of pass 1
+    (60_000, 1920, 1080, None, "row"),         # ... in one tile row: one bin holds every entry of pass 2
+    (40_000, 640, 368, np.log(0.004), "tile"), # ... in one tile: a single 40 k-entry list
+    (2048 * 3 + 1, 320, 192, np.log(0.3), None)])   # whole partition blocks + one Gaussian, footprints of hundreds of tiles
+def test_binning_version_2_edge_shapes_and_skew_equal_version_1(R, N, W, H, log_scale, squeeze):
+    """Shapes the partition kernels' geometry assumptions could break on — one-tile images, one tile column / row (gx or gy =
+    1 or 256), entry counts far above the LDS image (several groups), and maximal skew (all entries in one bin: the bin's few
+    owner threads walk everything) — version 2 against version 1, bit for bit, plus the binning properties."""
+    cam = syn.make_camera(W, H, 50.0)
+    kw = {} if log_scale is None else dict(log_scale_mean=log_scale)
+    sc = syn.make_scene(N, cam, 0, seed=33, **kw)
+    if squeeze:
+        m = sc["means3D"].copy()
+        if squeeze in ("column", "tile"):
+            m[:, 0] *= 0.004                      # x within a few pixels of the image centre
+        if squeeze in ("row", "tile"):
+            m[:, 1] *= 0.004
+        sc["means3D"] = m
+    t = _to_dev(sc)
+    a, st2 = _binning_outputs(R, cam, t, 0, 2)
+    b, _ = _binning_outputs(R, cam, t, 0, 1)
+    assert a["D"] == b["D"]
+    assert torch.equal(a["radii"], b["radii"])
+    assert torch.equal(a["plist"], b["plist"]), "point lists differ"
+    assert torch.equal(a["tids"], b["tids"]), "tile ids differ"
+    assert torch.equal(a["ranges"], b["ranges"]), "tile ranges differ"
+    if a["D"]:
+        _assert_binning_properties(st2, a["radii"], W, H)
