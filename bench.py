@@ -178,8 +178,12 @@ def main():
     from multiview_inpaint_amd import dist as mdist
     L = _lib.lib()                                        # fails loudly if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MVI_BENCH_DEVICE / MVI_BENCH_BACKEND: rehearsal of the multi-rank control flow on a ONE-GPU box (every rank on the same
+    # device, gloo instead of RCCL, which refuses two ranks on one GPU) — never a performance number
+    dev_index = int(os.environ.get("MVI_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MVI_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_dist = os.environ.get("MVI_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path with a 1-rank group
     if world > 1 or force_dist:
         import torch.distributed as td
@@ -187,8 +191,10 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
             td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
+        elif backend == "nccl":
             td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(backend)
 
     W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
     M = (deg + 1) ** 2
@@ -338,7 +344,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
             # one process per GPU; `value` uses the slowest rank's time. rccl_ranks = size of the RCCL group the exchange ran in
-            "rccl_ranks": (td.get_world_size() if distributed else 0), "per_rank_ms_per_step": per_rank_ms,
+            "rccl_ranks": (td.get_world_size() if distributed and backend == "nccl" else 0), "per_rank_ms_per_step": per_rank_ms,
+            **({"rehearsal": f"backend {backend}, every rank on cuda:{dev_index}: control flow only, not a performance number"}
+               if backend != "nccl" or "MVI_BENCH_DEVICE" in os.environ else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rasterizer-with-depth fwd+bwd, one {W}x{H} view per GPU per step, "

@@ -631,14 +631,18 @@ __global__ __launch_bounds__(kPB) void preprocess_backward_kernel(
 // is exactly zero, so its outputs are exactly zero — the caller zeroed every output array beforehand (the render backward does
 // it on the side) and this kernel reads and writes the touched rows only, with per-lane accesses. Same expressions as
 // preprocess_backward_kernel (shared helpers), which stays the form for dense outputs (split / ranged backward).
-__global__ __launch_bounds__(256) void preprocess_backward_sparse_kernel(
+constexpr int kSparseBlock = 64;          // one-wave blocks: ~750 of them for the 48 k touched Gaussians of the bench scene, spread over
+                                          // every CU (256-thread blocks: 188 blocks, most CUs idle behind a 4-round-trip latency chain)
+__global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kernel(
     Frame f, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, GeomView g,
     const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx) {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (slot >= *g.touched_count) return;                     // the grid covers P; the list is a few per cent of that
+    // a fixed, moderate grid walks the list with a grid stride: the list's length is only known on the device, and a grid
+    // sized for P would be 23 k blocks of which a few hundred find work
+    const uint32_t n_touched = *g.touched_count;
+    for (uint32_t slot = blockIdx.x * (uint32_t)kSparseBlock + threadIdx.x; slot < n_touched; slot += gridDim.x * (uint32_t)kSparseBlock) {
     const int i = (int)g.touched_list[slot];
     const size_t si = (size_t)i;
     float gr[9];
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_sparse_kernel(
         dL_dscales[3 * si] = ds[0]; dL_dscales[3 * si + 1] = ds[1]; dL_dscales[3 * si + 2] = ds[2];
         dL_drots[4 * si] = dq[0]; dL_drots[4 * si + 1] = dq[1]; dL_drots[4 * si + 2] = dq[2]; dL_drots[4 * si + 3] = dq[3];
     }
+    }   // grid-stride loop over the touched list
 }
 
 // touched flags -> compact list of Gaussian indices (any order) + their number: the chain rule then runs full waves.
@@ -787,7 +792,8 @@ int launch_preprocess_backward_sparse(const Frame& f, const float* means3D, cons
     constexpr int kPerBlock = kCompactThreads * kCompactPer;
     hipLaunchKernelGGL(compact_touched_kernel, dim3((f.P + kPerBlock - 1) / kPerBlock), dim3(kCompactThreads), 0, st, f.P, g.touched,
                        g.touched_list, g.touched_count);
-    hipLaunchKernelGGL(preprocess_backward_sparse_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, f, means3D, shs, scales,
+    const int sparse_blocks = min((f.P + kSparseBlock - 1) / kSparseBlock, 2048);
+    hipLaunchKernelGGL(preprocess_backward_sparse_kernel, dim3(sparse_blocks), dim3(kSparseBlock), 0, st, f, means3D, shs, scales,
                        rotations, cov3D_precomp, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dshs,
                        dL_dcov3D, dL_dscales, dL_drots, rawx);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
