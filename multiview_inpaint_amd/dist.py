@@ -233,7 +233,20 @@ class CompactedGradExchange(FactoredGradExchange):
         P = self.P
         mask = visible.to(torch.uint8).contiguous().clone()
         td.all_reduce(mask, op=td.ReduceOp.MAX, group=self.group)
-        idx = mask.nonzero().squeeze(1)
+        names = [name for name, _ in self.SMALL]
+        if mask.is_cuda:
+            # one scan of the mask + ONE gather launch for the row ids, the four small gradients, the colour factors and the
+            # positions (train_ops.compact_rows: the prune kernels of csrc/compact_rows.hip); one read-back (the row count)
+            from .train_ops import compact_rows
+            if getattr(self, "_row_ids", None) is None or self._row_ids.device != mask.device:
+                self._row_ids = torch.arange(P, dtype=torch.int32, device=mask.device)
+            outs = compact_rows(mask, [self._row_ids] + [self.views[nm] for nm in names] +
+                                [self.views["sh_color_factor"], means3D])
+            idx, parts, fac_c, means_c = outs[0].long(), outs[1:1 + len(names)], outs[-2], outs[-1]
+        else:
+            idx = mask.nonzero().squeeze(1)
+            parts = [self.views[nm][idx] for nm in names]
+            fac_c, means_c = self.views["sh_color_factor"][idx], means3D[idx]
         n = int(idx.numel())                                   # identical on every rank: derived from the reduced mask
         self.last_union_fraction = n / P if P else 0.0
         self.last_compacted = bool(P) and n <= self.THRESHOLD * P
@@ -241,13 +254,13 @@ class CompactedGradExchange(FactoredGradExchange):
             self._shs_rows = "all"
             return self.exchange(means3D, campos)
         widths = [w for _, w in self.SMALL]
-        rows = torch.cat([self.views[name][idx] for name, _ in self.SMALL], 1).contiguous()          # [n, 11]
-        send = torch.cat([self.views["sh_color_factor"][idx].reshape(-1), campos.reshape(3).to(rows.dtype)])
+        rows = torch.cat(parts, 1).contiguous()                                                       # [n, 11]
+        send = torch.cat([fac_c.reshape(-1), campos.reshape(3).to(rows.dtype)])
         recv = torch.empty(self.world, 3 * n + 3, dtype=rows.dtype, device=rows.device)
         h = td.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)
         td.all_reduce(rows, op=td.ReduceOp.SUM, group=self.group)
         h.wait()
-        sh_c = sh_grad_from_factors(means3D[idx].contiguous(), recv[:, 3 * n:].contiguous(),
+        sh_c = sh_grad_from_factors(means_c.contiguous(), recv[:, 3 * n:].contiguous(),
                                     recv[:, :3 * n].reshape(self.world, n, 3).contiguous(), self.M, self.deg)
         # the full-size outputs are zero outside the rows written here: the small arrays are the backward's own outputs
         # (zero outside this rank's support, which the union contains), self.shs is cleared where the last step wrote it
