@@ -512,6 +512,16 @@ def test_raw_parameter_path_equals_activations_plus_standard_path(R, deg, store_
 
     c0, r0, d0, g0 = run(False)
     c1, r1, d1, g1 = run(True)
+    # the raw-parameter backward once more with the DENSE chain-rule kernel (the default is the sparse one): same gradients
+    from multiview_inpaint_amd import _lib
+    prev = _lib.lib().mvi_raster_backward_mode(1)
+    try:
+        _, _, _, g2 = run(True)
+    finally:
+        _lib.lib().mvi_raster_backward_mode(prev)
+    for k in g1:
+        if g1[k].numel():
+            assert _same_to_summation_order(g2[k].cpu().numpy(), g1[k].cpu().numpy()), ("dense vs sparse", k)
     assert torch.equal(r0, r1) and int((r0 > 0).sum()) > P // 3
     assert torch.equal(c0, c1) and torch.equal(d0, d1)                 # forward has no atomics: identical
     for k in g0:
