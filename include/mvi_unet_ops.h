@@ -139,6 +139,15 @@ int mvi_linear_n320_supported(int32_t K, int32_t out_features, int32_t dtype);
 int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
                     int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
 
+/* 3x3 / stride 1 / padding 1 convolution with 320 output channels on token-major (NHWC) activations, as an implicit GEMM in the
+ * kernel above (replaces F.conv2d in ResBlock.in_layers[2] / out_layers[3] at level 0,
+ * svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318). x [N, H, W, C_in]; weight [320][9 C_in] =
+ * conv.weight.permute(0, 2, 3, 1) flattened; bias fp32 [320] or NULL; out rows of out_row_stride elements with room for
+ * mvi_ff_geglu_out_rows(N H W) rows. */
+int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype);
+int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W, int32_t C_in,
+                     int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* stream);
+
 /* y = act(conv2d(x, weight, padding = 1) + bias) for a 3x3, stride-1 convolution with 16 output channels and at most 16 input
  * channels, 32 and at most 32, or 320 and at most 8 (the networks' input convolution), on NCHW bf16 / f16 tensors (csrc/stem_conv.hip) — the stride-1 layers of ControlNet.input_hint_block
  * at its two finest resolutions

@@ -89,10 +89,18 @@ __device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) 
     return r;
 }
 
-template <typename T>
+// kConv: the same kernel as a 3x3 / stride 1 / padding 1 convolution of token-major (NHWC) activations — an implicit GEMM with
+// K = 9 C_in ordered (tap, channel): x row r is pixel r of [N, H, W], chunk c = (tap c / cpc, channels 64 (c % cpc) ..), and the
+// lane's load address moves by the tap's pixel offset. A lane whose tap falls outside the image loads its own pixel instead (a
+// valid address) and the fragment is zeroed before the MFMAs (a wave-uniform branch: interior waves skip it).
+struct ConvGeom {
+    int H, W, cpc;                                   // image height / width, 64-channel chunks per tap (C_in / 64)
+};
+
+template <typename T, bool kConv>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks) {
+                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg) {
     using M = Mma<T>;
     using frag = typename M::frag;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -119,13 +127,41 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the compiler's own loads are done before the hand-counted ones start
 
     // ---- x: A operand, element e of lane (col, hh), k-step s of chunk c: x[row][64 c + 16 s + 8 hh + e]; rows past the end read the last row
-    const char* const xbase = reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
-    const int64_t rclamp = row < rows ? (row - (row0 < rows ? row0 : rows - 1)) : 0;                       // (a block never starts past the end)
+    // (kConv: the base is the tensor and the lane offset absolute — a tap's row may lie before the wave's first one)
+    const char* const xbase = kConv ? reinterpret_cast<const char*>(x)
+                                    : reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
+    const int64_t rclamp = kConv ? (row < rows ? row : rows - 1)
+                                 : (row < rows ? (row - (row0 < rows ? row0 : rows - 1)) : 0);             // (a block never starts past the end)
     const uint32_t x_voff = (uint32_t)(rclamp * x_rs * 2 + 16 * hh);
-    auto load_x = [&](int c, u32x4 (&xr)[4]) __attribute__((always_inline)) {
-        const char* const base = xbase + (int64_t)c * (kKC * 2);
+    uint32_t tap_ok = 0x1FFu;                        // bit 3 (dy + 1) + (dx + 1): that neighbour of the lane's pixel is inside the image
+    if (kConv) {
+        const int pix = (int)(rclamp % ((int64_t)cg.H * cg.W));
+        const int py = pix / cg.W, px = pix - py * cg.W;
+        if (py == 0) tap_ok &= ~0x007u;
+        if (py == cg.H - 1) tap_ok &= ~0x1C0u;
+        if (px == 0) tap_ok &= ~0x049u;
+        if (px == cg.W - 1) tap_ok &= ~0x124u;
+    }
+    int ld_tap = 0, ld_cc = 0;                       // kConv: (tap, channel chunk) of the next load_x call — they come in chunk order
+    // returns the lane's keep mask for the fragment (all ones unless kConv and the tap is outside the image)
+    auto load_x = [&](int c, u32x4 (&xr)[4]) __attribute__((always_inline)) -> uint32_t {
+        if (!kConv) {
+            const char* const base = xbase + (int64_t)c * (kKC * 2);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, x_voff);
+            for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, x_voff);
+            return ~0u;
+        }
+        const int dy = ld_tap / 3 - 1, dx = ld_tap - 3 * (ld_tap / 3) - 1;
+        const int delta = (dy * cg.W + dx) * (int)(x_rs * 2);
+        const bool ok = (tap_ok >> ld_tap) & 1u;
+        const uint32_t voff = ok ? x_voff + (uint32_t)delta : x_voff;
+        const char* const base = xbase + ld_cc * (kKC * 2);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, voff);
+        if (c + 1 < n_chunks) {                      // (the calls past the end repeat the last chunk)
+            if (++ld_cc == cg.cpc) { ld_cc = 0; ++ld_tap; }
+        }
+        return ok ? ~0u : 0u;
     };
 
     // ---- LDS-DMA source addressing: piece p = W rows 8 p .. 8 p + 7 of the chunk (128 bytes each); lane i fills (row 8 p + i / 8,
@@ -160,7 +196,14 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
     // One chunk: 40 MFMAs, W fragments requested kAhead ahead. Ten independent accumulator chains: no MFMA waits for the one before it.
     constexpr int kAhead = LN3_AHEAD;
-    auto chunk_fn = [&](uint32_t slot_base, const u32x4 (&xr)[4]) __attribute__((always_inline)) {
+    auto chunk_fn = [&](uint32_t slot_base, u32x4 (&xr)[4], uint32_t keep) __attribute__((always_inline)) {
+        if (kConv && __builtin_amdgcn_ballot_w64(keep == 0u) != 0ull) {
+            // the fragment is an output of assembly the compiler believes complete: this statement (volatile, so it stays behind the
+            // wait that closed the previous chunk) is what the masking depends on
+            asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xr[s] &= keep;
+        }
         u32x4 wf[kAhead + 1];
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) wf[q] = wfrag(slot_base, q);
@@ -187,7 +230,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
     // ---- prologue: W chunks 0 and 1 in flight, x of chunk 0; chunk 0 landed
     u32x4 xa[4], xb[4];
-    load_x(0, xa);
+    uint32_t ka_keep = load_x(0, xa), kb_keep = ~0u;
     if (loader) {
         issue_chunk(0);
         issue_chunk(1);
@@ -201,16 +244,16 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     uint32_t slot = 0;
     int c = 0;
     for (; c + 1 < n_chunks; c += 2) {
-        load_x(c + 1, xb);                                           // (c + 1 < n_chunks)
-        chunk_fn(slot, xa);
+        kb_keep = load_x(c + 1, xb);                                 // (c + 1 < n_chunks)
+        chunk_fn(slot, xa, ka_keep);
         close_chunk(c);
         slot = next_slot(slot);
-        load_x(c + 2 < n_chunks ? c + 2 : n_chunks - 1, xa);         // past the end: re-read the last chunk's rows (never used)
-        chunk_fn(slot, xb);
+        ka_keep = load_x(c + 2 < n_chunks ? c + 2 : n_chunks - 1, xa);   // past the end: re-read the last chunk's rows (never used)
+        chunk_fn(slot, xb, kb_keep);
         close_chunk(c + 1);
         slot = next_slot(slot);
     }
-    if (c < n_chunks) chunk_fn(slot, xa);                            // K / 64 odd: one chunk left
+    if (c < n_chunks) chunk_fn(slot, xa, ka_keep);                   // K / 64 odd: one chunk left
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // trailing (unused) pieces and rows land before the block ends
 
     // ---- outputs: two column tiles at a time through the wave's LDS tile [32 rows][64 columns], then four 16-byte stores per lane
@@ -243,23 +286,23 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
 }  // namespace ln3
 
-template <typename T>
+template <typename T, bool kConv = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
-                              hipStream_t st) {
+                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0}) {
     using namespace ln3;
     const int64_t n_blocks = (rows + kRows - 1) / kRows;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T>;
+    auto kern = &linear_n320_kernel<T, kConv>;
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
-                       o_rs, (int)n_blocks);
+                       o_rs, (int)n_blocks, cg);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -287,4 +330,33 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
     const int rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st)
                                         : mvi::linear_n320_launch<__half>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st);
     return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
+}
+
+// 3x3 / stride 1 / padding 1 convolution of token-major activations (the level-0 ResBlock convolutions of both networks,
+// svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318 `in_layers[2]` / `out_layers[3]`): x [N, H, W, C_in],
+// weight [320][9 C_in] = conv.weight.permute(0, 2, 3, 1) flattened (tap-major), out [N H W, 320] rows of out_row_stride elements.
+extern "C" int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype) {
+    return C_out == mvi::ln3::kN && C_in >= mvi::ln3::kKC && C_in % mvi::ln3::kKC == 0 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+extern "C" int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
+                                int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                                void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || !mvi_conv3x3_n320_supported(C_in, C_out, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: needs C_out = 320, C_in a multiple of 64, bf16 or f16");
+    const int64_t rows = N * H * W;
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: NULL pointer");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: out needs room for mvi_ff_geglu_out_rows(N H W) rows (whole 256-row blocks are stored)");
+    if (out_row_stride < C_out || out_row_stride % 8 || ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
+        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: x, weight and out rows must be 16-byte aligned");
+    if ((int64_t)C_out * 9 * C_in * 2 > 0xFFFFFFFFll || rows * C_in * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
+        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: weight / activation tensor exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC};
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::linear_n320_launch<__hip_bfloat16, true>(x, weight, bias, out, rows, 9 * C_in, C_in, out_row_stride, st, cg)
+                       : mvi::linear_n320_launch<__half, true>(x, weight, bias, out, rows, 9 * C_in, C_in, out_row_stride, st, cg);
+    return rc ? mvi::unet_fail(rc, "conv3x3_n320: kernel launch failed") : MVI_OK;
 }

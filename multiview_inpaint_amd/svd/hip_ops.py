@@ -365,6 +365,33 @@ def linear_n320(x, weight, bias):
     return full[:rows].reshape(*x.shape[:-1], N)
 
 
+def conv3x3_n320_supported(C_in, C_out, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_conv3x3_n320_supported(int(C_in), int(C_out), _DT[dtype]))
+
+
+def conv3x3_n320_weight(weight):
+    """conv.weight [320, C_in, 3, 3] in the kernel's order: [320][9 C_in], tap-major (ky, kx, c)."""
+    return weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()
+
+
+def conv3x3_n320(tok, weight_taps, bias, H, W):
+    """3x3 / stride 1 / padding 1 convolution with 320 output channels of token-major activations tok [N, H W, C_in]
+    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, H W, 320]; weight_taps from conv3x3_n320_weight."""
+    L = _lib.lib()
+    N, S, C = tok.shape
+    if S != H * W or weight_taps.shape[1] != 9 * C or weight_taps.dtype != tok.dtype:
+        raise ValueError("conv3x3_n320: tok [N, H W, C_in] and weight [320, 9 C_in] of one dtype expected")
+    xc = tok if tok.is_contiguous() and tok.data_ptr() % 16 == 0 else tok.contiguous().clone()
+    rows, Co = N * S, weight_taps.shape[0]
+    cap = int(L.mvi_ff_geglu_out_rows(rows))
+    full = torch.empty(cap, Co, dtype=tok.dtype, device=tok.device)
+    b = None if bias is None else _f32(bias)
+    with torch.cuda.device(tok.device), _Timed("conv3x3_n320", 2.0 * rows * 9 * C * Co, tok.device):
+        _check(L.mvi_conv3x3_n320(xc.data_ptr(), weight_taps.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C,
+                                  Co, cap, full.stride(0), _DT[tok.dtype], _stream(tok.device)), "conv3x3_n320")
+    return full[:rows].view(N, S, Co)
+
+
 def stem_conv3x3_supported(conv, x):
     """A 3x3 / padding 1 Conv2d of the shapes csrc/stem_conv.hip builds (stride 1: <= 16 -> 16, <= 32 -> 32; stride 2: <= 16 -> 32) on a
     contiguous NCHW half tensor."""

@@ -482,10 +482,33 @@ def _channels_last_weight(w):
     return hit[2]
 
 
+CONV_N320 = os.environ.get("MVI_SVD_CONV_N320", "1") != "0"
+_tap_weights = {}
+
+
+def _tap_major_weight(w):
+    """The convolution weight as [C_out][9 C_in] (tap-major: csrc/linear_n320.hip's implicit-GEMM order), once per parameter version."""
+    from . import hip_ops
+    key = id(w)
+    hit = _tap_weights.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version, w.dtype, w.device):
+        import weakref
+        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device),
+               hip_ops.conv3x3_n320_weight(w.detach()))
+        _tap_weights[key] = hit
+    return hit[2]
+
+
 def _conv_tokens(conv, tok, H, W):
-    """3x3 convolution of token-major activations [N, H W, C_in] -> [N, H W, C_out], bias withheld: the tensor is handed to
-    the library as a channels-last view, so MIOpen's NHWC kernel runs without the transposes it wraps around NCHW tensors."""
+    """3x3 convolution of token-major activations [N, H W, C_in] -> [N, H W, C_out], bias withheld. 320 output channels (level 0:
+    31 of the 72 ResBlock convolutions of a step, the ones the library runs slowest) go to the hand-written implicit GEMM; the
+    others are handed to the library as a channels-last view, so MIOpen's NHWC kernel runs without the transposes it wraps
+    around NCHW tensors."""
     N, S, C = tok.shape
+    if CONV_N320:
+        from . import hip_ops
+        if hip_ops.conv3x3_n320_supported(C, conv.out_channels, tok.dtype) and N * S * C * 2 < 2 ** 32:
+            return hip_ops.conv3x3_n320(tok, _tap_major_weight(conv.weight), None, H, W)
     x = tok.view(N, H, W, C).permute(0, 3, 1, 2)                  # [N, C, H, W] with channels-last strides: no copy
     y = F.conv2d(x, _channels_last_weight(conv.weight), None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not y.is_contiguous(memory_format=torch.channels_last):     # (the library answered in NCHW: still correct, one copy)

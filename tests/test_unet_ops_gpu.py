@@ -1094,3 +1094,69 @@ def test_resblock_with_channels_last_convolutions_equals_the_nchw_path(dtype, to
         assert outs[True].shape == ref.shape and outs[True].is_contiguous()
         assert rel(outs[True], ref) < tol and rel(outs[False], ref) < tol
         assert rel(outs[True], outs[False].double()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("N,H,W,C", [(2, 24, 32, 320), (3, 9, 16, 64), (1, 7, 5, 128), (5, 1, 1, 64), (2, 3, 96, 640), (1, 40, 33, 192)])
+def test_conv3x3_n320_equals_conv2d(dtype, tol, N, H, W, C):
+    """csrc/linear_n320.hip as an implicit GEMM: 3x3 / padding 1 convolution to 320 channels on token-major activations against
+    F.conv2d in fp64 on the same rounded inputs (openaimodel.py:256-275 `in_layers[2]`): image borders, rows that straddle image
+    rows and images inside one wave (W = 5, 16, 33), a last partial row block, one-pixel images, bias on and off."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(320, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)).to(dtype)
+    b = torch.randn(320, generator=g)
+    assert hip_ops.conv3x3_n320_supported(C, 320, dtype)
+    tok = x.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous().cuda()
+    wt = hip_ops.conv3x3_n320_weight(w.cuda())
+    for bias in (None, b):
+        ref = F.conv2d(x.double(), w.double(), None if bias is None else bias.double(), padding=1)
+        out = hip_ops.conv3x3_n320(tok, wt, None if bias is None else bias.cuda(), H, W)
+        torch.cuda.synchronize()
+        assert out.shape == (N, H * W, 320)
+        got = out.view(N, H, W, 320).permute(0, 3, 1, 2).double().cpu()
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        assert rel(got, ref) < tol
+
+
+def test_conv3x3_n320_refuses_other_shapes():
+    from multiview_inpaint_amd.svd import hip_ops
+    assert not hip_ops.conv3x3_n320_supported(320, 640, torch.bfloat16)        # 640 outputs: the library's
+    assert not hip_ops.conv3x3_n320_supported(8, 320, torch.bfloat16)          # the stem's 8 channels: csrc/stem_conv.hip
+    assert not hip_ops.conv3x3_n320_supported(320, 320, torch.float32)
+    tok = torch.zeros(1, 12, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        hip_ops.conv3x3_n320(tok, torch.zeros(320, 9 * 64, device="cuda", dtype=torch.bfloat16), None, 3, 5)   # H W != 12
+
+
+def test_resblock_at_320_channels_takes_the_implicit_gemm_convolution():
+    """At 320 output channels ResBlock._forward_fused's convolutions run in csrc/linear_n320.hip (layers.CONV_N320): same block through
+    both routes and against the fp64 NCHW evaluation; the op profile shows which kernel ran."""
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    g = torch.Generator().manual_seed(18)
+    for cin in (320, 640):
+        blk = LY.ResBlock(cin, 256, 0.0, out_channels=320, dims=2).eval()
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.03 if p.dim() > 1 else 0.3))
+        x = torch.randn(2, cin, 16, 24, generator=g)
+        emb = torch.randn(2, 256, generator=g)
+        with torch.no_grad():
+            ref = blk.double()(x.double(), emb.double())
+            blk = blk.to(torch.bfloat16).cuda()
+            xs, es = x.bfloat16().cuda(), emb.bfloat16().cuda()
+            outs = {}
+            old = LY.CONV_N320
+            try:
+                for mode in (False, True):
+                    LY.CONV_N320 = mode
+                    hip_ops.PROFILE = []
+                    outs[mode] = blk(xs, es)
+                    torch.cuda.synchronize()
+                    assert sum(1 for rec in hip_ops.PROFILE if rec[0] == "conv3x3_n320") == (2 if mode else 0)
+            finally:
+                LY.CONV_N320 = old
+                hip_ops.PROFILE = None
+        assert rel(outs[True], ref) < 3.0 / 128 and rel(outs[True], outs[False].double()) < 3.0 / 128
