@@ -139,14 +139,19 @@ int mvi_linear_n320_supported(int32_t K, int32_t out_features, int32_t dtype);
 int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
                     int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
 
-/* 3x3 / stride 1 / padding 1 convolution with 320 output channels on token-major (NHWC) activations, as an implicit GEMM in the
- * kernel above (replaces F.conv2d in ResBlock.in_layers[2] / out_layers[3] at level 0,
- * svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318). x [N, H, W, C_in]; weight [320][9 C_in] =
- * conv.weight.permute(0, 2, 3, 1) flattened; bias fp32 [320] or NULL; out rows of out_row_stride elements with room for
- * mvi_ff_geglu_out_rows(N H W) rows. */
+/* Convolutions with C_out a multiple of 320 on token-major (NHWC) activations, as implicit GEMMs in the kernel above (a block
+ * computes 320 output channels of 256 rows; C_in a multiple of 64; bf16 / f16). bias fp32 [C_out] or NULL; out [rows, C_out] in rows
+ * of out_row_stride elements with room for mvi_ff_geglu_out_rows(rows) rows.
+ *   mvi_conv3x3_n320: 3x3 / stride 1 / padding 1 (replaces F.conv2d in ResBlock.in_layers[2] / out_layers[3] and Upsample.conv,
+ *     svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318, :118-134). x [N, H, W, C_in];
+ *     weight [C_out][9 C_in] = conv.weight.permute(0, 2, 3, 1) flattened.
+ *   mvi_conv3t_n320: (3, 1, 1) / padding (1, 0, 0) over frames (the Conv3d of VideoResBlock.time_stack, video_model.py:41-54).
+ *     x [B, T, pixels, C_in]; weight [C_out][3 C_in] = conv.weight[:, :, :, 0, 0].permute(0, 2, 1) flattened. */
 int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype);
 int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W, int32_t C_in,
                      int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* stream);
+int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels, int32_t C_in,
+                    int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* stream);
 
 /* y = act(conv2d(x, weight, padding = 1) + bias) for a 3x3, stride-1 convolution with 16 output channels and at most 16 input
  * channels, 32 and at most 32, or 320 and at most 8 (the networks' input convolution), on NCHW bf16 / f16 tensors (csrc/stem_conv.hip) — the stride-1 layers of ControlNet.input_hint_block

@@ -21,6 +21,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -93,8 +94,10 @@ __device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) 
 // K = 9 C_in ordered (tap, channel): x row r is pixel r of [N, H, W], chunk c = (tap c / cpc, channels 64 (c % cpc) ..), and the
 // lane's load address moves by the tap's pixel offset. A lane whose tap falls outside the image loads its own pixel instead (a
 // valid address) and the fragment is zeroed before the MFMAs (a wave-uniform branch: interior waves skip it).
+// taps = 3 is the same thing with the taps along H only ((3,1,1) over frames: H = T frames, W = pixels of a frame).
+// groups > 1: C_out = 320 groups; a block computes 320 of them (blocks of one row block are neighbours and share x through L2).
 struct ConvGeom {
-    int H, W, cpc;                                   // image height / width, 64-channel chunks per tap (C_in / 64)
+    int H, W, cpc, taps, groups;                     // image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
 };
 
 template <typename T, bool kConv>
@@ -112,6 +115,13 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     const int col = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
+    if (kConv && cg.groups > 1) {                    // (row block, column group): the groups of one row block run side by side
+        const int g = bid % cg.groups;
+        bid /= cg.groups;
+        w += (int64_t)g * kN * K;
+        out += g * kN;
+        if (bias) bias += g * kN;
+    }
     const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
     const int64_t row = row0 + col;
     const int n_chunks = K / kKC;
@@ -137,10 +147,15 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     if (kConv) {
         const int pix = (int)(rclamp % ((int64_t)cg.H * cg.W));
         const int py = pix / cg.W, px = pix - py * cg.W;
-        if (py == 0) tap_ok &= ~0x007u;
-        if (py == cg.H - 1) tap_ok &= ~0x1C0u;
-        if (px == 0) tap_ok &= ~0x049u;
-        if (px == cg.W - 1) tap_ok &= ~0x124u;
+        if (cg.taps == 9) {
+            if (py == 0) tap_ok &= ~0x007u;
+            if (py == cg.H - 1) tap_ok &= ~0x1C0u;
+            if (px == 0) tap_ok &= ~0x049u;
+            if (px == cg.W - 1) tap_ok &= ~0x124u;
+        } else {                                     // bit dy + 1
+            if (py == 0) tap_ok &= ~0x1u;
+            if (py == cg.H - 1) tap_ok &= ~0x4u;
+        }
     }
     int ld_tap = 0, ld_cc = 0;                       // kConv: (tap, channel chunk) of the next load_x call — they come in chunk order
     // returns the lane's keep mask for the fragment (all ones unless kConv and the tap is outside the image)
@@ -151,7 +166,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, x_voff);
             return ~0u;
         }
-        const int dy = ld_tap / 3 - 1, dx = ld_tap - 3 * (ld_tap / 3) - 1;
+        const int dy = cg.taps == 9 ? ld_tap / 3 - 1 : ld_tap - 1, dx = cg.taps == 9 ? ld_tap - 3 * (ld_tap / 3) - 1 : 0;
         const int delta = (dy * cg.W + dx) * (int)(x_rs * 2);
         const bool ok = (tap_ok >> ld_tap) & 1u;
         const uint32_t voff = ok ? x_voff + (uint32_t)delta : x_voff;
@@ -288,9 +303,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
 template <typename T, bool kConv = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
-                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0}) {
+                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1}) {
     using namespace ln3;
-    const int64_t n_blocks = (rows + kRows - 1) / kRows;
+    const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
@@ -332,31 +347,56 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
     return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
 }
 
-// 3x3 / stride 1 / padding 1 convolution of token-major activations (the level-0 ResBlock convolutions of both networks,
-// svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318 `in_layers[2]` / `out_layers[3]`): x [N, H, W, C_in],
-// weight [320][9 C_in] = conv.weight.permute(0, 2, 3, 1) flattened (tap-major), out [N H W, 320] rows of out_row_stride elements.
+// Convolutions of token-major activations with C_out a multiple of 320 (all four levels of both networks):
+//   * 3x3 / stride 1 / padding 1 (ResBlock in_layers[2] / out_layers[3], svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275,
+//     :301-318; Upsample.conv :118-134): x [N, H, W, C_in], weight [C_out][9 C_in] = conv.weight.permute(0, 2, 3, 1) flattened;
+//   * (3, 1, 1) / padding (1, 0, 0) over frames (the time_stack ResBlock of VideoResBlock, video_model.py:41-54): x [B, T, pixels, C_in],
+//     weight [C_out][3 C_in] = conv.weight[:, :, :, 0, 0].permute(0, 2, 1) flattened.
+// out [rows, C_out] in rows of out_row_stride elements.
 extern "C" int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype) {
-    return C_out == mvi::ln3::kN && C_in >= mvi::ln3::kKC && C_in % mvi::ln3::kKC == 0 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+    return C_out > 0 && C_out % mvi::ln3::kN == 0 && C_in >= mvi::ln3::kKC && C_in % mvi::ln3::kKC == 0 &&
+           (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+static int conv_taps_n320(const char* what, const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
+                          int32_t taps, int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                          void* stream) {
+    char msg[160];
+    auto fail = [&](const char* m) {
+        snprintf(msg, sizeof msg, "%s: %s", what, m);
+        return mvi::unet_fail(MVI_EINVAL, msg);
+    };
+    if (N < 0 || H <= 0 || W <= 0 || !mvi_conv3x3_n320_supported(C_in, C_out, dtype))
+        return fail("needs C_out a multiple of 320, C_in a multiple of 64, bf16 or f16");
+    const int64_t rows = N * H * W;
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !out) return fail("NULL pointer");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return fail("out needs room for mvi_ff_geglu_out_rows(rows) rows (whole 256-row blocks are stored)");
+    if (out_row_stride < C_out || out_row_stride % 8 || ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
+        return fail("x, weight and out rows must be 16-byte aligned");
+    if ((int64_t)mvi::ln3::kN * taps * C_in * 2 > 0xFFFFFFFFll || rows * C_in * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
+        return fail("weight / activation tensor exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN};
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::linear_n320_launch<__hip_bfloat16, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg)
+                       : mvi::linear_n320_launch<__half, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg);
+    if (rc) {
+        snprintf(msg, sizeof msg, "%s: kernel launch failed", what);
+        return mvi::unet_fail(rc, msg);
+    }
+    return MVI_OK;
 }
 
 extern "C" int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
                                 int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
                                 void* stream) {
-    if (N < 0 || H <= 0 || W <= 0 || !mvi_conv3x3_n320_supported(C_in, C_out, dtype))
-        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: needs C_out = 320, C_in a multiple of 64, bf16 or f16");
-    const int64_t rows = N * H * W;
-    if (rows == 0) return MVI_OK;
-    if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: NULL pointer");
-    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
-        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: out needs room for mvi_ff_geglu_out_rows(N H W) rows (whole 256-row blocks are stored)");
-    if (out_row_stride < C_out || out_row_stride % 8 || ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
-        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: x, weight and out rows must be 16-byte aligned");
-    if ((int64_t)C_out * 9 * C_in * 2 > 0xFFFFFFFFll || rows * C_in * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
-        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320: weight / activation tensor exceeds 32-bit byte offsets");
-    hipStream_t st = (hipStream_t)stream;
-    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC};
-    const int rc = dtype == MVI_DT_BF16
-                       ? mvi::linear_n320_launch<__hip_bfloat16, true>(x, weight, bias, out, rows, 9 * C_in, C_in, out_row_stride, st, cg)
-                       : mvi::linear_n320_launch<__half, true>(x, weight, bias, out, rows, 9 * C_in, C_in, out_row_stride, st, cg);
-    return rc ? mvi::unet_fail(rc, "conv3x3_n320: kernel launch failed") : MVI_OK;
+    return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, C_in, C_out, out_rows_capacity, out_row_stride, dtype, stream);
+}
+
+extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels,
+                               int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                               void* stream) {
+    return conv_taps_n320("conv3t_n320", x, weight, bias, out, B, T, pixels, 3, C_in, C_out, out_rows_capacity, out_row_stride, dtype, stream);
 }

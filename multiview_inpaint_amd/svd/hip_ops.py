@@ -370,26 +370,49 @@ def conv3x3_n320_supported(C_in, C_out, dtype):
 
 
 def conv3x3_n320_weight(weight):
-    """conv.weight [320, C_in, 3, 3] in the kernel's order: [320][9 C_in], tap-major (ky, kx, c)."""
+    """conv.weight [C_out, C_in, 3, 3] in the kernel's order: [C_out][9 C_in], tap-major (ky, kx, c)."""
     return weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()
 
 
-def conv3x3_n320(tok, weight_taps, bias, H, W):
-    """3x3 / stride 1 / padding 1 convolution with 320 output channels of token-major activations tok [N, H W, C_in]
-    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, H W, 320]; weight_taps from conv3x3_n320_weight."""
+def conv3t_n320_weight(weight):
+    """Conv3d weight [C_out, C_in, 3, 1, 1] in the kernel's order: [C_out][3 C_in], tap-major (kt, c)."""
+    return weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(weight.shape[0], -1).contiguous()
+
+
+def _conv_taps_n320(kind, fn, tok, weight_taps, bias, N, H, W, taps):
     L = _lib.lib()
-    N, S, C = tok.shape
-    if S != H * W or weight_taps.shape[1] != 9 * C or weight_taps.dtype != tok.dtype:
-        raise ValueError("conv3x3_n320: tok [N, H W, C_in] and weight [320, 9 C_in] of one dtype expected")
+    C = tok.shape[-1]
+    rows = N * H * W
+    if tok.numel() != rows * C or weight_taps.shape[1] != taps * C or weight_taps.dtype != tok.dtype:
+        raise ValueError(f"{kind}: token-major activations [.., C_in] of N H W rows and weight [C_out, {taps} C_in] of one dtype expected")
     xc = tok if tok.is_contiguous() and tok.data_ptr() % 16 == 0 else tok.contiguous().clone()
-    rows, Co = N * S, weight_taps.shape[0]
+    wc = weight_taps if weight_taps.is_contiguous() else weight_taps.contiguous()
+    Co = wc.shape[0]
     cap = int(L.mvi_ff_geglu_out_rows(rows))
     full = torch.empty(cap, Co, dtype=tok.dtype, device=tok.device)
     b = None if bias is None else _f32(bias)
-    with torch.cuda.device(tok.device), _Timed("conv3x3_n320", 2.0 * rows * 9 * C * Co, tok.device):
-        _check(L.mvi_conv3x3_n320(xc.data_ptr(), weight_taps.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C,
-                                  Co, cap, full.stride(0), _DT[tok.dtype], _stream(tok.device)), "conv3x3_n320")
-    return full[:rows].view(N, S, Co)
+    with torch.cuda.device(tok.device), _Timed(kind, 2.0 * rows * taps * C * Co, tok.device):
+        _check(fn(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, cap, full.stride(0),
+                  _DT[tok.dtype], _stream(tok.device)), kind)
+    return full[:rows]
+
+
+def conv3x3_n320(tok, weight_taps, bias, H, W):
+    """3x3 / stride 1 / padding 1 convolution to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
+    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, H W, C_out]; weight_taps from conv3x3_n320_weight."""
+    N, S, C = tok.shape
+    if S != H * W:
+        raise ValueError("conv3x3_n320: tok [N, H W, C_in] expected")
+    return _conv_taps_n320("conv3x3_n320", _lib.lib().mvi_conv3x3_n320, tok, weight_taps, bias, N, H, W, 9).view(N, S, -1)
+
+
+def conv3t_n320(tok, weight_taps, bias, T):
+    """(3, 1, 1) / padding (1, 0, 0) convolution over the frame axis of token-major activations tok [(b T), S, C_in] (frames of a video
+    consecutive) -> [(b T), S, C_out]; weight_taps from conv3t_n320_weight."""
+    BT, S, C = tok.shape
+    if BT % T:
+        raise ValueError("conv3t_n320: tok [(b T), S, C_in] expected")
+    return _conv_taps_n320("conv3t_n320", _lib.lib().mvi_conv3t_n320, tok, weight_taps, bias, BT // T, T, S, 3).view(BT, S, -1)
 
 
 def stem_conv3x3_supported(conv, x):

@@ -483,6 +483,7 @@ def _channels_last_weight(w):
 
 
 CONV_N320 = os.environ.get("MVI_SVD_CONV_N320", "1") != "0"
+CONV_N320_MIN_BLOCKS = 128         # fewer blocks of 256 rows x 320 channels than this leave most of the 256 CUs idle: the library's
 _tap_weights = {}
 
 
@@ -507,7 +508,8 @@ def _conv_tokens(conv, tok, H, W):
     N, S, C = tok.shape
     if CONV_N320:
         from . import hip_ops
-        if hip_ops.conv3x3_n320_supported(C, conv.out_channels, tok.dtype) and N * S * C * 2 < 2 ** 32:
+        if (hip_ops.conv3x3_n320_supported(C, conv.out_channels, tok.dtype) and N * S * C * 2 < 2 ** 32
+                and -(-N * S // 256) * (conv.out_channels // 320) >= CONV_N320_MIN_BLOCKS):
             return hip_ops.conv3x3_n320(tok, _tap_major_weight(conv.weight), None, H, W)
     x = tok.view(N, H, W, C).permute(0, 3, 1, 2)                  # [N, C, H, W] with channels-last strides: no copy
     y = F.conv2d(x, _channels_last_weight(conv.weight), None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -1120,9 +1120,45 @@ def test_conv3x3_n320_equals_conv2d(dtype, tol, N, H, W, C):
         assert rel(got, ref) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("N,H,W,C,Co", [(2, 12, 16, 128, 640), (1, 9, 16, 64, 1280), (3, 5, 7, 192, 960)])
+def test_conv3x3_n320_column_groups(dtype, tol, N, H, W, C, Co):
+    """C_out = 640 / 960 / 1280: one launch, a block per (256 rows, 320 output channels); bias per group."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator().manual_seed(N + H + Co)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)).to(dtype)
+    b = torch.randn(Co, generator=g)
+    tok = x.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous().cuda()
+    out = hip_ops.conv3x3_n320(tok, hip_ops.conv3x3_n320_weight(w.cuda()), b.cuda(), H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    got = out.view(N, H, W, Co).permute(0, 3, 1, 2).double().cpu()
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("B,T,S,C,Co", [(2, 14, 40, 320, 320), (1, 3, 33, 64, 640), (3, 1, 8, 128, 320), (2, 2, 300, 64, 320), (1, 14, 5, 192, 320)])
+def test_conv3t_n320_equals_conv3d(dtype, tol, B, T, S, C, Co):
+    """The (3, 1, 1) frame-axis convolution of VideoResBlock.time_stack (video_model.py:41-54, openaimodel.py:256-275 with dims = 3)
+    on token-major frames [(b T), S, C] against F.conv3d in fp64 on b c t h w: first / last frame of every video (zero padding,
+    nothing leaks between videos), T = 1, frames smaller and larger than a wave's 32 rows."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator().manual_seed(B * 100 + T * 10 + S)
+    tok = torch.randn(B * T, S, C, generator=g).to(dtype)
+    w = (torch.randn(Co, C, 3, 1, 1, generator=g) * (1.0 / (3 * C) ** 0.5)).to(dtype)
+    b = torch.randn(Co, generator=g)
+    x5 = tok.double().view(B, T, S, 1, C).permute(0, 4, 1, 2, 3)                           # b c t h w (w = 1)
+    ref = F.conv3d(x5, w.double(), b.double(), 1, (1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(B * T, S, Co)
+    out = hip_ops.conv3t_n320(tok.cuda(), hip_ops.conv3t_n320_weight(w.cuda()), b.cuda(), T)
+    torch.cuda.synchronize()
+    assert out.shape == (B * T, S, Co)
+    assert (out.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_conv3x3_n320_refuses_other_shapes():
     from multiview_inpaint_amd.svd import hip_ops
-    assert not hip_ops.conv3x3_n320_supported(320, 640, torch.bfloat16)        # 640 outputs: the library's
+    assert not hip_ops.conv3x3_n320_supported(320, 4, torch.bfloat16)          # the output convolution (320 -> 4): the library's
+    assert not hip_ops.conv3x3_n320_supported(320, 480, torch.bfloat16)        # not whole groups of 320 outputs
     assert not hip_ops.conv3x3_n320_supported(8, 320, torch.bfloat16)          # the stem's 8 channels: csrc/stem_conv.hip
     assert not hip_ops.conv3x3_n320_supported(320, 320, torch.float32)
     tok = torch.zeros(1, 12, 64, device="cuda", dtype=torch.bfloat16)
@@ -1148,8 +1184,9 @@ def test_resblock_at_320_channels_takes_the_implicit_gemm_convolution():
             blk = blk.to(torch.bfloat16).cuda()
             xs, es = x.bfloat16().cuda(), emb.bfloat16().cuda()
             outs = {}
-            old = LY.CONV_N320
+            old = LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS
             try:
+                LY.CONV_N320_MIN_BLOCKS = 1                  # (a test-sized image is far below the launch size the gate asks for)
                 for mode in (False, True):
                     LY.CONV_N320 = mode
                     hip_ops.PROFILE = []
@@ -1157,6 +1194,6 @@ def test_resblock_at_320_channels_takes_the_implicit_gemm_convolution():
                     torch.cuda.synchronize()
                     assert sum(1 for rec in hip_ops.PROFILE if rec[0] == "conv3x3_n320") == (2 if mode else 0)
             finally:
-                LY.CONV_N320 = old
+                LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS = old
                 hip_ops.PROFILE = None
         assert rel(outs[True], ref) < 3.0 / 128 and rel(outs[True], outs[False].double()) < 3.0 / 128
