@@ -53,7 +53,10 @@ constexpr int kRing = 3;
 #define LN3_LOADERS 4
 #endif
 #ifndef LN3_AHEAD
-#define LN3_AHEAD 3
+#define LN3_AHEAD 4
+#endif
+#ifndef LN3_SGB
+#define LN3_SGB 1
 #endif
 constexpr int kLoaders = LN3_LOADERS;
 constexpr int kPiecesPerLoader = kPieces / kLoaders; // 10
@@ -227,6 +230,16 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             if (q + kAhead < 4 * kNT) wf[(q + kAhead) % (kAhead + 1)] = wfrag(slot_base, q + kAhead);
             acc[q % kNT] = M::mfma(as_frag<frag>(xr[q / kNT]), as_frag<frag>(wf[q % (kAhead + 1)]), acc[q % kNT]);
         }
+        // the order above is the order wanted: left alone, the scheduler sinks every read to just before its MFMA (ds_read, wait
+        // lgkmcnt(0), MFMA, 40 times per chunk) and the LDS latency is exposed: 1.13-1.24 PFLOP/s instead of 1.23-1.32
+#if LN3_SGB
+        __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+        for (int q = 0; q < 4 * kNT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q + kAhead < 4 * kNT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
     };
     // Loaders issue the chunk two ahead (its slot held chunk c - 1, which nobody reads any more), then every wave waits for
     // everything older than those pieces — the next chunk's W pieces and its own next x rows among them — and the block meets.

@@ -1,10 +1,13 @@
 """A/B of csrc/linear_n320.hip's implicit-GEMM convolutions against the library (MIOpen on channels-last views) at the SVD shapes."""
+import os
+
 import torch
 import torch.nn.functional as F
 from multiview_inpaint_amd.svd import hip_ops
 
 torch.manual_seed(0)
 dev = "cuda"
+LIB = os.environ.get("AB_LIBRARY", "1") != "0"          # AB_LIBRARY=0: time only the hand-written kernel
 
 
 def timed(fn, n=20):
@@ -33,7 +36,7 @@ for (N, H, W, C, Co) in [(28, 72, 128, 320, 320), (28, 72, 128, 640, 320), (28, 
     a = lib().permute(0, 2, 3, 1).reshape(N, H * W, Co)
     b = mine()
     fl = 2.0 * N * H * W * 9 * C * Co
-    ms_l, ms_m = timed(lib), timed(mine)
+    ms_l, ms_m = (timed(lib) if LIB else float("nan")), timed(mine)
     print(f"3x3 {H}x{W} {C}->{Co}: maxdiff {(a.float() - b.float()).abs().max().item():.3f} of {a.float().abs().max().item():.1f} | "
           f"library {ms_l * 1e3:.0f} us {fl / ms_l / 1e9:.0f} TF | n320 {ms_m * 1e3:.0f} us {fl / ms_m / 1e9:.0f} TF", flush=True)
 
@@ -52,6 +55,6 @@ for (H, W, C) in [(72, 128, 320), (36, 64, 640), (18, 32, 1280), (9, 16, 1280)]:
     mine = lambda: hip_ops.conv3t_n320(tok, wt, None, T)
     b = mine()
     fl = 2.0 * BT * S * 3 * C * C
-    ms_l, ms_m = timed(lib), timed(mine)
+    ms_l, ms_m = (timed(lib) if LIB else float("nan")), timed(mine)
     print(f"3t {H}x{W} {C}: maxdiff {(ref.float() - b.float()).abs().max().item():.3f} of {ref.float().abs().max().item():.1f} | "
           f"library 1x1 on stacked NCHW {ms_l * 1e3:.0f} us {fl / ms_l / 1e9:.0f} TF | n320 {ms_m * 1e3:.0f} us {fl / ms_m / 1e9:.0f} TF", flush=True)
