@@ -234,6 +234,10 @@ int mvi_attention_forward_strided(const void* q, const void* k, const void* v, v
 int mvi_attention_temporal_strided(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
                                    int32_t S, int32_t H, int32_t D, float scale, int32_t dtype,
                                    int64_t qkv_token_stride, int64_t out_token_stride, void* stream);
+/* Which kernel serves a temporal-attention call of this shape: 1 = the MFMA kernel of csrc/attn_temporal.hip (bf16 / f16, D = 64,
+ * T <= 16, 16-byte aligned rows), 0 = the fp32-math kernel of csrc/attn_rowtile.hip. Strides in elements, 0 = H*D. */
+int mvi_attention_temporal_kernel_variant(int32_t T, int32_t H, int32_t D, int32_t dtype, int64_t qkv_token_stride,
+                                          int64_t out_token_stride);
 
 /* x[r, :] = softmax(scale * x[r, :]) in place, x [rows, cols] contiguous, scale > 0, fp32 statistics. The scaled
  * softmax between the two library GEMMs of the first-stage autoencoder's single-head attention with D = C = 512

@@ -452,6 +452,21 @@ extern "C" int mvi_attention_forward_strided(const void* q, const void* k, const
                                   out_token_stride, stream);
 }
 
+namespace mvi {
+bool attn_temporal16_ok(int T, int D, int dtype, int64_t hd, int64_t qkv_ts, int64_t o_ts, const void* q, const void* k, const void* v,
+                        const void* out);
+template <typename T>
+int attn_temporal16_launch(const void* q, const void* k, const void* v, void* out, int Bo, int Tn, int S, int H, float scale, hipStream_t st,
+                           int64_t qkv_ts, int64_t o_ts);
+}  // namespace mvi
+
+// 1 when the MFMA kernel of csrc/attn_temporal.hip serves this call, 0 for the fp32-math kernel of csrc/attn_rowtile.hip
+extern "C" int mvi_attention_temporal_kernel_variant(int32_t T, int32_t H, int32_t D, int32_t dtype, int64_t qkv_token_stride,
+                                                     int64_t out_token_stride) {
+    static const bool off = getenv("MVI_ATTN_TEMPORAL_MFMA") && getenv("MVI_ATTN_TEMPORAL_MFMA")[0] == '0';     // same-box A/B runs
+    return !off && mvi::attn_temporal16_ok(T, D, dtype, (int64_t)H * D, qkv_token_stride, out_token_stride, nullptr, nullptr, nullptr, nullptr);
+}
+
 static int attention_temporal_impl(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T, int32_t S,
                                    int32_t H, int32_t D, float scale, int32_t dtype, int64_t qkv_ts, int64_t o_ts, void* stream) {
     if (Bo < 0 || T <= 0 || S <= 0 || H <= 0 || D <= 0) return mvi::unet_fail(MVI_EINVAL, "temporal attention: bad shape");
@@ -465,6 +480,11 @@ static int attention_temporal_impl(const void* q, const void* k, const void* v, 
     hipStream_t st = (hipStream_t)stream;
     const int B = Bo * S;
     int rc;
+    if (mvi_attention_temporal_kernel_variant(T, H, D, dtype, qkv_ts, o_ts) && mvi::attn_temporal16_ok(T, D, dtype, hd, qkv_ts, o_ts, q, k, v, out)) {
+        rc = dtype == MVI_DT_BF16 ? mvi::attn_temporal16_launch<__hip_bfloat16>(q, k, v, out, Bo, T, S, H, scale, st, qkv_ts, o_ts)
+                                  : mvi::attn_temporal16_launch<__half>(q, k, v, out, Bo, T, S, H, scale, st, qkv_ts, o_ts);
+        return rc ? mvi::unet_fail(rc, "temporal attention: kernel launch failed") : MVI_OK;
+    }
     switch (dtype) {
         case MVI_DT_F32: rc = mvi::attn_rowtile_launch<float>(q, k, v, out, B, H, T, T, D, scale, st, S, qkv_ts, qkv_ts, o_ts); break;
         case MVI_DT_BF16: rc = mvi::attn_rowtile_launch<__hip_bfloat16>(q, k, v, out, B, H, T, T, D, scale, st, S, qkv_ts, qkv_ts, o_ts); break;

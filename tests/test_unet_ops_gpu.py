@@ -698,6 +698,30 @@ def test_attention_packed_equals_separate_tensors(ops, dtype, B, S, H, D):
     assert torch.equal(got, want)                       # same kernel, same arithmetic, only the addressing differs
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("bo,T,S,Hh", [(2, 14, 333, 5), (1, 16, 40, 10), (3, 1, 17, 5), (1, 3, 4100, 20), (2, 7, 1, 1)])
+def test_attention_temporal_mfma_kernel(ops, dtype, tol, bo, T, S, Hh):
+    """csrc/attn_temporal.hip (bf16 / f16, D = 64, T <= 16: every temporal attention of the SVD step) against fp64 softmax attention on
+    the same rounded inputs, separate and packed q/k/v; frames 1 .. 16 (padding keys masked, padding rows never stored), more
+    problems than waves (the grid-stride walk with its prefetch) and fewer, and large logits (one dominant key per row)."""
+    from multiview_inpaint_amd import _lib
+    D = 64
+    assert _lib.lib().mvi_attention_temporal_kernel_variant(T, Hh, D, 1 if dtype == torch.bfloat16 else 2, 3 * Hh * D, Hh * D) == 1
+    assert _lib.lib().mvi_attention_temporal_kernel_variant(25, Hh, D, 1, 0, 0) == 0 and _lib.lib().mvi_attention_temporal_kernel_variant(T, Hh, 32, 1, 0, 0) == 0
+    g = torch.Generator().manual_seed(T * 100 + S)
+    for gain in (1.0, 6.0):
+        qkv = (torch.randn(bo * T, S, 3 * Hh * D, generator=g) * gain ** 0.5).to(dtype)
+        q, k, v = (t.contiguous() for t in qkv.chunk(3, dim=-1))
+        out_p = ops.attention_temporal_packed(qkv.cuda(), Hh, T)
+        out_s = ops.attention_temporal(q.cuda(), k.cuda(), v.cuda(), Hh, T)
+        torch.cuda.synchronize()
+        assert torch.equal(out_p, out_s)
+        rg = lambda t: t.double().reshape(bo, T, S, Hh, D).permute(0, 2, 3, 1, 4)                  # bo s h t d
+        att = torch.softmax(rg(q) @ rg(k).transpose(-1, -2) * D ** -0.5, -1) @ rg(v)
+        ref = att.permute(0, 3, 1, 2, 4).reshape(bo * T, S, Hh * D)
+        assert out_p.dtype == dtype and (out_p.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_temporal_packed_equals_separate_tensors(ops, dtype):
     bo, T, S, H, D = 2, 5, 37, 3, 32
