@@ -215,6 +215,13 @@ int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void* out, int64
 /* ... + bias[c] (fp32 [C]): the bias of the convolution that produced the tokens rides on the same pass. */
 int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, const float* bias, void* out, int64_t N, int32_t C,
                                   int64_t spatial, int32_t dtype, void* stream);
+/* (x_in may be NULL in both: the plain layout change "b (h w) c -> b c h w", + bias.) */
+
+/* out[n, p', c] = x[n, c, p]: "b c h w -> b (h w) c" for x [N, C, H, W]; upsample = 2 folds the nearest-neighbour 2x upsampling of
+ * Upsample.forward (svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:118-134, F.interpolate(scale_factor=2, mode="nearest"))
+ * into the token write: out [N, (2H)(2W), C]; upsample = 1: out [N, H W, C]. C and H W multiples of the 16-byte vector width. */
+int mvi_planes_to_tokens(const void* x, void* out, int64_t N, int32_t C, int32_t H, int32_t W, int32_t upsample, int32_t dtype,
+                         void* stream);
 
 /* out = silu(h + bias[c]) for h [N, C, spatial]: convolution bias + SiLU of the ControlNet hint stem
  * (svd_inpaint1/models/csvd.py:234-250: eight convolutions with SiLU between, at up to 576x1024) in one pass instead of

@@ -169,11 +169,64 @@ __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __re
         if (c0 + cr < C && p0 + pv * V < S) {
             const int64_t o = (n * C + c0 + cr) * S + p0 + pv * V;
             float t[V], xi[V];
-            Io<T>::load(x_in + o, xi);
+            if (x_in) {
+                Io<T>::load(x_in + o, xi);
+            } else {                                              // plain "b (h w) c -> b c h w"
+#pragma unroll
+                for (int k = 0; k < V; ++k) xi[k] = 0.f;
+            }
             const float bc = bias ? bias[c0 + cr] : 0.f;          // per-channel bias of the convolution that produced the tokens
 #pragma unroll
             for (int k = 0; k < V; ++k) t[k] = s_t[pv * V + k][cr] + bc + xi[k];
             Io<T>::store(out + o, t);
+        }
+    }
+}
+
+
+// out[n, up(p), c] = x[n, c, p]: "b c h w -> b (h w) c" through the same 64 x 64 LDS tile, optionally with the nearest-neighbour 2x
+// upsampling of Upsample (openaimodel.py:118-134, F.interpolate(scale_factor=2, mode="nearest")) folded into the token write: source
+// pixel (y, x) of a W-wide image lands on tokens (2 y + a)(2 W) + 2 x + b, a, b in {0, 1} — the 4x larger NCHW tensor never exists.
+template <typename T>
+__global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restrict__ x, T* __restrict__ out, int C, int64_t S, int p_tiles,
+                                                               int c_tiles, int W, int up) {
+    constexpr int V = Io<T>::kVec;
+    constexpr int VPR = kTpTile / V;
+    __shared__ float s_t[kTpTile][kTpTile + 1];      // [c][p]
+    int bid = blockIdx.x;
+    const int pt = bid % p_tiles; bid /= p_tiles;
+    const int ct = bid % c_tiles;
+    const int64_t n = bid / c_tiles;
+    const int64_t p0 = (int64_t)pt * kTpTile;
+    const int c0 = ct * kTpTile;
+    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
+        const int cr = i / VPR, pv = i % VPR;
+        if (c0 + cr < C && p0 + pv * V < S) {
+            float t[V];
+            Io<T>::load(x + ((n * C + c0 + cr) * S + p0 + pv * V), t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s_t[cr][pv * V + k] = t[k];
+        }
+    }
+    __syncthreads();
+    const int64_t So = up == 2 ? 4 * S : S;
+    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
+        const int pr = i / VPR, cv = i % VPR;
+        const int64_t p = p0 + pr;
+        if (p < S && c0 + cv * V < C) {
+            float t[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) t[k] = s_t[cv * V + k][pr];
+            if (up == 2) {
+                const int64_t y = p / W, xx = p - y * W;
+                T* const o = out + ((n * So + (2 * y) * (2 * (int64_t)W) + 2 * xx) * C + c0 + cv * V);
+                Io<T>::store(o, t);
+                Io<T>::store(o + C, t);
+                Io<T>::store(o + 2 * (int64_t)W * C, t);
+                Io<T>::store(o + (2 * (int64_t)W + 1) * C, t);
+            } else {
+                Io<T>::store(out + ((n * So + p) * C + c0 + cv * V), t);
+            }
         }
     }
 }
@@ -258,7 +311,7 @@ extern "C" int mvi_tokens_to_planes_add(const void* tok, const void* x_in, void*
                                         int32_t dtype, void* stream) {
     if (N < 0 || C <= 0 || spatial < 0) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: bad shape");
     if (N == 0 || spatial == 0) return MVI_OK;
-    if (!tok || !x_in || !out) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: NULL pointer");
+    if (!tok || !out) return unet_fail(MVI_EINVAL, "tokens_to_planes_add: NULL pointer");
     int rc;
     switch (dtype) {
         case MVI_DT_F32: rc = tokens_to_planes_launch<float>(tok, x_in, out, N, C, spatial, (hipStream_t)stream); break;
@@ -274,7 +327,7 @@ extern "C" int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, 
                                         int32_t dtype, void* stream) {
     if (N < 0 || C <= 0 || spatial < 0) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: bad shape");
     if (N == 0 || spatial == 0) return MVI_OK;
-    if (!tok || !x_in || !out) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: NULL pointer");
+    if (!tok || !out) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: NULL pointer");
     int rc;
     switch (dtype) {
         case MVI_DT_F32: rc = tokens_to_planes_launch<float>(tok, x_in, out, N, C, spatial, (hipStream_t)stream, bias); break;
@@ -284,4 +337,32 @@ extern "C" int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, 
     }
     if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "tokens_to_planes_add_bias: C and spatial must be multiples of the 16-byte vector width");
     return rc ? unet_fail(MVI_EHIP, "tokens_to_planes_add_bias: kernel launch failed") : MVI_OK;
+}
+
+template <typename T>
+static int planes_to_tokens_launch(const void* x, void* out, int64_t N, int C, int64_t S, int W, int up, hipStream_t st) {
+    constexpr int V = Io<T>::kVec;
+    if (C % V || S % V) return MVI_EINVAL;
+    const int p_tiles = (int)((S + kTpTile - 1) / kTpTile), c_tiles = (C + kTpTile - 1) / kTpTile;
+    const int64_t blocks = N * p_tiles * c_tiles;
+    if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
+    hipLaunchKernelGGL((planes_to_tokens_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, C, S, p_tiles, c_tiles, W, up);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
+extern "C" int mvi_planes_to_tokens(const void* x, void* out, int64_t N, int32_t C, int32_t H, int32_t W, int32_t upsample, int32_t dtype,
+                                    void* stream) {
+    if (N < 0 || C <= 0 || H < 0 || W < 0 || (upsample != 1 && upsample != 2)) return unet_fail(MVI_EINVAL, "planes_to_tokens: bad shape / upsample must be 1 or 2");
+    const int64_t S = (int64_t)H * W;
+    if (N == 0 || S == 0) return MVI_OK;
+    if (!x || !out) return unet_fail(MVI_EINVAL, "planes_to_tokens: NULL pointer");
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = planes_to_tokens_launch<float>(x, out, N, C, S, W, upsample, (hipStream_t)stream); break;
+        case MVI_DT_BF16: rc = planes_to_tokens_launch<__hip_bfloat16>(x, out, N, C, S, W, upsample, (hipStream_t)stream); break;
+        case MVI_DT_F16: rc = planes_to_tokens_launch<__half>(x, out, N, C, S, W, upsample, (hipStream_t)stream); break;
+        default: return unet_fail(MVI_EINVAL, "planes_to_tokens: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "planes_to_tokens: C and H W must be multiples of the 16-byte vector width");
+    return rc ? unet_fail(MVI_EHIP, "planes_to_tokens: kernel launch failed") : MVI_OK;
 }

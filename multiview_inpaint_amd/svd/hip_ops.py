@@ -1,6 +1,7 @@
 """GPU implementations of multiview_inpaint_amd.svd.ops through the C-ABI HIP library
 (include/mvi_unet_ops.h). Importing this module without libmvi_hip.so raises."""
 import ctypes as C
+import math
 import weakref
 
 import torch
@@ -581,24 +582,44 @@ def add_lerp(x, h, base, alpha):
     return out
 
 
-def tokens_to_planes_add(tok, x_in, bias=None):
-    """tok [N, S, C] (+ bias[c]) + x_in [N, C, *spatial] -> [N, C, *spatial]."""
+def tokens_to_planes_add(tok, x_in, bias=None, spatial=None):
+    """tok [N, S, C] (+ bias[c]) + x_in [N, C, *spatial] -> [N, C, *spatial]; x_in None: the layout change alone, into `spatial`."""
     L = _lib.lib()
-    if tok.dtype not in _DT or x_in.dtype != tok.dtype:
+    if tok.dtype not in _DT or (x_in is not None and x_in.dtype != tok.dtype):
         raise TypeError("tokens_to_planes_add: tok and x_in must share a supported dtype")
     N, S, Cc = tok.shape
-    if x_in.shape[0] != N or x_in.shape[1] != Cc or x_in.numel() != tok.numel():
-        raise ValueError(f"tokens_to_planes_add: tok {tuple(tok.shape)} does not match x_in {tuple(x_in.shape)}")
+    if x_in is None:
+        if spatial is None or math.prod(int(v) for v in spatial) != S:
+            raise ValueError("tokens_to_planes_add: without x_in, `spatial` must be given and multiply to the token count")
+        xc, out = None, torch.empty(N, Cc, *spatial, dtype=tok.dtype, device=tok.device)
+    else:
+        if x_in.shape[0] != N or x_in.shape[1] != Cc or x_in.numel() != tok.numel():
+            raise ValueError(f"tokens_to_planes_add: tok {tuple(tok.shape)} does not match x_in {tuple(x_in.shape)}")
+        xc = x_in if x_in.is_contiguous() else x_in.contiguous()
+        out = torch.empty_like(xc)
     tc = tok if tok.is_contiguous() else tok.contiguous()
-    xc = x_in if x_in.is_contiguous() else x_in.contiguous()
-    out = torch.empty_like(xc)
-    with torch.cuda.device(tok.device), _Timed("tokens_to_planes_add", 3.0 * tc.numel() * tc.element_size(), tok.device):
+    xp = None if xc is None else xc.data_ptr()
+    with torch.cuda.device(tok.device), _Timed("tokens_to_planes_add", (2.0 + (xc is not None)) * tc.numel() * tc.element_size(), tok.device):
         if bias is None:
-            _check(L.mvi_tokens_to_planes_add(tc.data_ptr(), xc.data_ptr(), out.data_ptr(), N, Cc, S, _DT[tok.dtype],
+            _check(L.mvi_tokens_to_planes_add(tc.data_ptr(), xp, out.data_ptr(), N, Cc, S, _DT[tok.dtype],
                                               _stream(tok.device)), "tokens_to_planes_add")
         else:
-            _check(L.mvi_tokens_to_planes_add_bias(tc.data_ptr(), xc.data_ptr(), _f32(bias).data_ptr(), out.data_ptr(), N, Cc, S,
+            _check(L.mvi_tokens_to_planes_add_bias(tc.data_ptr(), xp, _f32(bias).data_ptr(), out.data_ptr(), N, Cc, S,
                                                    _DT[tok.dtype], _stream(tok.device)), "tokens_to_planes_add")
+    return out
+
+
+def planes_to_tokens(x, upsample=1):
+    """x [N, C, H, W] -> tokens [N, H W, C]; upsample = 2: nearest-neighbour 2x upsampling folded in -> [N, (2H)(2W), C]."""
+    L = _lib.lib()
+    if x.dtype not in _DT or x.dim() != 4:
+        raise TypeError("planes_to_tokens: [N, C, H, W] of a supported dtype expected")
+    N, Cc, H, W = x.shape
+    xc = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(N, H * W * upsample * upsample, Cc, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device), _Timed("planes_to_tokens", float(xc.numel() + out.numel()) * x.element_size(), x.device):
+        _check(L.mvi_planes_to_tokens(xc.data_ptr(), out.data_ptr(), N, Cc, H, W, int(upsample), _DT[x.dtype], _stream(x.device)),
+               "planes_to_tokens")
     return out
 
 

@@ -191,6 +191,12 @@ class Upsample(nn.Module):
         if self.dims == 3:
             x = F.interpolate(x, ((s if self.third_up else 1) * x.shape[2], x.shape[3] * s, x.shape[4] * s), mode="nearest")
         else:
+            if s == 2 and self.use_conv and _upsample_tokens_ok(self.conv, x):
+                # upsampling folded into the layout change, the convolution on tokens (csrc/linear_n320.hip), bias in its accumulators
+                from . import hip_ops
+                N, _, H, W = x.shape
+                t = hip_ops.conv3x3_n320(hip_ops.planes_to_tokens(x, upsample=2), _tap_major_weight(self.conv.weight), self.conv.bias, 2 * H, 2 * W)
+                return hip_ops.tokens_to_planes_add(t, None, spatial=(2 * H, 2 * W))
             x = F.interpolate(x, scale_factor=s, mode="nearest")
         return self.conv(x) if self.use_conv else x
 
@@ -498,6 +504,21 @@ def _tap_major_weight(w):
                hip_ops.conv3x3_n320_weight(w.detach()))
         _tap_weights[key] = hit
     return hit[2]
+
+
+def _upsample_tokens_ok(conv, x):
+    """Upsample.forward's nearest 2x + 3x3 convolution on tokens: reduced precision on the GPU, outside autograd, a shape the
+    implicit-GEMM kernel takes and enough rows (after upsampling) to fill the chip."""
+    if not (CONV_N320 and NHWC_CONVS and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+            and not torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.weight.dtype == x.dtype
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1):
+        return False
+    from . import hip_ops
+    N, C, H, W = x.shape
+    rows = 4 * N * H * W
+    return (C % 8 == 0 and (H * W) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype) and rows * C * 2 < 2 ** 32
+            and -(-rows // 256) * (conv.out_channels // 320) >= CONV_N320_MIN_BLOCKS)
 
 
 def _conv_tokens(conv, tok, H, W):

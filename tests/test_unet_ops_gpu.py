@@ -1221,3 +1221,56 @@ def test_resblock_at_320_channels_takes_the_implicit_gemm_convolution():
                 LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS = old
                 hip_ops.PROFILE = None
         assert rel(outs[True], ref) < 3.0 / 128 and rel(outs[True], outs[False].double()) < 3.0 / 128
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 16), (1, 72, 5, 8), (3, 320, 9, 16), (1, 8, 24, 40)])
+def test_planes_to_tokens_and_back(dtype, N, C, H, W):
+    """mvi_planes_to_tokens: "b c h w -> b (h w) c" alone and with Upsample's nearest 2x folded in (openaimodel.py:118-134), bit for bit
+    against permute / F.interpolate; mvi_tokens_to_planes_add without x_in is its inverse (+ bias)."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype).cuda()
+    t1 = hip_ops.planes_to_tokens(x)
+    assert torch.equal(t1, x.permute(0, 2, 3, 1).reshape(N, H * W, C))
+    t2 = hip_ops.planes_to_tokens(x, upsample=2)
+    up = F.interpolate(x.float(), scale_factor=2, mode="nearest").to(dtype)
+    assert torch.equal(t2, up.permute(0, 2, 3, 1).reshape(N, 4 * H * W, C))
+    assert torch.equal(hip_ops.tokens_to_planes_add(t2, None, spatial=(2 * H, 2 * W)), up)
+    b = torch.randn(C, generator=g).cuda()
+    back = hip_ops.tokens_to_planes_add(t1, None, b, spatial=(H, W))
+    assert torch.equal(back, (x.float() + b.view(1, C, 1, 1)).to(dtype))
+    with pytest.raises(ValueError):
+        hip_ops.tokens_to_planes_add(t1, None, spatial=(H, W + 1))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 2.0 / 1024)])   # (the library adds the bias in a second rounding)
+def test_upsample_on_tokens_equals_interpolate_then_conv(dtype, tol):
+    """Upsample.forward (openaimodel.py:118-134) through planes_to_tokens(upsample = 2) + the implicit-GEMM convolution + the layout
+    change back, against F.interpolate + F.conv2d in fp64; both routes of the module (layers.CONV_N320)."""
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    g = torch.Generator().manual_seed(3)
+    up = LY.Upsample(640, True, dims=2, out_channels=640).eval()
+    with torch.no_grad():
+        up.conv.weight.copy_(torch.randn(up.conv.weight.shape, generator=g) * 0.02)
+        up.conv.bias.copy_(torch.randn(640, generator=g) * 0.3)
+    x = torch.randn(2, 640, 6, 8, generator=g).to(dtype)
+    up = up.to(dtype).cuda()
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), up.conv.weight.double().cpu(), up.conv.bias.double().cpu(), padding=1)
+    old = LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS
+    outs = {}
+    try:
+        LY.CONV_N320_MIN_BLOCKS = 1
+        for mode in (False, True):
+            LY.CONV_N320 = mode
+            hip_ops.PROFILE = []
+            with torch.no_grad():
+                outs[mode] = up(x.cuda())
+            torch.cuda.synchronize()
+            assert sum(1 for rec in hip_ops.PROFILE if rec[0] == "conv3x3_n320") == (1 if mode else 0)
+    finally:
+        LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS = old
+        hip_ops.PROFILE = None
+    for o in outs.values():
+        assert o.shape == ref.shape and o.is_contiguous() and (o.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
