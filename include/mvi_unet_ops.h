@@ -148,10 +148,17 @@ int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* 
  *   mvi_conv3t_n320: (3, 1, 1) / padding (1, 0, 0) over frames (the Conv3d of VideoResBlock.time_stack, video_model.py:41-54).
  *     x [B, T, pixels, C_in]; weight [C_out][3 C_in] = conv.weight[:, :, :, 0, 0].permute(0, 2, 1) flattened. */
 int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype);
+/* Small images (fewer than 128 blocks of 256 rows x 320 channels) split K over up to 8 blocks per tile: fp32 partial sums in
+ * `workspace` (..._workspace_bytes(); 0 = this shape is not split), reduced with the bias by a second launch. workspace NULL or too
+ * small: the unsplit launch. */
+size_t mvi_conv3x3_n320_workspace_bytes(int64_t N, int32_t H, int32_t W, int32_t C_in, int32_t C_out);
+size_t mvi_conv3t_n320_workspace_bytes(int64_t B, int32_t T, int32_t pixels, int32_t C_in, int32_t C_out);
 int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W, int32_t C_in,
-                     int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* stream);
+                     int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
+                     size_t workspace_bytes, void* stream);
 int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels, int32_t C_in,
-                    int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* stream);
+                    int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* y = act(conv2d(x, weight, padding = 1) + bias) for a 3x3, stride-1 convolution with 16 output channels and at most 16 input
  * channels, 32 and at most 32, or 320 and at most 8 (the networks' input convolution), on NCHW bf16 / f16 tensors (csrc/stem_conv.hip) — the stride-1 layers of ControlNet.input_hint_block

@@ -99,14 +99,16 @@ __device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) 
 // valid address) and the fragment is zeroed before the MFMAs (a wave-uniform branch: interior waves skip it).
 // taps = 3 is the same thing with the taps along H only ((3,1,1) over frames: H = T frames, W = pixels of a frame).
 // groups > 1: C_out = 320 groups; a block computes 320 of them (blocks of one row block are neighbours and share x through L2).
+// kSplit (small images: fewer than half the CUs would get a block): ksplit blocks share a (row block, column group), each over a
+// contiguous range of K chunks, and store fp32 partial sums [ksplit][padded rows][C_out]; splitk_reduce_kernel adds them and the bias.
 struct ConvGeom {
-    int H, W, cpc, taps, groups;                     // image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
+    int H, W, cpc, taps, groups, ksplit;             // image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
 };
 
-template <typename T, bool kConv>
+template <typename T, bool kConv, bool kSplit = false>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg) {
+                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part) {
     using M = Mma<T>;
     using frag = typename M::frag;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -118,22 +120,30 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     const int col = lane & 31, hh = lane >> 5;
     int bid = blockIdx.x;
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
+    int part_col0 = 0, ks = 0;
     if (kConv && cg.groups > 1) {                    // (row block, column group): the groups of one row block run side by side
         const int g = bid % cg.groups;
         bid /= cg.groups;
         w += (int64_t)g * kN * K;
         out += g * kN;
+        part_col0 = g * kN;
         if (bias) bias += g * kN;
+    }
+    if (kSplit) {
+        ks = bid % cg.ksplit;
+        bid /= cg.ksplit;
     }
     const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
     const int64_t row = row0 + col;
-    const int n_chunks = K / kKC;
+    // this block's chunks: c0 .. c0 + n_chunks - 1 of the K / 64 (all of them unless kSplit); chunk indices below are relative to c0
+    const int c0 = kSplit ? (int)((int64_t)ks * (K / kKC) / cg.ksplit) : 0;
+    const int n_chunks = kSplit ? (int)((int64_t)(ks + 1) * (K / kKC) / cg.ksplit) - c0 : K / kKC;
 
     // ---- accumulators start from the bias: column 32 j + col of every row this lane holds
     f32x16 acc[kNT];
 #pragma unroll
     for (int j = 0; j < kNT; ++j) {
-        const float b = bias ? bias[32 * j + col] : 0.f;
+        const float b = bias && !kSplit ? bias[32 * j + col] : 0.f;      // (kSplit: the reduction adds it)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = b;
     }
@@ -160,11 +170,11 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             if (py == cg.H - 1) tap_ok &= ~0x4u;
         }
     }
-    int ld_tap = 0, ld_cc = 0;                       // kConv: (tap, channel chunk) of the next load_x call — they come in chunk order
+    int ld_tap = kConv ? c0 / cg.cpc : 0, ld_cc = kConv ? c0 - ld_tap * cg.cpc : 0;   // kConv: (tap, channel chunk) of the next load_x call — they come in chunk order
     // returns the lane's keep mask for the fragment (all ones unless kConv and the tap is outside the image)
     auto load_x = [&](int c, u32x4 (&xr)[4]) __attribute__((always_inline)) -> uint32_t {
         if (!kConv) {
-            const char* const base = xbase + (int64_t)c * (kKC * 2);
+            const char* const base = xbase + (int64_t)(c0 + c) * (kKC * 2);
 #pragma unroll
             for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, x_voff);
             return ~0u;
@@ -193,7 +203,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         const uint32_t r = 8u * pc + (uint32_t)(lane >> 3), slot = (uint32_t)(lane & 7);
         p_voff[i] = r * w_row_bytes + 16u * (slot ^ ((r >> 1) & 7u));
     }
-    const char* const wbase = reinterpret_cast<const char*>(w);
+    const char* const wbase = reinterpret_cast<const char*>(w) + (int64_t)c0 * (kKC * 2);
     auto issue_chunk = [&](int c) __attribute__((always_inline)) {
         // chunks past the end re-load the last one (never read): every call issues the same number of pieces, the counted wait stays valid
         const int cc = c < n_chunks ? c : n_chunks - 1;
@@ -284,6 +294,16 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     if (c < n_chunks) chunk_fn(slot, xa, ka_keep);                   // K / 64 odd: one chunk left
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // trailing (unused) pieces and rows land before the block ends
 
+    if (kSplit) {
+        // fp32 partial sums straight from the accumulators: register i of column tile j = row (i & 3) + 8 (i >> 2) + 4 hh, column 32 j + col
+        const int64_t c_tot = (int64_t)cg.groups * kN, rows_pad = (int64_t)(n_blocks / (cg.groups * cg.ksplit)) * kRows;
+        float* const pbase = part + ((int64_t)ks * rows_pad + row0 + 4 * hh) * c_tot + part_col0 + col;
+#pragma unroll
+        for (int j = 0; j < kNT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pbase[((i & 3) + 8 * (i >> 2)) * c_tot + 32 * j] = acc[j][i];
+        return;
+    }
     // ---- outputs: two column tiles at a time through the wave's LDS tile [32 rows][64 columns], then four 16-byte stores per lane
     char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
     const int64_t orow_bytes = o_rs * 2;
@@ -312,25 +332,54 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     }
 }
 
+// out[r][c] = sum_s part[s][r][c] + bias[c], eight columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, T* __restrict__ out,
+                                                            int64_t rows, int c_tot, int64_t o_rs, int ksplit, int64_t rows_pad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int vpr = c_tot / 8;
+    if (i >= rows * vpr) return;
+    const int64_t r = i / vpr;
+    const int c = (int)(i - r * vpr) * 8;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = bias ? bias[c + k] : 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float4* const p = reinterpret_cast<const float4*>(part + ((int64_t)s * rows_pad + r) * c_tot + c);
+        const float4 u = p[0], v = p[1];
+        a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w; a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = Mma<T>::pack2(a[2 * k], a[2 * k + 1]);
+    *reinterpret_cast<u32x4*>(out + r * o_rs + c) = o;
+}
+
 }  // namespace ln3
 
-template <typename T, bool kConv = false>
+template <typename T, bool kConv = false, bool kSplit = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
-                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1}) {
+                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1}, float* part = nullptr) {
     using namespace ln3;
-    const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups;
+    const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups * cg.ksplit;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T, kConv>;
+    auto kern = &linear_n320_kernel<T, kConv, kSplit>;
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
-                       o_rs, (int)n_blocks, cg);
+                       o_rs, (int)n_blocks, cg, part);
+    if (kSplit) {
+        const int c_tot = cg.groups * kN;
+        const int64_t threads = rows * (c_tot / 8), rows_pad = (rows + kRows - 1) / kRows * kRows;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, (T*)out,
+                           rows, c_tot, o_rs, cg.ksplit, rows_pad);
+    }
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -371,9 +420,28 @@ extern "C" int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t d
            (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
 }
 
+// K split of a convolution launch: 1 (none) when the (row block, column group) grid already covers half the chip; otherwise enough
+// parts to cover it, each with at least 8 chunks of 64.
+static int conv_ksplit(int64_t rows, int32_t taps, int32_t C_in, int32_t C_out) {
+    static const bool off = getenv("MVI_CONV_KSPLIT") && getenv("MVI_CONV_KSPLIT")[0] == '0';      // same-box A/B runs
+    if (off) return 1;
+    const int64_t blocks = (rows + mvi::ln3::kRows - 1) / mvi::ln3::kRows * (C_out / mvi::ln3::kN);
+    if (blocks >= 128) return 1;
+    const int chunks = taps * C_in / mvi::ln3::kKC;
+    int ks = (int)(256 / blocks);
+    if (ks > 8) ks = 8;
+    if (ks > chunks / 8) ks = chunks / 8;
+    return ks < 2 ? 1 : ks;
+}
+
+static size_t conv_workspace_bytes(int64_t rows, int32_t taps, int32_t C_in, int32_t C_out) {
+    const int ks = conv_ksplit(rows, taps, C_in, C_out);
+    return ks == 1 ? 0 : (size_t)ks * (size_t)mvi_ff_geglu_out_rows(rows) * (size_t)C_out * sizeof(float);
+}
+
 static int conv_taps_n320(const char* what, const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
                           int32_t taps, int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
-                          void* stream) {
+                          void* workspace, size_t workspace_bytes, void* stream) {
     char msg[160];
     auto fail = [&](const char* m) {
         snprintf(msg, sizeof msg, "%s: %s", what, m);
@@ -391,10 +459,19 @@ static int conv_taps_n320(const char* what, const void* x, const void* weight, c
     if ((int64_t)mvi::ln3::kN * taps * C_in * 2 > 0xFFFFFFFFll || rows * C_in * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
         return fail("weight / activation tensor exceeds 32-bit byte offsets");
     hipStream_t st = (hipStream_t)stream;
-    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN};
-    const int rc = dtype == MVI_DT_BF16
-                       ? mvi::linear_n320_launch<__hip_bfloat16, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg)
-                       : mvi::linear_n320_launch<__half, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg);
+    // the K split is taken when the caller brought its workspace (mvi_conv3x3_n320_workspace_bytes); without one the launch is unsplit
+    int ks = conv_ksplit(rows, taps, C_in, C_out);
+    if (ks > 1 && (!workspace || workspace_bytes < conv_workspace_bytes(rows, taps, C_in, C_out) || (uintptr_t)workspace % 16)) ks = 1;
+    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks};
+    int rc;
+    if (ks > 1)
+        rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16, true, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st,
+                                                                                        cg, (float*)workspace)
+                                  : mvi::linear_n320_launch<__half, true, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg,
+                                                                                (float*)workspace);
+    else
+        rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg)
+                                  : mvi::linear_n320_launch<__half, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg);
     if (rc) {
         snprintf(msg, sizeof msg, "%s: kernel launch failed", what);
         return mvi::unet_fail(rc, msg);
@@ -402,14 +479,24 @@ static int conv_taps_n320(const char* what, const void* x, const void* weight, c
     return MVI_OK;
 }
 
+extern "C" size_t mvi_conv3x3_n320_workspace_bytes(int64_t N, int32_t H, int32_t W, int32_t C_in, int32_t C_out) {
+    return N <= 0 || H <= 0 || W <= 0 || C_in <= 0 || C_out <= 0 ? 0 : conv_workspace_bytes(N * H * W, 9, C_in, C_out);
+}
+
+extern "C" size_t mvi_conv3t_n320_workspace_bytes(int64_t B, int32_t T, int32_t pixels, int32_t C_in, int32_t C_out) {
+    return B <= 0 || T <= 0 || pixels <= 0 || C_in <= 0 || C_out <= 0 ? 0 : conv_workspace_bytes(B * T * pixels, 3, C_in, C_out);
+}
+
 extern "C" int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
                                 int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
-                                void* stream) {
-    return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, C_in, C_out, out_rows_capacity, out_row_stride, dtype, stream);
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, C_in, C_out, out_rows_capacity, out_row_stride, dtype, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels,
                                int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
-                               void* stream) {
-    return conv_taps_n320("conv3t_n320", x, weight, bias, out, B, T, pixels, 3, C_in, C_out, out_rows_capacity, out_row_stride, dtype, stream);
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_taps_n320("conv3t_n320", x, weight, bias, out, B, T, pixels, 3, C_in, C_out, out_rows_capacity, out_row_stride, dtype, workspace,
+                          workspace_bytes, stream);
 }

@@ -380,7 +380,7 @@ def conv3t_n320_weight(weight):
     return weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(weight.shape[0], -1).contiguous()
 
 
-def _conv_taps_n320(kind, fn, tok, weight_taps, bias, N, H, W, taps):
+def _conv_taps_n320(kind, fn, ws_fn, tok, weight_taps, bias, N, H, W, taps, split=True):
     L = _lib.lib()
     C = tok.shape[-1]
     rows = N * H * W
@@ -392,28 +392,41 @@ def _conv_taps_n320(kind, fn, tok, weight_taps, bias, N, H, W, taps):
     cap = int(L.mvi_ff_geglu_out_rows(rows))
     full = torch.empty(cap, Co, dtype=tok.dtype, device=tok.device)
     b = None if bias is None else _f32(bias)
+    ws_bytes = int(ws_fn(N, H, W, C, Co)) if split else 0       # > 0: a small image, K split over several blocks per tile
+    ws = _workspace(tok.device, ws_bytes) if ws_bytes else None
     with torch.cuda.device(tok.device), _Timed(kind, 2.0 * rows * taps * C * Co, tok.device):
         _check(fn(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, cap, full.stride(0),
-                  _DT[tok.dtype], _stream(tok.device)), kind)
+                  _DT[tok.dtype], None if ws is None else ws.data_ptr(), ws_bytes, _stream(tok.device)), kind)
     return full[:rows]
 
 
-def conv3x3_n320(tok, weight_taps, bias, H, W):
+def conv3x3_n320_fills_chip(N, H, W, C_in, C_out, min_blocks):
+    """Does a launch of this shape put at least min_blocks blocks on the chip (256 rows x 320 channels each, times the K split
+    small images get)?"""
+    blocks = -(-N * H * W // 256) * (C_out // 320)
+    return blocks >= min_blocks or int(_lib.lib().mvi_conv3x3_n320_workspace_bytes(N, H, W, C_in, C_out)) > 0
+
+
+def conv3x3_n320(tok, weight_taps, bias, H, W, split=True):
     """3x3 / stride 1 / padding 1 convolution to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
     (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, H W, C_out]; weight_taps from conv3x3_n320_weight."""
     N, S, C = tok.shape
     if S != H * W:
         raise ValueError("conv3x3_n320: tok [N, H W, C_in] expected")
-    return _conv_taps_n320("conv3x3_n320", _lib.lib().mvi_conv3x3_n320, tok, weight_taps, bias, N, H, W, 9).view(N, S, -1)
+    L = _lib.lib()
+    return _conv_taps_n320("conv3x3_n320", L.mvi_conv3x3_n320, L.mvi_conv3x3_n320_workspace_bytes, tok, weight_taps, bias, N, H, W, 9,
+                           split).view(N, S, -1)
 
 
-def conv3t_n320(tok, weight_taps, bias, T):
+def conv3t_n320(tok, weight_taps, bias, T, split=True):
     """(3, 1, 1) / padding (1, 0, 0) convolution over the frame axis of token-major activations tok [(b T), S, C_in] (frames of a video
     consecutive) -> [(b T), S, C_out]; weight_taps from conv3t_n320_weight."""
     BT, S, C = tok.shape
     if BT % T:
         raise ValueError("conv3t_n320: tok [(b T), S, C_in] expected")
-    return _conv_taps_n320("conv3t_n320", _lib.lib().mvi_conv3t_n320, tok, weight_taps, bias, BT // T, T, S, 3).view(BT, S, -1)
+    L = _lib.lib()
+    return _conv_taps_n320("conv3t_n320", L.mvi_conv3t_n320, L.mvi_conv3t_n320_workspace_bytes, tok, weight_taps, bias, BT // T, T, S, 3,
+                           split).view(BT, S, -1)
 
 
 def stem_conv3x3_supported(conv, x):

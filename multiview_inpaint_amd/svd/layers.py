@@ -489,7 +489,8 @@ def _channels_last_weight(w):
 
 
 CONV_N320 = os.environ.get("MVI_SVD_CONV_N320", "1") != "0"
-CONV_N320_MIN_BLOCKS = 128         # fewer blocks of 256 rows x 320 channels than this leave most of the 256 CUs idle: the library's
+CONV_N320_MIN_BLOCKS = 128         # fewer blocks of 256 rows x 320 channels than this leave most of the 256 CUs idle: the kernel splits K
+                                   # then (level 3: 64 blocks x 4), or, for a K too short to split, the library runs
 _tap_weights = {}
 
 
@@ -518,7 +519,7 @@ def _upsample_tokens_ok(conv, x):
     N, C, H, W = x.shape
     rows = 4 * N * H * W
     return (C % 8 == 0 and (H * W) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype) and rows * C * 2 < 2 ** 32
-            and -(-rows // 256) * (conv.out_channels // 320) >= CONV_N320_MIN_BLOCKS)
+            and hip_ops.conv3x3_n320_fills_chip(N, 2 * H, 2 * W, C, conv.out_channels, CONV_N320_MIN_BLOCKS))
 
 
 def _conv_tokens(conv, tok, H, W):
@@ -530,7 +531,7 @@ def _conv_tokens(conv, tok, H, W):
     if CONV_N320:
         from . import hip_ops
         if (hip_ops.conv3x3_n320_supported(C, conv.out_channels, tok.dtype) and N * S * C * 2 < 2 ** 32
-                and -(-N * S // 256) * (conv.out_channels // 320) >= CONV_N320_MIN_BLOCKS):
+                and hip_ops.conv3x3_n320_fills_chip(N, H, W, C, conv.out_channels, CONV_N320_MIN_BLOCKS)):
             return hip_ops.conv3x3_n320(tok, _tap_major_weight(conv.weight), None, H, W)
     x = tok.view(N, H, W, C).permute(0, 3, 1, 2)                  # [N, C, H, W] with channels-last strides: no copy
     y = F.conv2d(x, _channels_last_weight(conv.weight), None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -1134,9 +1134,9 @@ def test_conv3x3_n320_equals_conv2d(dtype, tol, N, H, W, C):
     assert hip_ops.conv3x3_n320_supported(C, 320, dtype)
     tok = x.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous().cuda()
     wt = hip_ops.conv3x3_n320_weight(w.cuda())
-    for bias in (None, b):
+    for bias, split in ((None, False), (b, False), (b, True)):     # split: K over several blocks per tile + the fp32 reduction (small images)
         ref = F.conv2d(x.double(), w.double(), None if bias is None else bias.double(), padding=1)
-        out = hip_ops.conv3x3_n320(tok, wt, None if bias is None else bias.cuda(), H, W)
+        out = hip_ops.conv3x3_n320(tok, wt, None if bias is None else bias.cuda(), H, W, split=split)
         torch.cuda.synchronize()
         assert out.shape == (N, H * W, 320)
         got = out.view(N, H, W, 320).permute(0, 3, 1, 2).double().cpu()
@@ -1154,10 +1154,11 @@ def test_conv3x3_n320_column_groups(dtype, tol, N, H, W, C, Co):
     w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)).to(dtype)
     b = torch.randn(Co, generator=g)
     tok = x.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous().cuda()
-    out = hip_ops.conv3x3_n320(tok, hip_ops.conv3x3_n320_weight(w.cuda()), b.cuda(), H, W)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
-    got = out.view(N, H, W, Co).permute(0, 3, 1, 2).double().cpu()
-    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    for split in (False, True):
+        out = hip_ops.conv3x3_n320(tok, hip_ops.conv3x3_n320_weight(w.cuda()), b.cuda(), H, W, split=split)
+        got = out.view(N, H, W, Co).permute(0, 3, 1, 2).double().cpu()
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
@@ -1173,10 +1174,23 @@ def test_conv3t_n320_equals_conv3d(dtype, tol, B, T, S, C, Co):
     b = torch.randn(Co, generator=g)
     x5 = tok.double().view(B, T, S, 1, C).permute(0, 4, 1, 2, 3)                           # b c t h w (w = 1)
     ref = F.conv3d(x5, w.double(), b.double(), 1, (1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(B * T, S, Co)
-    out = hip_ops.conv3t_n320(tok.cuda(), hip_ops.conv3t_n320_weight(w.cuda()), b.cuda(), T)
-    torch.cuda.synchronize()
-    assert out.shape == (B * T, S, Co)
-    assert (out.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    for split in (False, True):
+        out = hip_ops.conv3t_n320(tok.cuda(), hip_ops.conv3t_n320_weight(w.cuda()), b.cuda(), T, split=split)
+        torch.cuda.synchronize()
+        assert out.shape == (B * T, S, Co)
+        assert (out.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_n320_k_split_policy():
+    """Which shapes split K (mvi_conv3x3_n320_workspace_bytes > 0): the level-3 images of the SVD step do, levels 0-2 do not, and a K
+    too short for 8 chunks per part does not either."""
+    from multiview_inpaint_amd import _lib
+    L = _lib.lib()
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 9, 16, 1280, 1280) == 4 * 4096 * 1280 * 4      # 64 blocks -> 4 parts of 45 chunks
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 9, 16, 2560, 1280) == 4 * 4096 * 1280 * 4
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 18, 32, 1280, 1280) == 0 and L.mvi_conv3x3_n320_workspace_bytes(28, 72, 128, 320, 320) == 0
+    assert L.mvi_conv3x3_n320_workspace_bytes(1, 4, 4, 64, 320) == 0                                # 9 chunks: nothing to split
+    assert L.mvi_conv3t_n320_workspace_bytes(2, 14, 144, 1280, 1280) == 4 * 4096 * 1280 * 4       # 60 chunks
 
 
 def test_conv3x3_n320_refuses_other_shapes():

@@ -25,7 +25,7 @@ def timed(fn, n=20):
 
 for (N, H, W, C, Co) in [(28, 72, 128, 320, 320), (28, 72, 128, 640, 320), (28, 72, 128, 960, 320), (28, 72, 128, 640, 640),
                          (28, 36, 64, 640, 640), (28, 36, 64, 1280, 640), (28, 36, 64, 1280, 1280), (28, 18, 32, 1280, 1280),
-                         (28, 18, 32, 2560, 1280), (28, 9, 16, 1280, 1280)]:
+                         (28, 18, 32, 2560, 1280), (28, 9, 16, 1280, 1280), (28, 9, 16, 2560, 1280)]:
     tok = torch.randn(N, H * W, C, device=dev, dtype=torch.bfloat16)
     w = (torch.randn(Co, C, 3, 3, device=dev) * 0.02).bfloat16()
     wt = hip_ops.conv3x3_n320_weight(w)
