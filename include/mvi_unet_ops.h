@@ -85,6 +85,12 @@ size_t mvi_groupnorm_tok2tok_workspace_bytes(int64_t N, int32_t C, int64_t spati
 int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int64_t N,
                                int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t dtype,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* The same with TEMPORAL statistics: the N samples are videos of `frames` consecutive frames, a group's mean / variance are taken
+ * over all frames of a video (the GroupNorm of VideoResBlock.time_stack on b c t h w, video_model.py:71-75); chan_bias stays per frame
+ * [N, C] (the per-frame timestep embedding). Same workspace. */
+int mvi_groupnorm_silu_tok2tok_frames(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int64_t N,
+                                      int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                      int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out = softmax(q k^T * scale) v per (batch, head). Token-major layout, as the Linear projections
  * produce it: q/out [B, Sq, H, D], k/v [B, Sk, H, D], contiguous. No mask (none is used on the
@@ -229,6 +235,18 @@ int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, const float
  * into the token write: out [N, (2H)(2W), C]; upsample = 1: out [N, H W, C]. C and H W multiples of the 16-byte vector width. */
 int mvi_planes_to_tokens(const void* x, void* out, int64_t N, int32_t C, int32_t H, int32_t W, int32_t upsample, int32_t dtype,
                          void* stream);
+
+/* The token-major evaluation of a VideoResBlock (video_model.py:41-81) needs its spatial ResBlock to END on tokens and its tail to
+ * restore b c h w:
+ *   mvi_planes_add_to_tokens:  out[n, p, c] = x[n, c, p] + tok[n, p, c] + bias[c] — `skip_connection(x) + h` (openaimodel.py:354) with h
+ *     (the second convolution's tokens, bias withheld) and the result token-major;
+ *   mvi_tokens_blend_to_planes: out[n, c, p] = base[n, p, c] + (1 - alpha[n]) * (tok[n, p, c] + bias[c]) — the temporal ResBlock's skip
+ *     add and the AlphaBlender (util.py:358-372) in the pass that restores b c h w; alpha fp32 [N].
+ * bias fp32 [C] or NULL; C and spatial multiples of the 16-byte vector width. */
+int mvi_planes_add_to_tokens(const void* x, const void* tok, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial,
+                             int32_t dtype, void* stream);
+int mvi_tokens_blend_to_planes(const void* tok, const void* base, const float* bias, const float* alpha, void* out, int64_t N, int32_t C,
+                               int64_t spatial, int32_t dtype, void* stream);
 
 /* out = silu(h + bias[c]) for h [N, C, spatial]: convolution bias + SiLU of the ControlNet hint stem
  * (svd_inpaint1/models/csvd.py:234-250: eight convolutions with SiLU between, at up to 576x1024) in one pass instead of

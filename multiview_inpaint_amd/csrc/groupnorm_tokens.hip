@@ -115,12 +115,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
 }
 
 // one block per sample: Chan merge per group, then per-channel scale / shift
+// frames > 1: the temporal GroupNorm of VideoResBlock.time_stack (statistics over the `frames` consecutive samples of a video,
+// video_model.py:71-75): a block merges the chunks of all its frames — they are consecutive in `part` — and writes every frame's
+// scale / shift (the frames differ in chan_bias only).
 __global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__ part, const float* __restrict__ weight, const float* __restrict__ bias,
                                                        const float* __restrict__ chan_bias, float* __restrict__ scale_shift, int C, int G,
-                                                       int chunks, float eps) {
+                                                       int chunks_per_frame, float eps, int frames) {
     __shared__ float s_mean[kGtMaxGroups], s_rstd[kGtMaxGroups];
     __shared__ float s_p[256][3];
-    const int64_t n = blockIdx.x;
+    const int64_t n = (int64_t)blockIdx.x * frames;         // first frame of the video
+    const int chunks = chunks_per_frame * frames;
     const int tid = threadIdx.x;
     // 256 / G threads per group take the chunks round-robin (a serial walk over 144 chunks by one thread cost 20 us per call),
     // then one thread per group merges their partials in a fixed order
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
     if (sub < per) {
         for (int c = sub; c < chunks; c += per) {
-            const float* p = part + ((n * chunks + c) * G + g) * 3;
+            const float* p = part + ((n * chunks_per_frame + c) * G + g) * 3;
             const float nb = p[0], mb = p[1], qb = p[2];
             const float nt = cnt + nb, d = mb - mean;
             mean += d * (nb / nt);
@@ -154,12 +158,12 @@ __global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__
     }
     __syncthreads();
     const int Cg = C / G;
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / Cg;
+    for (int i = tid; i < C * frames; i += 256) {             // (frame, channel): n * C + i is the flat index
+        const int c = i % C, g = c / Cg;
         const float w = weight[c] * s_rstd[g];
-        const float add = chan_bias ? chan_bias[n * C + c] : 0.f;
-        scale_shift[(n * C + c) * 2 + 0] = w;
-        scale_shift[(n * C + c) * 2 + 1] = bias[c] + (add - s_mean[g]) * w;
+        const float add = chan_bias ? chan_bias[n * C + i] : 0.f;
+        scale_shift[(n * C + i) * 2 + 0] = w;
+        scale_shift[(n * C + i) * 2 + 1] = bias[c] + (add - s_mean[g]) * w;
     }
 }
 
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(1024) void gt_apply_kernel(const T* __restrict__ x,
 
 template <typename T>
 static int gt_launch(const void* x, void* y, const float* w, const float* b, const float* cb, int64_t N, int C, int64_t S, int G, float eps,
-                     int silu, float* ws, hipStream_t st) {
+                     int silu, float* ws, hipStream_t st, int frames = 1) {
     constexpr int V = Io<T>::kVec;
     const int vpr = C / V, rp = gt_rows_per_pass(vpr);
     const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
@@ -209,7 +213,7 @@ static int gt_launch(const void* x, void* y, const float* w, const float* b, con
     const dim3 grid((unsigned)chunks, (unsigned)N), block((unsigned)(vpr * rp));
     const size_t lds = ((size_t)rp * C + G) * sizeof(float);
     hipLaunchKernelGGL((gt_stats_kernel<T>), grid, block, lds, st, (const T*)x, cb, part, C, S, G, vpr, rp, chunks);
-    hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)N), dim3(256), 0, st, part, w, b, cb, ss, C, G, chunks, eps);
+    hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)(N / frames)), dim3(256), 0, st, part, w, b, cb, ss, C, G, chunks, eps, frames);
     hipLaunchKernelGGL((gt_apply_kernel<T>), grid, block, 0, st, (const T*)x, (T*)y, ss, C, S, vpr, rp, silu);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
@@ -233,12 +237,13 @@ extern "C" size_t mvi_groupnorm_tok2tok_workspace_bytes(int64_t N, int32_t C, in
     return (size_t)(N * chunks * groups * 3 + N * C * 2) * sizeof(float);
 }
 
-extern "C" int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
-                                          int64_t N, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
-                                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+static int tok2tok_impl(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias, int64_t N, int32_t C,
+                        int64_t spatial, int32_t groups, float eps, int32_t fuse_silu, int32_t frames, int32_t dtype, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     if (N == 0 || spatial == 0) return MVI_OK;
     if (!gt_geometry_ok(N, C, spatial, groups, dtype))
         return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: C must be a multiple of groups (<= 64) and of the 16-byte vector width");
+    if (frames < 1 || N % frames) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: N must be a whole number of videos of `frames` samples");
     if (!x || !y || !weight || !bias || !workspace) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: NULL pointer");
     if (((uintptr_t)x | (uintptr_t)y) % 16) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: x / y must be 16-byte aligned");
     if (workspace_bytes < mvi_groupnorm_tok2tok_workspace_bytes(N, C, spatial, groups, dtype))
@@ -246,10 +251,22 @@ extern "C" int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* w
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (dtype) {
-        case MVI_DT_F32: rc = mvi::gt_launch<float>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st); break;
-        case MVI_DT_BF16: rc = mvi::gt_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st); break;
-        case MVI_DT_F16: rc = mvi::gt_launch<__half>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st); break;
+        case MVI_DT_F32: rc = mvi::gt_launch<float>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st, frames); break;
+        case MVI_DT_BF16: rc = mvi::gt_launch<__hip_bfloat16>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st, frames); break;
+        case MVI_DT_F16: rc = mvi::gt_launch<__half>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, st, frames); break;
         default: return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: unknown dtype");
     }
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                          int64_t N, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return tok2tok_impl(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, 1, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_groupnorm_silu_tok2tok_frames(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                                 int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps,
+                                                 int32_t fuse_silu, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return tok2tok_impl(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, frames, dtype, workspace, workspace_bytes, stream);
 }

@@ -139,13 +139,17 @@ __global__ __launch_bounds__(256) void add_lerp_kernel(const T* __restrict__ x, 
 
 // out[n, c, p] = tok[n, p, c] + x_in[n, c, p]; 64 x 64 (p x c) tiles through LDS
 constexpr int kTpTile = 64;
-template <typename T>
+// base (optional, tokens like tok) + alpha [N] fp32: out = base + (1 - alpha[n]) * (tok + bias) — the tail of VideoResBlock on tokens:
+// the temporal ResBlock's skip add and the AlphaBlender (video_model.py:67-81, util.py:358-372) in the pass that restores b c h w.
+template <typename T, bool kBlend>
 __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __restrict__ tok, const T* __restrict__ x_in,
                                                                    T* __restrict__ out, int C, int64_t S, int p_tiles,
-                                                                   int c_tiles, const float* __restrict__ bias) {
+                                                                   int c_tiles, const float* __restrict__ bias,
+                                                                   const T* __restrict__ base = nullptr, const float* __restrict__ alpha = nullptr) {
     constexpr int V = Io<T>::kVec;
     constexpr int VPR = kTpTile / V;            // 16-B vectors per tile row
     __shared__ float s_t[kTpTile][kTpTile + 1];
+    __shared__ float s_b[kBlend ? kTpTile : 1][kTpTile + 1];  // (base != nullptr exactly when kBlend)
     int bid = blockIdx.x;
     const int pt = bid % p_tiles; bid /= p_tiles;
     const int ct = bid % c_tiles;
@@ -160,16 +164,22 @@ __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __re
             Io<T>::load(tok + ((n * S + p0 + pr) * C + c0 + cv * V), t);
 #pragma unroll
             for (int k = 0; k < V; ++k) s_t[pr][cv * V + k] = t[k];
+            if (kBlend) {
+                Io<T>::load(base + ((n * S + p0 + pr) * C + c0 + cv * V), t);
+#pragma unroll
+                for (int k = 0; k < V; ++k) s_b[pr][cv * V + k] = t[k];
+            }
         }
     }
     __syncthreads();
+    const float wgt = kBlend ? 1.0f - alpha[n] : 1.0f;
     // write out[n, c0 + cr, p0 + 8 pv ..]
     for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
         const int cr = i / VPR, pv = i % VPR;
         if (c0 + cr < C && p0 + pv * V < S) {
             const int64_t o = (n * C + c0 + cr) * S + p0 + pv * V;
             float t[V], xi[V];
-            if (x_in) {
+            if (!kBlend && x_in) {
                 Io<T>::load(x_in + o, xi);
             } else {                                              // plain "b (h w) c -> b c h w"
 #pragma unroll
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __re
             }
             const float bc = bias ? bias[c0 + cr] : 0.f;          // per-channel bias of the convolution that produced the tokens
 #pragma unroll
-            for (int k = 0; k < V; ++k) t[k] = s_t[pv * V + k][cr] + bc + xi[k];
+            for (int k = 0; k < V; ++k) t[k] = kBlend ? s_b[pv * V + k][cr] + wgt * (s_t[pv * V + k][cr] + bc) : s_t[pv * V + k][cr] + bc + xi[k];
             Io<T>::store(out + o, t);
         }
     }
@@ -187,9 +197,12 @@ __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __re
 // out[n, up(p), c] = x[n, c, p]: "b c h w -> b (h w) c" through the same 64 x 64 LDS tile, optionally with the nearest-neighbour 2x
 // upsampling of Upsample (openaimodel.py:118-134, F.interpolate(scale_factor=2, mode="nearest")) folded into the token write: source
 // pixel (y, x) of a W-wide image lands on tokens (2 y + a)(2 W) + 2 x + b, a, b in {0, 1} — the 4x larger NCHW tensor never exists.
+// tok_add (optional, tokens) / bias (optional, fp32 [C]): out = x^T + tok_add + bias — the last add of a ResBlock whose result stays
+// token-major for the temporal ResBlock that follows (openaimodel.py:354 `skip_connection(x) + h` with h and the result as tokens).
 template <typename T>
 __global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restrict__ x, T* __restrict__ out, int C, int64_t S, int p_tiles,
-                                                               int c_tiles, int W, int up) {
+                                                               int c_tiles, int W, int up, const T* __restrict__ tok_add = nullptr,
+                                                               const float* __restrict__ bias = nullptr) {
     constexpr int V = Io<T>::kVec;
     constexpr int VPR = kTpTile / V;
     __shared__ float s_t[kTpTile][kTpTile + 1];      // [c][p]
@@ -225,7 +238,14 @@ __global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restri
                 Io<T>::store(o + 2 * (int64_t)W * C, t);
                 Io<T>::store(o + (2 * (int64_t)W + 1) * C, t);
             } else {
-                Io<T>::store(out + ((n * So + p) * C + c0 + cv * V), t);
+                const int64_t o = (n * So + p) * C + c0 + cv * V;
+                if (tok_add) {
+                    float a[V];
+                    Io<T>::load(tok_add + o, a);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) t[k] += a[k] + (bias ? bias[c0 + cv * V + k] : 0.f);
+                }
+                Io<T>::store(out + o, t);
             }
         }
     }
@@ -296,14 +316,18 @@ extern "C" int mvi_add_lerp(const void* x, const void* h, const void* base, cons
 
 template <typename T>
 static int tokens_to_planes_launch(const void* tok, const void* x_in, void* out, int64_t N, int C, int64_t S, hipStream_t st,
-                                   const float* bias = nullptr) {
+                                   const float* bias = nullptr, const void* base = nullptr, const float* alpha = nullptr) {
     constexpr int V = Io<T>::kVec;
     if (C % V || S % V) return MVI_EINVAL;
     const int p_tiles = (int)((S + kTpTile - 1) / kTpTile), c_tiles = (C + kTpTile - 1) / kTpTile;
     const int64_t blocks = N * p_tiles * c_tiles;
     if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
-    hipLaunchKernelGGL((tokens_to_planes_add_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)tok,
-                       (const T*)x_in, (T*)out, C, S, p_tiles, c_tiles, bias);
+    if (base)
+        hipLaunchKernelGGL((tokens_to_planes_add_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)tok,
+                           (const T*)x_in, (T*)out, C, S, p_tiles, c_tiles, bias, (const T*)base, alpha);
+    else
+        hipLaunchKernelGGL((tokens_to_planes_add_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)tok,
+                           (const T*)x_in, (T*)out, C, S, p_tiles, c_tiles, bias, (const T*)base, alpha);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -340,13 +364,15 @@ extern "C" int mvi_tokens_to_planes_add_bias(const void* tok, const void* x_in, 
 }
 
 template <typename T>
-static int planes_to_tokens_launch(const void* x, void* out, int64_t N, int C, int64_t S, int W, int up, hipStream_t st) {
+static int planes_to_tokens_launch(const void* x, void* out, int64_t N, int C, int64_t S, int W, int up, hipStream_t st,
+                                   const void* tok_add = nullptr, const float* bias = nullptr) {
     constexpr int V = Io<T>::kVec;
     if (C % V || S % V) return MVI_EINVAL;
     const int p_tiles = (int)((S + kTpTile - 1) / kTpTile), c_tiles = (C + kTpTile - 1) / kTpTile;
     const int64_t blocks = N * p_tiles * c_tiles;
     if (blocks > 0x7FFFFFFFll) return MVI_EINVAL;
-    hipLaunchKernelGGL((planes_to_tokens_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, C, S, p_tiles, c_tiles, W, up);
+    hipLaunchKernelGGL((planes_to_tokens_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, C, S, p_tiles, c_tiles, W, up,
+                       (const T*)tok_add, bias);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -365,4 +391,38 @@ extern "C" int mvi_planes_to_tokens(const void* x, void* out, int64_t N, int32_t
     }
     if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "planes_to_tokens: C and H W must be multiples of the 16-byte vector width");
     return rc ? unet_fail(MVI_EHIP, "planes_to_tokens: kernel launch failed") : MVI_OK;
+}
+
+/* out[n, p, c] = x[n, c, p] + tok[n, p, c] + bias[c] (bias optional): a ResBlock's last add with tokens in and tokens out. */
+extern "C" int mvi_planes_add_to_tokens(const void* x, const void* tok, const float* bias, void* out, int64_t N, int32_t C, int64_t spatial,
+                                        int32_t dtype, void* stream) {
+    if (N < 0 || C <= 0 || spatial < 0) return unet_fail(MVI_EINVAL, "planes_add_to_tokens: bad shape");
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!x || !tok || !out) return unet_fail(MVI_EINVAL, "planes_add_to_tokens: NULL pointer");
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = planes_to_tokens_launch<float>(x, out, N, C, spatial, 1, 1, (hipStream_t)stream, tok, bias); break;
+        case MVI_DT_BF16: rc = planes_to_tokens_launch<__hip_bfloat16>(x, out, N, C, spatial, 1, 1, (hipStream_t)stream, tok, bias); break;
+        case MVI_DT_F16: rc = planes_to_tokens_launch<__half>(x, out, N, C, spatial, 1, 1, (hipStream_t)stream, tok, bias); break;
+        default: return unet_fail(MVI_EINVAL, "planes_add_to_tokens: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "planes_add_to_tokens: C and spatial must be multiples of the 16-byte vector width");
+    return rc ? unet_fail(MVI_EHIP, "planes_add_to_tokens: kernel launch failed") : MVI_OK;
+}
+
+/* out[n, c, p] = base[n, p, c] + (1 - alpha[n]) * (tok[n, p, c] + bias[c]): the tail of a VideoResBlock evaluated on tokens. */
+extern "C" int mvi_tokens_blend_to_planes(const void* tok, const void* base, const float* bias, const float* alpha, void* out, int64_t N,
+                                          int32_t C, int64_t spatial, int32_t dtype, void* stream) {
+    if (N < 0 || C <= 0 || spatial < 0) return unet_fail(MVI_EINVAL, "tokens_blend_to_planes: bad shape");
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!tok || !base || !alpha || !out) return unet_fail(MVI_EINVAL, "tokens_blend_to_planes: NULL pointer");
+    int rc;
+    switch (dtype) {
+        case MVI_DT_F32: rc = tokens_to_planes_launch<float>(tok, nullptr, out, N, C, spatial, (hipStream_t)stream, bias, base, alpha); break;
+        case MVI_DT_BF16: rc = tokens_to_planes_launch<__hip_bfloat16>(tok, nullptr, out, N, C, spatial, (hipStream_t)stream, bias, base, alpha); break;
+        case MVI_DT_F16: rc = tokens_to_planes_launch<__half>(tok, nullptr, out, N, C, spatial, (hipStream_t)stream, bias, base, alpha); break;
+        default: return unet_fail(MVI_EINVAL, "tokens_blend_to_planes: unknown dtype");
+    }
+    if (rc == MVI_EINVAL) return unet_fail(MVI_EINVAL, "tokens_blend_to_planes: C and spatial must be multiples of the 16-byte vector width");
+    return rc ? unet_fail(MVI_EHIP, "tokens_blend_to_planes: kernel launch failed") : MVI_OK;
 }

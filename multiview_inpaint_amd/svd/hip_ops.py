@@ -407,6 +407,11 @@ def conv3x3_n320_fills_chip(N, H, W, C_in, C_out, min_blocks):
     return blocks >= min_blocks or int(_lib.lib().mvi_conv3x3_n320_workspace_bytes(N, H, W, C_in, C_out)) > 0
 
 
+def conv3t_n320_fills_chip(B, T, S, C_in, C_out, min_blocks):
+    blocks = -(-B * T * S // 256) * (C_out // 320)
+    return blocks >= min_blocks or int(_lib.lib().mvi_conv3t_n320_workspace_bytes(B, T, S, C_in, C_out)) > 0
+
+
 def conv3x3_n320(tok, weight_taps, bias, H, W, split=True):
     """3x3 / stride 1 / padding 1 convolution to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
     (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, H W, C_out]; weight_taps from conv3x3_n320_weight."""
@@ -622,6 +627,41 @@ def tokens_to_planes_add(tok, x_in, bias=None, spatial=None):
     return out
 
 
+def planes_add_to_tokens(x, tok, bias=None):
+    """x [N, C, *spatial] + tok [N, S, C] (+ bias[c]) -> tokens [N, S, C]: a ResBlock's last add, result token-major."""
+    L = _lib.lib()
+    if x.dtype not in _DT or tok.dtype != x.dtype:
+        raise TypeError("planes_add_to_tokens: x and tok must share a supported dtype")
+    N, S, Cc = tok.shape
+    if x.shape[0] != N or x.shape[1] != Cc or x.numel() != tok.numel():
+        raise ValueError(f"planes_add_to_tokens: x {tuple(x.shape)} does not match tok {tuple(tok.shape)}")
+    xc = x if x.is_contiguous() else x.contiguous()
+    tc = tok if tok.is_contiguous() else tok.contiguous()
+    out = torch.empty_like(tc)
+    with torch.cuda.device(x.device), _Timed("planes_add_to_tokens", 3.0 * tc.numel() * tc.element_size(), x.device):
+        _check(L.mvi_planes_add_to_tokens(xc.data_ptr(), tc.data_ptr(), None if bias is None else _f32(bias).data_ptr(), out.data_ptr(), N, Cc, S,
+                                          _DT[x.dtype], _stream(x.device)), "planes_add_to_tokens")
+    return out
+
+
+def tokens_blend_to_planes(tok, base, bias, alpha, spatial):
+    """base + (1 - alpha[n]) * (tok + bias[c]) for token-major tok, base [N, S, C] -> [N, C, *spatial]; alpha [N]."""
+    L = _lib.lib()
+    if tok.dtype not in _DT or base.dtype != tok.dtype or base.shape != tok.shape:
+        raise TypeError("tokens_blend_to_planes: tok and base must share shape and a supported dtype")
+    N, S, Cc = tok.shape
+    if math.prod(int(v) for v in spatial) != S or alpha.numel() != N:
+        raise ValueError("tokens_blend_to_planes: `spatial` must multiply to the token count and alpha hold one value per sample")
+    tc = tok if tok.is_contiguous() else tok.contiguous()
+    bc = base if base.is_contiguous() else base.contiguous()
+    a = alpha.detach().reshape(N).float().contiguous()
+    out = torch.empty(N, Cc, *spatial, dtype=tok.dtype, device=tok.device)
+    with torch.cuda.device(tok.device), _Timed("tokens_blend_to_planes", 3.0 * tc.numel() * tc.element_size(), tok.device):
+        _check(L.mvi_tokens_blend_to_planes(tc.data_ptr(), bc.data_ptr(), None if bias is None else _f32(bias).data_ptr(), a.data_ptr(),
+                                            out.data_ptr(), N, Cc, S, _DT[tok.dtype], _stream(tok.device)), "tokens_blend_to_planes")
+    return out
+
+
 def planes_to_tokens(x, upsample=1):
     """x [N, C, H, W] -> tokens [N, H W, C]; upsample = 2: nearest-neighbour 2x upsampling folded in -> [N, (2H)(2W), C]."""
     L = _lib.lib()
@@ -636,8 +676,9 @@ def planes_to_tokens(x, upsample=1):
     return out
 
 
-def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=None):
-    """GroupNorm(+SiLU) of token-major t [N, S, C] -> [N, S, C] (csrc/groupnorm_tokens.hip)."""
+def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=None, frames=1):
+    """GroupNorm(+SiLU) of token-major t [N, S, C] -> [N, S, C] (csrc/groupnorm_tokens.hip); frames > 1: statistics over the `frames`
+    consecutive samples of a video (the temporal ResBlock's norm), chan_bias still per sample."""
     L = _lib.lib()
     if t.dtype not in _DT:
         raise TypeError(f"group_norm_tok2tok: unsupported dtype {t.dtype}")
@@ -653,10 +694,12 @@ def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=No
             raise ValueError(f"group_norm_tok2tok: chan_bias must be [{N}, {Cc}], got {tuple(cb.shape)}")
     y = torch.empty_like(tc)
     ws = _workspace(tc.device, nbytes)
+    if frames < 1 or N % frames:
+        raise ValueError(f"group_norm_tok2tok: {N} samples are not whole videos of {frames} frames")
     with torch.cuda.device(tc.device), _Timed("groupnorm_tok2tok", 2.0 * tc.numel() * tc.element_size(), tc.device):
-        _check(L.mvi_groupnorm_silu_tok2tok(tc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
-                                            None if cb is None else cb.data_ptr(), N, Cc, S, num_groups, float(eps),
-                                            int(bool(silu)), _DT[t.dtype], ws.data_ptr(), ws.numel(), _stream(tc.device)),
+        _check(L.mvi_groupnorm_silu_tok2tok_frames(tc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
+                                                   None if cb is None else cb.data_ptr(), N, int(frames), Cc, S, num_groups, float(eps),
+                                                   int(bool(silu)), _DT[t.dtype], ws.data_ptr(), ws.numel(), _stream(tc.device)),
                "group_norm_tok2tok")
     return y
 

@@ -522,6 +522,23 @@ def _upsample_tokens_ok(conv, x):
             and hip_ops.conv3x3_n320_fills_chip(N, 2 * H, 2 * W, C, conv.out_channels, CONV_N320_MIN_BLOCKS))
 
 
+TIME_STACK_TOKENS = os.environ.get("MVI_SVD_TIME_STACK_TOKENS", "1") != "0"
+_tap_weights3 = {}
+
+
+def _tap_major_weight3(w):
+    """A (3,1,1) Conv3d weight as [C_out][3 C_in] (tap-major), once per parameter version."""
+    from . import hip_ops
+    key = id(w)
+    hit = _tap_weights3.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version, w.dtype, w.device):
+        import weakref
+        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights3.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device),
+               hip_ops.conv3t_n320_weight(w.detach()))
+        _tap_weights3[key] = hit
+    return hit[2]
+
+
 def _conv_tokens(conv, tok, H, W):
     """3x3 convolution of token-major activations [N, H W, C_in] -> [N, H W, C_out], bias withheld. 320 output channels (level 0:
     31 of the 72 ResBlock convolutions of a step, the ones the library runs slowest) go to the hand-written implicit GEMM; the
@@ -557,7 +574,12 @@ def _tok2tok_ok(N, C, S, groups, dtype):
     return hip_ops._lib.lib().mvi_groupnorm_tok2tok_workspace_bytes(int(N), int(C), int(S), int(groups), hip_ops._DT[dtype]) != 0
 
 
-def _resblock_forward_fused(self, x, emb):
+def _planes_add_to_tokens(t, x, bias):
+    from . import hip_ops
+    return hip_ops.planes_add_to_tokens(x, t, bias)
+
+
+def _resblock_forward_fused(self, x, emb, tokens_out=False):
     """The common ResBlock configuration (no up/down-sampling, additive embedding) with every bias and
     broadcast add folded into a neighbouring kernel: conv1's bias rides with the embedding bias inside the
     second GroupNorm, conv2's bias is added together with the skip tensor in one pass.
@@ -573,11 +595,14 @@ def _resblock_forward_fused(self, x, emb):
         e = _emb_chan_bias(self.emb_layers, emb, conv1)
         t = ops.group_norm_tok2tok(t, g2.num_groups, g2.weight, g2.bias, g2.eps, silu=True, chan_bias=e)
         t = _conv_tokens(conv2, self.out_layers[2](t), H, W)
+        # tokens_out (VideoResBlock with a token-major temporal ResBlock behind): the same add with the result left token-major
+        last_add = _planes_add_to_tokens if tokens_out else ops.tokens_to_planes_add
         if isinstance(self.skip_connection, nn.Identity):
-            return ops.tokens_to_planes_add(t, x, conv2.bias)
+            return last_add(t, x, conv2.bias)
         sk = self.skip_connection
         sb = sk.bias if conv2.bias is None else (conv2.bias if sk.bias is None else _sum_param(sk.bias, conv2.bias))
-        return ops.tokens_to_planes_add(t, conv_no_bias(sk, x, None), sb)      # both biases ride on the transposing add
+        return last_add(t, conv_no_bias(sk, x, None), sb)                      # both biases ride on the transposing add
+    assert not tokens_out, "tokens_out is only offered on the channels-last route (_nhwc_path_ok)"
     h = conv_no_bias(conv1, norm_act(self.in_layers, x))
     e = _emb_chan_bias(self.emb_layers, emb, conv1)
     h = self.out_layers[0](h, silu=True, chan_bias=e)
@@ -634,9 +659,49 @@ class VideoResBlock(ResBlock):
             return ops.bias_residual_blend(h, c2.bias, x, blend)
         return ops.bias_residual_add(h, c2.bias, x)
 
+    def _tokens_path_ok(self, x, t):
+        """The whole block on tokens (spatial ResBlock ending token-major, temporal ResBlock on tokens with the (3,1,1) convolutions
+        in csrc/linear_n320.hip, b c h w restored by the blending tail): the channels-last route of the spatial block must apply, the
+        temporal block must be the plain configuration, and the temporal convolutions shapes the implicit-GEMM kernel takes."""
+        if not (TIME_STACK_TOKENS and CONV_N320 and self._frames_path_ok()           # (no autograd here: checkpointing is moot)
+                and not (self.updown or self.use_scale_shift_norm or self.skip_t_emb or self.exchange_temb_dims) and _nhwc_path_ok(self, x)):
+            return False
+        from . import hip_ops
+        ts = self.time_stack
+        c1, c2 = ts.in_layers[2], ts.out_layers[3]
+        bt, c, h, w = x.shape
+        co = self.out_channels
+        return (bt % t == 0 and c1.weight.dtype == x.dtype and c1.in_channels == co and c1.out_channels == co and c2.out_channels == co
+                and hip_ops.conv3x3_n320_supported(co, co, x.dtype) and bt * h * w * co * 2 < 2 ** 32
+                and _tok2tok_ok(bt, co, h * w, ts.in_layers[0].num_groups, x.dtype)
+                and hip_ops.conv3t_n320_fills_chip(bt // t, t, h * w, co, co, CONV_N320_MIN_BLOCKS))
+
+    def _time_stack_tokens(self, xt, emb, T, blend, hw):
+        """_time_stack_frames on token-major xt [(b T), S, c] (the spatial ResBlock's output as tokens): temporal GroupNorm + SiLU with
+        token-major input and output, the (3,1,1) convolutions as three-tap implicit GEMMs over the frame axis, and the skip add +
+        AlphaBlender in the pass that restores b c h w. No channel-stacked tensor, no library convolution."""
+        from . import hip_ops
+        ts = self.time_stack
+        g0, g1 = ts.in_layers[0], ts.out_layers[0]
+        c1, c2 = ts.in_layers[2], ts.out_layers[3]
+        h = ops.group_norm_tok2tok(xt, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, frames=T)
+        h = hip_ops.conv3t_n320(h, _tap_major_weight3(c1.weight), None, T)
+        e = _emb_chan_bias(ts.emb_layers, emb, c1)                 # [(b T), c] fp32 incl. the first convolution's bias
+        h = ops.group_norm_tok2tok(h, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, frames=T)
+        h = hip_ops.conv3t_n320(ts.out_layers[2](h), _tap_major_weight3(c2.weight), None, T)
+        return hip_ops.tokens_blend_to_planes(h, xt, c2.bias, blend, hw)
+
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):
-        x = super().forward(x, emb)
         t = int(num_video_frames)
+        if x.dim() == 4 and self._tokens_path_ok(x, t):
+            a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)
+            if a.ndim == 5:
+                bt = x.shape[0]
+                if a.size(0) != bt // t:
+                    a = self.time_mixer.get_alpha(image_only_indicator, rows=bt // t)   # CFG-doubled batch (util.py:365-367)
+                xt = self._forward_fused(x, emb, tokens_out=True)
+                return self._time_stack_tokens(xt, emb, t, a.reshape(bt), tuple(x.shape[2:]))
+        x = super().forward(x, emb)
         bt, c, h, w = x.shape
         if self._frames_path_ok():
             a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)

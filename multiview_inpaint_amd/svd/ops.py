@@ -89,15 +89,18 @@ def group_norm_tokens(x, num_groups, weight, bias, eps, silu=False, chan_bias=No
     return group_norm(x, num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
 
 
-def group_norm_tok2tok(t, num_groups, weight, bias, eps, silu=False, chan_bias=None):
+def group_norm_tok2tok(t, num_groups, weight, bias, eps, silu=False, chan_bias=None, frames=1):
     """GroupNorm(+SiLU) of token-major t [N, S, C] with token-major output (statistics per sample and group over (S, C/G));
-    chan_bias [N, C] is added first. The norm between two convolutions that run on channels-last tensors."""
+    chan_bias [N, C] is added first. The norm between two convolutions that run on channels-last tensors. frames > 1: the temporal
+    layers' norm — statistics over the `frames` consecutive samples of a video (video_model.py:71-75), chan_bias still per sample."""
     if t.is_cuda and not _needs_autograd(t, weight, bias, chan_bias):
         from . import hip_ops
-        return hip_ops.group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=chan_bias)
+        return hip_ops.group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, frames=frames)
     _fallback(t, "group_norm_tok2tok", _why(t, weight, bias, chan_bias))
-    y = group_norm(t.transpose(1, 2), num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias)
-    return y.transpose(1, 2).contiguous()
+    N, S, C = t.shape
+    tf = t.float() if chan_bias is None else t.float() + chan_bias.float().reshape(N, 1, C)
+    y = group_norm(tf.reshape(N // frames, frames * S, C).transpose(1, 2), num_groups, weight, bias, eps, silu=silu)
+    return y.transpose(1, 2).reshape(N, S, C).to(t.dtype).contiguous()
 
 
 def group_norm_frames(x, T, num_groups, weight, bias, eps, silu=False, chan_bias=None, stack3=False):

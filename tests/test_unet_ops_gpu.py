@@ -1288,3 +1288,87 @@ def test_upsample_on_tokens_equals_interpolate_then_conv(dtype, tol):
         hip_ops.PROFILE = None
     for o in outs.values():
         assert o.shape == ref.shape and o.is_contiguous() and (o.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.0 / 64), (torch.float16, 1.0 / 512)])
+@pytest.mark.parametrize("b,T,S,C", [(2, 14, 144, 320), (1, 3, 40, 64), (3, 1, 17, 96)])
+def test_groupnorm_tok2tok_with_temporal_statistics(ops, dtype, tol, b, T, S, C):
+    """mvi_groupnorm_silu_tok2tok_frames: token-major [(b T), S, C] with a group's statistics over all T frames of a video and a
+    per-frame chan_bias — the GroupNorm of VideoResBlock.time_stack on b c t h w (video_model.py:71-75, openaimodel.py:341-352)."""
+    g = torch.Generator().manual_seed(C + T)
+    x = (torch.randn(b * T, S, C, generator=g) * 1.5 + 0.2).to(dtype)
+    w, bb = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    cb = torch.randn(b * T, C, generator=g)
+    for chan_bias in (None, cb):
+        xf = x.double() if chan_bias is None else x.double() + chan_bias.double()[:, None, :]
+        x5 = xf.reshape(b, T * S, C).transpose(1, 2)                                                   # b c (t s)
+        ref = F.silu(F.group_norm(x5, 32, w.double(), bb.double(), 1e-5)).transpose(1, 2).reshape(b * T, S, C)
+        y = ops.group_norm_silu_tok2tok(x.cuda(), 32, w.cuda(), bb.cuda(), 1e-5, True, chan_bias=None if chan_bias is None else chan_bias.cuda(),
+                                        frames=T)
+        assert y.dtype == dtype and (y.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.group_norm_silu_tok2tok(x.cuda(), 32, w.cuda(), bb.cuda(), 1e-5, True, frames=T + 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_token_forms_of_the_resblock_adds(ops, dtype):
+    """mvi_planes_add_to_tokens = tokens_to_planes_add with the result left token-major (bit for bit: one rounding of the same fp32
+    sum); mvi_tokens_blend_to_planes = bias_residual_blend (AlphaBlender after the temporal skip add) fed with tokens."""
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 4, 72, 6, 12
+    x = torch.randn(N, C, H, W, generator=g).to(dtype).cuda()
+    t = torch.randn(N, H * W, C, generator=g).to(dtype).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    alpha = torch.rand(N, generator=g).cuda()
+    for bb in (None, bias):
+        planes = ops.tokens_to_planes_add(t, x, bb)
+        toks = ops.planes_add_to_tokens(x, t, bb)
+        assert torch.equal(toks, planes.permute(0, 2, 3, 1).reshape(N, H * W, C))
+    base = torch.randn(N, H * W, C, generator=g).to(dtype).cuda()
+    out = ops.tokens_blend_to_planes(t, base, bias, alpha, (H, W))
+    to_planes = lambda z: z.view(N, H, W, C).permute(0, 3, 1, 2).contiguous()
+    ref = ops.bias_residual_blend(to_planes(t), bias, to_planes(base), alpha)      # (same formula; the compilers contract it differently)
+    ulp = {torch.float32: 2.0 ** -22, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    assert (out.double() - ref.double()).abs().max().item() <= ulp * max(1.0, ref.abs().max().item())
+    want = to_planes(base).double() + (1.0 - alpha.double()).view(N, 1, 1, 1) * (to_planes(t).double() + bias.double().view(1, C, 1, 1))
+    assert (out.double() - want).abs().max().item() <= ulp * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4.0 / 128), (torch.float16, 4.0 / 1024)])
+def test_video_resblock_on_tokens_equals_the_frames_path(dtype, tol):
+    """VideoResBlock (video_model.py:12-81) with the temporal ResBlock evaluated token-major (layers.TIME_STACK_TOKENS: spatial block
+    ending on tokens, temporal norms token-major with frame statistics, (3,1,1) convolutions in csrc/linear_n320.hip, blend + b c h w in
+    one pass) against the NCHW frames path of the same module and the fp64 evaluation of the reference formulation."""
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    g = torch.Generator().manual_seed(28)
+    T = 3
+    for cin in (320, 640):
+        blk = LY.VideoResBlock(cin, 256, 0.0, video_kernel_size=[3, 1, 1], out_channels=320, merge_strategy="learned_with_images", merge_factor=0.3).eval()
+        with torch.no_grad():
+            for p in blk.parameters():
+                if p.dim() > 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * (0.03 if p.dim() > 1 else 0.3))
+        x = torch.randn(2 * T, cin, 8, 16, generator=g)
+        emb = torch.randn(2 * T, 256, generator=g)
+        ind = torch.zeros(2, T)
+        ind[1, 1] = 1.0                                                   # one frame treated as an image (alpha = 1 there)
+        with torch.no_grad():
+            ref = blk.double()(x.double(), emb.double(), T, ind.double())
+            blk = blk.to(dtype).cuda()
+            xs, es, inds = x.to(dtype).cuda(), emb.to(dtype).cuda(), ind.cuda()
+            outs = {}
+            old = LY.TIME_STACK_TOKENS, LY.CONV_N320_MIN_BLOCKS
+            try:
+                LY.CONV_N320_MIN_BLOCKS = 1
+                for mode in (False, True):
+                    LY.TIME_STACK_TOKENS = mode
+                    hip_ops.PROFILE = []
+                    outs[mode] = blk(xs, es, T, inds)
+                    torch.cuda.synchronize()
+                    assert sum(1 for rec in hip_ops.PROFILE if rec[0] == "conv3t_n320") == (2 if mode else 0)
+            finally:
+                LY.TIME_STACK_TOKENS, LY.CONV_N320_MIN_BLOCKS = old
+                hip_ops.PROFILE = None
+        assert outs[True].shape == ref.shape and outs[True].is_contiguous()
+        assert rel(outs[True], ref) < tol and rel(outs[False], ref) < tol and rel(outs[True], outs[False].double()) < tol
