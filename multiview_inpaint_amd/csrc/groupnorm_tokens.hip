@@ -6,9 +6,9 @@
 // convolutions, whose input and output are both NHWC. The timestep-embedding bias is fused as in the NCHW kernels (chan_bias).
 //
 // Three launches, x read twice, y written once (the two-launch NCHW form's traffic):
-//   stats : block = VPR x RP threads (VPR = C / vec 16-byte vectors per token, RP rows per pass), 8 passes = a chunk of 8 RP
-//           tokens held in registers; a thread owns the SAME vec channels in every pass. Chunk moments per group are exact
-//           (mean first, then the centred second moment from the registers), written as (count, mean, M2);
+//   stats : block = VPR x RP threads (VPR = C / vec 16-byte vectors per token, RP rows per pass) over up to 16 chunks of 8 RP tokens;
+//           a thread owns the SAME vec channels in every row; shifted sums per channel (see the kernel), assembled into the
+//           block's (count, mean, M2) per group;
 //   merge : one block per sample: Chan-merges the chunks of every group, then writes per-channel scale / shift
 //           (weight * rstd, bias + (chan_bias - mean) * weight * rstd) — 2 C floats per sample;
 //   apply : same thread layout as stats, y = act(x * scale[c] + shift[c]).
@@ -25,92 +25,81 @@ int unet_fail(int code, const char* msg);
 
 constexpr int kGtPasses = 8;          // token rows per thread and chunk
 constexpr int kGtMaxGroups = 64;
+constexpr int kGtMergeThreads = 1024;
 
 __host__ __device__ inline int gt_rows_per_pass(int vpr) { int rp = 512 / vpr; return rp < 1 ? 1 : (rp > 8 ? 8 : rp); }
 
+// A block walks `sets` consecutive chunks of 8 rp tokens (a thread owns the SAME vec channels in every row it reads) and keeps, per
+// channel, the sums S1 = sum(x - x0) and S2 = sum((x - x0)^2) SHIFTED by the block's first token x0 of that channel — the shifted-data
+// form of the variance: S1 and S2 are of the size of the spread, so nothing cancels when the group's moments are assembled from them
+// (chan_bias drops out of both; it only moves the mean). One LDS reduction per block instead of six barriers per 8 rp tokens: the
+// first form of this pass ran at 2.5 TB/s.
 template <typename T>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
-                                                        int C, int64_t S, int G, int vpr, int rp, int chunks) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 8))) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
+                                                        int C, int64_t S, int G, int vpr, int rp, int chunks, int sets) {
     constexpr int V = Io<T>::kVec;
     extern __shared__ float s_mem[];
-    float* s_ch = s_mem;                       // [rp][C] per-channel partials of the block's row groups
-    float* s_grp = s_mem + (size_t)rp * C;     // [G] group sums, then group means
+    float* s_1 = s_mem;                        // [rp][C] S1 per row group, then per channel in row 0
+    float* s_2 = s_mem + (size_t)rp * C;       // [rp][C] S2
+    float* s_0 = s_mem + (size_t)2 * rp * C;   // [C] x0 + chan_bias
     const int tid = threadIdx.x, v = tid % vpr, r0 = tid / vpr;
     const int64_t n = blockIdx.y;
     const int chunk = blockIdx.x;
-    const int64_t row0 = (int64_t)chunk * (kGtPasses * rp);
+    const int rows_set = kGtPasses * rp;
+    const int64_t row0 = (int64_t)chunk * rows_set * sets;
+    const int64_t row_end = row0 + (int64_t)rows_set * sets < S ? row0 + (int64_t)rows_set * sets : S;
     const int Cg = C / G;
     const T* xb = x + (n * S) * C + (int64_t)v * V;
-    const float* cb = chan_bias ? chan_bias + n * C + v * V : nullptr;
-    // The chunk is kept as loaded (16 bytes per row: 4 registers instead of 8 floats) and decoded once per pass: 32 registers
-    // of payload instead of 64, so more waves — and more loads in flight — fit a CU (the pass runs at a read-only 2.5 TB/s).
+    float x0[V], s1[V], s2[V];
+    Io<T>::load(xb + row0 * C, x0);                              // (row0 < S: the grid covers S)
+#pragma unroll
+    for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
+    // the rows of a set as loaded (4 registers each: 32 registers of payload, so six to eight waves — and their loads — fit a SIMD;
+    // a second set in flight per wave cost more in occupancy than it hid). No load sits in a branch: a row past the block's end
+    // reads x0 again (adds 0 to both sums)
     uint4 raw[kGtPasses];
-    float add[V];
+    for (int st = 0; st < sets; ++st) {
+        const int64_t base = row0 + (int64_t)st * rows_set;
 #pragma unroll
-    for (int k = 0; k < V; ++k) add[k] = cb ? cb[k] : 0.f;
+        for (int p = 0; p < kGtPasses; ++p) {
+            const int64_t row = base + p * rp + r0;
+            raw[p] = *reinterpret_cast<const uint4*>(xb + (row < row_end ? row : row0) * C);
+        }
 #pragma unroll
-    for (int p = 0; p < kGtPasses; ++p) {
-        const int64_t row = row0 + p * rp + r0;
-        raw[p] = row < S ? *reinterpret_cast<const uint4*>(xb + row * C) : make_uint4(0, 0, 0, 0);
-    }
-    float csum[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) csum[k] = 0.f;
-#pragma unroll
-    for (int p = 0; p < kGtPasses; ++p) {
-        if (row0 + p * rp + r0 < S) {
+        for (int p = 0; p < kGtPasses; ++p) {
             float t[V];
             Io<T>::load(reinterpret_cast<const T*>(&raw[p]), t);
 #pragma unroll
-            for (int k = 0; k < V; ++k) csum[k] += t[k] + add[k];
+            for (int k = 0; k < V; ++k) { const float d = t[k] - x0[k]; s1[k] += d; s2[k] += d * d; }
         }
     }
-    const int64_t rows_chunk = (S - row0) < (int64_t)(kGtPasses * rp) ? (S - row0) : (int64_t)(kGtPasses * rp);
-    // per-channel sums of the chunk -> group means
 #pragma unroll
-    for (int k = 0; k < V; ++k) s_ch[(size_t)r0 * C + v * V + k] = csum[k];
+    for (int k = 0; k < V; ++k) {
+        s_1[(size_t)r0 * C + v * V + k] = s1[k];
+        s_2[(size_t)r0 * C + v * V + k] = s2[k];
+        if (r0 == 0) s_0[v * V + k] = x0[k];
+    }
     __syncthreads();
-    // two short steps instead of one walk of Cg * rp values by G threads: channel sums over the rp row groups, then group sums
     for (int c = tid; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
-        s_ch[c] = s;
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rp; ++r) { a += s_1[(size_t)r * C + c]; b += s_2[(size_t)r * C + c]; }
+        s_1[c] = a;                                              // (row 0 of both: every column is written by the thread that read it)
+        s_2[c] = b;
     }
     __syncthreads();
     if (tid < G) {
-        float s = 0.f;
-        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) s += s_ch[c];
-        s_grp[tid] = s / (float)(rows_chunk * Cg);
-    }
-    __syncthreads();
-    // centred second moments from the registers
-    float m2[V], gmean[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) { m2[k] = 0.f; gmean[k] = s_grp[(v * V + k) / Cg] - add[k]; }
-#pragma unroll
-    for (int p = 0; p < kGtPasses; ++p) {
-        if (row0 + p * rp + r0 < S) {
-            float t[V];
-            Io<T>::load(reinterpret_cast<const T*>(&raw[p]), t);
-#pragma unroll
-            for (int k = 0; k < V; ++k) { const float dd = t[k] - gmean[k]; m2[k] += dd * dd; }
+        const float rows = (float)(row_end - row0);
+        const float* cb = chan_bias ? chan_bias + n * C : nullptr;
+        float tot = 0.f;
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) tot += s_1[c] + rows * (s_0[c] + (cb ? cb[c] : 0.f));
+        const float mean = tot / (rows * Cg);
+        float m2 = 0.f;
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) {
+            const float d = mean - (s_0[c] + (cb ? cb[c] : 0.f));          // the group mean seen from this channel's shift
+            m2 += s_2[c] - 2.f * d * s_1[c] + rows * d * d;
         }
-    }
-    __syncthreads();                           // s_ch is reused
-#pragma unroll
-    for (int k = 0; k < V; ++k) s_ch[(size_t)r0 * C + v * V + k] = m2[k];
-    __syncthreads();
-    for (int c = tid; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int r = 0; r < rp; ++r) s += s_ch[(size_t)r * C + c];
-        s_ch[c] = s;
-    }
-    __syncthreads();
-    if (tid < G) {
-        float s = 0.f;
-        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) s += s_ch[c];
         float* p = part + ((n * chunks + chunk) * G + tid) * 3;
-        p[0] = (float)(rows_chunk * Cg); p[1] = s_grp[tid]; p[2] = s;
+        p[0] = rows * Cg; p[1] = mean; p[2] = m2 > 0.f ? m2 : 0.f;
     }
 }
 
@@ -118,26 +107,40 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) vo
 // frames > 1: the temporal GroupNorm of VideoResBlock.time_stack (statistics over the `frames` consecutive samples of a video,
 // video_model.py:71-75): a block merges the chunks of all its frames — they are consecutive in `part` — and writes every frame's
 // scale / shift (the frames differ in chan_bias only).
-__global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__ part, const float* __restrict__ weight, const float* __restrict__ bias,
+__global__ __launch_bounds__(kGtMergeThreads) void gt_merge_kernel(const float* __restrict__ part, const float* __restrict__ weight, const float* __restrict__ bias,
                                                        const float* __restrict__ chan_bias, float* __restrict__ scale_shift, int C, int G,
                                                        int chunks_per_frame, float eps, int frames) {
     __shared__ float s_mean[kGtMaxGroups], s_rstd[kGtMaxGroups];
-    __shared__ float s_p[256][3];
-    const int64_t n = (int64_t)blockIdx.x * frames;         // first frame of the video
+    __shared__ float s_p[kGtMergeThreads][3];
+    // one block per FRAME: it merges the chunks of its whole video (redundantly with its frames - 1 siblings: a few hundred partials
+    // from L2) and writes its own frame's scale / shift — one block per video left 2 blocks walking frames x C channels (25-37 us)
+    const int64_t frame = blockIdx.x;
+    const int64_t n = frame / frames * frames;              // first frame of the video
     const int chunks = chunks_per_frame * frames;
     const int tid = threadIdx.x;
-    // 256 / G threads per group take the chunks round-robin (a serial walk over 144 chunks by one thread cost 20 us per call),
-    // then one thread per group merges their partials in a fixed order
-    const int per = 256 / G, g = tid % G, sub = tid / G;
+    // 1024 / G threads per group take the chunks round-robin, four loads ahead of the merge chain (a walk with one dependent load per
+    // step costs a memory latency per chunk: 20-37 us per call with hundreds of chunks per group), then one thread per group merges
+    // their partials in a fixed order
+    const int per = kGtMergeThreads / G, g = tid % G, sub = tid / G;
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
     if (sub < per) {
-        for (int c = sub; c < chunks; c += per) {
-            const float* p = part + ((n * chunks_per_frame + c) * G + g) * 3;
-            const float nb = p[0], mb = p[1], qb = p[2];
-            const float nt = cnt + nb, d = mb - mean;
-            mean += d * (nb / nt);
-            m2 += qb + d * d * (cnt * nb / nt);
-            cnt = nt;
+        for (int c = sub; c < chunks; c += 4 * per) {
+            float nb[4], mb[4], qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = c + u * per;
+                const float* p = part + ((n * chunks_per_frame + (cc < chunks ? cc : c)) * G + g) * 3;
+                nb[u] = cc < chunks ? p[0] : 0.f; mb[u] = p[1]; qb[u] = p[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (nb[u] > 0.f) {
+                    const float nt = cnt + nb[u], d = mb[u] - mean;
+                    mean += d * (nb[u] / nt);
+                    m2 += qb[u] + d * d * (cnt * nb[u] / nt);
+                    cnt = nt;
+                }
+            }
         }
     }
     s_p[tid][0] = cnt; s_p[tid][1] = mean; s_p[tid][2] = m2;
@@ -158,12 +161,12 @@ __global__ __launch_bounds__(256) void gt_merge_kernel(const float* __restrict__
     }
     __syncthreads();
     const int Cg = C / G;
-    for (int i = tid; i < C * frames; i += 256) {             // (frame, channel): n * C + i is the flat index
-        const int c = i % C, g = c / Cg;
+    for (int c = tid; c < C; c += kGtMergeThreads) {
+        const int g = c / Cg;
         const float w = weight[c] * s_rstd[g];
-        const float add = chan_bias ? chan_bias[n * C + i] : 0.f;
-        scale_shift[(n * C + i) * 2 + 0] = w;
-        scale_shift[(n * C + i) * 2 + 1] = bias[c] + (add - s_mean[g]) * w;
+        const float add = chan_bias ? chan_bias[frame * C + c] : 0.f;
+        scale_shift[(frame * C + c) * 2 + 0] = w;
+        scale_shift[(frame * C + c) * 2 + 1] = bias[c] + (add - s_mean[g]) * w;
     }
 }
 
@@ -208,12 +211,16 @@ static int gt_launch(const void* x, void* y, const float* w, const float* b, con
     constexpr int V = Io<T>::kVec;
     const int vpr = C / V, rp = gt_rows_per_pass(vpr);
     const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
+    // the statistics pass walks `sets` chunks per block: as many as leave ~3 blocks per CU (at most 16)
+    int sets = (int)((int64_t)chunks * N / 768);
+    sets = sets < 1 ? 1 : (sets > 16 ? 16 : sets);
+    const int schunks = (chunks + sets - 1) / sets;
     float* part = ws;
-    float* ss = ws + (size_t)N * chunks * G * 3;
+    float* ss = ws + (size_t)N * chunks * G * 3;              // (sized for sets = 1)
     const dim3 grid((unsigned)chunks, (unsigned)N), block((unsigned)(vpr * rp));
-    const size_t lds = ((size_t)rp * C + G) * sizeof(float);
-    hipLaunchKernelGGL((gt_stats_kernel<T>), grid, block, lds, st, (const T*)x, cb, part, C, S, G, vpr, rp, chunks);
-    hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)(N / frames)), dim3(256), 0, st, part, w, b, cb, ss, C, G, chunks, eps, frames);
+    const size_t lds = ((size_t)2 * rp * C + C) * sizeof(float);
+    hipLaunchKernelGGL((gt_stats_kernel<T>), dim3((unsigned)schunks, (unsigned)N), block, lds, st, (const T*)x, cb, part, C, S, G, vpr, rp, schunks, sets);
+    hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)N), dim3(kGtMergeThreads), 0, st, part, w, b, cb, ss, C, G, schunks, eps, frames);
     hipLaunchKernelGGL((gt_apply_kernel<T>), grid, block, 0, st, (const T*)x, (T*)y, ss, C, S, vpr, rp, silu);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
@@ -224,9 +231,9 @@ static int gt_geometry_ok(int64_t N, int32_t C, int64_t S, int32_t G, int32_t dt
     const int V = dtype == MVI_DT_F32 ? 4 : 8;
     if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || G > mvi::kGtMaxGroups || C % G || C % V) return 0;
     const int vpr = C / V;
-    if (vpr > 1024 || N > 65535) return 0;
+    if (vpr > 512 || N > 65535) return 0;                      // (the statistics kernel is built for blocks of at most 512 threads)
     const int rp = mvi::gt_rows_per_pass(vpr);
-    return ((size_t)rp * C + G) * sizeof(float) <= 64 * 1024;
+    return ((size_t)2 * rp * C + C) * sizeof(float) <= 64 * 1024;
 }
 
 extern "C" size_t mvi_groupnorm_tok2tok_workspace_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups, int32_t dtype) {
