@@ -25,6 +25,15 @@ LATENT_HW64 = (16, 16)
 # 8-wave kernel (csrc/attn_flash8.hip: S_q >= 1024 and S_k >= 256); level 1 (S = 256) stays on the 4-wave kernel
 LATENT_HW64_L = (32, 32)
 
+# Third small configuration with the PRODUCTION widths (model_channels 320 -> channels 320 / 640, num_head_channels 64,
+# configs/test/svd_f_est_ctrl_simp1.yaml:18-31) on a 16x16 latent: the shapes the round-3 kernels are built for — the 3x3 and
+# (3,1,1) convolutions as implicit GEMMs with C_out = 320 g (csrc/linear_n320.hip, K split at this image size), the token-major
+# VideoResBlock, the temporal attention on MFMA (csrc/attn_temporal.hip, D = 64, H = 5 / 10), Upsample on tokens.
+SMALL_UNET320 = dict(SMALL_UNET, model_channels=320, num_head_channels=64)
+SMALL_CTRL320 = {k: v for k, v in SMALL_UNET320.items() if k != "out_channels"}
+SMALL_CTRL320["hint_channels"] = 7
+LATENT_HW320 = (16, 16)
+
 
 def seeded_state_dict(module, seed):
     """Every parameter/buffer re-drawn (zero-initialised ones too, SURVEY.md §8c caveat) in sorted-key order."""

@@ -285,3 +285,31 @@ def test_head_dim_64_config_matches_reference_golden(golden_dir):
         assert rel(c, G64[f"ctrl_{i}_f32"]) < RTOL, i
     # the reference's own reduced-precision error is what the bf16 GPU path is budgeted against: it must be a real number
     assert 1e-3 < rel(G64["unet_out_bf16ac"], G64["unet_out_f32"]) < 0.1
+
+
+def test_production_width_config_matches_reference_golden(golden_dir):
+    """The production channel widths (model_channels 320 -> 320 / 640 channels, num_head_channels 64) on a 16x16 latent: CPU fp32
+    restatement vs the reference's fp32 outputs (tests/golden/sgm_c320.npz, tools/gen_golden_sgm_c320.py). The GPU suite runs the same
+    nets in bf16 / f16 through the implicit-GEMM convolutions, the token-major VideoResBlock and the MFMA temporal attention and holds
+    them to the reference's own autocast error recorded in the same fixture."""
+    G = np.load(os.path.join(golden_dir, "sgm_c320.npz"))
+    unet = instantiate_from_config({"target": "sgm.modules.diffusionmodules.video_model.VideoUNet", "params": H.SMALL_UNET320}).eval()
+    cunet = instantiate_from_config({"target": "models.csvd.ControlledVideoUNet", "params": H.SMALL_UNET320}).eval()
+    cnet = instantiate_from_config({"target": "models.csvd.ControlNet", "params": H.SMALL_CTRL320}).eval()
+    unet.load_state_dict(H.seeded_state_dict(unet, 51), strict=True)
+    cunet.load_state_dict(H.seeded_state_dict(cunet, 51), strict=True)
+    cnet.load_state_dict(H.seeded_state_dict(cnet, 52), strict=True)
+    inp = H.seeded_inputs(53, hw=H.LATENT_HW320, cfg=H.SMALL_UNET320)
+    inp["image_only_indicator"][0, 1] = 1.0
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    tt = 0.25 * inp["sigma"].log()
+    with torch.no_grad():
+        y = unet(xin, tt, inp["crossattn"], inp["vector"], **kw)
+        ctrls = cnet(xin, inp["control_hint"], tt, inp["crossattn"], inp["vector"], **kw)
+        yc = cunet(xin, tt, inp["crossattn"], inp["vector"], control=list(ctrls), **kw)
+    assert len(ctrls) == int(G["n_ctrl"])
+    assert rel(y, G["unet_out_f32"]) < RTOL
+    assert rel(yc, G["cunet_out_f32"]) < RTOL
+    assert rel(ctrls[-1], G["ctrl_last_f32"]) < RTOL
+    assert 1e-3 < rel(G["unet_out_bf16ac"], G["unet_out_f32"]) < 0.1 and 1e-4 < rel(G["cunet_out_f16ac"], G["cunet_out_f32"]) < 0.1

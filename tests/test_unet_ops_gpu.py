@@ -915,6 +915,70 @@ def test_hd64_nets_on_a_32x32_latent_run_the_8_wave_kernel_within_the_reference_
           f"error = {worst:.2f}")
 
 
+@pytest.mark.parametrize("dtype,tag", [(torch.bfloat16, "bf16ac"), (torch.float16, "f16ac")])
+def test_production_width_nets_run_the_round3_kernels_within_the_reference_autocast_budget(golden_dir, strict, dtype, tag):
+    """The round-3 kernels under the reference pin: model_channels = 320 and num_head_channels = 64 (the production widths,
+    configs/test/svd_f_est_ctrl_simp1.yaml:18-31) on a 16x16 latent, so that INSIDE the module graphs of VideoUNet, ControlNet and
+    ControlledVideoUNet the 3x3 convolutions (320 / 640 outputs, K split at this image size) and the (3,1,1) frame convolutions run
+    in csrc/linear_n320.hip, VideoResBlock runs token-major (temporal GroupNorm on tokens, blend + b c h w in one pass), Upsample
+    runs on tokens, and the temporal attention (T = 3, D = 64, H = 5 / 10) runs csrc/attn_temporal.hip. Which kernels ran is read
+    from the op profile and from mvi_attention_temporal_kernel_variant (the function the C dispatch uses). Reference semantics:
+    openaimodel.py:256-354, video_model.py:12-81, video_attention.py:110-141; precision recipe models/csvd.py:27-31.
+    Bar, in bf16 and in f16 (the reference's own GPU recipe): the build's error against the reference's fp32 output is at most 2x the
+    error of the reference's OWN autocast run in that type, per tensor, in max norm and in rms (fixture tests/golden/sgm_c320.npz,
+    generated from the imported reference by tools/gen_golden_sgm_c320.py)."""
+    from sgm.modules.diffusionmodules.video_model import VideoUNet
+    from models.csvd import ControlNet, ControlledVideoUNet
+    from multiview_inpaint_amd import _lib
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    G = np.load(os.path.join(golden_dir, "sgm_c320.npz"))
+    unet = VideoUNet(**H.SMALL_UNET320).eval()
+    unet.load_state_dict(H.seeded_state_dict(unet, 51))
+    cunet = ControlledVideoUNet(**H.SMALL_UNET320).eval()
+    cunet.load_state_dict(H.seeded_state_dict(cunet, 51))
+    cnet = ControlNet(**H.SMALL_CTRL320).eval()
+    cnet.load_state_dict(H.seeded_state_dict(cnet, 52))
+    unet, cunet, cnet = (m.cuda().to(dtype) for m in (unet, cunet, cnet))
+    inp = H.seeded_inputs(53, hw=H.LATENT_HW320, cfg=H.SMALL_UNET320)
+    inp["image_only_indicator"][0, 1] = 1.0
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1).to(dtype)
+    tt = 0.25 * inp["sigma"].log()
+    ctx, vec, hint = inp["crossattn"].to(dtype), inp["vector"].to(dtype), inp["control_hint"].to(dtype)
+    dt = 1 if dtype == torch.bfloat16 else 2
+    assert _lib.lib().mvi_attention_temporal_kernel_variant(H.T_FRAMES, 5, 64, dt, 3 * 320, 320) == 1
+    old = LY.CONV_N320_MIN_BLOCKS
+    hip_ops.PROFILE = []
+    try:
+        LY.CONV_N320_MIN_BLOCKS = 1              # (a launch-size gate of the 576x1024 step: a 16x16 latent is far below it)
+        with torch.no_grad():
+            y = unet(xin, tt, ctx, vec, **kw)
+            ctrls = cnet(xin, hint, tt, ctx, vec, **kw)
+            yc = cunet(xin, tt, ctx, vec, control=list(ctrls), **kw)
+        torch.cuda.synchronize()
+        kinds = [rec[0] for rec in hip_ops.PROFILE]
+    finally:
+        LY.CONV_N320_MIN_BLOCKS = old
+        hip_ops.PROFILE = None
+    count = lambda k: sum(1 for x in kinds if x == k)
+    # per network: 5 VideoResBlocks (UNet: 2 down, middle 2, ... ) — every one token-major: 2 spatial + 2 frame convolutions each
+    n_vrb = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ == "VideoResBlock")
+    assert count("conv3t_n320") == 2 * n_vrb and count("tokens_blend_to_planes") == n_vrb and count("planes_add_to_tokens") == n_vrb, kinds
+    assert count("conv3x3_n320") >= 2 * n_vrb + 2 and count("planes_to_tokens") == 2          # + Upsample.conv of the two UNets
+    assert count("attention_temporal") > 0 and count("groupnorm_tok2tok") == 3 * n_vrb
+    worst = 0.0
+    for name, got in (("unet_out", y), ("cunet_out", yc), ("ctrl_last", ctrls[-1])):
+        ref = G[name + "_f32"]
+        e_max, e_rms = _err(got.float(), ref)
+        r_max, r_rms = _err(torch.tensor(G[name + "_" + tag]), ref)
+        worst = max(worst, e_max / r_max, e_rms / r_rms)
+        assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
+    print(f"{dtype}: {n_vrb} token-major VideoResBlocks, {count('conv3x3_n320')} 3x3 + {count('conv3t_n320')} frame convolutions in the "
+          f"implicit-GEMM kernel; worst error ratio to the reference's own autocast error = {worst:.2f}")
+
+
 def _attn_ref_chunked(q, k, v, heads, rows=1536):
     """fp64 softmax(QK^T d^-1/2)V, one head and a block of query rows at a time (S = 9216 does not fit otherwise)."""
     B, Sq, HD = q.shape
