@@ -433,6 +433,15 @@ def main():
                     "achieved": am["TFLOPs"], "peak": bench_svd.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": am["frac_of_bf16_mfma_peak"], "calls_per_step": am["calls_per_step"], "ms_per_step": am["ms_per_step"],
                     "traffic": None}
+            cv = svd.get("hip_ops", {}).get("conv3x3_n320")
+            if cv:
+                # the other hand-written contraction of path B (round 3): the 3x3 convolutions as implicit GEMMs in
+                # csrc/linear_n320.hip — 2 * pixels * 9 C_in * C_out FLOPs per call / summed launch time / 2.5 PFLOP/s
+                out["roofline_svd_conv"] = {
+                    "bound": "mfma", "kernel": "linear_n320_kernel<kConv> (3x3 convolutions, C_out = 320 g; K split at level 3)",
+                    "achieved": cv["TFLOPs"], "peak": bench_svd.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": cv["frac_of_bf16_mfma_peak"], "calls_per_step": cv["calls_per_step"], "ms_per_step": cv["ms_per_step"],
+                    "traffic": None}
             out["svd_steps_per_s"] = svd.get("steps_per_s")
     if world > 1 or force_dist:
         td.destroy_process_group()
