@@ -35,7 +35,7 @@ __host__ __device__ inline int gt_rows_per_pass(int vpr) { int rp = 512 / vpr; r
 // (chan_bias drops out of both; it only moves the mean). One LDS reduction per block instead of six barriers per 8 rp tokens: the
 // first form of this pass ran at 2.5 TB/s.
 template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 8))) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) void gt_stats_kernel(const T* __restrict__ x, const float* __restrict__ chan_bias, float* __restrict__ part,
                                                         int C, int64_t S, int G, int vpr, int rp, int chunks, int sets) {
     constexpr int V = Io<T>::kVec;
     extern __shared__ float s_mem[];
@@ -231,7 +231,7 @@ static int gt_geometry_ok(int64_t N, int32_t C, int64_t S, int32_t G, int32_t dt
     const int V = dtype == MVI_DT_F32 ? 4 : 8;
     if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || G > mvi::kGtMaxGroups || C % G || C % V) return 0;
     const int vpr = C / V;
-    if (vpr > 512 || N > 65535) return 0;                      // (the statistics kernel is built for blocks of at most 512 threads)
+    if (vpr > 1024 || N > 65535) return 0;
     const int rp = mvi::gt_rows_per_pass(vpr);
     return ((size_t)2 * rp * C + C) * sizeof(float) <= 64 * 1024;
 }

@@ -495,14 +495,15 @@ _tap_weights = {}
 
 
 def _tap_major_weight(w):
-    """The convolution weight as [C_out][9 C_in] (tap-major: csrc/linear_n320.hip's implicit-GEMM order), once per parameter version."""
+    """A convolution weight in csrc/linear_n320.hip's implicit-GEMM order, [C_out][taps C_in] tap-major — 3x3 Conv2d weights
+    ([C_out, C_in, 3, 3] -> 9 taps) and (3,1,1) Conv3d weights ([C_out, C_in, 3, 1, 1] -> 3 taps) — once per parameter version."""
     from . import hip_ops
     key = id(w)
     hit = _tap_weights.get(key)
     if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version, w.dtype, w.device):
         import weakref
-        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device),
-               hip_ops.conv3x3_n320_weight(w.detach()))
+        build = hip_ops.conv3t_n320_weight if w.dim() == 5 else hip_ops.conv3x3_n320_weight
+        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device), build(w.detach()))
         _tap_weights[key] = hit
     return hit[2]
 
@@ -523,26 +524,12 @@ def _upsample_tokens_ok(conv, x):
 
 
 TIME_STACK_TOKENS = os.environ.get("MVI_SVD_TIME_STACK_TOKENS", "1") != "0"
-_tap_weights3 = {}
-
-
-def _tap_major_weight3(w):
-    """A (3,1,1) Conv3d weight as [C_out][3 C_in] (tap-major), once per parameter version."""
-    from . import hip_ops
-    key = id(w)
-    hit = _tap_weights3.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version, w.dtype, w.device):
-        import weakref
-        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights3.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device),
-               hip_ops.conv3t_n320_weight(w.detach()))
-        _tap_weights3[key] = hit
-    return hit[2]
 
 
 def _conv_tokens(conv, tok, H, W):
-    """3x3 convolution of token-major activations [N, H W, C_in] -> [N, H W, C_out], bias withheld. 320 output channels (level 0:
-    31 of the 72 ResBlock convolutions of a step, the ones the library runs slowest) go to the hand-written implicit GEMM; the
-    others are handed to the library as a channels-last view, so MIOpen's NHWC kernel runs without the transposes it wraps
+    """3x3 convolution of token-major activations [N, H W, C_in] -> [N, H W, C_out], bias withheld. Output channels in multiples
+    of 320 (every ResBlock convolution of the SVD networks) go to the hand-written implicit GEMM; anything else is handed to the
+    library as a channels-last view, so MIOpen's NHWC kernel runs without the transposes it wraps
     around NCHW tensors."""
     N, S, C = tok.shape
     if CONV_N320:
@@ -685,10 +672,10 @@ class VideoResBlock(ResBlock):
         g0, g1 = ts.in_layers[0], ts.out_layers[0]
         c1, c2 = ts.in_layers[2], ts.out_layers[3]
         h = ops.group_norm_tok2tok(xt, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, frames=T)
-        h = hip_ops.conv3t_n320(h, _tap_major_weight3(c1.weight), None, T)
+        h = hip_ops.conv3t_n320(h, _tap_major_weight(c1.weight), None, T)
         e = _emb_chan_bias(ts.emb_layers, emb, c1)                 # [(b T), c] fp32 incl. the first convolution's bias
         h = ops.group_norm_tok2tok(h, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, frames=T)
-        h = hip_ops.conv3t_n320(ts.out_layers[2](h), _tap_major_weight3(c2.weight), None, T)
+        h = hip_ops.conv3t_n320(ts.out_layers[2](h), _tap_major_weight(c2.weight), None, T)
         return hip_ops.tokens_blend_to_planes(h, xt, c2.bias, blend, hw)
 
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):
