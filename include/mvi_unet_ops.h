@@ -148,8 +148,9 @@ int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* 
 /* Convolutions with C_out a multiple of 320 on token-major (NHWC) activations, as implicit GEMMs in the kernel above (a block
  * computes 320 output channels of 256 rows; C_in a multiple of 64; bf16 / f16). bias fp32 [C_out] or NULL; out [rows, C_out] in rows
  * of out_row_stride elements with room for mvi_ff_geglu_out_rows(rows) rows.
- *   mvi_conv3x3_n320: 3x3 / stride 1 / padding 1 (replaces F.conv2d in ResBlock.in_layers[2] / out_layers[3] and Upsample.conv,
- *     svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318, :118-134). x [N, H, W, C_in];
+ *   mvi_conv3x3_n320: 3x3 / padding 1, stride 1 (replaces F.conv2d in ResBlock.in_layers[2] / out_layers[3] and Upsample.conv,
+ *     svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275, :301-318, :118-134) or stride 2 (Downsample.op, :150-166: rows
+ *     = the N Ho Wo output pixels, Ho = (H - 1) / 2 + 1). x [N, H, W, C_in];
  *     weight [C_out][9 C_in] = conv.weight.permute(0, 2, 3, 1) flattened.
  *   mvi_conv3t_n320: (3, 1, 1) / padding (1, 0, 0) over frames (the Conv3d of VideoResBlock.time_stack, video_model.py:41-54).
  *     x [B, T, pixels, C_in]; weight [C_out][3 C_in] = conv.weight[:, :, :, 0, 0].permute(0, 2, 1) flattened. */
@@ -157,10 +158,10 @@ int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype);
 /* Small images (fewer than 128 blocks of 256 rows x 320 channels) split K over up to 8 blocks per tile: fp32 partial sums in
  * `workspace` (..._workspace_bytes(); 0 = this shape is not split), reduced with the bias by a second launch. workspace NULL or too
  * small: the unsplit launch. */
-size_t mvi_conv3x3_n320_workspace_bytes(int64_t N, int32_t H, int32_t W, int32_t C_in, int32_t C_out);
+size_t mvi_conv3x3_n320_workspace_bytes(int64_t N, int32_t H, int32_t W, int32_t C_in, int32_t C_out, int32_t stride);
 size_t mvi_conv3t_n320_workspace_bytes(int64_t B, int32_t T, int32_t pixels, int32_t C_in, int32_t C_out);
 int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W, int32_t C_in,
-                     int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
+                     int32_t C_out, int32_t stride, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
                      size_t workspace_bytes, void* stream);
 int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels, int32_t C_in,
                     int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,

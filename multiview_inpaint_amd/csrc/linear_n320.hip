@@ -101,8 +101,11 @@ __device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) 
 // groups > 1: C_out = 320 groups; a block computes 320 of them (blocks of one row block are neighbours and share x through L2).
 // kSplit (small images: fewer than half the CUs would get a block): ksplit blocks share a (row block, column group), each over a
 // contiguous range of K chunks, and store fp32 partial sums [ksplit][padded rows][C_out]; splitk_reduce_kernel adds them and the bias.
+// stride 2 (Downsample.op, openaimodel.py:150-166): rows are OUTPUT pixels [N, Ho, Wo]; the lane's centre is input pixel
+// (2 yo, 2 xo) of the H x W input image, the taps' offsets and border tests are those of the input image.
 struct ConvGeom {
-    int H, W, cpc, taps, groups, ksplit;             // image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
+    int H, W, cpc, taps, groups, ksplit;             // INPUT image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
+    int stride, Ho, Wo;                              // 1 or 2 (3x3 only); output height / width (= H, W at stride 1)
 };
 
 template <typename T, bool kConv, bool kSplit = false>
@@ -155,11 +158,13 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
                                     : reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
     const int64_t rclamp = kConv ? (row < rows ? row : rows - 1)
                                  : (row < rows ? (row - (row0 < rows ? row0 : rows - 1)) : 0);             // (a block never starts past the end)
-    const uint32_t x_voff = (uint32_t)(rclamp * x_rs * 2 + 16 * hh);
+    uint32_t x_voff = (uint32_t)(rclamp * x_rs * 2 + 16 * hh);
     uint32_t tap_ok = 0x1FFu;                        // bit 3 (dy + 1) + (dx + 1): that neighbour of the lane's pixel is inside the image
     if (kConv) {
-        const int pix = (int)(rclamp % ((int64_t)cg.H * cg.W));
-        const int py = pix / cg.W, px = pix - py * cg.W;
+        const int64_t img = rclamp / ((int64_t)cg.Ho * cg.Wo);
+        const int pix = (int)(rclamp - img * ((int64_t)cg.Ho * cg.Wo));
+        const int py = pix / cg.Wo * cg.stride, px = (pix - pix / cg.Wo * cg.Wo) * cg.stride;      // the centre, in the input image
+        if (cg.stride != 1) x_voff = (uint32_t)(((img * cg.H + py) * cg.W + px) * x_rs * 2 + 16 * hh);
         if (cg.taps == 9) {
             if (py == 0) tap_ok &= ~0x007u;
             if (py == cg.H - 1) tap_ok &= ~0x1C0u;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <typename T, bool kConv = false, bool kSplit = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
-                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1}, float* part = nullptr) {
+                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0}, float* part = nullptr) {
     using namespace ln3;
     const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups * cg.ksplit;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
@@ -440,29 +445,30 @@ static size_t conv_workspace_bytes(int64_t rows, int32_t taps, int32_t C_in, int
 }
 
 static int conv_taps_n320(const char* what, const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
-                          int32_t taps, int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride,
+                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
     char msg[160];
     auto fail = [&](const char* m) {
         snprintf(msg, sizeof msg, "%s: %s", what, m);
         return mvi::unet_fail(MVI_EINVAL, msg);
     };
-    if (N < 0 || H <= 0 || W <= 0 || !mvi_conv3x3_n320_supported(C_in, C_out, dtype))
-        return fail("needs C_out a multiple of 320, C_in a multiple of 64, bf16 or f16");
-    const int64_t rows = N * H * W;
+    if (N < 0 || H <= 0 || W <= 0 || !mvi_conv3x3_n320_supported(C_in, C_out, dtype) || (stride != 1 && stride != 2))
+        return fail("needs C_out a multiple of 320, C_in a multiple of 64, bf16 or f16, stride 1 or 2");
+    const int32_t Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;          // (padding 1, kernel 3)
+    const int64_t rows = N * Ho * Wo;
     if (rows == 0) return MVI_OK;
     if (!x || !weight || !out) return fail("NULL pointer");
     if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
         return fail("out needs room for mvi_ff_geglu_out_rows(rows) rows (whole 256-row blocks are stored)");
     if (out_row_stride < C_out || out_row_stride % 8 || ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
         return fail("x, weight and out rows must be 16-byte aligned");
-    if ((int64_t)mvi::ln3::kN * taps * C_in * 2 > 0xFFFFFFFFll || rows * C_in * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
+    if ((int64_t)mvi::ln3::kN * taps * C_in * 2 > 0xFFFFFFFFll || N * H * W * C_in * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
         return fail("weight / activation tensor exceeds 32-bit byte offsets");
     hipStream_t st = (hipStream_t)stream;
     // the K split is taken when the caller brought its workspace (mvi_conv3x3_n320_workspace_bytes); without one the launch is unsplit
     int ks = conv_ksplit(rows, taps, C_in, C_out);
     if (ks > 1 && (!workspace || workspace_bytes < conv_workspace_bytes(rows, taps, C_in, C_out) || (uintptr_t)workspace % 16)) ks = 1;
-    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks};
+    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo};
     int rc;
     if (ks > 1)
         rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16, true, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st,
@@ -479,8 +485,9 @@ static int conv_taps_n320(const char* what, const void* x, const void* weight, c
     return MVI_OK;
 }
 
-extern "C" size_t mvi_conv3x3_n320_workspace_bytes(int64_t N, int32_t H, int32_t W, int32_t C_in, int32_t C_out) {
-    return N <= 0 || H <= 0 || W <= 0 || C_in <= 0 || C_out <= 0 ? 0 : conv_workspace_bytes(N * H * W, 9, C_in, C_out);
+extern "C" size_t mvi_conv3x3_n320_workspace_bytes(int64_t N, int32_t H, int32_t W, int32_t C_in, int32_t C_out, int32_t stride) {
+    if (N <= 0 || H <= 0 || W <= 0 || C_in <= 0 || C_out <= 0 || (stride != 1 && stride != 2)) return 0;
+    return conv_workspace_bytes(N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1), 9, C_in, C_out);
 }
 
 extern "C" size_t mvi_conv3t_n320_workspace_bytes(int64_t B, int32_t T, int32_t pixels, int32_t C_in, int32_t C_out) {
@@ -488,15 +495,15 @@ extern "C" size_t mvi_conv3t_n320_workspace_bytes(int64_t B, int32_t T, int32_t 
 }
 
 extern "C" int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
-                                int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                                int32_t C_in, int32_t C_out, int32_t stride, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, C_in, C_out, out_rows_capacity, out_row_stride, dtype, workspace,
-                          workspace_bytes, stream);
+    return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, stride, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
+                          workspace, workspace_bytes, stream);
 }
 
 extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels,
                                int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_taps_n320("conv3t_n320", x, weight, bias, out, B, T, pixels, 3, C_in, C_out, out_rows_capacity, out_row_stride, dtype, workspace,
-                          workspace_bytes, stream);
+    return conv_taps_n320("conv3t_n320", x, weight, bias, out, B, T, pixels, 3, 1, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
+                          workspace, workspace_bytes, stream);
 }

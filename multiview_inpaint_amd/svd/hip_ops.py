@@ -380,11 +380,13 @@ def conv3t_n320_weight(weight):
     return weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(weight.shape[0], -1).contiguous()
 
 
-def _conv_taps_n320(kind, fn, ws_fn, tok, weight_taps, bias, N, H, W, taps, split=True):
+def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split=True):
+    """tok: token-major activations of N images of H x W pixels (or, taps = 3, N videos of H frames of W pixels)."""
     L = _lib.lib()
     C = tok.shape[-1]
-    rows = N * H * W
-    if tok.numel() != rows * C or weight_taps.shape[1] != taps * C or weight_taps.dtype != tok.dtype:
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    rows = N * Ho * Wo
+    if tok.numel() != N * H * W * C or weight_taps.shape[1] != taps * C or weight_taps.dtype != tok.dtype:
         raise ValueError(f"{kind}: token-major activations [.., C_in] of N H W rows and weight [C_out, {taps} C_in] of one dtype expected")
     xc = tok if tok.is_contiguous() and tok.data_ptr() % 16 == 0 else tok.contiguous().clone()
     wc = weight_taps if weight_taps.is_contiguous() else weight_taps.contiguous()
@@ -392,19 +394,28 @@ def _conv_taps_n320(kind, fn, ws_fn, tok, weight_taps, bias, N, H, W, taps, spli
     cap = int(L.mvi_ff_geglu_out_rows(rows))
     full = torch.empty(cap, Co, dtype=tok.dtype, device=tok.device)
     b = None if bias is None else _f32(bias)
-    ws_bytes = int(ws_fn(N, H, W, C, Co)) if split else 0       # > 0: a small image, K split over several blocks per tile
+    # > 0: a small image, K split over several blocks per tile
+    ws_bytes = 0 if not split else int(L.mvi_conv3x3_n320_workspace_bytes(N, H, W, C, Co, stride) if taps == 9
+                                       else L.mvi_conv3t_n320_workspace_bytes(N, H, W, C, Co))
     ws = _workspace(tok.device, ws_bytes) if ws_bytes else None
+    wsp = None if ws is None else ws.data_ptr()
     with torch.cuda.device(tok.device), _Timed(kind, 2.0 * rows * taps * C * Co, tok.device):
-        _check(fn(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, cap, full.stride(0),
-                  _DT[tok.dtype], None if ws is None else ws.data_ptr(), ws_bytes, _stream(tok.device)), kind)
+        if taps == 9:
+            rc = L.mvi_conv3x3_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, stride,
+                                    cap, full.stride(0), _DT[tok.dtype], wsp, ws_bytes, _stream(tok.device))
+        else:
+            rc = L.mvi_conv3t_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, cap,
+                                   full.stride(0), _DT[tok.dtype], wsp, ws_bytes, _stream(tok.device))
+        _check(rc, kind)
     return full[:rows]
 
 
-def conv3x3_n320_fills_chip(N, H, W, C_in, C_out, min_blocks):
-    """Does a launch of this shape put at least min_blocks blocks on the chip (256 rows x 320 channels each, times the K split
-    small images get)?"""
-    blocks = -(-N * H * W // 256) * (C_out // 320)
-    return blocks >= min_blocks or int(_lib.lib().mvi_conv3x3_n320_workspace_bytes(N, H, W, C_in, C_out)) > 0
+def conv3x3_n320_fills_chip(N, H, W, C_in, C_out, min_blocks, stride=1):
+    """Does a launch of this shape put at least min_blocks blocks on the chip (256 output pixels x 320 channels each, times the K
+    split small images get)?"""
+    rows = N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1)
+    blocks = -(-rows // 256) * (C_out // 320)
+    return blocks >= min_blocks or int(_lib.lib().mvi_conv3x3_n320_workspace_bytes(N, H, W, C_in, C_out, stride)) > 0
 
 
 def conv3t_n320_fills_chip(B, T, S, C_in, C_out, min_blocks):
@@ -412,15 +423,13 @@ def conv3t_n320_fills_chip(B, T, S, C_in, C_out, min_blocks):
     return blocks >= min_blocks or int(_lib.lib().mvi_conv3t_n320_workspace_bytes(B, T, S, C_in, C_out)) > 0
 
 
-def conv3x3_n320(tok, weight_taps, bias, H, W, split=True):
-    """3x3 / stride 1 / padding 1 convolution to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
-    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, H W, C_out]; weight_taps from conv3x3_n320_weight."""
+def conv3x3_n320(tok, weight_taps, bias, H, W, stride=1, split=True):
+    """3x3 / padding 1 convolution (stride 1 or 2) to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
+    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, Ho Wo, C_out]; weight_taps from conv3x3_n320_weight."""
     N, S, C = tok.shape
     if S != H * W:
         raise ValueError("conv3x3_n320: tok [N, H W, C_in] expected")
-    L = _lib.lib()
-    return _conv_taps_n320("conv3x3_n320", L.mvi_conv3x3_n320, L.mvi_conv3x3_n320_workspace_bytes, tok, weight_taps, bias, N, H, W, 9,
-                           split).view(N, S, -1)
+    return _conv_taps_n320("conv3x3_n320", tok, weight_taps, bias, N, H, W, 9, stride, split).view(N, -1, weight_taps.shape[0])
 
 
 def conv3t_n320(tok, weight_taps, bias, T, split=True):
@@ -429,9 +438,7 @@ def conv3t_n320(tok, weight_taps, bias, T, split=True):
     BT, S, C = tok.shape
     if BT % T:
         raise ValueError("conv3t_n320: tok [(b T), S, C_in] expected")
-    L = _lib.lib()
-    return _conv_taps_n320("conv3t_n320", L.mvi_conv3t_n320, L.mvi_conv3t_n320_workspace_bytes, tok, weight_taps, bias, BT // T, T, S, 3,
-                           split).view(BT, S, -1)
+    return _conv_taps_n320("conv3t_n320", tok, weight_taps, bias, BT // T, T, S, 3, 1, split).view(BT, S, -1)
 
 
 def stem_conv3x3_supported(conv, x):

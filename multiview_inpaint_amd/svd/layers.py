@@ -215,6 +215,12 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if self.use_conv and _downsample_tokens_ok(self.op, x):
+            # the stride-2 convolution on tokens (csrc/linear_n320.hip: a row = an output pixel), bias in its accumulators
+            from . import hip_ops
+            N, _, H, W = x.shape
+            t = hip_ops.conv3x3_n320(hip_ops.planes_to_tokens(x), _tap_major_weight(self.op.weight), self.op.bias, H, W, stride=2)
+            return hip_ops.tokens_to_planes_add(t, None, spatial=((H - 1) // 2 + 1, (W - 1) // 2 + 1))
         return self.op(x)
 
 
@@ -506,6 +512,21 @@ def _tap_major_weight(w):
         hit = (weakref.ref(w, lambda _r, k=key: _tap_weights.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device), build(w.detach()))
         _tap_weights[key] = hit
     return hit[2]
+
+
+def _downsample_tokens_ok(conv, x):
+    """Downsample.op (3x3 / stride 2 / padding 1) on tokens: reduced precision on the GPU, outside autograd, a shape the implicit-GEMM
+    kernel takes, enough output pixels to fill the chip (or a K long enough to split)."""
+    if not (CONV_N320 and NHWC_CONVS and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+            and not torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.weight.dtype == x.dtype
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1):
+        return False
+    from . import hip_ops
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    return (C % 8 == 0 and (H * W) % 8 == 0 and (Ho * Wo) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype)
+            and N * H * W * C * 2 < 2 ** 32 and hip_ops.conv3x3_n320_fills_chip(N, H, W, C, conv.out_channels, CONV_N320_MIN_BLOCKS, stride=2))
 
 
 def _upsample_tokens_ok(conv, x):

@@ -966,7 +966,8 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     # per network: 5 VideoResBlocks (UNet: 2 down, middle 2, ... ) — every one token-major: 2 spatial + 2 frame convolutions each
     n_vrb = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ == "VideoResBlock")
     assert count("conv3t_n320") == 2 * n_vrb and count("tokens_blend_to_planes") == n_vrb and count("planes_add_to_tokens") == n_vrb, kinds
-    assert count("conv3x3_n320") >= 2 * n_vrb + 2 and count("planes_to_tokens") == 2          # + Upsample.conv of the two UNets
+    n_updown = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ in ("Upsample", "Downsample"))
+    assert count("conv3x3_n320") == 2 * n_vrb + n_updown and count("planes_to_tokens") == n_updown      # + Upsample.conv, Downsample.op
     assert count("attention_temporal") > 0 and count("groupnorm_tok2tok") == 3 * n_vrb
     worst = 0.0
     for name, got in (("unet_out", y), ("cunet_out", yc), ("ctrl_last", ctrls[-1])):
@@ -1245,15 +1246,68 @@ def test_conv3t_n320_equals_conv3d(dtype, tol, B, T, S, C, Co):
         assert (out.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("N,H,W,C,Co", [(2, 24, 32, 320, 320), (1, 9, 15, 64, 640), (3, 8, 6, 128, 320), (1, 1, 1, 64, 320), (2, 7, 40, 192, 320)])
+def test_conv3x3_n320_stride_2(dtype, tol, N, H, W, C, Co):
+    """Downsample.op (openaimodel.py:150-166: 3x3, stride 2, padding 1) in the implicit-GEMM kernel: a row = an output pixel, its taps
+    around input pixel (2 yo, 2 xo); even and odd image sizes (the last row / column of taps falls outside only for odd sizes), with
+    and without the K split, against F.conv2d in fp64."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator().manual_seed(N * 100 + H + W)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)).to(dtype)
+    b = torch.randn(Co, generator=g)
+    tok = x.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous().cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    for split in (False, True):
+        out = hip_ops.conv3x3_n320(tok, hip_ops.conv3x3_n320_weight(w.cuda()), b.cuda(), H, W, stride=2, split=split)
+        torch.cuda.synchronize()
+        assert out.shape == (N, Ho * Wo, Co)
+        got = out.view(N, Ho, Wo, Co).permute(0, 3, 1, 2).double().cpu()
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_downsample_on_tokens_equals_the_library_route():
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    g = torch.Generator().manual_seed(4)
+    ds = LY.Downsample(320, True, dims=2, out_channels=320).eval()
+    with torch.no_grad():
+        ds.op.weight.copy_(torch.randn(ds.op.weight.shape, generator=g) * 0.02)
+        ds.op.bias.copy_(torch.randn(320, generator=g) * 0.3)
+    x = torch.randn(2, 320, 16, 24, generator=g).bfloat16()
+    ds = ds.bfloat16()
+    ref = F.conv2d(x.double(), ds.op.weight.detach().double(), ds.op.bias.detach().double(), stride=2, padding=1)   # (the rounded parameters)
+    ds = ds.cuda()
+    old = LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS
+    try:
+        LY.CONV_N320_MIN_BLOCKS = 1
+        for mode in (False, True):
+            LY.CONV_N320 = mode
+            hip_ops.PROFILE = []
+            with torch.no_grad():
+                y = ds(x.cuda())
+            torch.cuda.synchronize()
+            assert sum(1 for rec in hip_ops.PROFILE if rec[0] == "conv3x3_n320") == (1 if mode else 0)
+            err = (y.double().cpu() - ref).abs().max().item()
+            # (the library's stride-2 solver is the less accurate of the two routes: 0.043 against 0.012 on this input)
+            assert y.shape == ref.shape and y.is_contiguous() and err <= ref.abs().max().item() * (1 if mode else 2) / 128, (mode, err)
+    finally:
+        LY.CONV_N320, LY.CONV_N320_MIN_BLOCKS = old
+        hip_ops.PROFILE = None
+
+
 def test_conv3x3_n320_k_split_policy():
     """Which shapes split K (mvi_conv3x3_n320_workspace_bytes > 0): the level-3 images of the SVD step do, levels 0-2 do not, and a K
     too short for 8 chunks per part does not either."""
     from multiview_inpaint_amd import _lib
     L = _lib.lib()
-    assert L.mvi_conv3x3_n320_workspace_bytes(28, 9, 16, 1280, 1280) == 4 * 4096 * 1280 * 4      # 64 blocks -> 4 parts of 45 chunks
-    assert L.mvi_conv3x3_n320_workspace_bytes(28, 9, 16, 2560, 1280) == 4 * 4096 * 1280 * 4
-    assert L.mvi_conv3x3_n320_workspace_bytes(28, 18, 32, 1280, 1280) == 0 and L.mvi_conv3x3_n320_workspace_bytes(28, 72, 128, 320, 320) == 0
-    assert L.mvi_conv3x3_n320_workspace_bytes(1, 4, 4, 64, 320) == 0                                # 9 chunks: nothing to split
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 9, 16, 1280, 1280, 1) == 4 * 4096 * 1280 * 4   # 64 blocks -> 4 parts of 45 chunks
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 9, 16, 2560, 1280, 1) == 4 * 4096 * 1280 * 4
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 18, 32, 1280, 1280, 1) == 0 and L.mvi_conv3x3_n320_workspace_bytes(28, 72, 128, 320, 320, 1) == 0
+    assert L.mvi_conv3x3_n320_workspace_bytes(28, 18, 32, 1280, 1280, 2) == 4 * 4096 * 1280 * 4   # Downsample at level 2: 9x16 outputs
+    assert L.mvi_conv3x3_n320_workspace_bytes(1, 4, 4, 64, 320, 1) == 0                             # 9 chunks: nothing to split
     assert L.mvi_conv3t_n320_workspace_bytes(2, 14, 144, 1280, 1280) == 4 * 4096 * 1280 * 4       # 60 chunks
 
 
