@@ -191,12 +191,10 @@ class Upsample(nn.Module):
         if self.dims == 3:
             x = F.interpolate(x, ((s if self.third_up else 1) * x.shape[2], x.shape[3] * s, x.shape[4] * s), mode="nearest")
         else:
-            if s == 2 and self.use_conv and _upsample_tokens_ok(self.conv, x):
-                # upsampling folded into the layout change, the convolution on tokens (csrc/linear_n320.hip), bias in its accumulators
-                from . import hip_ops
-                N, _, H, W = x.shape
-                t = hip_ops.conv3x3_n320(hip_ops.planes_to_tokens(x, upsample=2), _tap_major_weight(self.conv.weight), self.conv.bias, 2 * H, 2 * W)
-                return hip_ops.tokens_to_planes_add(t, None, spatial=(2 * H, 2 * W))
+            if s == 2 and self.use_conv:
+                y = conv3x3_planes_via_tokens(self.conv, x, upsample=2)      # upsampling folded into the layout change
+                if y is not None:
+                    return y
             x = F.interpolate(x, scale_factor=s, mode="nearest")
         return self.conv(x) if self.use_conv else x
 
@@ -215,12 +213,10 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
-        if self.use_conv and _downsample_tokens_ok(self.op, x):
-            # the stride-2 convolution on tokens (csrc/linear_n320.hip: a row = an output pixel), bias in its accumulators
-            from . import hip_ops
-            N, _, H, W = x.shape
-            t = hip_ops.conv3x3_n320(hip_ops.planes_to_tokens(x), _tap_major_weight(self.op.weight), self.op.bias, H, W, stride=2)
-            return hip_ops.tokens_to_planes_add(t, None, spatial=((H - 1) // 2 + 1, (W - 1) // 2 + 1))
+        if self.use_conv:
+            y = conv3x3_planes_via_tokens(self.op, x)                        # the stride-2 convolution on tokens
+            if y is not None:
+                return y
         return self.op(x)
 
 
@@ -514,34 +510,28 @@ def _tap_major_weight(w):
     return hit[2]
 
 
-def _downsample_tokens_ok(conv, x):
-    """Downsample.op (3x3 / stride 2 / padding 1) on tokens: reduced precision on the GPU, outside autograd, a shape the implicit-GEMM
-    kernel takes, enough output pixels to fill the chip (or a K long enough to split)."""
+def conv3x3_planes_via_tokens(conv, x, upsample=1):
+    """`conv(x)` — or `conv(F.interpolate(x, scale_factor=2, mode="nearest"))` with upsample = 2 — for a 3x3 / padding 1 Conv2d of
+    stride 1 or 2 on an NCHW tensor, evaluated on tokens: layout pass (the upsampling folded into it), the implicit-GEMM kernel of
+    csrc/linear_n320.hip with the bias in its accumulators, layout pass back. None when the route does not apply: reduced precision
+    on the GPU outside autograd, a shape the kernel takes (C_out = 320 g, C_in = 64 k), enough output pixels to fill the chip (or a K
+    long enough to split). Used by Upsample, Downsample and the last convolution of the ControlNet hint stem."""
     if not (CONV_N320 and NHWC_CONVS and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
             and not torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.weight.dtype == x.dtype
-            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) in ((1, 1), (2, 2)) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1):
-        return False
+        return None
     from . import hip_ops
     N, C, H, W = x.shape
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    return (C % 8 == 0 and (H * W) % 8 == 0 and (Ho * Wo) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype)
-            and N * H * W * C * 2 < 2 ** 32 and hip_ops.conv3x3_n320_fills_chip(N, H, W, C, conv.out_channels, CONV_N320_MIN_BLOCKS, stride=2))
-
-
-def _upsample_tokens_ok(conv, x):
-    """Upsample.forward's nearest 2x + 3x3 convolution on tokens: reduced precision on the GPU, outside autograd, a shape the
-    implicit-GEMM kernel takes and enough rows (after upsampling) to fill the chip."""
-    if not (CONV_N320 and NHWC_CONVS and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
-            and not torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.weight.dtype == x.dtype
-            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
-            and tuple(conv.dilation) == (1, 1) and conv.groups == 1):
-        return False
-    from . import hip_ops
-    N, C, H, W = x.shape
-    rows = 4 * N * H * W
-    return (C % 8 == 0 and (H * W) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype) and rows * C * 2 < 2 ** 32
-            and hip_ops.conv3x3_n320_fills_chip(N, 2 * H, 2 * W, C, conv.out_channels, CONV_N320_MIN_BLOCKS))
+    stride = conv.stride[0]
+    Hi, Wi = upsample * H, upsample * W
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    if not (C % 8 == 0 and (H * W) % 8 == 0 and (Ho * Wo) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype)
+            and N * Hi * Wi * C * 2 < 2 ** 32
+            and hip_ops.conv3x3_n320_fills_chip(N, Hi, Wi, C, conv.out_channels, CONV_N320_MIN_BLOCKS, stride=stride)):
+        return None
+    t = hip_ops.conv3x3_n320(hip_ops.planes_to_tokens(x, upsample=upsample), _tap_major_weight(conv.weight), conv.bias, Hi, Wi, stride=stride)
+    return hip_ops.tokens_to_planes_add(t, None, spatial=(Ho, Wo))
 
 
 TIME_STACK_TOKENS = os.environ.get("MVI_SVD_TIME_STACK_TOKENS", "1") != "0"

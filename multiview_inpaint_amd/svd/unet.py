@@ -249,7 +249,9 @@ class ControlNet(_Encoder):
                     h = ops.bias_silu(conv_no_bias(conv, h), conv.bias)
                 i += 2
             else:
-                h = conv(h)
+                from .layers import conv3x3_planes_via_tokens
+                y = conv3x3_planes_via_tokens(conv, h)            # the last layer, 256 -> model_channels: the implicit-GEMM kernel
+                h = conv(h) if y is None else y
                 i += 1
         return h
 

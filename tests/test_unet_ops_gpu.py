@@ -967,7 +967,8 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     n_vrb = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ == "VideoResBlock")
     assert count("conv3t_n320") == 2 * n_vrb and count("tokens_blend_to_planes") == n_vrb and count("planes_add_to_tokens") == n_vrb, kinds
     n_updown = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ in ("Upsample", "Downsample"))
-    assert count("conv3x3_n320") == 2 * n_vrb + n_updown and count("planes_to_tokens") == n_updown      # + Upsample.conv, Downsample.op
+    # + Upsample.conv, Downsample.op and the last convolution of the ControlNet's hint stem (256 -> 320)
+    assert count("conv3x3_n320") == 2 * n_vrb + n_updown + 1 and count("planes_to_tokens") == n_updown + 1
     assert count("attention_temporal") > 0 and count("groupnorm_tok2tok") == 3 * n_vrb
     worst = 0.0
     for name, got in (("unet_out", y), ("cunet_out", yc), ("ctrl_last", ctrls[-1])):
