@@ -171,12 +171,18 @@ int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* 
  * channels, 32 and at most 32, or 320 and at most 8 (the networks' input convolution), on NCHW bf16 / f16 tensors (csrc/stem_conv.hip) — the stride-1 layers of ControlNet.input_hint_block
  * at its two finest resolutions
  * (models/csvd.py:234-250: conv(7 -> 16) SiLU conv(16 -> 16) SiLU at the hint's 576 x 1024), which the library's wide-channel
- * kernels run 5x off their memory time. x [N, C_in, H, W], weight [C_out, C_in, 3, 3] in the activation type, bias fp32 [C_out] or
- * NULL, y [N, C_out, H_out, W_out]; W a multiple of 8, x / y 16-byte aligned; fuse_silu != 0 applies SiLU. stride 2 (H_out =
- * (H - 1) / 2 + 1, likewise W_out; W a multiple of 16) is built for the 16 -> 32 layer that halves the hint's resolution. */
+ * kernels run 5x off their memory time. x [N, C_in, H, W], bias fp32 [C_out] or NULL, y [N, C_out, H_out, W_out]; W a multiple of
+ * 8, x / y 16-byte aligned; fuse_silu != 0 applies SiLU. stride 2 (H_out = (H - 1) / 2 + 1, likewise W_out; W a multiple of 16) is
+ * built for the 16 -> 32 layer that halves the hint's resolution.
+ * `packed_weight`: the weight in the order of the kernel's MFMA B fragments, made ONCE per parameter version from the module's
+ * [C_out, C_in, 3, 3] tensor (activation type) by mvi_stem_conv3x3_pack into mvi_stem_conv3x3_packed_bytes(...) bytes (16-byte
+ * aligned): [C_out / 16][k-steps][64 lanes][8 elements]. */
 int mvi_stem_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t W, int32_t stride, int32_t dtype);
-int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout, int32_t H,
-                          int32_t W, int32_t stride, int32_t fuse_silu, int32_t dtype, void* stream);
+size_t mvi_stem_conv3x3_packed_bytes(int32_t Cin, int32_t Cout, int32_t stride);
+int mvi_stem_conv3x3_pack(const void* weight, void* packed_weight, int32_t Cin, int32_t Cout, int32_t W, int32_t stride, int32_t dtype,
+                          void* stream);
+int mvi_stem_conv3x3_silu(const void* x, const void* packed_weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout,
+                          int32_t H, int32_t W, int32_t stride, int32_t fuse_silu, int32_t dtype, void* stream);
 
 /* out[n, c, p] = h[n, c, p] + bias[c] + x[n, c, p] over [N, C, spatial] activations in one pass; x and bias are
  * optional (NULL). Folds a convolution's bias (PyTorch-ROCm adds it in a separate kernel) and the ResBlock skip

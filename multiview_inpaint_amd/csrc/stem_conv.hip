@@ -57,7 +57,7 @@ template <> struct Mma<__half> {
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
 template <typename T, int CINP, int COUT, int kTH, int STRIDE>
-__global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
                                                                 T* __restrict__ y, int Cin, int H, int W, int Ho, int Wo, int silu) {
     using M = Mma<T>;
     using frag = typename M::frag;
@@ -107,15 +107,10 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     }
 
     // ---- weights: B operand. Lane (n = lane & 15, g = lane >> 4), k-step s, element j: tap = kTapsPerStep s + g / (CINP / 8),
-    // channel = 8 (g % (CINP / 8)) + j; zero past tap 8 and past the real input channels
-    // The weights reach LDS as they are (16 C_in 9 elements, 16-byte loads by the whole block) and every lane picks its fragments from
-    // there: gathered straight from memory they were 24 - 40 two-byte loads per lane, and a vector-memory instruction costs the issuing
-    // wave 100+ cycles whatever it moves — that, not the convolution, set the kernel's time (1.1 ms for the 16-channel layer)
-    __shared__ __attribute__((aligned(16))) uint16_t s_w[COUT * CINP * 9];
-    {
-        const int n_vec = (COUT * Cin * 9 * 2) / 16;                 // 18 or 36 C_in: the tensor is a whole number of 16-byte pieces
-        for (int i = tid; i < n_vec; i += 64 * kTH) reinterpret_cast<u32x4*>(s_w)[i] = reinterpret_cast<const u32x4*>(w)[i];
-    }
+    // channel = 8 (g % (CINP / 8)) + j; zero past tap 8 and past the real input channels. They arrive PACKED in that order
+    // (stem_pack_weights_kernel, once per parameter version: [C_out / 16][k-steps][64 lanes][8]), one 16-byte load per fragment:
+    // picked out of the raw [C_out][C_in][3][3] tensor they were 24 - 144 two-byte reads + as many pack operations per lane and
+    // block — for the 32 -> 32 layer (18 fragments, 4-row tiles) more work than the convolution itself (0.50 ms for 528 MB).
     const int n = lane & 15, g = lane >> 4;
     __syncthreads();
     const int row = wave;                                         // tile row; input rows STRIDE row .. + 2 of the patch
@@ -133,15 +128,8 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
             b[nt] = bias ? bias[16 * (nc + nt) + n] : 0.f;
-            const uint16_t* wp = s_w + (16 * (nc + nt) + n) * Cin * 9;
 #pragma unroll
-            for (int s = 0; s < kSteps; ++s) {
-                const int tap = kTapsPerStep * s + g / (CINP / 8), c0 = 8 * (g % (CINP / 8));
-                uint32_t e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = (tap < 9 && c0 + j < Cin) ? (uint32_t)wp[(c0 + j) * 9 + tap] : 0u;
-                wf[nt][s] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-            }
+            for (int s = 0; s < kSteps; ++s) wf[nt][s] = reinterpret_cast<const u32x4*>(wp)[((nc + nt) * kSteps + s) * 64 + lane];
         }
 #pragma unroll
         for (int mt = 0; mt < kTW / 16; ++mt) {
@@ -176,6 +164,22 @@ __global__ __launch_bounds__(64 * kTH) void stem_conv3x3_kernel(const T* __restr
     }
 }
 
+// weight [C_out][C_in][3][3] (16-bit elements) -> [C_out / 16][k-steps][64 lanes][8]: lane (n, g) of tile nt, k-step s, element j
+// = w[16 nt + n][8 (g % (CINP / 8)) + j][tap kTapsPerStep s + g / (CINP / 8)], zero past tap 8 / past C_in
+__global__ __launch_bounds__(256) void stem_pack_weights_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ packed, int Cin, int cinp,
+                                                                int n_tiles, int k_steps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                 // (tile, step, lane)
+    if (i >= n_tiles * k_steps * 64) return;
+    const int lane = i & 63, s = (i >> 6) % k_steps, nt = (i >> 6) / k_steps;
+    const int n = lane & 15, g = lane >> 4, taps_per_step = 32 / cinp;
+    const int tap = taps_per_step * s + g / (cinp / 8), c0 = 8 * (g % (cinp / 8));
+    for (int j = 0; j < 8; ++j) packed[(int64_t)i * 8 + j] = (tap < 9 && c0 + j < Cin) ? w[((16 * nt + n) * Cin + c0 + j) * 9 + tap] : (uint16_t)0;
+}
+
+// the kernel form that serves (C_in, C_out, stride): padded input channels of its k-steps
+static int stem_cinp(int Cin, int Cout, int stride) { return Cout == 320 ? 8 : stride == 2 ? 16 : Cout == 32 ? 32 : Cin <= 8 ? 8 : 16; }
+static int stem_ksteps(int cinp) { const int tps = 32 / cinp; return (9 + tps - 1) / tps; }
+
 }  // namespace sc
 }  // namespace mvi
 
@@ -207,6 +211,21 @@ static void stem_conv_launch(const void* x, const void* w, const float* bias, vo
     else
         hipLaunchKernelGGL((stem_conv3x3_kernel<T, 16, 16, 8, 1>), dim3(gx, (unsigned)((Ho + 7) / 8), (unsigned)N), dim3(512), 0, st, (const T*)x, (const T*)w,
                            bias, (T*)y, Cin, H, W, Ho, Wo, silu);
+}
+
+extern "C" size_t mvi_stem_conv3x3_packed_bytes(int32_t Cin, int32_t Cout, int32_t stride) {
+    if (Cin < 1 || Cout < 16 || Cout % 16) return 0;
+    return (size_t)(Cout / 16) * mvi::sc::stem_ksteps(mvi::sc::stem_cinp(Cin, Cout, stride)) * 64 * 8 * 2;
+}
+
+extern "C" int mvi_stem_conv3x3_pack(const void* weight, void* packed, int32_t Cin, int32_t Cout, int32_t W, int32_t stride, int32_t dtype,
+                                     void* stream) {
+    if (!mvi_stem_conv3x3_supported(Cin, Cout, W, stride, dtype)) return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3_pack: unsupported shape");
+    if (!weight || !packed || (uintptr_t)packed % 16) return mvi::unet_fail(MVI_EINVAL, "stem_conv3x3_pack: NULL / unaligned pointer");
+    const int cinp = mvi::sc::stem_cinp(Cin, Cout, stride), ks = mvi::sc::stem_ksteps(cinp), nt = Cout / 16;
+    hipLaunchKernelGGL(mvi::sc::stem_pack_weights_kernel, dim3((unsigned)((nt * ks * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)weight, (uint16_t*)packed, Cin, cinp, nt, ks);
+    return hipGetLastError() == hipSuccess ? MVI_OK : mvi::unet_fail(MVI_EHIP, "stem_conv3x3_pack: kernel launch failed");
 }
 
 extern "C" int mvi_stem_conv3x3_silu(const void* x, const void* weight, const float* bias, void* y, int64_t N, int32_t Cin, int32_t Cout,

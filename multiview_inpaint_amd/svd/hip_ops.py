@@ -451,11 +451,32 @@ def stem_conv3x3_supported(conv, x):
                                                            _DT[x.dtype])))
 
 
+_stem_packed = {}
+
+
+def _stem_packed_weight(weight, W, stride):
+    """The weight in the kernel's fragment order (mvi_stem_conv3x3_pack), once per parameter version, width class and stride."""
+    L = _lib.lib()
+    key = (id(weight), int(stride))
+    ver = (weight.data_ptr(), weight._version, weight.dtype, weight.device)
+    hit = _stem_packed.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != ver:
+        Co, Ci = weight.shape[0], weight.shape[1]
+        wc = weight.detach().contiguous()
+        packed = torch.empty(int(L.mvi_stem_conv3x3_packed_bytes(Ci, Co, int(stride))), dtype=torch.uint8, device=weight.device)
+        with torch.cuda.device(weight.device):
+            _check(L.mvi_stem_conv3x3_pack(wc.data_ptr(), packed.data_ptr(), Ci, Co, int(W), int(stride), _DT[weight.dtype], _stream(weight.device)),
+                   "stem_conv3x3_pack")
+        hit = (weakref.ref(weight, lambda _r, k=key: _stem_packed.pop(k, None)), ver, packed)
+        _stem_packed[key] = hit
+    return hit[2]
+
+
 def stem_conv3x3_silu(x, weight, bias, silu=True, stride=1):
     """silu(conv2d(x, weight, bias, stride, padding=1)) in one kernel; x [N, C_in, H, W], weight [C_out, C_in, 3, 3]."""
     L = _lib.lib()
     N, Cin, H, W = x.shape
-    wc = weight if weight.is_contiguous() else weight.contiguous()
+    wc = _stem_packed_weight(weight, W, stride)
     b = None if bias is None else _f32(bias)
     y = torch.empty(N, weight.shape[0], (H - 1) // stride + 1, (W - 1) // stride + 1, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device), _Timed("stem_conv", float(x.numel() + y.numel()) * x.element_size(), x.device):
