@@ -169,31 +169,54 @@ __global__ __launch_bounds__(256) void tokens_to_planes_add_kernel(const T* __re
     const int64_t n = bid / c_tiles;
     const int64_t p0 = (int64_t)pt * kTpTile;
     const int c0 = ct * kTpTile;
+    // Every load of a phase is issued before the first use, from an address clamped into the tensor instead of behind its bounds
+    // test: a load inside a branch makes the compiler wait vmcnt(0) at the first use — one memory latency per piece.
+    constexpr int kIt = kTpTile * VPR / 256;     // pieces per thread and phase (2 in bf16 / f16, 4 in fp32)
     // read tok[n, p0 + pr, c0 + 8 cv ..]: rows of the token-major tile
-    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
-        const int pr = i / VPR, cv = i % VPR;
+    uint4 rt[kIt], rb[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = threadIdx.x + 256 * it, pr = i / VPR, cv = i % VPR;
+        const bool ok = p0 + pr < S && c0 + cv * V < C;
+        const int64_t o = ok ? (n * S + p0 + pr) * C + c0 + cv * V : n * S * C;
+        rt[it] = *reinterpret_cast<const uint4*>(tok + o);
+        if (kBlend) rb[it] = *reinterpret_cast<const uint4*>(base + o);
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = threadIdx.x + 256 * it, pr = i / VPR, cv = i % VPR;
         if (p0 + pr < S && c0 + cv * V < C) {
             float t[V];
-            Io<T>::load(tok + ((n * S + p0 + pr) * C + c0 + cv * V), t);
+            Io<T>::load(reinterpret_cast<const T*>(&rt[it]), t);
 #pragma unroll
             for (int k = 0; k < V; ++k) s_t[pr][cv * V + k] = t[k];
             if (kBlend) {
-                Io<T>::load(base + ((n * S + p0 + pr) * C + c0 + cv * V), t);
+                Io<T>::load(reinterpret_cast<const T*>(&rb[it]), t);
 #pragma unroll
                 for (int k = 0; k < V; ++k) s_b[pr][cv * V + k] = t[k];
             }
         }
     }
-    __syncthreads();
     const float wgt = kBlend ? 1.0f - alpha[n] : 1.0f;
     // write out[n, c0 + cr, p0 + 8 pv ..]
-    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
-        const int cr = i / VPR, pv = i % VPR;
+    uint4 rx[kIt];
+    if (!kBlend && x_in) {
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = threadIdx.x + 256 * it, cr = i / VPR, pv = i % VPR;
+            const bool ok = c0 + cr < C && p0 + pv * V < S;
+            rx[it] = *reinterpret_cast<const uint4*>(x_in + (ok ? (n * C + c0 + cr) * S + p0 + pv * V : n * C * S));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = threadIdx.x + 256 * it, cr = i / VPR, pv = i % VPR;
         if (c0 + cr < C && p0 + pv * V < S) {
             const int64_t o = (n * C + c0 + cr) * S + p0 + pv * V;
             float t[V], xi[V];
             if (!kBlend && x_in) {
-                Io<T>::load(x_in + o, xi);
+                Io<T>::load(reinterpret_cast<const T*>(&rx[it]), xi);
             } else {                                              // plain "b (h w) c -> b c h w"
 #pragma unroll
                 for (int k = 0; k < V; ++k) xi[k] = 0.f;
@@ -225,19 +248,37 @@ __global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restri
     const int64_t n = bid / c_tiles;
     const int64_t p0 = (int64_t)pt * kTpTile;
     const int c0 = ct * kTpTile;
-    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
-        const int cr = i / VPR, pv = i % VPR;
+    constexpr int kIt = kTpTile * VPR / 256;     // (loads hoisted and clamped as in tokens_to_planes_add_kernel)
+    uint4 rx[kIt], ra[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = threadIdx.x + 256 * it, cr = i / VPR, pv = i % VPR;
+        const bool ok = c0 + cr < C && p0 + pv * V < S;
+        rx[it] = *reinterpret_cast<const uint4*>(x + (ok ? (n * C + c0 + cr) * S + p0 + pv * V : n * C * S));
+    }
+    const int64_t So = up == 2 ? 4 * S : S;
+    if (tok_add) {                                   // (up == 1)
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = threadIdx.x + 256 * it, pr = i / VPR, cv = i % VPR;
+            const bool ok = p0 + pr < S && c0 + cv * V < C;
+            ra[it] = *reinterpret_cast<const uint4*>(tok_add + (ok ? (n * So + p0 + pr) * C + c0 + cv * V : n * So * C));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = threadIdx.x + 256 * it, cr = i / VPR, pv = i % VPR;
         if (c0 + cr < C && p0 + pv * V < S) {
             float t[V];
-            Io<T>::load(x + ((n * C + c0 + cr) * S + p0 + pv * V), t);
+            Io<T>::load(reinterpret_cast<const T*>(&rx[it]), t);
 #pragma unroll
             for (int k = 0; k < V; ++k) s_t[cr][pv * V + k] = t[k];
         }
     }
     __syncthreads();
-    const int64_t So = up == 2 ? 4 * S : S;
-    for (int i = threadIdx.x; i < kTpTile * VPR; i += 256) {
-        const int pr = i / VPR, cv = i % VPR;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = threadIdx.x + 256 * it, pr = i / VPR, cv = i % VPR;
         const int64_t p = p0 + pr;
         if (p < S && c0 + cv * V < C) {
             float t[V];
@@ -254,7 +295,7 @@ __global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restri
                 const int64_t o = (n * So + p) * C + c0 + cv * V;
                 if (tok_add) {
                     float a[V];
-                    Io<T>::load(tok_add + o, a);
+                    Io<T>::load(reinterpret_cast<const T*>(&ra[it]), a);
 #pragma unroll
                     for (int k = 0; k < V; ++k) t[k] += a[k] + (bias ? bias[c0 + cv * V + k] : 0.f);
                 }
