@@ -185,9 +185,9 @@ __global__ __launch_bounds__(1024) void gt_apply_kernel(const T* __restrict__ x,
     T* yb = y + (n * S) * C + (int64_t)v * V;
     uint4 raw[kGtPasses];                       // as loaded (4 registers per row, decoded one row at a time): see gt_stats_kernel
 #pragma unroll
-    for (int p = 0; p < kGtPasses; ++p) {
+    for (int p = 0; p < kGtPasses; ++p) {       // (no load in a branch: rows past the end read the last row and are not stored)
         const int64_t row = row0 + p * rp + r0;
-        if (row < S) raw[p] = *reinterpret_cast<const uint4*>(xb + row * C);
+        raw[p] = *reinterpret_cast<const uint4*>(xb + (row < S ? row : S - 1) * C);
     }
 #pragma unroll
     for (int p = 0; p < kGtPasses; ++p) {
