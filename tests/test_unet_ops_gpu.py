@@ -1491,3 +1491,34 @@ def test_video_resblock_on_tokens_equals_the_frames_path(dtype, tol):
                 hip_ops.PROFILE = None
         assert outs[True].shape == ref.shape and outs[True].is_contiguous()
         assert rel(outs[True], ref) < tol and rel(outs[False], ref) < tol and rel(outs[True], outs[False].double()) < tol
+
+
+def test_round3_kernels_at_the_full_size_of_the_step():
+    """The shapes of the 14-frame 576x1024 step (BASELINE configs[3]), where no fp64 reference fits the time budget: the implicit-GEMM
+    convolution against the library's convolution of the same bf16 tensors (level 0 with the 960-channel concatenated input: 495 MB
+    of activations, the largest 32-bit lane offsets the kernel sees; level 3 with the K split), linearity of the convolution in its
+    input, and the MFMA temporal attention against the fp32-math kernel it replaced."""
+    from multiview_inpaint_amd import _lib
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for (N, H, W, C, Co) in [(28, 72, 128, 960, 320), (28, 9, 16, 1280, 1280)]:
+        tok = torch.randn(N, H * W, C, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(Co, C, 3, 3, device="cuda", generator=g) * (1.0 / (9 * C) ** 0.5)).bfloat16()
+        wt = hip_ops.conv3x3_n320_weight(w)
+        mine = hip_ops.conv3x3_n320(tok, wt, None, H, W)
+        lib = F.conv2d(tok.view(N, H, W, C).permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None, 1, 1)
+        lib = lib.permute(0, 2, 3, 1).reshape(N, H * W, Co)
+        scale = lib.float().abs().max().item()
+        assert (mine.float() - lib.float()).abs().max().item() <= scale / 64                        # two bf16 roundings of ~unit values
+        assert (mine.float() - lib.float()).pow(2).mean().sqrt().item() <= scale / 1024
+        # linearity in the input (exact products, fp32 accumulation): conv(2 x) == 2 conv(x) bit for bit
+        assert torch.equal(hip_ops.conv3x3_n320(tok * 2, wt, None, H, W), mine * 2)
+        del tok, w, wt, mine, lib
+    # temporal attention, level 0: 2 x 9216 x 5 problems of 14 frames
+    T, S, Hh = 14, 72 * 128, 5
+    qkv = torch.randn(2 * T, S, 3 * Hh * 64, device="cuda", generator=g).bfloat16()
+    assert _lib.lib().mvi_attention_temporal_kernel_variant(T, Hh, 64, 1, 3 * Hh * 64, Hh * 64) == 1
+    out = hip_ops.attention_temporal_packed(qkv, Hh, T)
+    q, k, v = (t.float().contiguous() for t in qkv.chunk(3, dim=-1))                              # fp32 I/O: the fp32-math kernel
+    ref = hip_ops.attention_temporal(q, k, v, Hh, T)
+    assert (out.float() - ref).abs().max().item() <= 1.0 / 64 and (out.float() - ref).pow(2).mean().sqrt().item() <= 1.0 / 512
