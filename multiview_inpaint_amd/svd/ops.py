@@ -233,9 +233,12 @@ def linear(x, weight, bias=None):
     if K320_KERNELS and x.is_cuda and not _needs_autograd(x, weight, bias) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
+        n320 = N320_KERNEL and hip_ops.linear_n320_supported(x.shape[-1], weight.shape[0], x.dtype)
+        if n320 and x.shape[-1] == 320:            # 320 -> 320 (to_out, proj_in / proj_out): both kernels apply, this one is 6 % faster (93 / 99 us)
+            return hip_ops.linear_n320(x, weight, bias)
         if hip_ops.linear_k320_supported(x.shape[-1], weight.shape[0], x.dtype):
             return hip_ops.linear_k320(x, weight, bias)
-        if N320_KERNEL and hip_ops.linear_n320_supported(x.shape[-1], weight.shape[0], x.dtype):
+        if n320:
             return hip_ops.linear_n320(x, weight, bias)
     return F.linear(x, weight, bias)
 
