@@ -530,8 +530,8 @@ def test_linear_k320_kernel(ops, dtype, tol):
         assert y.shape == (rows, N) and y.dtype == dtype
         assert rel(y, ref) < tol and rel(y, lib.double()) < tol
     x = torch.randn(dev_ops.FF_GEGLU_MIN_ROWS, 320, generator=g).to(dtype).cuda()
-    w = (torch.randn(320, 320, generator=g) * 320 ** -0.5).to(dtype).cuda()
-    lin = torch.nn.Linear(320, 320).to(dtype).cuda()
+    w = (torch.randn(960, 320, generator=g) * 320 ** -0.5).to(dtype).cuda()         # (the packed q | k | v projection)
+    lin = torch.nn.Linear(320, 960).to(dtype).cuda()
     ops.PROFILE = []
     big = dev_ops.linear(x, w)
     small = dev_ops.linear(x[:100], w)
@@ -542,6 +542,11 @@ def test_linear_k320_kernel(ops, dtype, tol):
     ops.PROFILE = None
     assert kinds == ["linear_k320", "linear_k320"] and with_grad.requires_grad
     assert rel(big[:100], small.double()) < tol and rel(viamod, with_grad.detach().double()) < tol
+    # 320 -> 320 (to_out, proj_in / proj_out): both hand-written kernels apply; the dispatcher takes the output-stationary one
+    ops.PROFILE = []
+    sq = dev_ops.linear(x, w[:320].contiguous())
+    assert [e[0] for e in ops.PROFILE] == ["linear_n320"] and rel(sq, F.linear(x, w[:320]).double()) < tol
+    ops.PROFILE = None
     assert not ops.linear_k320_supported(320, 96, dtype) and not ops.linear_k320_supported(640, 640, dtype)
 
 
