@@ -257,12 +257,15 @@ __global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restri
         rx[it] = *reinterpret_cast<const uint4*>(x + (ok ? (n * C + c0 + cr) * S + p0 + pv * V : n * C * S));
     }
     const int64_t So = up == 2 ? 4 * S : S;
+    float bb[kIt][V];                                // the bias of the thread's channels (phase 2): loaded here, not per element there
     if (tok_add) {                                   // (up == 1)
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int i = threadIdx.x + 256 * it, pr = i / VPR, cv = i % VPR;
             const bool ok = p0 + pr < S && c0 + cv * V < C;
             ra[it] = *reinterpret_cast<const uint4*>(tok_add + (ok ? (n * So + p0 + pr) * C + c0 + cv * V : n * So * C));
+#pragma unroll
+            for (int k = 0; k < V; ++k) bb[it][k] = bias ? bias[ok ? c0 + cv * V + k : 0] : 0.f;
         }
     }
 #pragma unroll
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void planes_to_tokens_kernel(const T* __restri
                     float a[V];
                     Io<T>::load(reinterpret_cast<const T*>(&ra[it]), a);
 #pragma unroll
-                    for (int k = 0; k < V; ++k) t[k] += a[k] + (bias ? bias[c0 + cv * V + k] : 0.f);
+                    for (int k = 0; k < V; ++k) t[k] += a[k] + bb[it][k];
                 }
                 Io<T>::store(out + o, t);
             }
