@@ -83,7 +83,7 @@ def _to_dev(sc):
     return {k: torch.tensor(v, device="cuda") for k, v in sc.items() if k != "sh_degree"}
 
 
-def _check_forward(R, ro, cam, sc, bg, full=True):
+def _check_forward(R, ro, cam, sc, bg, full=True, max_marginal=5e-3):
     deg = sc["sh_degree"]
     p = oracle_params(ro, cam, sc, bg)
     f = ro.forward(p, sc["means3D"], sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
@@ -126,7 +126,7 @@ def _check_forward(R, ro, cam, sc, bg, full=True):
     # ---- image outputs: elementwise 1e-4 on every pixel the oracle does not mark marginal; marginal ones are counted
     fr = ro.margins(p, f)
     colour_marginal, any_marginal = (fr & 1) != 0, fr != 0
-    assert any_marginal.mean() < 5e-3, "margin too wide: the test would excuse too many pixels"
+    assert any_marginal.mean() < max_marginal, "margin too wide: the test would excuse too many pixels"
     allow = _flip_allowance(int(f["n_contrib"].sum()))
     bad_c, worst_c = _viol(color.cpu().numpy(), f["color"], 1.0)                       # floor 1.0: colours are O(1)
     bad_c = bad_c.any(0)
@@ -276,6 +276,37 @@ def test_bringup_config_100k_800(R, ro):
     f, p, rs, t, st = _check_forward(R, ro, cam, sc, bg)
     g_img = np.random.default_rng(0).normal(size=(3, 800, 800)).astype(np.float32)
     b = ro.backward(p, f, g_img, sc["means3D"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
+                             rotations=t["rotations"])
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
+
+
+def test_headline_config_1p5M_1080p_against_the_oracle(R, ro):
+    """BASELINE.json configs[2] at FULL size (1.5 M Gaussians, 1920x1080, sh_degree 3 — the scene bench.py times) against
+    oracle/raster_oracle.c: num_rendered, radii, tiles touched, point list, sort keys (tile ids) and ranges bit-exact, the
+    per-Gaussian floats bit-exact, image / depth / n_contrib by the margin rule, all six gradient arrays elementwise 1e-4.
+    The oracle's per-Gaussian and per-pixel loops run on the host's cores for this one test (forward results do not depend
+    on the thread count; the backward sums each thread's band of tile rows in thread order, an fp32 reordering of the same
+    kind as the GPU's float atomics, inside the elementwise bar's floor)."""
+    import os
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cam = syn.make_camera(1920, 1080, 50.0)
+    sc = syn.make_scene(1_500_000, cam, 3, seed=0)
+    bg = np.zeros(3, np.float32)
+    ro.set_threads(max(1, min(32, avail)))
+    try:
+        # marked pixels: 0.55 % here (a pixel of this scene walks ~5x the list entries of the 100k / 800x800 scene, each one
+        # a chance to sit on a threshold); the differing ones among them are still counted against 2 + 1e-7 per pair
+        f, p, rs, t, st = _check_forward(R, ro, cam, sc, bg, max_marginal=8e-3)
+        assert f["num_rendered"] > 10_000_000 and (f["radii"] > 0).sum() > 1_000_000      # the case means what it says
+        g_img = np.random.default_rng(0).normal(size=(3, 1080, 1920)).astype(np.float32)
+        b = ro.backward(p, f, g_img, sc["means3D"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    finally:
+        ro.set_threads(1)
     g = R.rasterize_backward(rs, st, torch.tensor(g_img, device="cuda"), t["means3D"], shs=t["shs"], scales=t["scales"],
                              rotations=t["rotations"])
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):

@@ -1088,7 +1088,7 @@ def test_full_size_svd_step_properties(strict):
         a = eng.denoise(x, sig, cond, num_video_frames=T, image_only_indicator=ind1)
         b = eng.denoise(x[perm2], sig, {k: v[perm2] for k, v in cond.items()}, num_video_frames=T, image_only_indicator=ind1)
         assert torch.isfinite(a).all() and rel_(b, a[perm2]) < tol
-        assert rel_(a, out) > 10 * tol or True            # (informational: the temporal path does contribute)
+        assert rel_(a, out) > tol                         # the temporal path does contribute: switching it off moves the output
         # hint-stem cache on == off
         with eng.control_model.hint_cache():
             c1 = eng.denoise(x, sig, cond, **kw)
