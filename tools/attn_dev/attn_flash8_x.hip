@@ -1,3 +1,5 @@
+// EXPERIMENT COPY of csrc/attn_flash8.hip as of round 3 (not built into the package): the same kernel with its timing ablations
+// (kX), in-kernel shader-clock stamps, block timeline and the other kWaves / kLoaders instantiations. Built by build_x.sh.
 // bf16/f16 MFMA flash attention (forward), head dim 64, 8-wave workgroups — the kernel behind the large spatial
 // self-attentions of the SVD denoise step: (B*H, S) = (140, 9216) and (280, 2304) at 14 x 576x1024, 99.7 % of the
 // attention FLOPs. Replaces xformers.ops.memory_efficient_attention / SDPA
@@ -37,8 +39,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "../../include/mvi_raster.h"
-#include "../../include/mvi_unet_ops.h"
+#include "mvi_raster.h"
+#include "mvi_unet_ops.h"
 
 namespace mvi {
 namespace f8 {
@@ -93,27 +95,34 @@ template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *re
 __device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
 }
-template <int N> __device__ __forceinline__ void wait_vm_then_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+template <int N, bool kBarrier = true> __device__ __forceinline__ void wait_vm_then_barrier() {
+    if (kBarrier) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");        // (timing experiment only)
 }
 
-// kWaves = 8: one 512-thread block per CU (2 waves per SIMD, 256 query rows share a K/V tile). kLoaders = 4: waves 0 .. 3
-// move the LDS-DMA pieces, at the END of a tile (see issue_tile). The timing ablations, in-kernel stamps and block timeline
-// that led here (MVI_ATTN_EXPERIMENT, other kWaves / kLoaders) live in tools/attn_dev/attn_flash8_x.hip, not in this file.
+// kWaves = 8: one 512-thread block per CU (2 waves per SIMD, 256 query rows share a K/V tile) — the shipped form.
+// (kWaves = 6, two 384-thread blocks per CU = 3 waves per SIMD with independent barriers, measured 17 % SLOWER with the
+// one-quarter-ahead fragment prefetch and does not fit 168 registers with the two-quarter one: not instantiated.)
 // kExact: the softmax scale is applied to the fp32 scores (one v_mul per score) instead of being rounded into Q. Folding
 // scale * log2(e) into Q saves those 32 multiplies per wave and tile but rounds Q a second time to bf16: an error of
 // |logit| * 2^-9 in the exponent, i.e. a few per cent on P where two keys with logits of ~60 compete (2.7e-2 of the
 // output scale on the adversarial rows of tests/test_unet_ops_gpu.py, against 5e-3 with the exact form).
-constexpr int kWaves = 8;
-constexpr int kLoaders = 4;
+#ifdef MVI_ATTN_EXPERIMENTS
+__device__ uint64_t g_timeline[8 * 8192];      // kX 20: per block {entry, loop start, loop end, exit} in 10 ns ticks, HW_ID, XCC_ID, cycles
+#endif
 
-template <typename T, bool kExact>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <typename T, int kWaves, bool kExact = true, int kX = 0, int kLoaders = kWaves>   // kX != 0: timing experiments that drop one kind of work (results are wrong on purpose)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves == 6 ? 3 : 2, kWaves == 6 ? 3 : 2)))
 void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
                         int H, int Sq, int Sk, float scale_log2e, int q_blocks, int total_blocks, int64_t q_rs,
                         int64_t kv_rs, int64_t o_rs) {
     using M = Mma<T>;
     using frag = typename M::frag;
+    const uint64_t t_entry = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t t_loop0 = 0, t_loop1 = 0;
+    const uint64_t rt_entry = kX == 20 ? __builtin_amdgcn_s_memrealtime() : 0;       // (kX 20: block timeline)
+    const uint64_t ck_entry = kX == 20 ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t rt_loop0 = 0, rt_loop1 = 0;
     constexpr int kQB = 32 * kWaves;             // query rows per block
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
@@ -182,7 +191,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         const int64_t off = (int64_t)tt * kKT * row_bytes;
 #pragma unroll
         for (int i = 0; i < kMaxPieces; ++i) {
-            if (i >= n_pieces) break;
+            if (i >= n_pieces || kX == 6) break;
             const char* const base = p_is_v[i] ? vbase : kbase;
             if (full) {
                 dma_piece(base + off, p_voff[i], p_dst[i] + ring_off);
@@ -196,9 +205,10 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     // counted waits: "at most `tiles_in_flight` tiles' worth of this wave's own pieces still outstanding", then the barrier
     auto wait_tiles_then_barrier = [&](auto tiles_c) __attribute__((always_inline)) {
         constexpr int kT = decltype(tiles_c)::value;
-        static_assert(16 % kLoaders == 0, "every loader moves 16 / kLoaders pieces");
-        if (n_pieces == 0) wait_vm_then_barrier<0>();
-        else wait_vm_then_barrier<kMaxPieces * kT>();
+        if (n_pieces == 0) wait_vm_then_barrier<0, kX != 7>();
+        else if (16 % kLoaders == 0) wait_vm_then_barrier<kMaxPieces * kT, kX != 7>();   // every loader moves 16 / kLoaders pieces
+        else if (n_pieces == 2) wait_vm_then_barrier<2 * kT, kX != 7>();
+        else wait_vm_then_barrier<3 * kT, kX != 7>();
     };
 
     // ---- LDS read addressing (per lane, ring slot / key block / k-step enter as immediates)
@@ -262,6 +272,11 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     struct Frags { u32x4 k[3]; u32x2 v[2][2]; };
     auto load_frags = [&](int kslot, int kb, int s_lo, bool with_k, int vslot, int vkeys) __attribute__((always_inline)) {
         Frags f;
+        if (kX == 5) {                       // no LDS fragment reads
+            f.k[0] = f.k[1] = f.k[2] = u32x4{0x3c003c00u, 0, 0, 0};
+            f.v[0][0] = f.v[0][1] = f.v[1][0] = f.v[1][1] = u32x2{0x3c003c00u, 0};
+            return f;
+        }
         const int nk = s_lo == 0 ? 3 : 1;    // d-steps 0, 1, 2 in the first quarter, 3 in the second
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -284,9 +299,9 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         for (int i = 0; i < 4; ++i) {
             const float x0 = kExact ? sc[8 * s2 + 2 * i] * sc_mul : sc[8 * s2 + 2 * i];
             const float x1 = kExact ? sc[8 * s2 + 2 * i + 1] * sc_mul : sc[8 * s2 + 2 * i + 1];
-            const float p0 = __builtin_amdgcn_exp2f(x0);
-            const float p1 = __builtin_amdgcn_exp2f(x1);
-            rsum += p0 + p1;
+            const float p0 = kX == 1 ? x0 : __builtin_amdgcn_exp2f(x0);
+            const float p1 = kX == 1 ? x1 : __builtin_amdgcn_exp2f(x1);
+            if (kX != 2) rsum += p0 + p1;
             pr[i] = M::pack2(p0, p1);
         }
         asm volatile("" : "+v"(rsum));       // the sum is complete HERE: without this, the fast form (which reads rsum only
@@ -301,7 +316,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         const u32x4 av0 = {pd.v[0][0][0], pd.v[0][0][1], pd.v[0][1][0], pd.v[0][1][1]};
         const u32x4 av1 = {pd.v[1][0][0], pd.v[1][0][1], pd.v[1][1][0], pd.v[1][1][1]};
         const frag pf = as_frag<frag>(pd.p);
-        const bool qk = with_k;
+        const bool qk = with_k && kX != 4;
         // The S' MFMAs of a block are ONE accumulator chain (3 + 1 over its two quarters) with the P V MFMAs between the
         // links; the scheduler spreads the quarter's exp / add / pack between them. Measured and not kept: 2 + 2 links per
         // quarter ordered S', PV, PV, S' behind scheduling fences (two independent MFMAs between dependent ones): the
@@ -338,7 +353,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             Pending now;
             now.p = probs(s2, sc);
             now.v[0][0] = f.v[0][0]; now.v[0][1] = f.v[0][1]; now.v[1][0] = f.v[1][0]; now.v[1][1] = f.v[1][1];
-            matrix_part(f, with_k, s_lo, acc, now, true);
+            matrix_part(f, with_k, s_lo, acc, now, kX != 3);
         }
     };
 
@@ -391,6 +406,11 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
         // Fragments are requested TWO quarters before their use (measured: an MFMA that waits on its K fragment costs 19 %
         // of the kernel), also across the tile boundary: while tile t runs, tiles t and t + 1 are complete in LDS (the
         // closing wait of tile t - 1 covered tile t + 1), so its last two quarters request the first two of tile t + 1.
+        uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};                  // (kX 15 / 16: cycles per quarter and per barrier, summed over tiles)
+        const uint64_t clk0 = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memtime() : 0;
+        t_loop0 = clk0;
+        if (kX == 20 && !kSafe) rt_loop0 = __builtin_amdgcn_s_memrealtime();
+        const uint64_t rt0 = (kX >= 15 && kX <= 16) ? __builtin_amdgcn_s_memrealtime() : 0;
         Pending pend;                                            // fast form: the quarter whose P V is still to be issued
         pend.p = u32x4{0, 0, 0, 0};
         pend.v[0][0] = pend.v[0][1] = pend.v[1][0] = pend.v[1][1] = u32x2{0, 0};
@@ -399,34 +419,53 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             const int slot = slot_c, next = (slot + 1) & (kRing - 1);
             const bool has_next = has_next_c;
             const int k0 = t * kKT;
+            // slot (t + 3) % 4 held tile t - 1: nobody reads it after the barrier that opened this tile
+            if (has_next && kLoaders == kWaves) issue_tile(t + 3);
             const bool ragged = !has_next && k0 + kKT > Sk;      // only the last tile can be ragged: keys >= Sk never win
             if (ragged && t > 0) {                               // (tile 0's first block was masked before it set m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((k0 + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) s0[r] = -INFINITY;
             }
+            uint64_t ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+            if (kX >= 15 && kX <= 16) ts0 = __builtin_amdgcn_s_memtime();
             decide(s0);
             Frags f2 = load_frags(next, 0, 0, has_next, slot, 32);
             quarter(pipe_c, fq0, true, 0, s1, 0, s0, pend, t > 0);          // (before tile 0 nothing is pending)
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) ts1 = __builtin_amdgcn_s_memtime();
             Frags f3 = load_frags(next, 0, 3, has_next, slot, 48);
             quarter(pipe_c, fq1, true, 3, s1, 1, s0, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) ts2 = __builtin_amdgcn_s_memtime();
             if (ragged) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) >= Sk) s1[r] = -INFINITY;
             }
             decide(s1);
+            if (kX == 18 && young) __builtin_amdgcn_s_setprio(2);        // (experiment) second half of the tile: the late half wins
             if (has_next) fq0 = load_frags(next, 1, 0, true, next, 0);
             quarter(pipe_c, f2, has_next, 0, s0, 0, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) ts3 = __builtin_amdgcn_s_memtime();
             if (has_next) fq1 = load_frags(next, 1, 3, true, next, 16);
             quarter(pipe_c, f3, has_next, 3, s0, 1, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+            if (kX >= 15 && kX <= 16) {
+                ts4 = __builtin_amdgcn_s_memtime();
+                stamp[0] += ts1 - ts0; stamp[1] += ts2 - ts1; stamp[2] += ts3 - ts2; stamp[3] += ts4 - ts3;
+                if (has_next) {
+                    if (kLoaders != kWaves) issue_tile(t + 3);
+                    wait_tiles_then_barrier(std::integral_constant<int, 1>{});
+                    stamp[4] += __builtin_amdgcn_s_memtime() - ts4;
+                    stamp[5] += 1;
+                    return;
+                }
+            }
+            if (kX == 18 && young) __builtin_amdgcn_s_setprio(0);
             if (has_next) {
-                // slot (t + 3) % 4 held tile t - 1: nobody reads it after the barrier that opened this tile
-                issue_tile(t + 3);
+                if (kLoaders != kWaves) issue_tile(t + 3);
                 wait_tiles_then_barrier(std::integral_constant<int, 1>{});   // own pieces of tile t + 2 (and everything older) landed
             }
         };
@@ -441,6 +480,14 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             tile(t + 3, integral_constant<int, 3>{}, true_type{});
         }
         for (; t < n_tiles; ++t) tile(t, t & (kRing - 1), t + 1 < n_tiles);
+        if (kX >= 15 && kX <= 16) t_loop1 = __builtin_amdgcn_s_memtime();
+        if (kX == 20 && !kSafe) rt_loop1 = __builtin_amdgcn_s_memrealtime();
+        if (kX >= 15 && kX <= 16 && !kSafe && lane == 0 && blockIdx.x == 7 && (wave == 0 || wave == kWaves - 1))
+            printf("block %d wave %d: %llu tiles; cycles per tile: q0 %llu q1 %llu q2 %llu q3 %llu wait+barrier %llu; in-kernel clock %.0f MHz\n",
+                   (int)blockIdx.x, wave, (unsigned long long)stamp[5], (unsigned long long)(stamp[0] / stamp[5]),
+                   (unsigned long long)(stamp[1] / stamp[5]), (unsigned long long)(stamp[2] / stamp[5]),
+                   (unsigned long long)(stamp[3] / stamp[5]), (unsigned long long)(stamp[4] / stamp[5]),
+                   100.0 * (double)(__builtin_amdgcn_s_memtime() - clk0) / (double)(__builtin_amdgcn_s_memrealtime() - rt0));
         if (!kSafe) {                                            // the last quarter's P V
             Frags none;
             none.k[0] = none.k[1] = none.k[2] = u32x4{0, 0, 0, 0};
@@ -478,13 +525,40 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                 *reinterpret_cast<u32x2*>(op + 32 * db + 8 * g + 4 * hh) = w;
             }
     }
+#ifdef MVI_ATTN_EXPERIMENTS
+    if (kX == 20 && wave == 0 && blockIdx.x < 8192) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t rt_exit = __builtin_amdgcn_s_memrealtime();
+        const uint64_t ck_exit = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            uint64_t* rec = g_timeline + 8 * blockIdx.x;
+            rec[0] = rt_entry; rec[1] = rt_loop0; rec[2] = rt_loop1; rec[3] = rt_exit;
+            rec[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+            rec[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+            rec[6] = ck_exit - ck_entry;
+            rec[7] = 1;
+        }
+    }
+#endif
+    if (kX >= 15 && kX <= 16 && lane == 0 && blockIdx.x == 3001 && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t_exit = __builtin_amdgcn_s_memtime();
+        printf("block 3001 wave 0: cycles entry->loop %llu, loop (incl. DMA prologue) %llu, loop->exit (vote, epilogue stores) %llu\n",
+               (unsigned long long)(t_loop0 - t_entry), (unsigned long long)(t_loop1 - t_loop0), (unsigned long long)(t_exit - t_loop1));
+    }
 }
 
 }  // namespace f8
 
-template <typename T>
-static int flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, float scale,
-                         hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
+#ifdef MVI_ATTN_EXPERIMENTS
+extern "C" int mvi_attn_debug_timeline(uint64_t* host, int n_blocks) {           // tools/attn_dev only
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(f8::g_timeline), sizeof(uint64_t) * 8 * (size_t)(n_blocks < 8192 ? n_blocks : 8192)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+template <typename T, int kWaves>
+static int flash8_launch_w(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, float scale,
+                           hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
     using namespace f8;
     constexpr int kQB = 32 * kWaves;
     const int q_blocks = (Sq + kQB - 1) / kQB;
@@ -500,16 +574,78 @@ static int flash8_launch(const void* q, const void* k, const void* v, void* out,
     static const int fold_env = getenv("MVI_ATTN_FOLD_SCALE") ? atoi(getenv("MVI_ATTN_FOLD_SCALE")) : -1;
     const bool fold = fold_env >= 0 ? fold_env != 0 : std::is_same<T, __half>::value;
     if (!((attr_set >> dev) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, kWaves, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes + 16) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, kWaves, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes + 16) != hipSuccess)
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
-    auto kern = fold ? &attn_flash8_kernel<T, false> : &attn_flash8_kernel<T, true>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q, (const T*)k, (const T*)v,
-                       (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
+#ifdef MVI_ATTN_EXPERIMENTS
+    static const int xp = getenv("MVI_ATTN_EXPERIMENT") ? atoi(getenv("MVI_ATTN_EXPERIMENT")) : 0;
+    if (xp == 16 && std::is_same<T, __hip_bfloat16>::value) {
+        constexpr int kW4 = 4;
+        const int qb4 = (Sq + 32 * kW4 - 1) / (32 * kW4);
+        const int64_t tot4 = (int64_t)B * H * qb4;
+        const int lds = 100 * 1024;
+        auto kern = &attn_flash8_kernel<T, kW4, false, 16>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tot4), dim3(64 * kW4), lds, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, H, Sq, Sk,
+                           scale * 1.4426950408889634f, qb4, (int)tot4, q_rs, kv_rs, o_rs);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
+    if ((xp == 14 || xp == 24) && std::is_same<T, __hip_bfloat16>::value) {
+        // ONE (14) or TWO (24) waves per SIMD running the same program: 4-wave workgroups, residency set through the LDS size
+        constexpr int kW4 = 4;
+        const int qb4 = (Sq + 32 * kW4 - 1) / (32 * kW4);
+        const int64_t tot4 = (int64_t)B * H * qb4;
+        const int lds = xp == 14 ? 100 * 1024 : 70 * 1024;
+        auto kern = &attn_flash8_kernel<T, kW4, false, 0>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tot4), dim3(64 * kW4), lds, st, (const T*)q, (const T*)k, (const T*)v, (T*)out, H, Sq, Sk,
+                           scale * 1.4426950408889634f, qb4, (int)tot4, q_rs, kv_rs, o_rs);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
+    if (xp && kWaves == 8 && std::is_same<T, __hip_bfloat16>::value) {
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 16);
+            hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q, (const T*)k, (const T*)v,
+                               (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
+        };
+        switch (xp) {
+            case 1: go(&attn_flash8_kernel<T, kWaves, false, 1>); break;
+            case 2: go(&attn_flash8_kernel<T, kWaves, false, 2>); break;
+            case 3: go(&attn_flash8_kernel<T, kWaves, false, 3>); break;
+            case 4: go(&attn_flash8_kernel<T, kWaves, false, 4>); break;
+            case 5: go(&attn_flash8_kernel<T, kWaves, false, 5>); break;
+            case 7: go(&attn_flash8_kernel<T, kWaves, false, 7>); break;
+            case 9: go(&attn_flash8_kernel<T, kWaves, false, 9>); break;
+            case 15: go(&attn_flash8_kernel<T, kWaves, false, 15>); break;
+            case 17: go(&attn_flash8_kernel<T, kWaves, false, 15, 4>); break;
+            case 18: go(&attn_flash8_kernel<T, kWaves, false, 18, 4>); break;
+            case 19: go(&attn_flash8_kernel<T, kWaves, false, 0, 4>); break;
+            case 20: go(&attn_flash8_kernel<T, kWaves, true, 20, 4>); break;       // the shipped form + block timeline
+            default: go(&attn_flash8_kernel<T, kWaves, false, 6>); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
+#endif
+    static const int loaders = getenv("MVI_ATTN_LOADERS") ? atoi(getenv("MVI_ATTN_LOADERS")) : 4;   // 8: every wave loads (A/B runs)
+    if (loaders == 4 && kWaves == 8) {
+        auto kern = fold ? &attn_flash8_kernel<T, kWaves, false, 0, 4> : &attn_flash8_kernel<T, kWaves, true, 0, 4>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + 16);
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q, (const T*)k, (const T*)v,
+                           (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
+        return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+    }
+    if (fold)
+        hipLaunchKernelGGL((attn_flash8_kernel<T, kWaves, false>), dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q,
+                           (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs,
+                           kv_rs, o_rs);
+    else
+        hipLaunchKernelGGL((attn_flash8_kernel<T, kWaves, true>), dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q,
+                           (const T*)k, (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs,
+                           kv_rs, o_rs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -520,7 +656,7 @@ int attn_flash8_launch(const void* q, const void* k, const void* v, void* out, i
     if (q_rs == 0) q_rs = hd;
     if (kv_rs == 0) kv_rs = hd;
     if (o_rs == 0) o_rs = hd;
-    return flash8_launch<T>(q, k, v, out, B, H, Sq, Sk, scale, st, q_rs, kv_rs, o_rs);
+    return flash8_launch_w<T, 8>(q, k, v, out, B, H, Sq, Sk, scale, st, q_rs, kv_rs, o_rs);
 }
 template int attn_flash8_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
 template int attn_flash8_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
