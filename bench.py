@@ -224,7 +224,9 @@ def main():
     # (dist.CompactedGradExchange; the support of a view is 3 % of this scene's Gaussians, so the union over 8 views is a
     # fraction of the rows); it falls back to the full-size factored exchange when the union is above 80 %.
     # MVI_BENCH_EXCHANGE=factored / dense select the other forms.
-    compacted = distributed and M > 1 and (mode == "compacted" or (mode == "auto" and world > 1 and n_ranges <= 1))
+    # (auto only where the factored form it is built on — and falls back to — moves fewer bytes than the dense bucket: W < 2M)
+    compacted = distributed and M > 1 and (mode == "compacted" or (mode == "auto" and world > 1 and n_ranges <= 1 and
+                                                                   mdist.FactoredGradExchange.pays(M, world)))
     bucket = (mdist.CompactedGradExchange(N, M, deg, dev) if compacted else
               mdist.RangedGradExchange(N, M, deg, dev, n_ranges=n_ranges) if ranged else
               mdist.FactoredGradExchange(N, M, deg, dev) if factored else mdist.GradBucket(N, M, dev))

@@ -42,7 +42,8 @@ extern "C" {
 #define MVI_EHIP (-2)     /* a HIP call or kernel launch failed */
 #define MVI_ENOMEM (-3)   /* a caller-provided scratch buffer is too small */
 
-#define MVI_TILE 16       /* tile edge in pixels; block = MVI_TILE x MVI_TILE threads = 4 wave64 */
+#define MVI_TILE 16       /* tile edge in pixels; one workgroup per tile (forward: 4 wave64, one pixel per lane; backward: 2 wave64,
+                           * two pixels per lane) */
 
 typedef struct mvi_raster_settings {
     int32_t image_height;       /* GaussianRasterizationSettings.image_height */
@@ -74,9 +75,12 @@ int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M,
                             const float* cov3D_precomp, void* geom, size_t geom_bytes,
                             int32_t* radii, int64_t* num_rendered_host, void* stream);
 
-/* Forward, stage 2: key emission, radix sort by (tile, depth), tile ranges, per-tile
- * front-to-back compositing. out_color [3,H,W], out_depth [1,H,W] (15.0f where nothing composites,
- * gs-simp/gen_seq.py:50). */
+/* Forward, stage 2: binning — the (tile, depth)-sorted point list and the tile ranges — then per-tile front-to-back
+ * compositing. Binning version 2 (grids up to 256 x 256 tiles, the default): the Gaussians are depth-sorted once (32-bit keys),
+ * their tile rectangles expanded into column segments partitioned by tile column, then into pairs partitioned by tile row; no
+ * 64-bit key is materialised. Version 1 (larger grids): pair emission + radix sort of the tile ids. Same outputs bit for bit
+ * (mvi_raster_binning_version). out_color [3,H,W], out_depth [1,H,W] (15.0f where nothing composites, gs-simp/gen_seq.py:50).
+ * May run on another host thread than mvi_raster_forward_geom, after it returned, on the same geom scratch. */
 int mvi_raster_forward_render(const mvi_raster_settings* s, int32_t P, int64_t num_rendered,
                               const int32_t* radii, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                               void* image, size_t image_bytes, float* out_color, float* out_depth,

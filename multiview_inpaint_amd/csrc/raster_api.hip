@@ -17,9 +17,33 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 static thread_local char g_err[512] = "";
 // 0 (default): one-call backward with outputs zeroed on the side + sparse chain rule; 1: the dense chain-rule kernel
 static int g_dense_backward = [] { const char* e = getenv("MVI_RASTER_DENSE_BACKWARD"); return (e && e[0] == '1') ? 1 : 0; }();
-// column segments of the last forward_geom of this thread (binning version 2): a sizing hint for the launches of the
-// forward_render that follows on the same scratch; any other forward_render falls back to the bound num_rendered
-static thread_local struct { const void* geom = nullptr; int32_t P = 0; int64_t segments = 0; } g_last_segments;
+// Column segments counted by forward_geom (binning version 2), remembered PER GEOM SCRATCH: the exact grid size of the
+// forward_render that follows on that scratch. Process-wide and locked, so the two halves of a forward may run on different
+// threads; an entry describes the scratch's CONTENTS (the last forward_geom that wrote it replaces it), so it can only be
+// stale if the caller overwrites a scratch while using it. Unknown scratch (table full and evicted): the bound num_rendered.
+#include <mutex>
+namespace {
+struct SegmentHint { const void* geom; int32_t P; int64_t segments; uint64_t stamp; };
+constexpr int kSegmentHints = 64;
+SegmentHint g_seg_hints[kSegmentHints] = {};
+uint64_t g_seg_clock = 0;
+std::mutex g_seg_mutex;
+void remember_segments(const void* geom, int32_t P, int64_t segments) {
+    std::lock_guard<std::mutex> lock(g_seg_mutex);
+    int slot = 0;
+    for (int i = 0; i < kSegmentHints; ++i) {
+        if (g_seg_hints[i].geom == geom) { slot = i; break; }
+        if (g_seg_hints[i].stamp < g_seg_hints[slot].stamp) slot = i;      // else the least recently written
+    }
+    g_seg_hints[slot] = {geom, P, segments, ++g_seg_clock};
+}
+int64_t recall_segments(const void* geom, int32_t P) {
+    std::lock_guard<std::mutex> lock(g_seg_mutex);
+    for (int i = 0; i < kSegmentHints; ++i)
+        if (g_seg_hints[i].geom == geom && g_seg_hints[i].stamp) return g_seg_hints[i].P == P ? g_seg_hints[i].segments : 0;
+    return 0;
+}
+}  // namespace
 
 // ---- stage timing ------------------------------------------------------------------------------
 #include <vector>
@@ -210,7 +234,7 @@ static int forward_geom_impl(const mvi_raster_settings* s, mvi::Frame& f, int32_
     if (total > 0xFFFFFFFFull)
         return fail(MVI_EINVAL, "num_rendered exceeds the 32-bit pair offsets%s: %lld pairs", "", (long long)total);
     *num_rendered_host = (int64_t)total;
-    if (f.bin_v2) { g_last_segments.geom = geom; g_last_segments.P = P; g_last_segments.segments = (int64_t)pinned[1]; }
+    if (f.bin_v2) remember_segments(geom, P, (int64_t)pinned[1]);
     return MVI_OK;
 }
 
@@ -229,7 +253,7 @@ static int forward_render_impl(const mvi_raster_settings* s, int32_t P, int64_t 
     if (D > 0 && binning_bytes < b.bytes) return fail(MVI_ENOMEM, "binning scratch too small%s: %lld < %lld", "", (long long)binning_bytes, (long long)b.bytes);
     if (D > 0 && geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s", "");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t segments = (g_last_segments.geom == geom && g_last_segments.P == P) ? g_last_segments.segments : 0;
+    const int64_t segments = recall_segments(geom, P);
     if (f.bin_v2 ? mvi::launch_binning2(f, g, b, im, D, segments, st) : mvi::launch_binning(f, g, radii, b, im, D, st))
         return hip_fail("binning", hipGetLastError());
     {
@@ -342,6 +366,7 @@ static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means
         if (f.raw && rawx.dL_dshs_rest && Mz > 1) z.add(rawx.dL_dshs_rest, (3 * Mz - 3) * n);
         if (cov3D_precomp) z.add(dL_dcov3D, 6 * n);
         else { z.add(dL_dscales, 3 * n); z.add(dL_drotations, 4 * n); }
+        if (z.overflow) return fail(MVI_EINVAL, "more gradient outputs than the render backward can zero on the side%s (kMaxZero)");
         if (int rc = backward_render_impl(f, P, D, radii, geom, binning, image, dL_dout_color, dL_dconic_scratch, nullptr, 0,
                                           rawx.rows_prezeroed, stream, &z)) return rc;
         mvi::StageTimer tm(mvi::kStPreBwd, st);

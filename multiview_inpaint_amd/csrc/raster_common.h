@@ -294,8 +294,10 @@ struct ZeroRegions {
     float* tail[kMaxZero];
     uint32_t n_head[kMaxZero], n_body[kMaxZero], n_tail[kMaxZero];   // words, 16-byte units, words
     int n = 0;
+    bool overflow = false;      // an array was offered when all kMaxZero slots were taken: the caller must fail, not run
     void add(void* ptr, size_t words) {
-        if (!ptr || !words || n >= kMaxZero) return;
+        if (!ptr || !words) return;
+        if (n >= kMaxZero) { overflow = true; return; }
         float* p = (float*)ptr;
         const size_t mis = ((uintptr_t)p & 15u) / 4u;
         size_t h = mis ? 4 - mis : 0;

@@ -638,7 +638,8 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, GeomView g,
     const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx) {
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx,
+    int vec_ok) {   // bit 0: shs / dL_dshs rows may move as 16-byte accesses, bit 1: rotations (the caller's pointers are 16-byte aligned)
     // a fixed, moderate grid walks the list with a grid stride: the list's length is only known on the device, and a grid
     // sized for P would be 23 k blocks of which a few hundred find work
     const uint32_t n_touched = *g.touched_count;
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
         float* out0 = dL_dshs ? (f.raw ? dL_dshs + 3 * si : dL_dshs + si * M * 3) : nullptr;
         float* out_rest = dL_dshs ? (f.raw ? rawx.dL_dshs_rest + si * (3 * M - 3) - 3 : out0) : nullptr;
         float ddx = 0, ddy = 0, ddz = 0;
-        if (!f.raw && M == 16) {
+        if (!f.raw && M == 16 && (vec_ok & 1)) {
             // the common case (sh_degree <= 3 stored with 16 coefficients): the 192-byte row moves as twelve 16-byte
             // accesses per lane instead of 48 + 48 scattered words
             float rowv[48];
@@ -734,7 +735,8 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
 #pragma unroll
         for (int k = 0; k < 6; ++k) dL_dcov3D[6 * si + k] = g6[k];
     } else {
-        const float4 qrot = *reinterpret_cast<const float4*>(rotations + 4 * si);
+        const float4 qrot = (vec_ok & 2) ? *reinterpret_cast<const float4*>(rotations + 4 * si)
+                                         : make_float4(rotations[4 * si], rotations[4 * si + 1], rotations[4 * si + 2], rotations[4 * si + 3]);
         const float sa_in[3] = {scales[3 * si], scales[3 * si + 1], scales[3 * si + 2]};
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         backward_scale_rot(f, g6, qrot, sa_in, ds, dq);
@@ -793,9 +795,13 @@ int launch_preprocess_backward_sparse(const Frame& f, const float* means3D, cons
     hipLaunchKernelGGL(compact_touched_kernel, dim3((f.P + kPerBlock - 1) / kPerBlock), dim3(kCompactThreads), 0, st, f.P, g.touched,
                        g.touched_list, g.touched_count);
     const int sparse_blocks = min((f.P + kSparseBlock - 1) / kSparseBlock, 2048);
+    // the caller's arrays may sit at any 4-byte offset (e.g. inside dist.GradBucket, where dL_dshs starts 12 P bytes in):
+    // the 16-byte row accesses are taken only when every row is 16-byte aligned, else the per-word form
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    const int vec_ok = ((al16(shs) && al16(dL_dshs)) ? 1 : 0) | (al16(rotations) ? 2 : 0);
     hipLaunchKernelGGL(preprocess_backward_sparse_kernel, dim3(sparse_blocks), dim3(kSparseBlock), 0, st, f, means3D, shs, scales,
                        rotations, cov3D_precomp, g, grad_rows, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dshs,
-                       dL_dcov3D, dL_dscales, dL_drots, rawx);
+                       dL_dcov3D, dL_dscales, dL_drots, rawx, vec_ok);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
