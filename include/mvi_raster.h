@@ -68,7 +68,13 @@ size_t mvi_raster_binning_bytes(int64_t num_rendered, int32_t image_width, int32
 /* Forward, stage 1: per-Gaussian preprocess (cull, cov3D, EWA cov2D, conic, radius, tile rect,
  * SH colour) + scan of tiles touched. Exactly one of shs | colors_precomp and one of
  * (scales, rotations) | cov3D_precomp must be non-NULL. M = SH coefficients per channel in shs.
- * Writes radii [P] int32 and *num_rendered_host. */
+ * Writes radii [P] int32 and *num_rendered_host.
+ * SH colours are DEFERRED by default (mvi_raster_color_mode): this call records where means3D / shs live, and the render
+ * kernel of mvi_raster_forward_render evaluates a Gaussian's colour — with the arithmetic the eager evaluation uses, same
+ * bits — the first time a tile stages it. Only a few per cent of the visible Gaussians of a dense scene are ever staged
+ * (a tile's pixels saturate after the first few hundred entries of its list), and at degree 3 the coefficients are 63 % of
+ * what this call would read. means3D and shs must therefore stay valid and unchanged until mvi_raster_forward_render has
+ * run on the stream (they must until the backward anyway). */
 int mvi_raster_forward_geom(const mvi_raster_settings* s, int32_t P, int32_t M,
                             const float* means3D, const float* shs, const float* colors_precomp,
                             const float* opacities, const float* scales, const float* rotations,
@@ -211,6 +217,17 @@ int mvi_raster_timing_enable(int enable);
 int mvi_raster_timing_enable_stages(uint32_t stage_mask);
 int mvi_raster_timing_read(float* ms_sum_host, int32_t* calls_host);
 const char* mvi_raster_stage_name(int stage);
+
+/* SH colours: 1 (default) = deferred, evaluated by the render kernel on first use (see mvi_raster_forward_geom); 0 = eager,
+ * evaluated for every visible Gaussian by the preprocess kernel (MVI_RASTER_EAGER_COLORS=1 selects it at start-up). Images,
+ * gradients and every colour that IS evaluated are identical bit for bit; in deferred mode mvi_raster_views.rgbd holds
+ * (-1, -1, -1, depth) and clamped 0 for the Gaussians no tile staged. Pass 0 or 1 to select, anything else to query;
+ * returns the previous selection. Must not change between the two forward calls of one view. Not thread-safe. */
+int mvi_raster_color_mode(int deferred);
+/* Evaluates every colour still pending after a deferred forward (no-op after an eager one), so that mvi_raster_views.rgbd /
+ * clamped are complete: for the parity tests and for callers that inspect colours of Gaussians that were never composited.
+ * Needs the means3D / shs arrays of the forward still valid. */
+int mvi_raster_resolve_colors(const mvi_raster_settings* s, int32_t P, void* geom, size_t geom_bytes, void* stream);
 
 /* Binning implementation: 2 (default) = the rectangle-expanding partition of csrc/raster_binning2.hip, used for tile grids of
  * at most 256 x 256 tiles; 1 = the pair-emitting radix partition of csrc/raster_binning.hip (always used above that size,

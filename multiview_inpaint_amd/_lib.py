@@ -125,6 +125,10 @@ def lib():
     L.mvi_raster_binning_version.argtypes = [C.c_int]
     L.mvi_raster_backward_mode.restype = C.c_int
     L.mvi_raster_backward_mode.argtypes = [C.c_int]
+    L.mvi_raster_color_mode.restype = C.c_int
+    L.mvi_raster_color_mode.argtypes = [C.c_int]
+    L.mvi_raster_resolve_colors.restype = C.c_int
+    L.mvi_raster_resolve_colors.argtypes = [C.POINTER(RasterSettings), i32, vp, sz, vp]
     L.mvi_raster_dev_stamps.restype = C.c_int
     L.mvi_raster_dev_stamps.argtypes = [C.c_int, vp]
     _bind_unet_ops(L)

@@ -17,6 +17,9 @@ int launch_binning_level1(const Frame& f, GeomView g, hipStream_t st);
 static thread_local char g_err[512] = "";
 // 0 (default): one-call backward with outputs zeroed on the side + sparse chain rule; 1: the dense chain-rule kernel
 static int g_dense_backward = [] { const char* e = getenv("MVI_RASTER_DENSE_BACKWARD"); return (e && e[0] == '1') ? 1 : 0; }();
+// 1 (default): SH colours are evaluated by the render kernel when it first stages a Gaussian (raster_common.h, ColorSource);
+// 0: by the preprocess kernel for every visible Gaussian (MVI_RASTER_EAGER_COLORS=1 selects it at start-up)
+static int g_defer_colors = [] { const char* e = getenv("MVI_RASTER_EAGER_COLORS"); return (e && e[0] == '1') ? 0 : 1; }();
 // Column segments counted by forward_geom (binning version 2), remembered PER GEOM SCRATCH: the exact grid size of the
 // forward_render that follows on that scratch. Process-wide and locked, so the two halves of a forward may run on different
 // threads; an entry describes the scratch's CONTENTS (the last forward_geom that wrote it replaces it), so it can only be
@@ -97,6 +100,7 @@ static int make_frame(const mvi_raster_settings* s, int P, int M, mvi::Frame& f)
     f.scale_modifier = s->scale_modifier;
     f.view = s->viewmatrix; f.proj = s->projmatrix; f.campos = s->campos; f.bg = s->bg;
     f.bin_v2 = mvi::binning_v2_ok(f.gx, f.gy) ? 1 : 0;
+    f.defer_colors = g_defer_colors;
     return MVI_OK;
 }
 
@@ -133,6 +137,21 @@ int mvi_raster_backward_mode(int dense) {
     return old;
 }
 int mvi_raster_binning_version(int version) { return mvi::set_binning_version(version); }
+int mvi_raster_color_mode(int deferred) {
+    const int old = g_defer_colors;
+    if (deferred == 0 || deferred == 1) g_defer_colors = deferred;
+    return old;
+}
+int mvi_raster_resolve_colors(const mvi_raster_settings* s, int32_t P, void* geom, size_t geom_bytes, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, 0, f)) return rc;
+    if (P == 0) return MVI_OK;
+    if (!geom) return fail(MVI_EINVAL, "geom is NULL%s");
+    mvi::GeomView g = mvi::carve_geom(geom, P);
+    if (geom_bytes < g.bytes) return fail(MVI_ENOMEM, "geom scratch too small%s", "");
+    if (mvi::launch_resolve_colors(f, g, (hipStream_t)stream)) return hip_fail("resolve_colors", hipGetLastError());
+    return MVI_OK;
+}
 const char* mvi_version(void) { return "multiview_inpaint_amd 0.1.0 (gfx950)"; }
 
 size_t mvi_raster_geom_bytes(int32_t P) { return mvi::carve_geom(nullptr, P).bytes; }

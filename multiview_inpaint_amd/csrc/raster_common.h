@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 
 #include "../../include/mvi_raster.h"
 
@@ -48,6 +49,7 @@ struct Frame {
     const float* shs_rest = nullptr;
     int raw = 0;
     int bin_v2 = 0;      // binning version 2 (rectangle-expanding partition, raster_binning2.hip): set by make_frame
+    int defer_colors = 0;    // SH input: colours evaluated by the render kernel on first use (ColorSource below): set by make_frame
 };
 
 // ---- binning version 2 (raster_binning2.hip): tile grids of at most 256 x 256 tiles (images up to 4096 x 4096) ------------
@@ -63,6 +65,23 @@ void set_dev_stamps(int pass, void* buf);            // diagnostics: shader-cloc
 int set_binning_version(int v);                     // 1 | 2 (anything else: query only); returns the previous version
 inline bool binning_v2_ok(int gx, int gy) { return gx <= 256 && gy <= 256 && binning_v2_enabled(); }
 
+// Deferred SH colours. With SH input the forward preprocess does NOT evaluate SH -> RGB for every visible Gaussian (192 bytes
+// of coefficients each at degree 3, 63 % of everything that kernel reads, for colours of which ~3 % are ever composited: a
+// tile's pixels saturate after the first few hundred entries of its list). It writes rgbd = (-1, -1, -1, depth) instead and
+// leaves this record in the geom scratch; render_forward evaluates a colour the first time it STAGES the Gaussian (same
+// arithmetic, shared function sh_rgb below), writes it back for the other tiles and for the backward, and uses its own value.
+// Every channel of an evaluated colour is >= 0 (clamped), so "any channel < 0" means "not evaluated": a torn or stale read
+// of another block's write-back just evaluates again (same bits). Positions the backward replays were all staged by the
+// forward of the same tile. mvi_raster_resolve_colors evaluates what is left (tests / introspection).
+struct ColorSource {
+    const float* means3D;     // [P,3] the caller's array (must stay valid and unchanged until the backward, as before)
+    const float* shs;         // [P,M,3], or features_dc [P,1,3] in raw mode
+    const float* shs_rest;    // raw mode: features_rest [P,M-1,3]
+    int32_t M, deg, raw;
+    int32_t deferred;         // 0: every colour was evaluated by the preprocess kernel (or colours were given precomputed)
+    int32_t vec16;            // rows of shs may be read as 16-byte vectors (M % 4 == 0, base 16-byte aligned, not raw)
+};
+
 // ---- scratch layouts (all offsets 256-B aligned) ---------------------------------------------
 struct GeomView {
     float* depths;            // [P]
@@ -75,6 +94,8 @@ struct GeomView {
     uint2* rect;              // [P] tile rectangle (x0 | y0 << 16, w | h << 16); w * h = tiles touched, 0 when culled:
                               //     pair emission gathers this one 8-byte record per depth-ordered Gaussian
     uint8_t* clamped;         // [P] bit c set = colour channel c was clamped at 0
+    uint8_t* front;           // [P] deferred colours: 1 = named by a leading entry of some tile's list (zeroed by the preprocess)
+    struct ColorSource* color_src;   // [1] where the SH colours of this forward come from (deferred evaluation, see ColorSource)
     uint32_t* touched_list;   // [P] the touched Gaussians, compacted (any order); touched_count[0] of them
     uint32_t* touched_count;  // [1]
     uint8_t* touched;         // [P] 1 = the render backward added something to this Gaussian's accumulation row (gradient
@@ -149,6 +170,8 @@ inline GeomView carve_geom(void* base, int P) {
     g.touched = (uint8_t*)take(n);
     g.touched_list = (uint32_t*)take(4 * n);
     g.touched_count = (uint32_t*)take(4);
+    g.front = (uint8_t*)take(n);
+    g.color_src = (ColorSource*)take(sizeof(ColorSource));
     const size_t npre = (n + kPB - 1) / kPB;
     g.block_sums = (uint32_t*)take(4 * npre);
     g.block_offsets = (uint32_t*)take(4 * (npre + 1));
@@ -244,6 +267,190 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
     x1 = min(gx, max(0, (int)((px + (float)radius + (float)(kTile - 1)) / (float)kTile)));
     y1 = min(gy, max(0, (int)((py + (float)radius + (float)(kTile - 1)) / (float)kTile)));
 }
+
+// ---- SH -> RGB (gs-simp/utils/sh_utils.py:57-112 basis and signs; + 0.5 and clamp at 0 as gaussian_renderer/__init__.py:77-78)
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b) {
+#pragma clang fp contract(off)
+    b[0] = SH_C0;
+    if (deg > 0) {
+        b[1] = -SH_C1 * y;
+        b[2] = SH_C1 * z;
+        b[3] = -SH_C1 * x;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy;
+            b[5] = SH_C2[1] * yz;
+            b[6] = SH_C2[2] * (2.0f * zz - xx - yy);
+            b[7] = SH_C2[3] * xz;
+            b[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = SH_C3[0] * y * (3.0f * xx - yy);
+                b[10] = SH_C3[1] * xy * z;
+                b[11] = SH_C3[2] * y * (4.0f * zz - xx - yy);
+                b[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                b[13] = SH_C3[4] * x * (4.0f * zz - xx - yy);
+                b[14] = SH_C3[5] * z * (xx - yy);
+                b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+// Colour of one Gaussian seen from campos, in four steps that are the ONE piece of arithmetic behind both the eager evaluation
+// (preprocess kernel, coefficients from LDS: sh_rgb) and the deferred one (render / resolve kernels, coefficients loaded in
+// chunks: resolve_color_deg). Explicit fma chain in coefficient order, nothing else fused: shared with oracle/raster_oracle.c.
+__device__ __forceinline__ void sh_direction(float px, float py, float pz, const float* __restrict__ campos, float& dx, float& dy,
+                                             float& dz) {
+#pragma clang fp contract(off)
+    dx = px - campos[0]; dy = py - campos[1]; dz = pz - campos[2];
+    const float len = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+    dx = dx / len; dy = dy / len; dz = dz / len;
+}
+__device__ __forceinline__ void sh_first(float b0, float c0, float c1, float c2, float& r0, float& r1, float& r2) {
+#pragma clang fp contract(off)
+    r0 = b0 * c0; r1 = b0 * c1; r2 = b0 * c2;
+}
+__device__ __forceinline__ void sh_next(float bk, float c0, float c1, float c2, float& r0, float& r1, float& r2) {
+    r0 = __builtin_fmaf(bk, c0, r0); r1 = __builtin_fmaf(bk, c1, r1); r2 = __builtin_fmaf(bk, c2, r2);
+}
+__device__ __forceinline__ void sh_finish(float& r0, float& r1, float& r2, uint32_t& clamp_bits) {
+#pragma clang fp contract(off)
+    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+    clamp_bits = (r0 < 0.0f ? 1u : 0u) | (r1 < 0.0f ? 2u : 0u) | (r2 < 0.0f ? 4u : 0u);
+    r0 = fmaxf(r0, 0.0f); r1 = fmaxf(r1, 0.0f); r2 = fmaxf(r2, 0.0f);
+}
+// coef(k, c) returns coefficient k < (deg + 1)^2 of channel c
+template <typename Coef>
+__device__ __forceinline__ void sh_rgb(int deg, float px, float py, float pz, const float* __restrict__ campos, Coef coef,
+                                       float& r0, float& r1, float& r2, uint32_t& clamp_bits) {
+    float dx, dy, dz, bs[16];
+    sh_direction(px, py, pz, campos, dx, dy, dz);
+    sh_basis(deg, dx, dy, dz, bs);
+    const int nb = (deg + 1) * (deg + 1);
+    sh_first(bs[0], coef(0, 0), coef(0, 1), coef(0, 2), r0, r1, r2);
+    for (int k = 1; k < nb; ++k) sh_next(bs[k], coef(k, 0), coef(k, 1), coef(k, 2), r0, r1, r2);
+    sh_finish(r0, r1, r2, clamp_bits);
+}
+
+// Deferred evaluation of Gaussian `id` (see ColorSource): loads its active coefficients, evaluates, writes rgbd / clamped
+// back. DEG is a template parameter so that everything is indexed by constants (registers, no scratch). The coefficients come
+// in chunks of 8 (six 16-byte loads), each consumed before the next is requested: the render kernel runs this in a cold
+// branch beside ~25 live registers of compositing state and must stay within 80 (6 waves per SIMD); the latency of the
+// second chunk is covered by the CU's other tiles.
+template <int DEG>
+__device__ __forceinline__ float4 resolve_color_deg(const ColorSource& cs, const float* __restrict__ campos, uint32_t id, float depth,
+                                                    float4* rgbd, uint8_t* clamped) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), KC = 8;
+    const size_t si = (size_t)id;
+    const float* row = cs.raw ? cs.shs_rest + si * (size_t)(3 * cs.M - 3) - 3 : cs.shs + si * (size_t)(3 * cs.M);   // + 3 k (raw: k >= 1)
+    float dx, dy, dz, bs[NB > 1 ? NB : 1], r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    sh_direction(cs.means3D[3 * si], cs.means3D[3 * si + 1], cs.means3D[3 * si + 2], campos, dx, dy, dz);
+    {
+        float b16[16];
+        sh_basis(DEG, dx, dy, dz, b16);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) bs[k] = b16[k];
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < NB; k0 += KC) {
+        constexpr int kMaxF = 3 * KC;
+        const int nk = NB - k0 < KC ? NB - k0 : KC;          // compile-time after unrolling
+        float v[kMaxF];
+        if (!cs.raw && cs.vec16) {
+#pragma unroll
+            for (int q = 0; q < kMaxF / 4; ++q) {
+                if (4 * q < 3 * nk) {                         // whole vectors; a row holds 3 M >= the padded count (M % 4 == 0)
+                    const float4 t = reinterpret_cast<const float4*>(row + 3 * k0)[q];
+                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kMaxF; ++j)
+                if (j < 3 * nk) v[j] = (cs.raw && k0 == 0 && j < 3) ? cs.shs[3 * si + j] : row[3 * k0 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (k < nk) {
+                if (k0 + k == 0) sh_first(bs[0], v[0], v[1], v[2], r0, r1, r2);
+                else sh_next(bs[k0 + k], v[3 * k], v[3 * k + 1], v[3 * k + 2], r0, r1, r2);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                    // the next chunk's loads stay behind this chunk's arithmetic
+    }
+    uint32_t bits;
+    sh_finish(r0, r1, r2, bits);
+    const float4 out = make_float4(r0, r1, r2, depth);
+    rgbd[si] = out;
+    clamped[si] = (uint8_t)bits;
+    return out;
+}
+__device__ __forceinline__ float4 resolve_color(const ColorSource& cs, const float* __restrict__ campos, uint32_t id, float depth,
+                                             float4* rgbd, uint8_t* clamped) {
+    switch (cs.deg) {                 // uniform
+        case 0: return resolve_color_deg<0>(cs, campos, id, depth, rgbd, clamped);
+        case 1: return resolve_color_deg<1>(cs, campos, id, depth, rgbd, clamped);
+        case 2: return resolve_color_deg<2>(cs, campos, id, depth, rgbd, clamped);
+        default: return resolve_color_deg<3>(cs, campos, id, depth, rgbd, clamped);
+    }
+}
+// The same evaluation for the render kernel's cold branch, written for a SMALL register footprint instead of loads in
+// flight: one code path for every input form (a coefficient = one 12-byte load from wherever it lives), the coefficients of
+// at most four coefficients requested together and consumed before the next ones (uniform branches / scheduling barriers
+// keep the scheduler from hoisting all 16 loads, which cost the compositing loop its registers: 143 VGPRs / 3 waves per SIMD when
+// the fast form was inlined there). Identical arithmetic: sh_direction, sh_basis, sh_first / sh_next in coefficient
+// order, sh_finish.
+__device__ __forceinline__ float4 resolve_color_small(const ColorSource& cs, const float* __restrict__ campos, uint32_t id,
+                                                      float depth, float4* rgbd, uint8_t* clamped) {
+    const size_t si = (size_t)id;
+    const float* c0p = cs.shs + (cs.raw ? 3 * si : si * (size_t)(3 * cs.M));                                            // k = 0
+    const float* row = cs.raw ? cs.shs_rest + si * (size_t)(3 * cs.M - 3) - 3 : cs.shs + si * (size_t)(3 * cs.M);      // + 3 k, k >= 1
+    float dx, dy, dz, bs[16], r0, r1, r2;
+    sh_direction(cs.means3D[3 * si], cs.means3D[3 * si + 1], cs.means3D[3 * si + 2], campos, dx, dy, dz);
+    sh_basis(cs.deg, dx, dy, dz, bs);
+    struct F3 { float a, b, c; };
+    {
+        const F3 t = *reinterpret_cast<const F3*>(c0p);
+        sh_first(bs[0], t.a, t.b, t.c, r0, r1, r2);
+    }
+    auto band = [&](auto first_c, auto last_c) __attribute__((always_inline)) {
+        constexpr int kFirst = decltype(first_c)::value, kLast = decltype(last_c)::value;
+        F3 t[kLast - kFirst + 1];
+#pragma unroll
+        for (int k = kFirst; k <= kLast; ++k) t[k - kFirst] = *reinterpret_cast<const F3*>(row + 3 * k);
+#pragma unroll
+        for (int k = kFirst; k <= kLast; ++k) sh_next(bs[k], t[k - kFirst].a, t[k - kFirst].b, t[k - kFirst].c, r0, r1, r2);
+    };
+    using std::integral_constant;
+    if (cs.deg > 0) {
+        band(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+        if (cs.deg > 1) {
+            band(integral_constant<int, 4>{}, integral_constant<int, 6>{});
+            __builtin_amdgcn_sched_barrier(0);
+            band(integral_constant<int, 7>{}, integral_constant<int, 8>{});
+            if (cs.deg > 2) {
+                band(integral_constant<int, 9>{}, integral_constant<int, 12>{});
+                __builtin_amdgcn_sched_barrier(0);
+                band(integral_constant<int, 13>{}, integral_constant<int, 15>{});
+            }
+        }
+    }
+    uint32_t bits;
+    sh_finish(r0, r1, r2, bits);
+    const float4 out = make_float4(r0, r1, r2, depth);
+    rgbd[si] = out;
+    clamped[si] = (uint8_t)bits;
+    return out;
+}
+__device__ __forceinline__ bool color_pending(float4 cd) { return cd.x < 0.0f || cd.y < 0.0f || cd.z < 0.0f; }
 
 // Sum over the 64 lanes of a wave with DPP moves; the total lands in lane 63.
 template <int CTRL, int ROW_MASK>
@@ -356,6 +563,7 @@ int launch_binning2_level1(const Frame& f, GeomView g, hipStream_t st);
 int launch_binning2(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D, int64_t segments, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                           float* out_color, float* out_depth, hipStream_t st, float* zero_rows = nullptr);
+int launch_resolve_colors(const Frame& f, GeomView g, hipStream_t st);      // evaluates every colour still pending
 int launch_render_backward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                            const float* dL_dpix, float* grad_rows, hipStream_t st, const ZeroRegions* zero = nullptr);
 constexpr int kGradRow = 16;   // floats per Gaussian in the backward accumulation rows (64 B)

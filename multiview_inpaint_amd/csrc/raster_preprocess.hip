@@ -106,40 +106,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 __host__ __device__ inline int sh_stride(int M) { return 3 * M + 1 - ((3 * M) & 1); }   // odd row stride
 
-__device__ constexpr float SH_C0 = 0.28209479177387814f;
-__device__ constexpr float SH_C1 = 0.4886025119029199f;
-__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                       -1.0925484305920792f, 0.5462742152960396f};
-__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
-                                       -0.5900435899266435f};
-
-__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b) {
-#pragma clang fp contract(off)
-    b[0] = SH_C0;
-    if (deg > 0) {
-        b[1] = -SH_C1 * y;
-        b[2] = SH_C1 * z;
-        b[3] = -SH_C1 * x;
-        if (deg > 1) {
-            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            b[4] = SH_C2[0] * xy;
-            b[5] = SH_C2[1] * yz;
-            b[6] = SH_C2[2] * (2.0f * zz - xx - yy);
-            b[7] = SH_C2[3] * xz;
-            b[8] = SH_C2[4] * (xx - yy);
-            if (deg > 2) {
-                b[9] = SH_C3[0] * y * (3.0f * xx - yy);
-                b[10] = SH_C3[1] * xy * z;
-                b[11] = SH_C3[2] * y * (4.0f * zz - xx - yy);
-                b[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-                b[13] = SH_C3[4] * x * (4.0f * zz - xx - yy);
-                b[14] = SH_C3[5] * z * (xx - yy);
-                b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
-            }
-        }
-    }
-}
+// SH constants, sh_basis and the colour evaluation sh_rgb live in raster_common.h (shared with the render kernel's deferred
+// evaluation).
 
 __device__ __forceinline__ void quat_to_rot(float r, float x, float y, float z, float R[3][3]) {
 #pragma clang fp contract(off)
@@ -195,20 +163,27 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
     Frame f, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii) {
+    const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii, int defer_colors, int sh_vec16) {
 #pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [kPB][sh_stride(M)] SH rows, then [kPB][3] x 2
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [kPB][sh_stride(M)] SH rows (eager colours only), then [kPB][3] x 2
     __shared__ uint32_t s_sum;
     const int tid = threadIdx.x;
     const int blk0 = blockIdx.x * kPB;
     const int i = blk0 + tid;
     const int n_rec = min(kPB, f.P - blk0);
-    const int shs_w = shs ? sh_stride(f.M) : 0;
+    const bool eager_sh = shs && !defer_colors;          // deferred (raster_common.h, ColorSource): the SH rows are not even read here
+    const int shs_w = eager_sh ? sh_stride(f.M) : 0;
     float* s_sh = s_dyn;
     float* s_mean = s_dyn + (size_t)kPB * shs_w;        // [kPB][3]
     float* s_scale = s_mean + 3 * kPB;                  // [kPB][3]
     if (tid == 0) s_sum = 0;
-    if (shs) stage_sh_in(f, shs, s_sh, blk0, n_rec, shs_w);
+    if (blockIdx.x == 0 && tid == 0) {                   // where this forward's colours come from, for the render kernel
+        ColorSource cs;
+        cs.means3D = means3D; cs.shs = shs; cs.shs_rest = f.shs_rest; cs.M = f.M; cs.deg = f.deg; cs.raw = f.raw;
+        cs.deferred = (shs && defer_colors) ? 1 : 0; cs.vec16 = sh_vec16;
+        *g.color_src = cs;
+    }
+    if (eager_sh) stage_sh_in(f, shs, s_sh, blk0, n_rec, shs_w);
     stage_in(means3D + (size_t)blk0 * 3, s_mean, n_rec, 3, 3);
     if (scales) stage_in(scales + (size_t)blk0 * 3, s_scale, n_rec, 3, 3);
     // per-lane operands requested before the barrier so they travel with the staged rows
@@ -295,23 +270,11 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
             uint32_t clamp_bits = 0;
             if (colors_precomp) {
                 r0 = colors_precomp[3 * (size_t)i]; r1 = colors_precomp[3 * (size_t)i + 1]; r2 = colors_precomp[3 * (size_t)i + 2];
-            } else {
-                float dx = px - f.campos[0], dy = py - f.campos[1], dz = pz - f.campos[2];
-                float len = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-                dx = dx / len; dy = dy / len; dz = dz / len;
-                float bs[16];
-                sh_basis(f.deg, dx, dy, dz, bs);
-                const int nb = (f.deg + 1) * (f.deg + 1);
+            } else if (eager_sh) {
                 const float* sh = s_sh + (size_t)tid * shs_w;
-                r0 = bs[0] * sh[0]; r1 = bs[0] * sh[1]; r2 = bs[0] * sh[2];
-                for (int k = 1; k < nb; ++k) {
-                    r0 = __builtin_fmaf(bs[k], sh[3 * k], r0);
-                    r1 = __builtin_fmaf(bs[k], sh[3 * k + 1], r1);
-                    r2 = __builtin_fmaf(bs[k], sh[3 * k + 2], r2);
-                }
-                r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-                clamp_bits = (r0 < 0.0f ? 1u : 0u) | (r1 < 0.0f ? 2u : 0u) | (r2 < 0.0f ? 4u : 0u);
-                r0 = fmaxf(r0, 0.0f); r1 = fmaxf(r1, 0.0f); r2 = fmaxf(r2, 0.0f);
+                sh_rgb(f.deg, px, py, pz, f.campos, [&](int k, int c) { return sh[3 * k + c]; }, r0, r1, r2, clamp_bits);
+            } else {
+                r0 = r1 = r2 = -1.0f;                    // pending: evaluated by the render kernel when it first stages this Gaussian
             }
             g.clamped[i] = (uint8_t)clamp_bits;
             g.rgbd[i] = make_float4(r0, r1, r2, vz);
@@ -324,6 +287,7 @@ __global__ __launch_bounds__(kPB) void preprocess_forward_kernel(
             rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
         } while (false);
         radii[i] = rad_out;
+        if (defer_colors) g.front[i] = 0;
         g.tiles_touched[i] = touched;
         g.rect[i] = rect;
         // level-1 sort input (binning): depth bits (monotonic for depth > 0.2), culled Gaussians last
@@ -347,12 +311,14 @@ int launch_preprocess_forward(const Frame& f, const float* means3D, const float*
                               int32_t* radii, hipStream_t st) {
     if (f.P <= 0) return 0;
     int nblk = (f.P + kPB - 1) / kPB;
-    size_t lds = sizeof(float) * ((size_t)kPB * (shs ? sh_stride(f.M) : 0) + 6 * kPB);
+    const int defer = (shs && f.defer_colors) ? 1 : 0;
+    const int vec16 = (shs && !f.raw && (f.M & 3) == 0 && ((uintptr_t)shs & 15u) == 0) ? 1 : 0;
+    size_t lds = sizeof(float) * ((size_t)kPB * ((shs && !defer) ? sh_stride(f.M) : 0) + 6 * kPB);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)preprocess_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MVI_EHIP;
     hipLaunchKernelGGL(preprocess_forward_kernel, dim3(nblk), dim3(kPB), lds, st, f, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii);
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, defer, vec16);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -902,6 +868,22 @@ __global__ __launch_bounds__(256) void color_factor_kernel(int P, const int32_t*
     }
     out[3 * (size_t)i] = r; out[3 * (size_t)i + 1] = g_; out[3 * (size_t)i + 2] = b;
 }
+// Evaluates every colour the render kernel has not needed (ColorSource): for the parity tests and for callers that read
+// mvi_raster_views.rgbd / clamped of Gaussians that were never staged.
+__global__ __launch_bounds__(256) void resolve_colors_kernel(Frame f, GeomView g) {
+    const ColorSource cs = *g.color_src;
+    if (!cs.deferred) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= f.P || g.tiles_touched[i] == 0) return;
+    const float4 cd = g.rgbd[i];
+    if (color_pending(cd)) resolve_color(cs, f.campos, (uint32_t)i, cd.w, g.rgbd, g.clamped);
+}
+int launch_resolve_colors(const Frame& f, GeomView g, hipStream_t st) {
+    if (f.P <= 0) return 0;
+    hipLaunchKernelGGL(resolve_colors_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, f, g);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
 int launch_color_factors(int P, const int32_t* radii, const float* grad_rows, const uint8_t* clamped, float* out, hipStream_t st) {
     if (P <= 0) return 0;
     hipLaunchKernelGGL(color_factor_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, grad_rows, clamped, out);

@@ -9,6 +9,8 @@
 // "active ellipse" {alpha >= 1/255} = {d^T conic d <= 2 ln(255 o)} can reach the box (exact minimum of the
 // quadratic form over the box, quad_overlap). Only kept entries are evaluated per pixel. The test is conservative
 // (margin on 2 ln(255 o)), so results are identical to evaluating every entry.
+#include <cstdlib>
+
 #include "raster_common.h"
 
 namespace mvi {
@@ -85,9 +87,9 @@ __device__ __forceinline__ float gauss_power1(float4 co, float dx, float dy) {  
 // the body needs no per-lane "done" mask and no divergent branch.
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
+    const float2* __restrict__ xy, float4* rgbd, const float4* __restrict__ conic_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth, ZeroRegions zero) {
+    float* __restrict__ out_depth, ZeroRegions zero, const ColorSource* __restrict__ color_src, uint8_t* clamped) {
     __shared__ float2 s_xy[kBlock];
     __shared__ float s_t2[kBlock];
     __shared__ float4 s_co[kBlock];
@@ -112,19 +114,26 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     float T_out = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = kDepthSentinel;
     uint32_t last = 0;
 
+    // Deferred SH colours (raster_common.h, ColorSource): rgbd holds (-1, -1, -1, depth) until somebody needs the colour.
+    // The lane that stages an entry evaluates it (the same arithmetic as the eager preprocess), writes it back for the other
+    // tiles and for the backward, and stages its OWN value: whatever another block wrote meanwhile is either complete
+    // (every channel >= 0) or treated as pending.
+    const ColorSource cs = *color_src;              // uniform: scalar loads
     // software pipeline: the gathers of batch r+1 are issued before batch r is composited
     float2 n_xy = make_float2(0.f, 0.f);
     float4 n_co = make_float4(0.f, 0.f, 0.f, 0.f), n_cd = n_co;
+    uint32_t n_id = 0;
     auto fetch = [&](int r) {
         const uint32_t q = r0 + (uint32_t)(r * kBlock + tid);
         if (q < r1) {
-            const uint32_t id = point_list[q];
-            n_xy = xy[id]; n_co = conic_opacity[id]; n_cd = rgbd[id];
+            n_id = point_list[q];
+            n_xy = xy[n_id]; n_co = conic_opacity[n_id]; n_cd = rgbd[n_id];
         }
     };
     if (rounds > 0) fetch(0);
     for (int r = 0; r < rounds; ++r, todo -= kBlock) {
         if (__syncthreads_count(T <= 0.0f) == kBlock) break;
+        if (cs.deferred && tid < todo && color_pending(n_cd)) n_cd = resolve_color_small(cs, f.campos, n_id, n_cd.w, rgbd, clamped);
         s_xy[tid] = n_xy;
         s_co[tid] = n_co;
         s_t2[tid] = active_t2(n_co);
@@ -179,6 +188,53 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     }
 }
 
+// Deferred SH colours, ahead of the render kernel: the leading `n_front` entries of every tile's list are entries the render
+// kernel is going to stage for certain (its first round), and neighbouring tiles share most of them (2.1 M leading entries of
+// the bench view are 45 k distinct Gaussians): left to the render kernel, every one of those tiles finds the colour pending at
+// the same moment and evaluates it itself (measured: +140 us). Two small kernels instead: mark_front sets a byte per Gaussian
+// named by a leading entry (plain idempotent stores: no atomics, no reads), resolve_marked walks the P flags, collects the
+// marked Gaussians of 1024 in LDS and evaluates them with full waves. (Claiming with a device-scope compare-and-swap in one
+// kernel was measured at 53 us: ~2 M memory-side atomics, the claims invisible through the other XCDs' L2.) What the render
+// kernel meets later is either a colour or, beyond the leading entries, the rare Gaussian nobody needed yet.
+constexpr int kFrontTiles = 4;
+constexpr int kFrontMax = 1024;
+__global__ __launch_bounds__(kBlock) void mark_front_kernel(int tiles, const uint32_t* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ point_list, uint8_t* __restrict__ front,
+                                                            int n_front) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < kFrontTiles; ++t) {
+        const int tile = blockIdx.x * kFrontTiles + t;
+        if (tile >= tiles) break;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const uint32_t n = min(r1 - r0, (uint32_t)n_front);
+        for (uint32_t e = tid; e < n; e += kBlock) front[point_list[r0 + e]] = 1;
+    }
+}
+constexpr int kMarkedPer = 4;                            // flags per thread: one 4-byte load
+__global__ __launch_bounds__(kBlock) void resolve_marked_kernel(Frame f, GeomView g) {
+    const ColorSource cs = *g.color_src;
+    __shared__ uint32_t s_id[kBlock * kMarkedPer];
+    __shared__ uint32_t s_n;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int i0 = (blockIdx.x * kBlock + tid) * kMarkedPer;
+    if (i0 < f.P) {                                      // bytes past P are padding of the segment (zeroed with the flags)
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(g.front + i0);
+#pragma unroll
+        for (int k = 0; k < kMarkedPer; ++k)
+            if ((w >> (8 * k)) & 0xFFu) s_id[atomicAdd(&s_n, 1u)] = (uint32_t)(i0 + k);
+    }
+    __syncthreads();
+    const uint32_t total = s_n;
+    for (uint32_t i = tid; i < total; i += kBlock) {
+        const uint32_t id = s_id[i];
+        const float4 cd = g.rgbd[id];
+        if (color_pending(cd)) resolve_color(cs, f.campos, id, cd.w, g.rgbd, g.clamped);
+    }
+}
+
 int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView im, int64_t D,
                           float* out_color, float* out_depth, hipStream_t st, float* zero_rows) {
@@ -192,8 +248,19 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
     if (f.W <= 0 || f.H <= 0) return launch_zero_regions(z, st);
     const uint32_t* plist = b.vals[b.passes & 1];
     const unsigned blocks = (unsigned)(f.gx * f.gy);
+    if (f.defer_colors && D > 0) {
+        // MVI_RASTER_FRONT_ENTRIES: leading entries per tile evaluated ahead of the render kernel (0: none, A/B runs)
+        static const int n_front = [] { const char* e = getenv("MVI_RASTER_FRONT_ENTRIES"); const int v = e ? atoi(e) : kBlock;
+                                        return v < 0 ? 0 : (v > kFrontMax ? kFrontMax : v); }();
+        if (n_front > 0) {
+            hipLaunchKernelGGL(mark_front_kernel, dim3((blocks + kFrontTiles - 1) / kFrontTiles), dim3(kBlock), 0, st, (int)blocks,
+                               im.ranges, plist, g.front, n_front);
+            hipLaunchKernelGGL(resolve_marked_kernel, dim3((f.P + kBlock * kMarkedPer - 1) / (kBlock * kMarkedPer)), dim3(kBlock), 0, st,
+                               f, g);
+        }
+    }
     hipLaunchKernelGGL(render_forward_kernel, dim3(blocks), dim3(kBlock), 0, st, f, im.ranges, plist, g.xy,
-                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth, z);
+                       g.rgbd, g.conic_opacity, im.final_T, im.n_contrib, out_color, out_depth, z, g.color_src, g.clamped);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 

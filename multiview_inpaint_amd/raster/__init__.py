@@ -64,7 +64,19 @@ class _Frame:
 
 class RasterState:
     """Scratch buffers one forward leaves behind for its backward (and for the parity tests)."""
-    __slots__ = ("P", "M", "D", "W", "H", "geom", "binning", "image", "radii", "grad_rows", "rows_clean")
+    __slots__ = ("P", "M", "D", "W", "H", "geom", "binning", "image", "radii", "grad_rows", "rows_clean", "frame", "sources")
+
+    def resolve_colors(self):
+        """Evaluates the SH colours no tile needed (deferred colours, include/mvi_raster.h: mvi_raster_color_mode), so that
+        the `rgbd` / `clamped` views are complete. Tests and introspection only; the forward's inputs are kept alive in
+        `sources` for it."""
+        if self.P == 0:
+            return
+        dev = self.geom.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mvi_raster_resolve_colors(C.byref(self.frame.c), self.P, _ptr(self.geom), self.geom.numel(), stream),
+                       "resolve_colors")
 
     def take_rows(self, dev):
         """(accumulation rows [P,16], prezeroed flag) for one backward: the rows the forward zeroed inside its render kernel
@@ -132,6 +144,7 @@ def rasterize_forward(rs: GaussianRasterizationSettings, means3D, opacities, shs
     M = int(shs.shape[1]) if shs is not None and shs.numel() else 0
     st = RasterState()
     st.P, st.M, st.W, st.H = P, M, W, H
+    st.frame, st.sources = fr, (means3D, shs)        # deferred SH colours read these until the render kernel has run
     u8 = dict(dtype=torch.uint8, device=dev)
     st.geom = torch.empty(L.mvi_raster_geom_bytes(P), **u8)
     st.image = torch.empty(L.mvi_raster_image_bytes(W, H), **u8)
@@ -326,6 +339,7 @@ def rasterize_forward_raw(rs: GaussianRasterizationSettings, xyz, features_dc, f
     H, W = int(rs.image_height), int(rs.image_width)
     st = RasterState()
     st.P, st.M, st.W, st.H = P, M, W, H
+    st.frame, st.sources = fr, (xyz, features_dc, features_rest)
     u8 = dict(dtype=torch.uint8, device=dev)
     st.geom = torch.empty(L.mvi_raster_geom_bytes(P), **u8)
     st.image = torch.empty(L.mvi_raster_image_bytes(W, H), **u8)

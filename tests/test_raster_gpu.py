@@ -112,7 +112,20 @@ def _check_forward(R, ro, cam, sc, bg, full=True, max_marginal=5e-3):
     # ---- per-Gaussian floats: shared arithmetic contract -> bit-exact where visible
     cov = np.concatenate([st.tensor("cov3D_a", (P, 4), torch.float32).cpu().numpy(),
                           st.tensor("cov3D_b", (P, 2), torch.float32).cpu().numpy()], 1)
+    # SH colours are evaluated on first use by the render kernel (deferred colours, include/mvi_raster.h): what it evaluated
+    # must already be the oracle's bits, whatever it left pending is (-1, -1, -1, depth) / clamped 0 and is evaluated now
+    rgbd0 = st.tensor("rgbd", (P, 4), torch.float32).cpu().numpy()
+    cl0 = st.tensor("clamped", (P,), torch.uint8).cpu().numpy()
+    pending = (rgbd0[:, :3] < 0).any(1) & vis
+    done = vis & ~pending
+    assert np.array_equal(rgbd0[done, :3], f["rgb"][done]) and np.array_equal(rgbd0[vis, 3], f["depths"][vis])
+    assert (rgbd0[pending, :3] == -1.0).all() and (cl0[pending] == 0).all()
+    if D:
+        nc_ = st.tensor("n_contrib", (H, W), torch.int32).cpu().numpy()
+        assert done.any() or not (nc_ > 0).any(), "nothing was evaluated although pixels composited something"
+    st.resolve_colors()
     rgbd = st.tensor("rgbd", (P, 4), torch.float32).cpu().numpy()
+    assert np.array_equal(rgbd[done], rgbd0[done]), "resolve_colors touched a colour that was already evaluated"
     got = dict(depths=st.tensor("depths", (P,), torch.float32).cpu().numpy(),
                means2D=st.tensor("means2D", (P, 2), torch.float32).cpu().numpy(), cov3D=cov,
                conic_opacity=st.tensor("conic_opacity", (P, 4), torch.float32).cpu().numpy(), rgb=rgbd[:, :3])
@@ -280,6 +293,56 @@ def test_bringup_config_100k_800(R, ro):
                              rotations=t["rotations"])
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
         _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
+
+
+@pytest.mark.parametrize("N,W,H,deg,log_scale", [(1_500_000, 1920, 1080, 3, None), (60_000, 640, 400, 3, np.log(0.05)),
+                                                 (20_000, 320, 200, 2, np.log(0.04)), (20_000, 320, 200, 1, np.log(0.04)),
+                                                 (5_000, 160, 96, 0, np.log(0.1))])
+def test_deferred_colours_equal_eager_colours_bit_for_bit(R, N, W, H, deg, log_scale):
+    """SH -> RGB on first use in the render kernel (the default) against SH -> RGB for every visible Gaussian in the
+    preprocess kernel (mvi_raster_color_mode(0)): image, depth, final_T and n_contrib identical bit for bit, every colour the
+    deferred forward evaluated identical to the eager one, everything it left pending identical after resolve_colors();
+    the evaluated set contains the gradient support (the backward replays only staged entries) and is a small part of the
+    visible Gaussians at the headline size; gradients equal to summation order."""
+    from multiview_inpaint_amd import _lib
+    L = _lib.lib()
+    cam = syn.make_camera(W, H, 50.0)
+    kw = {} if log_scale is None else dict(log_scale_mean=log_scale)
+    sc = syn.make_scene(N, cam, deg, seed=3, **kw)
+    t = _to_dev(sc)
+    bg = np.array([0.1, 0.3, 0.2], np.float32)
+    rs = _settings(R, cam, bg, deg)
+    g_img = torch.randn(3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    okw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    out = {}
+    prev = L.mvi_raster_color_mode(-1)
+    try:
+        for mode in (0, 1):
+            L.mvi_raster_color_mode(mode)
+            c, radii, d, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **okw)
+            rgbd = st.tensor("rgbd", (N, 4), torch.float32)
+            cl = st.tensor("clamped", (N,), torch.uint8)
+            g = R.rasterize_backward(rs, st, g_img, t["means3D"], **okw)
+            sup = st.tensor("grad_support", (N,), torch.uint8).bool()
+            st.resolve_colors()
+            out[mode] = dict(c=c, d=d, radii=radii, ft=st.tensor("final_T", (H, W), torch.float32),
+                             nc=st.tensor("n_contrib", (H, W), torch.int32), rgbd=rgbd, cl=cl, g=g, sup=sup,
+                             rgbd_all=st.tensor("rgbd", (N, 4), torch.float32), cl_all=st.tensor("clamped", (N,), torch.uint8))
+    finally:
+        L.mvi_raster_color_mode(prev)
+    e, l = out[0], out[1]
+    for k in ("c", "d", "radii", "ft", "nc"):
+        assert torch.equal(e[k], l[k]), k
+    vis = e["radii"] > 0
+    assert not (e["rgbd"][vis][:, :3] < 0).any(), "the eager forward left a colour pending"
+    done = vis & ~(l["rgbd"][:, :3] < 0).any(1)
+    assert torch.equal(l["rgbd"][done], e["rgbd"][done]) and torch.equal(l["cl"][done], e["cl"][done])
+    assert torch.equal(l["rgbd_all"][vis], e["rgbd"][vis]) and torch.equal(l["cl_all"][vis], e["cl"][vis])
+    assert torch.equal(e["sup"], l["sup"]) and (done | ~l["sup"]).all(), "a Gaussian in the gradient support was never evaluated"
+    if N >= 1_000_000:
+        assert int(done.sum()) < 0.15 * int(vis.sum()), (int(done.sum()), int(vis.sum()))
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        assert _same_to_summation_order(l["g"][k].cpu().numpy(), e["g"][k].cpu().numpy()), k
 
 
 def test_headline_config_1p5M_1080p_against_the_oracle(R, ro):
