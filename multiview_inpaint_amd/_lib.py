@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvi_hip.so")
+# MVI_HIP_LIB: another build of the SAME library for same-box A/B timing (tools/ab_lib.sh); never set by tests or bench defaults
+LIB_PATH = os.environ.get("MVI_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvi_hip.so")
 INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
 
 

@@ -200,7 +200,8 @@ constexpr int kFrontTiles = 4;
 constexpr int kFrontMax = 1024;
 __global__ __launch_bounds__(kBlock) void mark_front_kernel(int tiles, const uint32_t* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list, uint8_t* __restrict__ front,
-                                                            int n_front) {
+                                                            int n_front, const ColorSource* __restrict__ color_src) {
+    if (!color_src->deferred) return;                    // precomputed colours: nothing is pending (the host does not know)
     const int tid = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < kFrontTiles; ++t) {
@@ -214,17 +215,18 @@ __global__ __launch_bounds__(kBlock) void mark_front_kernel(int tiles, const uin
 constexpr int kMarkedPer = 4;                            // flags per thread: one 4-byte load
 __global__ __launch_bounds__(kBlock) void resolve_marked_kernel(Frame f, GeomView g) {
     const ColorSource cs = *g.color_src;
+    if (!cs.deferred) return;                            // precomputed colours (or an eager forward): the flags were never zeroed
     __shared__ uint32_t s_id[kBlock * kMarkedPer];
     __shared__ uint32_t s_n;
     const int tid = threadIdx.x;
     if (tid == 0) s_n = 0;
     __syncthreads();
     const int i0 = (blockIdx.x * kBlock + tid) * kMarkedPer;
-    if (i0 < f.P) {                                      // bytes past P are padding of the segment (zeroed with the flags)
+    if (i0 < f.P) {                                      // the 4-byte load may reach into the segment's padding: bytes >= P are ignored
         const uint32_t w = *reinterpret_cast<const uint32_t*>(g.front + i0);
 #pragma unroll
         for (int k = 0; k < kMarkedPer; ++k)
-            if ((w >> (8 * k)) & 0xFFu) s_id[atomicAdd(&s_n, 1u)] = (uint32_t)(i0 + k);
+            if (((w >> (8 * k)) & 0xFFu) && i0 + k < f.P) s_id[atomicAdd(&s_n, 1u)] = (uint32_t)(i0 + k);
     }
     __syncthreads();
     const uint32_t total = s_n;
@@ -254,7 +256,7 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
                                         return v < 0 ? 0 : (v > kFrontMax ? kFrontMax : v); }();
         if (n_front > 0) {
             hipLaunchKernelGGL(mark_front_kernel, dim3((blocks + kFrontTiles - 1) / kFrontTiles), dim3(kBlock), 0, st, (int)blocks,
-                               im.ranges, plist, g.front, n_front);
+                               im.ranges, plist, g.front, n_front, g.color_src);
             hipLaunchKernelGGL(resolve_marked_kernel, dim3((f.P + kBlock * kMarkedPer - 1) / (kBlock * kMarkedPer)), dim3(kBlock), 0, st,
                                f, g);
         }
@@ -471,31 +473,40 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         }
         if (parked) drain(parked);
         __syncthreads();
-        // flush: 16 lanes per staged Gaussian turn the raw sums into gradients; one 64-byte row per request
-        const int comp = tid & 15;
-#pragma unroll 4
-        for (int it = 0; it < kB2 / 8; ++it) {
-            const int e = it * 8 + (tid >> 4);
-            if (e >= n || comp >= 9) continue;
-            const float* a = s_acc[e];
-            const float sw = a[0];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) any |= (a[k] != 0.0f);
-            if (!any) continue;                               // entry never evaluated by either half tile
-            const float4 co = s_co[e];
-            float v;
-            switch (comp) {
-                case 0: v = -0.5f * (float)f.W * (co.x * a[1] + co.y * a[2]); break;   // dL/dmean2D.x (NDC-scaled)
-                case 1: v = -0.5f * (float)f.H * (co.z * a[2] + co.y * a[1]); break;   // dL/dmean2D.y
-                case 2: v = -0.5f * a[3]; break;                                       // dL/dA
-                case 3: v = -a[4]; break;                                              // dL/dB
-                case 4: v = -0.5f * a[5]; break;                                       // dL/dC
-                case 5: v = sw / co.w; break;                                          // dL/dopacity = sum G dL/dalpha
-                default: v = a[comp]; break;                                           // 6,7,8: rgb
+        // flush, in two steps per wave (a wave handles the 64 staged entries with its own index range, so only the wave has to
+        // agree on LDS): (1) ONE lane per entry turns the raw sums into the nine gradients in place and marks entries that
+        // nobody evaluated; (2) 16 lanes per entry add the row with float atomics, one 64-byte request per Gaussian.
+        // (Before: every one of the 16 lanes of an entry read all nine sums, tested them and ran a switch over its component.)
+        {
+            const int e1 = wave * 64 + lane;
+            if (e1 < n) {
+                float* a = s_acc[e1];
+                const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
+                const bool any = (a0 != 0.0f) | (a1 != 0.0f) | (a2 != 0.0f) | (a3 != 0.0f) | (a4 != 0.0f) | (a5 != 0.0f) |
+                                 (a6 != 0.0f) | (a7 != 0.0f) | (a8 != 0.0f);
+                if (any) {
+                    const float4 co = s_co[e1];
+                    a[0] = -0.5f * (float)f.W * (co.x * a1 + co.y * a2);       // dL/dmean2D.x (NDC-scaled)
+                    a[1] = -0.5f * (float)f.H * (co.z * a2 + co.y * a1);       // dL/dmean2D.y
+                    a[2] = -0.5f * a3;                                         // dL/dA
+                    a[3] = -a4;                                                // dL/dB
+                    a[4] = -0.5f * a5;                                         // dL/dC
+                    a[5] = a0 / co.w;                                          // dL/dopacity = sum G dL/dalpha
+                } else {
+                    s_id[e1] = 0xFFFFFFFFu;                                    // never evaluated by either half tile
+                }
             }
-            atomicAdd(&grad_rows[(size_t)s_id[e] * kRow + comp], v);
-            if (comp == 0) touched[s_id[e]] = 1;              // gradient support (idempotent store)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int comp = lane & 15;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int e = wave * 64 + it * 4 + (lane >> 4);
+                const uint32_t id = e < n ? s_id[e] : 0xFFFFFFFFu;
+                if (id == 0xFFFFFFFFu || comp >= 9) continue;
+                atomicAdd(&grad_rows[(size_t)id * kRow + comp], s_acc[e][comp]);
+                if (comp == 0) touched[id] = 1;                // gradient support (idempotent store)
+            }
         }
     }
 }
