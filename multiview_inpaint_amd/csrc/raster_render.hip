@@ -200,12 +200,17 @@ constexpr int kFrontTiles = 4;
 constexpr int kFrontMax = 1024;
 __global__ __launch_bounds__(kBlock) void mark_front_kernel(int tiles, const uint32_t* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list, uint8_t* __restrict__ front,
-                                                            int n_front, const ColorSource* __restrict__ color_src) {
+                                                            int n_front, const ColorSource* __restrict__ color_src, int gx,
+                                                            int every) {
     if (!color_src->deferred) return;                    // precomputed colours: nothing is pending (the host does not know)
     const int tid = threadIdx.x;
+    // every == 2: only the tiles of even column AND even row name Gaussians (a Gaussian in the leading entries of a tile
+    // covers ~46 tiles of the bench view: it leads a sampled one too; whoever is missed is evaluated by the render kernel)
+    const int sx = (gx + every - 1) / every;
 #pragma unroll
     for (int t = 0; t < kFrontTiles; ++t) {
-        const int tile = blockIdx.x * kFrontTiles + t;
+        const int j = blockIdx.x * kFrontTiles + t;
+        const int tile = every == 1 ? j : (j / sx) * every * gx + (j % sx) * every;
         if (tile >= tiles) break;
         const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
         const uint32_t n = min(r1 - r0, (uint32_t)n_front);
@@ -254,9 +259,11 @@ int launch_render_forward(const Frame& f, GeomView g, BinningView b, ImageView i
         // MVI_RASTER_FRONT_ENTRIES: leading entries per tile evaluated ahead of the render kernel (0: none, A/B runs)
         static const int n_front = [] { const char* e = getenv("MVI_RASTER_FRONT_ENTRIES"); const int v = e ? atoi(e) : kBlock;
                                         return v < 0 ? 0 : (v > kFrontMax ? kFrontMax : v); }();
+        static const int every = [] { const char* e = getenv("MVI_RASTER_FRONT_EVERY"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
         if (n_front > 0) {
-            hipLaunchKernelGGL(mark_front_kernel, dim3((blocks + kFrontTiles - 1) / kFrontTiles), dim3(kBlock), 0, st, (int)blocks,
-                               im.ranges, plist, g.front, n_front, g.color_src);
+            const unsigned sampled = (unsigned)(((f.gx + every - 1) / every) * ((f.gy + every - 1) / every));
+            hipLaunchKernelGGL(mark_front_kernel, dim3((sampled + kFrontTiles - 1) / kFrontTiles), dim3(kBlock), 0, st, (int)blocks,
+                               im.ranges, plist, g.front, n_front, g.color_src, f.gx, every);
             hipLaunchKernelGGL(resolve_marked_kernel, dim3((f.P + kBlock * kMarkedPer - 1) / (kBlock * kMarkedPer)), dim3(kBlock), 0, st,
                                f, g);
         }
