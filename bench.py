@@ -306,6 +306,14 @@ def main():
         # the restated total next to it.
         G = int(st.tensor("grad_support", (N,), torch.uint8).sum().item()) if L.mvi_raster_backward_mode(-1) == 0 else N
         restated = dict(stage_bytes)
+        # Since round 4 the SH rows (12 M bytes per Gaussian) are not read by the preprocess kernel: a colour is evaluated the
+        # first time a tile stages the Gaussian, by the kernels of the render_forward stage (E Gaussians: their SH row, position
+        # and the 17 bytes written back). The restated split moves those bytes; the §8d total stays what it was.
+        rgbd = st.tensor("rgbd", (N, 4), torch.float32)
+        E = int(((radii > 0) & ~(rgbd[:, :3] < 0).any(1)).sum().item()) if L.mvi_raster_color_mode(-1) == 1 else V
+        if E < V:
+            restated["preprocess_forward"] = fwd_b["preprocess_forward"] - N * 12 * M
+            restated["render_forward"] = fwd_b["render_forward"] + E * (12 * M + 12 + 17)
         if G < N:
             restated["render_backward"] = bwd_b["render_backward"] + N * (52 + 12 * M)            # + zero-fill of the outputs
             restated["preprocess_backward"] = N + G * (129 + 12 * M) + G * (52 + 12 * M)           # flags + support rows in / out
@@ -384,7 +392,7 @@ def main():
                                         "formula": "SURVEY.md 8d, dense chain rule (comparable across rounds)",
                                         "restated_bytes": int(sum(restated.values())),
                                         "restated_frac": round(sum(restated.values()) / ms_step / 1e6 / HBM_PEAK_GBS, 5),
-                                        "gradient_support": G},
+                                        "gradient_support": G, "colours_evaluated": E},
                          "compute": {"evaluated_pairs": int(nc.double().sum().item()),
                                      "flops_per_pair": PAIR_FLOPS.get(dom),
                                      "TFLOPs": (round(float(nc.double().sum().item()) * PAIR_FLOPS[dom] / dom_ms / 1e9, 2)
@@ -400,7 +408,9 @@ def main():
             "stages_note": "per-stage times from a separate pass of K steps with every stage bracketed by hipEvents (each "
                            "bracketed boundary idles the GPU ~10 us); the timed region brackets only the roofline kernel. GB/s of "
                            "render_backward / preprocess_backward use the restated bytes (zero-fill inside the render backward, "
-                           "chain rule on the gradient support only), every other stage the SURVEY 8d bytes",
+                           "chain rule on the gradient support only), preprocess_forward / render_forward the restated bytes of the "
+                           "deferred SH colours (SH rows read for the colours_evaluated Gaussians only, by the render_forward stage: "
+                           "mark_front + resolve_marked + render_forward kernels), every other stage the SURVEY 8d bytes",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -22,7 +22,9 @@ STAGE = {"preprocess_forward_kernel": "preprocess_forward", "total_block_sums_ke
          "row_count_kernel": "radix_sort", "row_scan_kernel": "radix_sort",
          "expand_scatter_kernel<2, 128>": "radix_sort", "expand_scatter_kernel<2, 256>": "radix_sort",
          "compact_touched_kernel": "preprocess_backward", "preprocess_backward_sparse_kernel": "preprocess_backward",
-         "zero_regions_kernel": "render_backward"}
+         "zero_regions_kernel": "render_backward",
+         # deferred SH colours (round 4): evaluated ahead of / inside the render kernel, part of its stage
+         "mark_front_kernel": "render_forward", "resolve_marked_kernel": "render_forward", "resolve_colors_kernel": "render_forward"}
 STEPS = None       # launches of a once-per-step kernel in the profiled run (bench.py --steps 5 --warmup 1: 1 warm-up + 5
                    # instrumented + 5 timed = 11), read from the render_backward_kernel entry
 
