@@ -219,6 +219,10 @@ int main(int argc, char** argv) {
         bench(28, 5, 9216, 3);
         return 0;
     }
+    if (argc >= 2 && !strcmp(argv[1], "bench2")) {       // the second large shape of the step (level 1: S = 2304, 10 heads)
+        bench(28, 10, 2304, 6);
+        return 0;
+    }
     if (argc < 2 || strcmp(argv[1], "bench")) {
         fails += check(1, 2, 256, 256, false, 0, 1);
         fails += check(1, 1, 300, 200, false, 0, 2);      // ragged q block, ragged last key tile (200 = 3 * 64 + 8)
