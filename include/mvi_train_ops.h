@@ -84,6 +84,19 @@ int mvi_compact_plan(const uint8_t* keep_mask, int32_t P, void* workspace, size_
 int mvi_compact_gather(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P, uint32_t n_keep,
                        const void* workspace, void* stream);
 
+/* The gather and its inverse over a WINDOW of the plan's row list whose length only the device knows (view-parallel training,
+ * multiview_inpaint_amd/dist.py: the rows of the union of the ranks' gradient supports travel in buffers whose capacity the
+ * host chose from the previous step, so nothing waits for this step's count). With n = min(capacity, *n_keep_device - first)
+ * (0 when first >= *n_keep_device): gather  out[j, :] = in[src_row(first + j), :], in [P, width], out [capacity, width];
+ * scatter out[src_row(first + j), :] = in[j, :], in [capacity, width] (NULL: zeros), out [P, width]; j < n. Other rows of
+ * `out` are not touched. No counterpart in the reference (single GPU, gs-simp/train.sh:1). */
+int mvi_compact_gather_window(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P,
+                              const uint32_t* n_keep_device, uint32_t first, uint32_t capacity, const void* workspace,
+                              void* stream);
+int mvi_compact_scatter_window(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P,
+                               const uint32_t* n_keep_device, uint32_t first, uint32_t capacity, const void* workspace,
+                               void* stream);
+
 const char* mvi_train_last_error(void);
 
 #ifdef __cplusplus

@@ -165,6 +165,9 @@ def _bind_train_ops(L):
     L.mvi_compact_plan.argtypes = [vp, i32, vp, sz, vp, vp]
     L.mvi_compact_gather.restype = C.c_int
     L.mvi_compact_gather.argtypes = [C.POINTER(CompactTensor), i32, i32, C.c_uint32, vp, vp]
+    for f in (L.mvi_compact_gather_window, L.mvi_compact_scatter_window):
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CompactTensor), i32, i32, vp, C.c_uint32, C.c_uint32, vp, vp]
     L.mvi_gaussian_activations.restype = C.c_int
     L.mvi_gaussian_activations.argtypes = [i32, i32] + [vp] * 10
     L.mvi_gaussian_activations_backward.restype = C.c_int

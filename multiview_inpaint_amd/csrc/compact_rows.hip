@@ -110,6 +110,38 @@ __global__ __launch_bounds__(256) void compact_gather_kernel(GatherTable tab, co
     }
 }
 
+// The same gather — and its inverse — for a window [first, first + capacity) of the plan's row list whose length is only known
+// on the device (*n_keep): view-parallel training exchanges the rows of the union of the ranks' gradient supports, sized by a
+// capacity the host chose from the previous step, without waiting for this step's count (multiview_inpaint_amd/dist.py).
+// kScatter = false: out[j, :] = in[src_row(first + j), :];  kScatter = true: out[src_row(first + j), :] = in[j, :] (in == NULL:
+// zeros), for j < min(capacity, n_keep - first). Rows of `out` outside the window are not touched.
+template <bool kScatter>
+__global__ __launch_bounds__(256) void compact_window_kernel(GatherTable tab, const uint32_t* __restrict__ src_rows,
+                                                             const uint32_t* __restrict__ n_keep_dev, uint32_t first,
+                                                             uint32_t capacity) {
+    __shared__ uint32_t s_src[256];
+    const uint32_t n_all = *n_keep_dev;
+    const uint32_t n = n_all > first ? min(capacity, n_all - first) : 0u;
+    const mvi_compact_tensor t = tab.t[blockIdx.y];
+    const uint32_t w = (uint32_t)t.width;
+    const uint32_t* __restrict__ in = (const uint32_t*)t.in;
+    uint32_t* __restrict__ out = (uint32_t*)t.out;
+    const float inv = 1.0f / (float)w;
+    for (uint32_t row0 = blockIdx.x * 256u; row0 < n; row0 += gridDim.x * 256u) {
+        const uint32_t rows = min(256u, n - row0);
+        __syncthreads();
+        if (threadIdx.x < rows) s_src[threadIdx.x] = src_rows[first + row0 + threadIdx.x];
+        __syncthreads();
+        const uint32_t words = rows * w;
+        for (uint32_t e = threadIdx.x; e < words; e += 256u) {
+            const uint32_t j = (uint32_t)(((float)e + 0.5f) * inv);
+            const uint64_t full = (uint64_t)s_src[j] * w + (e - j * w), packed = (uint64_t)row0 * w + e;
+            if (kScatter) out[full] = in ? in[packed] : 0u;
+            else out[packed] = in[full];
+        }
+    }
+}
+
 }  // namespace mvi
 
 // workspace: [nblk + 1] block offsets (256-byte aligned segment) | [P] source rows of the kept entries
@@ -167,4 +199,35 @@ extern "C" int mvi_compact_gather(const mvi_compact_tensor* tensors_host, int32_
     const uint32_t* rows = cp_rows(const_cast<void*>(workspace), P);
     hipLaunchKernelGGL(compact_gather_kernel, dim3(blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, tab, rows, n_keep);
     return hipGetLastError() == hipSuccess ? MVI_OK : train_fail(MVI_EHIP, "compact_gather: kernel launch failed");
+}
+
+static int compact_window(bool scatter, const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P,
+                          const uint32_t* n_keep_device, uint32_t first, uint32_t capacity, const void* workspace, void* stream) {
+    using namespace mvi;
+    const char* who = scatter ? "compact_scatter_window: bad argument" : "compact_gather_window: bad argument";
+    if (n_tensors < 0 || n_tensors > MVI_COMPACT_MAX_TENSORS || P < 0 || capacity > (uint32_t)P || first > (uint32_t)P) return train_fail(MVI_EINVAL, who);
+    if (n_tensors == 0 || capacity == 0) return MVI_OK;
+    if (!tensors_host || !workspace || !n_keep_device) return train_fail(MVI_EINVAL, who);
+    GatherTable tab;
+    for (int i = 0; i < n_tensors; ++i) {
+        tab.t[i] = tensors_host[i];
+        // a scatter may have no input (zero fill); every other pointer is needed; 256 * width must stay below 2^22 (fp32 row index)
+        if ((!tab.t[i].in && !scatter) || !tab.t[i].out || tab.t[i].width <= 0 || tab.t[i].width > 8192) return train_fail(MVI_EINVAL, who);
+    }
+    uint32_t blocks = (capacity + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    const uint32_t* rows = cp_rows(const_cast<void*>(workspace), P);
+    if (scatter) hipLaunchKernelGGL(compact_window_kernel<true>, dim3(blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, tab, rows, n_keep_device, first, capacity);
+    else hipLaunchKernelGGL(compact_window_kernel<false>, dim3(blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, tab, rows, n_keep_device, first, capacity);
+    return hipGetLastError() == hipSuccess ? MVI_OK : train_fail(MVI_EHIP, "compact window: kernel launch failed");
+}
+extern "C" int mvi_compact_gather_window(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P,
+                                         const uint32_t* n_keep_device, uint32_t first, uint32_t capacity, const void* workspace,
+                                         void* stream) {
+    return compact_window(false, tensors_host, n_tensors, P, n_keep_device, first, capacity, workspace, stream);
+}
+extern "C" int mvi_compact_scatter_window(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P,
+                                          const uint32_t* n_keep_device, uint32_t first, uint32_t capacity, const void* workspace,
+                                          void* stream) {
+    return compact_window(true, tensors_host, n_tensors, P, n_keep_device, first, capacity, workspace, stream);
 }

@@ -208,45 +208,154 @@ class CompactedGradExchange(FactoredGradExchange):
     tile's list saturate its pixels), so the union over 8 views is at most a quarter of the rows.
 
         1. all-reduce(MAX) of the per-rank support bytes [P] (1.5 MB at P = 1.5 M) -> the union, identical on all ranks
-        2. idx = union.nonzero() (one host read-back of its length), u = len(idx) / P
-        3. u <= THRESHOLD: gather the union rows ([n, 11] and [n, 3]), all-reduce / all-gather those, rebuild dL/dSH for
-           them, scatter back into zeroed full-size outputs; else the full-size exchange of the base class
+        2. one scan of the union into a row list (csrc/compact_rows.hip); its length n stays on the device and is copied to
+           pinned host memory on the side
+        3. ONE gather launch packs the union rows of the four small gradients, the colour factors and the positions into
+           buffers of `capacity` rows (capacity = 1.25 x the PREVIOUS step's n, known to the host without waiting), the
+           all-reduce / all-gather run on those, dL/dSH is rebuilt for them, ONE scatter launch writes everything back
+        4. the host then looks at n — an event far upstream of the work just queued, so the device never idles for it — and
+           queues further pages of `capacity` rows if the union outgrew the buffers (exact in every case; round 3 read n back
+           in the middle, built the buffers with torch.cat and scattered with five index_put launches)
+       Unions above THRESHOLD of the rows take the full-size exchange of the base class.
 
-    Wire per GPU: u x the base class's 241 MB (W = 8, M = 16, P = 1.5 M), plus the mask: ~50 MB at u = 0.2. Costs: the mask's
-    all-reduce (latency-bound), one read-back, gather + scatter passes over the compacted rows. Passing a visibility filter
+    Wire per GPU: capacity / P x the base class's 241 MB (W = 8, M = 16, P = 1.5 M), plus the mask: ~35 MB at a union of 10 %.
+    Costs: the mask's all-reduce (latency-bound), plan + gather + scatter + one zero-fill pass over the compacted rows. Passing a visibility filter
     (radii > 0) instead of the support is valid too (any superset of the support is), but compacts little: the union of 8
     views' visibility is 94 % of this scene. The sums are those of FactoredGradExchange (same elements; rows outside the
     union are exact zeros on both paths)."""
 
     THRESHOLD = 0.8
+    HEADROOM = 1.25            # capacity of a step's buffers = HEADROOM x the previous step's union, rounded up to 4096 rows
+    MIN_CAPACITY = 16384
 
     def __init__(self, P: int, M: int, sh_degree: int, device, group=None):
         super().__init__(P, M, sh_degree, device, group=group)
         self.last_union_fraction = None
         self.last_compacted = None
-        self._shs_rows = None          # rows of self.shs that may be non-zero: None = none, "all", or an index tensor
+        self.last_pages = None
+        self.last_capacity = None
+        self._shs_rows = None          # rows of self.shs that may be non-zero: None = none, "all", an index tensor (CPU path) or
+                                       # "plan" (GPU path: the row list of the previous step's plan, self._ws[self._cur ^ 1])
+        self._cap = None               # GPU path: rows the compact buffers hold (None: not allocated yet)
+        self._next_cap = P             # first step: nothing known about the union yet
+
+    # ---- GPU path: nothing in the exchange waits for this step's row count -------------------------------------------------
+    def _alloc(self, cap: int):
+        dev, f32 = self.small.device, dict(dtype=torch.float32, device=self.small.device)
+        self._cap = cap
+        self._small_c = torch.zeros(11 * cap, **f32)               # SoA segments [means3D 3 | opacities 1 | scales 3 | rotations 4] x cap
+        self._send_c = torch.zeros(3 * cap + 3, **f32)
+        self._recv_c = torch.zeros(self.world * (3 * cap + 3), **f32)
+        self._means_c = torch.zeros(cap, 3, **f32)
+        self._sh_c = torch.zeros(cap, self.M, 3, **f32)
+        if getattr(self, "_ws", None) is None:
+            from . import _lib
+            nbytes = _lib.lib().mvi_compact_workspace_bytes(self.P)
+            self._ws_bytes = nbytes
+            self._ws = [torch.empty(nbytes + 256, dtype=torch.uint8, device=dev) for _ in range(2)]   # plan + its count, ping-pong
+            self._cur = 0
+            self._mask = torch.zeros(self.P, dtype=torch.uint8, device=dev)
+            self._count_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._count_ev = torch.cuda.Event()
+
+    def _window(self, scatter: bool, pairs, ws, first: int, cap: int):
+        """One launch of csrc/compact_rows.hip's window kernel over (full [P, w], compact [cap, w]) tensor pairs."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        tab = (_lib.CompactTensor * len(pairs))()
+        for e, (full, comp) in zip(tab, pairs):
+            src, dst = (comp, full) if scatter else (full, comp)
+            e.in_, e.out, e.width = (src.data_ptr() if src is not None else None), dst.data_ptr(), full[0].numel()
+        dev = self.small.device
+        fn = L.mvi_compact_scatter_window if scatter else L.mvi_compact_gather_window
+        with torch.cuda.device(dev):
+            _lib.check(fn(tab, len(pairs), self.P, C.c_void_p(ws.data_ptr() + self._ws_bytes), first, cap, C.c_void_p(ws.data_ptr()),
+                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "compact window")
+
+    def _page(self, means3D, campos, ws, first: int, cap: int):
+        """Rows [first, first + cap) of the union list: gather, exchange, rebuild dL/dSH, scatter back. Buffers are cut to `cap`
+        rows; rows past the list's end (the device knows where it ends) carry stale values that travel and are never scattered."""
+        names = [name for name, _ in self.SMALL]
+        widths = [w for _, w in self.SMALL]
+        segs, o = [], 0
+        for w in widths:
+            segs.append(self._small_c[o:o + cap * w].view(cap, w))
+            o += cap * w
+        send = self._send_c[:3 * cap + 3]
+        recv = self._recv_c[:self.world * (3 * cap + 3)].view(self.world, 3 * cap + 3)
+        fac_c, means_c, sh_c = send[:3 * cap].view(cap, 3), self._means_c[:cap], self._sh_c[:cap]
+        self._window(False, [(self.views[nm], sg) for nm, sg in zip(names, segs)] +
+                     [(self.views["sh_color_factor"], fac_c), (means3D, means_c)], ws, first, cap)
+        send[3 * cap:].copy_(campos.reshape(3).to(send.dtype))
+        h = td.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)
+        td.all_reduce(self._small_c[:11 * cap], op=td.ReduceOp.SUM, group=self.group)
+        h.wait()
+        sh_grad_from_factors(means_c, recv[:, 3 * cap:], recv[:, :3 * cap].view(self.world, cap, 3), self.M, self.deg, out=sh_c)
+        self._window(True, [(self.views[nm], sg) for nm, sg in zip(names, segs)] + [(self.shs.view(self.P, 3 * self.M), sh_c.view(cap, 3 * self.M))],
+                     ws, first, cap)
+
+    def _exchange_device(self, means3D: torch.Tensor, campos: torch.Tensor, visible: torch.Tensor):
+        import ctypes as C
+        from . import _lib
+        P, dev = self.P, self.small.device
+        cap = max(1, min(P, int(self._next_cap)))
+        if self._cap is None or cap > self._cap or 2 * cap < self._cap:
+            self._alloc(cap)
+        self._cur ^= 1
+        ws, ws_prev = self._ws[self._cur], self._ws[self._cur ^ 1]
+        self._mask.copy_(visible.to(torch.uint8).reshape(-1))
+        td.all_reduce(self._mask, op=td.ReduceOp.MAX, group=self.group)
+        cnt = ws[self._ws_bytes:self._ws_bytes + 4].view(torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mvi_compact_plan(C.c_void_p(self._mask.data_ptr()), P, C.c_void_p(ws.data_ptr()), self._ws_bytes,
+                                                   C.c_void_p(cnt.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "compact_plan")
+        self._count_pin.copy_(cnt, non_blocking=True)            # the host learns the count while the device works on page 0
+        self._count_ev.record()
+        # dL/dSH is zero outside the rows this step writes: clear what the previous step wrote (its row list is still in ws_prev)
+        if self._shs_rows == "plan":
+            self._window(True, [(self.shs.view(P, 3 * self.M), None)], ws_prev, 0, P)
+        elif self._shs_rows is not None:
+            self.shs.zero_()
+        self._page(means3D, campos, ws, 0, cap)
+        self._count_ev.synchronize()                             # upstream of everything queued above: the device is not idle
+        n = int(self._count_pin.item())
+        pages = max(1, -(-n // cap))
+        for p in range(1, pages):                                # the union outgrew the capacity chosen from the previous step
+            self._page(means3D, campos, ws, p * cap, cap)
+        self._shs_rows = "plan"
+        self.last_union_fraction, self.last_compacted, self.last_pages, self.last_capacity = (n / P if P else 0.0), True, pages, cap
+        self._next_cap = min(P, max(self.MIN_CAPACITY, -(-int(self.HEADROOM * n) // 4096) * 4096))
+        g = {name: self.views[name] for name, _ in self.SMALL}
+        g["shs"] = self.shs
+        return g
 
     def exchange_visible(self, means3D: torch.Tensor, campos: torch.Tensor, visible: torch.Tensor):
         """visible [P] bool / uint8: any superset of this rank's gradient support — RasterState.tensor("grad_support", ...)
         after the backward (tight), or the visibility filter radii > 0 (gaussian_renderer/__init__.py:100; loose). Returns
-        the same dict as exchange()."""
+        the same dict as exchange(). GPU tensors: the union rows travel in buffers sized from the PREVIOUS step's union
+        (x HEADROOM), nothing waits for this step's count; if the union outgrew them, further pages follow (exact either
+        way). Unions above THRESHOLD of the rows (previous step) take the full-size exchange of the base class."""
         P = self.P
+        if visible.is_cuda:
+            if self.last_union_fraction is not None and self.last_union_fraction > self.THRESHOLD:
+                # full-size exchange; the union is still measured (on the side) so that a later step can compact again
+                m = visible.to(torch.uint8).reshape(-1).clone()
+                td.all_reduce(m, op=td.ReduceOp.MAX, group=self.group)
+                frac = m.float().mean()
+                out = self.exchange(means3D, campos)
+                self._shs_rows = "all"
+                self.last_union_fraction, self.last_compacted, self.last_pages = float(frac.item()), False, 0
+                self._next_cap = P
+                return out
+            return self._exchange_device(means3D, campos, visible)
         mask = visible.to(torch.uint8).contiguous().clone()
         td.all_reduce(mask, op=td.ReduceOp.MAX, group=self.group)
         names = [name for name, _ in self.SMALL]
-        if mask.is_cuda:
-            # one scan of the mask + ONE gather launch for the row ids, the four small gradients, the colour factors and the
-            # positions (train_ops.compact_rows: the prune kernels of csrc/compact_rows.hip); one read-back (the row count)
-            from .train_ops import compact_rows
-            if getattr(self, "_row_ids", None) is None or self._row_ids.device != mask.device:
-                self._row_ids = torch.arange(P, dtype=torch.int32, device=mask.device)
-            outs = compact_rows(mask, [self._row_ids] + [self.views[nm] for nm in names] +
-                                [self.views["sh_color_factor"], means3D])
-            idx, parts, fac_c, means_c = outs[0].long(), outs[1:1 + len(names)], outs[-2], outs[-1]
-        else:
-            idx = mask.nonzero().squeeze(1)
-            parts = [self.views[nm][idx] for nm in names]
-            fac_c, means_c = self.views["sh_color_factor"][idx], means3D[idx]
+        idx = mask.nonzero().squeeze(1)
+        parts = [self.views[nm][idx] for nm in names]
+        fac_c, means_c = self.views["sh_color_factor"][idx], means3D[idx]
         n = int(idx.numel())                                   # identical on every rank: derived from the reduced mask
         self.last_union_fraction = n / P if P else 0.0
         self.last_compacted = bool(P) and n <= self.THRESHOLD * P

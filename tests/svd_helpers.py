@@ -33,6 +33,8 @@ SMALL_UNET320 = dict(SMALL_UNET, model_channels=320, num_head_channels=64)
 SMALL_CTRL320 = {k: v for k, v in SMALL_UNET320.items() if k != "out_channels"}
 SMALL_CTRL320["hint_channels"] = 7
 LATENT_HW320 = (16, 16)
+# submodules of the UNet whose outputs tests/golden/sgm_c320.npz records (subsampled [:, ::4, ::2, ::2])
+C320_PROBES = ("input_blocks.1", "input_blocks.3", "middle_block", "output_blocks.2")
 
 
 def seeded_state_dict(module, seed):

@@ -786,20 +786,21 @@ def test_ranged_backward_with_overlapped_exchange_equals_one_call(R, N):
 
 def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backward(R):
     """dist.CompactedGradExchange on ONE rank over RCCL with the compaction forced (THRESHOLD = 1), keyed on the gradient
-    support the render backward recorded: gather of the support's rows, all-reduce / all-gather of the compacted buffers, rebuild of dL/dSH for those rows, scatter into zeroed outputs —
-    the sums of one rank are the rank's own gradients, so everything equals rasterize_backward to fp32 rounding, and every
-    invisible row is exactly zero."""
+    support the render backward recorded: gather of the support's rows into capacity-sized buffers, all-reduce / all-gather of
+    those, rebuild of dL/dSH for the rows, scatter back — the sums of one rank are the rank's own gradients, so everything
+    equals rasterize_backward to fp32 rounding, and every row outside the support is exactly zero. Three steps over TWO
+    different views on one exchange object: step 1 has no history (capacity = P, one page), step 2 (the other view) runs with
+    the capacity step 1 left (1.25 x its union) and must clear the dL/dSH rows step 1 wrote, step 3 is forced to a capacity
+    far below its union and has to take several pages."""
     import os
     import socket
     import torch.distributed as td
     from multiview_inpaint_amd import dist as md
     cam, sc, bg = small_scene(19, N=5003, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
+    cam2, _, _ = small_scene(23, N=8, W=200, H=120, deg=3, pose=True)                 # another pose onto the same Gaussians
     t = _to_dev(sc)
-    rs = _settings(R, cam, bg, 3)
     kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
-    color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
     g_img = torch.randn(3, cam["H"], cam["W"], device="cuda", generator=torch.Generator("cuda").manual_seed(5))
-    one = R.rasterize_backward(rs, st, g_img, t["means3D"], **kw)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -809,20 +810,37 @@ def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backwar
     try:
         P, M = t["means3D"].shape[0], t["shs"].shape[1]
         ex = md.CompactedGradExchange(P, M, 3, "cuda")
-        ex.THRESHOLD = 1.0
-        R.rasterize_backward(rs, st, g_img, t["means3D"], out=ex.views, sh_grad="factor", **kw)
-        support = st.tensor("grad_support", (P,), torch.uint8)
-        got = ex.exchange_support(t["means3D"], rs.campos, support)
-        torch.cuda.synchronize()
-        assert ex.last_compacted and 0.0 < ex.last_union_fraction <= float((radii > 0).float().mean())
+        ex.THRESHOLD, ex.MIN_CAPACITY = 1.0, 64
+        fracs = []
+        for step, (c, force_cap) in enumerate(((cam, None), (cam2, None), (cam, 100))):
+            rs = _settings(R, c, bg, 3)
+            color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+            one = R.rasterize_backward(rs, st, g_img, t["means3D"], **kw)
+            R.rasterize_backward(rs, st, g_img, t["means3D"], out=ex.views, sh_grad="factor", **kw)
+            support = st.tensor("grad_support", (P,), torch.uint8)
+            if force_cap is not None:
+                ex._next_cap = force_cap
+            got = ex.exchange_support(t["means3D"], rs.campos, support)
+            torch.cuda.synchronize()
+            assert ex.last_compacted and 0.0 < ex.last_union_fraction <= float((radii > 0).float().mean())
+            n = int(support.sum())
+            assert abs(ex.last_union_fraction * P - n) < 0.5
+            if step == 0:
+                assert ex.last_pages == 1 and ex.last_capacity == P
+            elif step == 1:
+                assert ex.last_pages == 1 and ex.last_capacity < P, (ex.last_pages, ex.last_capacity)
+            else:
+                assert ex.last_pages == -(-n // 100) and ex.last_pages > 3, (ex.last_pages, n)
+            fracs.append(ex.last_union_fraction)
+            vis = support.bool().cpu().numpy()
+            for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+                a, b = got[k].cpu().numpy(), one[k].cpu().numpy()
+                assert a.shape == b.shape, k
+                assert _same_to_summation_order(a, b), (step, k)
+                assert (a[~vis] == 0).all(), (step, k)
+        assert fracs[0] != fracs[1], "the two views were meant to have different supports"
     finally:
         td.destroy_process_group()
-    vis = support.bool().cpu().numpy()
-    for k in ("means3D", "opacities", "scales", "rotations", "shs"):
-        a, b = got[k].cpu().numpy(), one[k].cpu().numpy()
-        assert a.shape == b.shape, k
-        assert _same_to_summation_order(a, b), k
-        assert (a[~vis] == 0).all(), k
 
 
 @pytest.mark.parametrize("N,W,H,deg,mode,log_scale", [(60_000, 640, 368, 3, "sh", None), (3001, 200, 120, 1, "sh", np.log(0.05)),

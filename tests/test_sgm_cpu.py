@@ -304,11 +304,17 @@ def test_production_width_config_matches_reference_golden(golden_dir):
     kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
     xin = torch.cat([inp["x"], inp["concat"]], 1)
     tt = 0.25 * inp["sigma"].log()
+    probes = {}
+    for name in H.C320_PROBES:                  # intermediate block outputs, subsampled like the fixture
+        unet.get_submodule(name).register_forward_hook(
+            lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[:, ::4, ::2, ::2].contiguous()))
     with torch.no_grad():
         y = unet(xin, tt, inp["crossattn"], inp["vector"], **kw)
         ctrls = cnet(xin, inp["control_hint"], tt, inp["crossattn"], inp["vector"], **kw)
         yc = cunet(xin, tt, inp["crossattn"], inp["vector"], control=list(ctrls), **kw)
     assert len(ctrls) == int(G["n_ctrl"])
+    for name in H.C320_PROBES:
+        assert rel(probes[name], G[f"probe_{name}_f32"]) < RTOL, name
     assert rel(y, G["unet_out_f32"]) < RTOL
     assert rel(yc, G["cunet_out_f32"]) < RTOL
     assert rel(ctrls[-1], G["ctrl_last_f32"]) < RTOL

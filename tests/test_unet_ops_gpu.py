@@ -931,7 +931,8 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     openaimodel.py:256-354, video_model.py:12-81, video_attention.py:110-141; precision recipe models/csvd.py:27-31.
     Bar, in bf16 and in f16 (the reference's own GPU recipe): the build's error against the reference's fp32 output is at most 2x the
     error of the reference's OWN autocast run in that type, per tensor, in max norm and in rms (fixture tests/golden/sgm_c320.npz,
-    generated from the imported reference by tools/gen_golden_sgm_c320.py)."""
+    generated from the imported reference by tools/gen_golden_sgm_c320.py) — for the three final tensors AND for four
+    intermediate block outputs of the UNet (first level-0 block, first level-1 block, middle block, an output block; round 4)."""
     from sgm.modules.diffusionmodules.video_model import VideoUNet
     from models.csvd import ControlNet, ControlledVideoUNet
     from multiview_inpaint_amd import _lib
@@ -958,6 +959,12 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     hip_ops.PROFILE = []
     try:
         LY.CONV_N320_MIN_BLOCKS = 1              # (a launch-size gate of the 576x1024 step: a 16x16 latent is far below it)
+        # intermediate block outputs of the UNet (same submodule names as the reference: the state-dict keys are identical),
+        # subsampled like the fixture: a wrong block that later layers wash out must not pass on the final tensors alone
+        probes, handles = {}, []
+        for name in H.C320_PROBES:
+            handles.append(unet.get_submodule(name).register_forward_hook(
+                lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[:, ::4, ::2, ::2].contiguous())))
         with torch.no_grad():
             y = unet(xin, tt, ctx, vec, **kw)
             ctrls = cnet(xin, hint, tt, ctx, vec, **kw)
@@ -967,6 +974,8 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     finally:
         LY.CONV_N320_MIN_BLOCKS = old
         hip_ops.PROFILE = None
+        for hd in handles:
+            hd.remove()
     count = lambda k: sum(1 for x in kinds if x == k)
     # per network: 5 VideoResBlocks (UNet: 2 down, middle 2, ... ) — every one token-major: 2 spatial + 2 frame convolutions each
     n_vrb = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ == "VideoResBlock")
@@ -976,7 +985,8 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     assert count("conv3x3_n320") == 2 * n_vrb + n_updown + 1 and count("planes_to_tokens") == n_updown + 1
     assert count("attention_temporal") > 0 and count("groupnorm_tok2tok") == 3 * n_vrb
     worst = 0.0
-    for name, got in (("unet_out", y), ("cunet_out", yc), ("ctrl_last", ctrls[-1])):
+    assert set(probes) == set(H.C320_PROBES)
+    for name, got in [("unet_out", y), ("cunet_out", yc), ("ctrl_last", ctrls[-1])] + [("probe_" + k, probes[k]) for k in H.C320_PROBES]:
         ref = G[name + "_f32"]
         e_max, e_rms = _err(got.float(), ref)
         r_max, r_rms = _err(torch.tensor(G[name + "_" + tag]), ref)

@@ -6,8 +6,8 @@ meet outputs the reference itself produced:
   * the same modules under the reference's own reduced-precision recipe — autocast over fp32 weights
     (svd_inpaint1/models/csvd.py:27-31, configs/test/svd_f_est_ctrl_simp1.yaml:214) — in bf16 and f16 on the CPU
     (`*_bf16ac`, `*_f16ac`): the error budget the build's reduced-precision path is held to.
-Run ONLY in the build container. Fixture = reference OUTPUTS for seeded inputs/weights (the two network outputs and the last
-control residual).
+Run ONLY in the build container. Fixture = reference OUTPUTS for seeded inputs/weights (the two network outputs, the last
+control residual and four subsampled intermediate block outputs of the UNet).
 
 Usage: python tools/gen_golden_sgm_c320.py
 """
@@ -42,8 +42,21 @@ xin = torch.cat([inp["x"], inp["concat"]], 1)
 tt = 0.25 * inp["sigma"].log()
 
 
+# Intermediate block outputs of the plain UNet (round 4: a wrong block that the later layers wash out would pass a test of the
+# final tensors only): the first level-0 block with its transformer, the first block of level 1, the middle block and the
+# second-to-last output block, subsampled [:, ::4, ::2, ::2] (1/16 of the elements) to keep the fixture small.
+PROBES = H.C320_PROBES
+_seen = {}
+for name in PROBES:
+    mod = unet.get_submodule(name)
+    mod.register_forward_hook(lambda m, i, o, name=name: _seen.__setitem__(name, o.detach().float()[:, ::4, ::2, ::2].contiguous().numpy()))
+
+
 def run(tag):
+    _seen.clear()
     y = unet(xin, tt, inp["crossattn"], inp["vector"], **kw)
+    for name in PROBES:
+        out[f"probe_{name}_{tag}"] = _seen[name]
     ctrls = cnet(xin, inp["control_hint"], tt, inp["crossattn"], inp["vector"], **kw)
     yc = cunet(xin, tt, inp["crossattn"], inp["vector"], control=[c.clone() for c in ctrls], **kw)
     out["unet_out_" + tag] = y.float().numpy()
