@@ -225,8 +225,9 @@ class CompactedGradExchange(FactoredGradExchange):
     union are exact zeros on both paths)."""
 
     THRESHOLD = 0.8
-    HEADROOM = 1.25            # capacity of a step's buffers = HEADROOM x the previous step's union, rounded up to 4096 rows
+    HEADROOM = 1.25            # capacity of a step's buffers = HEADROOM x the previous step's union, rounded up to ROUND rows
     MIN_CAPACITY = 16384
+    ROUND = 4096
 
     def __init__(self, P: int, M: int, sh_degree: int, device, group=None):
         super().__init__(P, M, sh_degree, device, group=group)
@@ -326,7 +327,7 @@ class CompactedGradExchange(FactoredGradExchange):
             self._page(means3D, campos, ws, p * cap, cap)
         self._shs_rows = "plan"
         self.last_union_fraction, self.last_compacted, self.last_pages, self.last_capacity = (n / P if P else 0.0), True, pages, cap
-        self._next_cap = min(P, max(self.MIN_CAPACITY, -(-int(self.HEADROOM * n) // 4096) * 4096))
+        self._next_cap = min(P, max(self.MIN_CAPACITY, -(-int(self.HEADROOM * n) // self.ROUND) * self.ROUND))
         g = {name: self.views[name] for name, _ in self.SMALL}
         g["shs"] = self.shs
         return g

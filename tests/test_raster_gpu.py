@@ -797,7 +797,9 @@ def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backwar
     import torch.distributed as td
     from multiview_inpaint_amd import dist as md
     cam, sc, bg = small_scene(19, N=5003, W=200, H=120, deg=3, pose=True, log_scale=np.log(0.05))
-    cam2, _, _ = small_scene(23, N=8, W=200, H=120, deg=3, pose=True)                 # another pose onto the same Gaussians
+    rng = np.random.default_rng(19)                                                    # small_scene's own pose, moved sideways
+    R0, T0 = syn.random_rotation(rng), rng.normal(size=3)
+    cam2 = syn.make_camera(200, 120, 50.0, R0, T0 + np.array([0.6, -0.2, 0.3]))
     t = _to_dev(sc)
     kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
     g_img = torch.randn(3, cam["H"], cam["W"], device="cuda", generator=torch.Generator("cuda").manual_seed(5))
@@ -810,8 +812,8 @@ def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backwar
     try:
         P, M = t["means3D"].shape[0], t["shs"].shape[1]
         ex = md.CompactedGradExchange(P, M, 3, "cuda")
-        ex.THRESHOLD, ex.MIN_CAPACITY = 1.0, 64
-        fracs = []
+        ex.THRESHOLD, ex.MIN_CAPACITY, ex.ROUND = 1.0, 64, 64
+        fracs, prev_n = [], None
         for step, (c, force_cap) in enumerate(((cam, None), (cam2, None), (cam, 100))):
             rs = _settings(R, c, bg, 3)
             color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
@@ -828,10 +830,12 @@ def test_visibility_compacted_exchange_on_one_rccl_rank_equals_the_plain_backwar
             if step == 0:
                 assert ex.last_pages == 1 and ex.last_capacity == P
             elif step == 1:
-                assert ex.last_pages == 1 and ex.last_capacity < P, (ex.last_pages, ex.last_capacity)
+                want = min(P, max(64, -(-int(1.25 * prev_n) // 64) * 64))
+                assert ex.last_capacity == want and ex.last_pages == -(-n // want), (ex.last_pages, ex.last_capacity, want, n)
             else:
                 assert ex.last_pages == -(-n // 100) and ex.last_pages > 3, (ex.last_pages, n)
             fracs.append(ex.last_union_fraction)
+            prev_n = n
             vis = support.bool().cpu().numpy()
             for k in ("means3D", "opacities", "scales", "rotations", "shs"):
                 a, b = got[k].cpu().numpy(), one[k].cpu().numpy()
