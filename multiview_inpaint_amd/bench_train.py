@@ -3,6 +3,10 @@ the optimizer step): parameter activations -> rasterize -> L1 + DSSIM loss -> ba
 1920x1080, sh_degree 3, synthetic scene. Two variants of everything AROUND the HIP rasterizer:
   hip_raw: raw parameters straight into the rasterizer (GaussianRasterizer.forward_raw), fused loss, fused Adam
   hip   : multiview_inpaint_amd.train_ops (fused activations, fused loss, fused Adam)
+  patched: what an UNCHANGED gs-simp/train.py gets under `python -m multiview_inpaint_amd.dropin.patch_gs_simp train.py ...`:
+          the reference's own activations (exp / normalize / sigmoid / cat), its loss expression
+          (1 - l) * l1_loss(image, gt) + l * (1 - ssim(image, gt)) with the two functions swapped for train_ops' (one fused kernel
+          pair EACH), FusedAdam in place of the torch.optim.Adam its training_setup creates
   torch : the reference's own PyTorch-ROCm formulation (exp / normalize / sigmoid / cat, loss_utils-style SSIM with
           five depthwise convs, torch.optim.Adam)
 Usage (GPU box): python -m multiview_inpaint_amd.bench_train [--steps 20]; bench.py reports the same numbers as
@@ -37,7 +41,7 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
     prm = {k: torch.nn.Parameter(v.clone()) for k, v in raw.items()}
     lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3)
     groups = [{"params": [prm[k]], "lr": lrs[k], "name": k} for k in prm]
-    opt = (T.FusedAdam if variant.startswith("hip") else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+    opt = (T.FusedAdam if variant != "torch" else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
     rs = R.GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
         scale_modifier=1.0, viewmatrix=torch.tensor(cam["viewmatrix"], device=dev),
@@ -64,7 +68,12 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
         means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
         image, radii, depth = rast(means3D=prm["xyz"], means2D=means2D, shs=shs, colors_precomp=None, opacities=opac,
                                    scales=scales, rotations=rots, cov3D_precomp=None)
-        loss = T.fused_l1_dssim_loss(image, gt, 0.2) if variant == "hip" else torch_loss(image, gt)
+        if variant == "hip":
+            loss = T.fused_l1_dssim_loss(image, gt, 0.2)
+        elif variant == "patched":                          # gs-simp/train.py:91-92 with the patched names
+            loss = (1.0 - 0.2) * T.l1_loss(image, gt) + 0.2 * (1.0 - T.ssim(image, gt))
+        else:
+            loss = torch_loss(image, gt)
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -84,13 +93,14 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
 
 
 def run_both(steps=20, warmup=3):
-    out = [run(v, steps, warmup) for v in ("hip_raw", "hip", "torch")]
+    out = [run(v, steps, warmup) for v in ("hip_raw", "hip", "patched", "torch")]
     return {"workload": "full 3DGS training iteration (activations, rasterize, L1+DSSIM, backward, Adam), N=1.5M, 1920x1080, "
                         "sh_degree 3; the HIP rasterizer in both variants, the ops around it fused HIP vs PyTorch-ROCm ops",
             "variants": {"hip_raw": "raw parameters into the rasterizer (activations + SH concat inside the preprocess kernels), "
                                     "fused loss, fused Adam", "hip": "fused activation kernel + standard rasterizer entry, fused "
-                                    "loss, fused Adam", "torch": "PyTorch-ROCm ops for activations, loss and Adam"},
-            "results": out, "speedup_of_the_surrounding_ops": round(out[2]["ms_per_iteration"] / out[0]["ms_per_iteration"], 2)}
+                                    "loss, fused Adam", "patched": "an unchanged train.py under dropin.patch_gs_simp: PyTorch activations, "
+                         "l1_loss + ssim swapped for the fused kernels (two calls), FusedAdam", "torch": "PyTorch-ROCm ops for activations, loss and Adam"},
+            "results": out, "speedup_of_the_surrounding_ops": round(out[3]["ms_per_iteration"] / out[0]["ms_per_iteration"], 2)}
 
 
 if __name__ == "__main__":
