@@ -94,7 +94,9 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     __shared__ float s_t2[kBlock];
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_cd[kBlock];                 // r, g, b, depth
-    __shared__ float4 w_a[4][64], w_co[4][64], w_cd[4][64];   // per-wave compacted strip: (x, y, list position, -)
+    // per-wave compacted strip: [0] (x, y, list position, -), [1] conic + opacity, [2] colour + depth — ONE array, so that the
+    // three reads of an entry share one address register (constant offsets) instead of costing an address add each
+    __shared__ float4 w_s[4][3][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the backward's accumulation rows (and the touched flags) are zeroed HERE: this kernel is issue-bound with the memory
     // pipes nearly idle, so the 65 bytes per Gaussian ride along for free instead of costing a 96 MB fill pass in front of
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const int rounds = (todo + kBlock - 1) / kBlock;
 
     float T = inside ? 1.0f : 0.0f;                 // 0 = this pixel takes no further contributions
-    float T_out = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = kDepthSentinel;
+    float T_out = 1.0f, C2 = 0.f, Dp = kDepthSentinel;
+    f2 C01 = {0.f, 0.f};                            // red, green: one packed fma on the (aligned) first two registers of the colour
     uint32_t last = 0;
 
     // Deferred SH colours (raster_common.h, ColorSource): rgbd holds (-1, -1, -1, depth) until somebody needs the colour.
@@ -150,15 +153,16 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
             if (keep) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 const float2 q = s_xy[e];
-                w_a[wave][pos] = make_float4(q.x, q.y, __uint_as_float((uint32_t)(r * kBlock + e + 1)), 0.f);
-                w_co[wave][pos] = s_co[e];
-                w_cd[wave][pos] = s_cd[e];
+                w_s[wave][0][pos] = make_float4(q.x, q.y, __uint_as_float((uint32_t)(r * kBlock + e + 1)), 0.f);
+                w_s[wave][1][pos] = s_co[e];
+                w_s[wave][2][pos] = s_cd[e];
             }
             const int cnt = __popcll(mask);
-            float4 a = w_a[wave][0], co = w_co[wave][0], cd = w_cd[wave][0];
+            float4 a = w_s[wave][0][0], co = w_s[wave][1][0], cd = w_s[wave][2][0];
             for (int k = 0; k < cnt; ++k) {
                 const int kn = k + 1 < 64 ? k + 1 : 63;
-                const float4 an = w_a[wave][kn], con = w_co[wave][kn], cdn = w_cd[wave][kn];   // next entry's reads overlap the math
+                const float4* nx = &w_s[wave][0][kn];
+                const float4 an = nx[0], con = nx[64], cdn = nx[128];   // next entry's reads overlap the math
                 float dx = a.x - pfx, dy = a.y - pfy;
                 float power = gauss_power1(co, dx, dy);
                 float alpha = fminf(kAlphaMax, co.w * __expf(power));
@@ -167,9 +171,12 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
                 const bool valid = alpha >= kAlphaMin;
                 const bool contrib = valid && test_T >= kTEps;
                 const float w = contrib ? alpha * T : 0.0f;
-                C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                const float Tn = contrib ? test_T : T;
-                Dp = (T > 0.5f && Tn < 0.5f) ? cd.w : Dp;               // median depth of the w-depth fork
+                C01 = pk_fma(f2{cd.x, cd.y}, splat(w), C01);
+                C2 = __builtin_fmaf(cd.z, w, C2);
+                // median depth of the w-depth fork = depth of the entry that takes T from above 0.5 to below it. Every
+                // contributing entry met while T > 0.5 overwrites the candidate: the last of them is that entry if T ever gets
+                // below 0.5 (checked once, after the loop), and two instructions per entry cheaper than testing the crossing here
+                Dp = (contrib && T > 0.5f) ? cd.w : Dp;
                 T_out = contrib ? test_T : T_out;
                 last = contrib ? __float_as_uint(a.z) : last;           // 1-based position in the tile's list
                 T = contrib ? test_T : (valid ? 0.0f : T);              // valid but below 1e-4: saturated from here on
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
         size_t pix = (size_t)pyi * f.W + pxi, hw = (size_t)f.H * f.W;
         final_T[pix] = T_out;
         n_contrib[pix] = last;
-        out_color[pix] = C0 + T_out * f.bg[0];
-        out_color[hw + pix] = C1 + T_out * f.bg[1];
+        out_color[pix] = C01.x + T_out * f.bg[0];
+        out_color[hw + pix] = C01.y + T_out * f.bg[1];
         out_color[2 * hw + pix] = C2 + T_out * f.bg[2];
-        out_depth[pix] = Dp;
+        out_depth[pix] = T_out < 0.5f ? Dp : kDepthSentinel;          // never crossed 0.5: the sentinel (gs-simp/gen_seq.py:50)
     }
 }
 
