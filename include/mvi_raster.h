@@ -188,9 +188,10 @@ typedef struct mvi_raster_views {
     const float* cov3D_a;         /* [P,4] xx, xy, xz, yy */
     const float* cov3D_b;         /* [P,2] yz, zz */
     const float* conic_opacity;   /* [P,4] */
-    const float* rgbd;            /* [P,4] r, g, b, depth */
+    const float* rgbd;            /* [P,4] r, g, b, depth; deferred SH colours (the default): (-1, -1, -1, depth) for a visible
+                                   * Gaussian no tile has staged yet — see mvi_raster_color_mode / mvi_raster_resolve_colors */
     const uint32_t* tiles_touched;/* [P] */
-    const uint8_t* clamped;       /* [P] bit c = colour channel c clamped at 0 */
+    const uint8_t* clamped;       /* [P] bit c = colour channel c clamped at 0 (0 while the colour is pending) */
     const void* tile_ids_sorted;  /* [D] high word of the sort key, tile_id_bytes (2 or 4) per entry; the full key of
                                    * pair i is tile_ids_sorted[i] << 32 | bits(depths[point_list[i]]) */
     const uint32_t* point_list;   /* [D] Gaussian index per sorted pair */
