@@ -370,7 +370,14 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const f2 T_final = {in0 ? final_T[pix0] : 0.0f, in1 ? final_T[pix1] : 0.0f};
     f2 T = T_final;
     const uint32_t last0 = in0 ? n_contrib[pix0] : 0u, last1 = in1 ? n_contrib[pix1] : 0u;
-    f2 acc_dot = {0.f, 0.f}, lc_dot = {0.f, 0.f}, last_alpha = {0.f, 0.f};
+    // The reference's recurrence carries (accum_rec, last_color, last_alpha) per pixel and forms
+    //     a_dot = last_alpha * last_color + (1 - last_alpha) * accum_rec
+    // when the next contributing entry arrives. Here ONE value per pixel is carried: that a_dot for the next entry, updated by
+    // the entry that changes it — A <- alpha * c_dot + (1 - alpha) * A, the same expression with the same operands, evaluated
+    // one entry earlier (same bits). An entry that is not active for a pixel enters with alpha = 0 and o G = 0: A, T and every
+    // moment are then unchanged by plain arithmetic (1 - 0 = 1, rcp(1) = 1, 0 * x = 0), so the eight selects that used to keep
+    // six state values apart for the two pixels are two selects on alpha and two on o G.
+    f2 A_dot = {0.f, 0.f};
     f2 dp0 = {0.f, 0.f}, dp1 = {0.f, 0.f}, dp2 = {0.f, 0.f};
     if (in0) { dp0.x = dL_dpix[pix0]; dp1.x = dL_dpix[hw + pix0]; dp2.x = dL_dpix[2 * hw + pix0]; }
     if (in1) { dp0.y = dL_dpix[pix1]; dp1.y = dL_dpix[hw + pix1]; dp2.y = dL_dpix[2 * hw + pix1]; }
@@ -444,19 +451,16 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const bool act0 = pos < last0 && power.x <= 0.0f && alpha.x >= kAlphaMin;
                 const bool act1 = pos < last1 && power.y <= 0.0f && alpha.y >= kAlphaMin;
                 const unsigned long long any_active = ballot64(act0) | ballot64(act1);
-                const f2 om = splat(1.0f) - alpha;                   // in [0.01, 1]
+                const f2 am = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};          // alpha, o G of the ACTIVE pixels, else 0
+                const f2 gm = {act0 ? oG.x : 0.0f, act1 ? oG.y : 0.0f};
+                const f2 om = splat(1.0f) - am;                      // in [0.01, 1]; exactly 1 for an inactive pixel
                 const f2 inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const f2 Tn = T * inv;
+                const f2 Tn = T * inv;                               // (= T for an inactive pixel)
                 const f2 c_dot = pk_fma(splat(col.z), dp2, pk_fma(splat(col.y), dp1, col.x * dp0));
-                const f2 a_dot = pk_fma(last_alpha, lc_dot, (splat(1.0f) - last_alpha) * acc_dot);
-                const f2 dL_dalpha = pk_fma(c_dot - a_dot, Tn, bg_term * inv);
-                f2 dch = alpha * Tn, mw = oG * dL_dalpha;
-                dch.x = act0 ? dch.x : 0.0f; dch.y = act1 ? dch.y : 0.0f;
-                mw.x = act0 ? mw.x : 0.0f;   mw.y = act1 ? mw.y : 0.0f;
-                T.x = act0 ? Tn.x : T.x;             T.y = act1 ? Tn.y : T.y;
-                acc_dot.x = act0 ? a_dot.x : acc_dot.x; acc_dot.y = act1 ? a_dot.y : acc_dot.y;
-                lc_dot.x = act0 ? c_dot.x : lc_dot.x;   lc_dot.y = act1 ? c_dot.y : lc_dot.y;
-                last_alpha.x = act0 ? alpha.x : last_alpha.x; last_alpha.y = act1 ? alpha.y : last_alpha.y;
+                const f2 dL_dalpha = pk_fma(c_dot - A_dot, Tn, bg_term * inv);
+                const f2 dch = am * Tn, mw = gm * dL_dalpha;
+                T = Tn;
+                A_dot = pk_fma(am, c_dot, om * A_dot);
                 if (any_active != 0ull) {                       // wave-uniform
                     const f2 vr = dch * dp0, vg = dch * dp1, vb = dch * dp2;
                     const f2 vx = mw * dx, vy = mw * dy;
