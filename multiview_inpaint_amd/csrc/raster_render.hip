@@ -450,9 +450,11 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const f2 alpha = __builtin_elementwise_min(splat(kAlphaMax), oG);
                 const bool act0 = pos < last0 && power.x <= 0.0f && alpha.x >= kAlphaMin;
                 const bool act1 = pos < last1 && power.y <= 0.0f && alpha.y >= kAlphaMin;
-                const unsigned long long any_active = ballot64(act0) | ballot64(act1);
                 const f2 am = {act0 ? alpha.x : 0.0f, act1 ? alpha.y : 0.0f};          // alpha, o G of the ACTIVE pixels, else 0
                 const f2 gm = {act0 ? oG.x : 0.0f, act1 ? oG.y : 0.0f};
+                // (an active alpha is >= 1/255: nonzero bits. Asking the two lane predicates themselves made the compiler
+                // materialise them as 0 / 1 and compare again: four vector instructions per entry)
+                const unsigned long long any_active = ballot64((__float_as_uint(am.x) | __float_as_uint(am.y)) != 0u);
                 const f2 om = splat(1.0f) - am;                      // in [0.01, 1]; exactly 1 for an inactive pixel
                 const f2 inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                 const f2 Tn = T * inv;                               // (= T for an inactive pixel)
@@ -500,8 +502,11 @@ __global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             if (e1 < n) {
                 float* a = s_acc[e1];
                 const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
-                const bool any = (a0 != 0.0f) | (a1 != 0.0f) | (a2 != 0.0f) | (a3 != 0.0f) | (a4 != 0.0f) | (a5 != 0.0f) |
-                                 (a6 != 0.0f) | (a7 != 0.0f) | (a8 != 0.0f);
+                // any sum != 0 (as floats: +0 and -0 both count as zero), on the bit patterns: nine compares and their 0 / 1
+                // bookkeeping became five bitwise instructions and one compare
+                const bool any = (((__float_as_uint(a0) | __float_as_uint(a1) | __float_as_uint(a2)) |
+                                   (__float_as_uint(a3) | __float_as_uint(a4) | __float_as_uint(a5)) |
+                                   (__float_as_uint(a6) | __float_as_uint(a7) | __float_as_uint(a8))) & 0x7FFFFFFFu) != 0u;
                 if (any) {
                     const float4 co = s_co[e1];
                     a[0] = -0.5f * (float)f.W * (co.x * a1 + co.y * a2);       // dL/dmean2D.x (NDC-scaled)
