@@ -37,6 +37,22 @@ LATENT_HW320 = (16, 16)
 C320_PROBES = ("input_blocks.1", "input_blocks.3", "middle_block", "output_blocks.2")
 
 
+# The FULL-SIZE configuration of BASELINE.json configs[3] (configs/test/svd_f_est_ctrl_simp1.yaml:19-61: model_channels 320,
+# channel_mult [1, 2, 4, 4], 2 ResBlocks per level, attention at 4 / 2 / 1) on the 72x128 latent of 14 x 576x1024 frames, CFG batch 28
+# — tests/golden/sgm_full.npz (tools/gen_golden_sgm_full.py). The reference side runs it with the plain softmax attention and
+# without gradient checkpointing (the same arithmetic).
+FULL_UNET = dict(in_channels=8, out_channels=4, model_channels=320, channel_mult=[1, 2, 4, 4], num_res_blocks=2,
+                 attention_resolutions=[4, 2, 1], num_head_channels=64, transformer_depth=1, context_dim=1024,
+                 adm_in_channels=768, num_classes="sequential", use_linear_in_transformer=True, extra_ff_mix_layer=True,
+                 use_spatial_context=True, merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1],
+                 use_checkpoint=False, spatial_transformer_attn_type="softmax")
+FULL_CTRL = {k: v for k, v in FULL_UNET.items() if k != "out_channels"}
+FULL_CTRL["hint_channels"] = 7
+FULL_T, FULL_HW = 14, (72, 128)
+FULL_PROBES = ("input_blocks.1", "input_blocks.7", "middle_block", "output_blocks.10")     # recorded subsampled [::7, ::16, ::4, ::4]
+FULL_SUB = (slice(None, None, 7), slice(None, None, 16), slice(None, None, 4), slice(None, None, 4))
+
+
 def seeded_state_dict(module, seed):
     """Every parameter/buffer re-drawn (zero-initialised ones too, SURVEY.md §8c caveat) in sorted-key order."""
     g = torch.Generator().manual_seed(seed)

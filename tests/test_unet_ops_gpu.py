@@ -996,6 +996,66 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
           f"implicit-GEMM kernel; worst error ratio to the reference's own autocast error = {worst:.2f}")
 
 
+def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, strict):
+    """BASELINE.json configs[3] at its REAL size against the reference itself (round 4): ControlNet + ControlledVideoUNet of
+    configs/test/svd_f_est_ctrl_simp1.yaml (1.52 B + 0.68 B parameters), 14 frames on the 72 x 128 latent, CFG batch 28, bf16 on the
+    HIP path (8-wave MFMA attention at S = 9216 and 2304, implicit-GEMM convolutions at every level, token-major VideoResBlocks,
+    hipBLASLt / MIOpen for the rest) against tests/golden/sgm_full.npz: ONE evaluation of the imported reference on the CPU in
+    fp32, plus the same evaluation under the reference's own bf16 autocast as the error budget (tools/gen_golden_sgm_full.py;
+    seeded weights and inputs, regenerated here bit for bit). Bar as at the production widths: error against the reference's
+    fp32 output <= 2 x the reference's own autocast error, in max norm and in rms, for the network output, the last control
+    residual and four intermediate block outputs (subsampled in the fixture)."""
+    from models.csvd import ControlNet, ControlledVideoUNet
+    from multiview_inpaint_amd.svd import bench_svd, hip_ops
+    path = os.path.join(golden_dir, "sgm_full.npz")
+    assert os.path.exists(path), "tests/golden/sgm_full.npz is missing (tools/gen_golden_sgm_full.py, build container only)"
+    G = np.load(path)
+    torch.backends.cudnn.benchmark = False
+    bench_svd.use_shipped_miopen_db()
+    dt = torch.bfloat16
+    nets = []
+    for cls, cfg, seed in ((ControlledVideoUNet, H.FULL_UNET, 71), (ControlNet, H.FULL_CTRL, 72)):
+        with torch.device("meta"):
+            m = cls(**cfg)
+        m.load_state_dict(H.seeded_state_dict(m, seed), strict=True, assign=True)      # the seeded tensors become the parameters
+        nets.append(m.eval().cuda().to(dt))
+    cunet, cnet = nets
+    T = H.FULL_T
+    inp = H.seeded_inputs(73, T=T, hw=H.FULL_HW, cfg=H.FULL_UNET)
+    inp["image_only_indicator"][0, 1] = 1.0
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    kw = dict(num_video_frames=T, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1).to(dt)
+    tt = 0.25 * inp["sigma"].log()
+    ctx, vec, hint = inp["crossattn"].to(dt), inp["vector"].to(dt), inp["control_hint"].to(dt)
+    probes, handles = {}, []
+    for name in H.FULL_PROBES:
+        handles.append(cunet.get_submodule(name).register_forward_hook(
+            lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[H.FULL_SUB].contiguous())))
+    hip_ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            ctrls = cnet(xin, hint, tt, ctx, vec, **kw)
+            yc = cunet(xin, tt, ctx, vec, control=list(ctrls), **kw)
+        torch.cuda.synchronize()
+        prof = list(hip_ops.PROFILE)
+    finally:
+        hip_ops.PROFILE = None
+        for hd in handles:
+            hd.remove()
+    assert len(ctrls) == int(G["n_ctrl"]) and torch.isfinite(yc).all()
+    big = [wk for kind, _, _, wk in prof if kind == "attention_mfma"]
+    assert big and max(big) == 4.0 * 28 * 5 * 9216 * 9216 * 64, "the level-0 self-attention did not run the MFMA kernel"
+    worst = 0.0
+    for name, got in [("cunet_out", yc.float()), ("ctrl_last", ctrls[-1].float()[H.FULL_SUB])] + [("probe_" + k, probes[k]) for k in H.FULL_PROBES]:
+        ref = G[name + "_f32"]
+        e_max, e_rms = _err(got, ref)
+        r_max, r_rms = (float(v) for v in G["budget_" + name])       # the reference's own bf16-autocast error against the same fp32 tensor
+        worst = max(worst, e_max / r_max, e_rms / r_rms)
+        assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
+    print(f"full-size step vs the reference: worst error ratio to the reference's own bf16 autocast error = {worst:.2f}")
+
+
 def _attn_ref_chunked(q, k, v, heads, rows=1536):
     """fp64 softmax(QK^T d^-1/2)V, one head and a block of query rows at a time (S = 9216 does not fit otherwise)."""
     B, Sq, HD = q.shape
