@@ -996,13 +996,15 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
           f"implicit-GEMM kernel; worst error ratio to the reference's own autocast error = {worst:.2f}")
 
 
-def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, strict):
+@pytest.mark.parametrize("dt,budget", [(torch.bfloat16, "budget_"), (torch.float16, "budget_f16_")])
+def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, strict, dt, budget):
     """BASELINE.json configs[3] at its REAL size against the reference itself (round 4): ControlNet + ControlledVideoUNet of
     configs/test/svd_f_est_ctrl_simp1.yaml (1.52 B + 0.68 B parameters), 14 frames on the 72 x 128 latent, CFG batch 28, bf16 on the
     HIP path (8-wave MFMA attention at S = 9216 and 2304, implicit-GEMM convolutions at every level, token-major VideoResBlocks,
     hipBLASLt / MIOpen for the rest) against tests/golden/sgm_full.npz: ONE evaluation of the imported reference on the CPU in
-    fp32, plus the same evaluation under the reference's own bf16 autocast as the error budget (tools/gen_golden_sgm_full.py;
-    seeded weights and inputs, regenerated here bit for bit). Bar as at the production widths: error against the reference's
+    fp32, plus the same evaluation under the reference's own bf16 autocast — and under f16 autocast, the reference's GPU recipe
+    (yaml :214), for the f16 run of this test — as the error budget (tools/gen_golden_sgm_full.py; seeded weights and inputs,
+    regenerated here bit for bit). Bar as at the production widths: error against the reference's
     fp32 output <= 2 x the reference's own autocast error, in max norm and in rms, for the network output, the last control
     residual and four intermediate block outputs (subsampled in the fixture)."""
     from models.csvd import ControlNet, ControlledVideoUNet
@@ -1010,9 +1012,9 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     path = os.path.join(golden_dir, "sgm_full.npz")
     assert os.path.exists(path), "tests/golden/sgm_full.npz is missing (tools/gen_golden_sgm_full.py, build container only)"
     G = np.load(path)
+    assert budget + "cunet_out" in G.files, f"the fixture holds no {budget}* entries (tools/gen_golden_sgm_full.py --add-f16)"
     torch.backends.cudnn.benchmark = False
     bench_svd.use_shipped_miopen_db()
-    dt = torch.bfloat16
     nets = []
     for cls, cfg, seed in ((ControlledVideoUNet, H.FULL_UNET, 71), (ControlNet, H.FULL_CTRL, 72)):
         with torch.device("meta"):
@@ -1050,10 +1052,10 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     for name, got in [("cunet_out", yc.float()), ("ctrl_last", ctrls[-1].float()[H.FULL_SUB])] + [("probe_" + k, probes[k]) for k in H.FULL_PROBES]:
         ref = G[name + "_f32"]
         e_max, e_rms = _err(got, ref)
-        r_max, r_rms = (float(v) for v in G["budget_" + name])       # the reference's own bf16-autocast error against the same fp32 tensor
+        r_max, r_rms = (float(v) for v in G[budget + name])          # the reference's own autocast error in this type against the same fp32 tensor
         worst = max(worst, e_max / r_max, e_rms / r_rms)
         assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
-    print(f"full-size step vs the reference: worst error ratio to the reference's own bf16 autocast error = {worst:.2f}")
+    print(f"full-size step in {dt} vs the reference: worst error ratio to the reference's own autocast error in that type = {worst:.2f}")
 
 
 def _attn_ref_chunked(q, k, v, heads, rows=1536):

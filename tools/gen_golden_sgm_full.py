@@ -5,7 +5,8 @@ error of the same evaluation under the reference's own reduced-precision recipe 
 models/csvd.py:27-31) against them (two numbers per tensor: max norm and rms). Weights and inputs are seeded (tests/svd_helpers.py: variance-preserving N(0, 1 / fan_in), norm scales 1 + 0.1 N): the GPU
 test regenerates them bit for bit. Run ONLY in the build container (~25 GB of memory, tens of minutes on 8 cores).
 
-Usage: python tools/gen_golden_sgm_full.py
+Usage: python tools/gen_golden_sgm_full.py            (fp32 tensors + bf16-autocast budgets)
+       python tools/gen_golden_sgm_full.py --add-f16  (adds f16-autocast budgets to the existing fixture)
 """
 import os
 import sys
@@ -59,6 +60,20 @@ def run(tag):
     return len(ctrls)
 
 
+path = os.path.join(HERE, "..", "tests", "golden", "sgm_full.npz")
+if "--add-f16" in sys.argv:
+    # second budget, added to an existing fixture: the same evaluation under f16 autocast (the reference's own GPU recipe,
+    # configs/test/svd_f_est_ctrl_simp1.yaml:214) against the fp32 tensors already recorded
+    G = dict(np.load(path))
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        run("f16ac")
+    for k in [k for k in G if k.endswith("_f32")]:
+        a, b = out[k[:-4] + "_f16ac"].astype(np.float64), G[k].astype(np.float64)
+        G["budget_f16_" + k[:-4]] = np.array([np.abs(a - b).max() / np.abs(b).max(), np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())])
+    np.savez_compressed(path, **G)
+    log("added f16 budgets:", {k: G[k].tolist() for k in G if k.startswith("budget_f16_")})
+    sys.exit(0)
+
 with torch.no_grad():
     n = run("f32")
     with torch.autocast("cpu", dtype=torch.bfloat16):
@@ -77,7 +92,6 @@ keep = {"n_ctrl": out["n_ctrl"]}
 for k in [k for k in out if k.endswith("_f32")]:
     keep[k] = out[k]
     keep["budget_" + k[:-4]] = np.array(rel_err(out[k[:-4] + "_bf16ac"], out[k]), np.float64)
-path = os.path.join(HERE, "..", "tests", "golden", "sgm_full.npz")
 np.savez_compressed(path, **keep)
 log("wrote", os.path.normpath(path), f"{os.path.getsize(path) / 1e6:.2f} MB; autocast-vs-fp32 (max, rms): cunet", keep["budget_cunet_out"],
     "mean|cunet_out|", float(np.abs(out["cunet_out_f32"]).mean()), "finite", bool(np.isfinite(out["cunet_out_f32"]).all()))
