@@ -51,6 +51,7 @@ FULL_CTRL["hint_channels"] = 7
 FULL_T, FULL_HW = 14, (72, 128)
 FULL_PROBES = ("input_blocks.1", "input_blocks.7", "middle_block", "output_blocks.10")     # recorded subsampled [::7, ::16, ::4, ::4]
 FULL_SUB = (slice(None, None, 7), slice(None, None, 16), slice(None, None, 4), slice(None, None, 4))
+FULL_SAMPLE_STEPS = 2          # steps of the sampling loop recorded at full size (tools/gen_golden_sgm_full_sample.py)
 
 
 def seeded_state_dict(module, seed):

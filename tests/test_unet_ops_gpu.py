@@ -1058,6 +1058,55 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     print(f"full-size step in {dt} vs the reference: worst error ratio to the reference's own autocast error in that type = {worst:.2f}")
 
 
+@pytest.mark.parametrize("dt,budget", [(torch.bfloat16, "budget_"), (torch.float16, "budget_f16_")])
+def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, budget):
+    """The first two steps of the reference's sampling loop at the full size of BASELINE.json configs[3] ("SVD-xt 14-frame
+    576x1024 masked-inpaint sampling"): EulerEDMSampler(num_steps = 2, sigma_max 700) + LinearPredictionGuider (1 -> 2.5,
+    control_hint as an additional condition key; the guider doubles the 14 frames to the CFG batch of 28) + Denoiser(
+    VScalingWithEDMcNoise) over SVDInpaintEngine.apply_model (ControlNet with the hint-stem cache -> ControlledVideoUNet) on
+    the HIP path, sampler state in fp32, networks in bf16 / f16 — against the same loop of the imported reference on the CPU in
+    fp32 (tools/gen_golden_sgm_full_sample.py -> tests/golden/sgm_full.npz `sample_final_f32`, subsampled [:, :, ::2, ::2]),
+    with the error of the reference's own bf16 / f16 autocast loop as the budget (bar: 2x, max norm and rms)."""
+    from models.csvd import ControlNet, ControlledVideoUNet, SVDInpaintEngine
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from sgm.util import instantiate_from_config
+    from multiview_inpaint_amd.svd import bench_svd
+    path = os.path.join(golden_dir, "sgm_full.npz")
+    G = np.load(path)
+    assert "sample_final_f32" in G.files and budget + "sample_final" in G.files, "run tools/gen_golden_sgm_full_sample.py (build container only)"
+    torch.backends.cudnn.benchmark = False
+    bench_svd.use_shipped_miopen_db()
+    nets = []
+    for cls, cfg, seed in ((ControlledVideoUNet, H.FULL_UNET, 71), (ControlNet, H.FULL_CTRL, 72)):
+        with torch.device("meta"):
+            m = cls(**cfg)
+        m.load_state_dict(H.seeded_state_dict(m, seed), strict=True, assign=True)
+        nets.append(m.eval().cuda().to(dt))
+    cunet, cnet = nets
+    T = H.FULL_T
+    one = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(74, T=T, hw=H.FULL_HW, cfg=H.FULL_UNET, cfg_doubled=False).items()}
+    sampler = instantiate_from_config({
+        "target": "sgm.modules.diffusionmodules.sampling.EulerEDMSampler",
+        "params": {"num_steps": H.FULL_SAMPLE_STEPS, "device": "cuda",
+                   "discretization_config": {"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+                   "guider_config": {"target": "sgm.modules.diffusionmodules.guiders.LinearPredictionGuider",
+                                     "params": {"max_scale": 2.5, "min_scale": 1.0, "num_frames": T, "additional_cond_keys": ["control_hint"]}}}})
+    eng = SVDInpaintEngine(cunet, cnet, Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}), sampler)
+    c = dict(crossattn=one["crossattn"], vector=one["vector"], concat=one["concat"], control_hint=one["control_hint"])
+    uc = dict(crossattn=torch.zeros_like(one["crossattn"]), vector=torch.zeros_like(one["vector"]),
+              concat=torch.zeros_like(one["concat"]), control_hint=one["control_hint"])
+    kw = dict(num_video_frames=T, image_only_indicator=one["image_only_indicator"])
+    fn = lambda x, sigma, cc: eng.denoise(x, sigma, cc, **kw)
+    with torch.no_grad(), cnet.hint_cache():
+        xs = sampler(fn, one["x"].clone(), c, uc=uc)
+    torch.cuda.synchronize()
+    assert xs.dtype == torch.float32 and torch.isfinite(xs).all()
+    e_max, e_rms = _err(xs[:, :, ::2, ::2], G["sample_final_f32"])
+    r_max, r_rms = (float(v) for v in G[budget + "sample_final"])
+    print(f"two sampling steps at full size in {dt}: error (max, rms) = ({e_max:.2e}, {e_rms:.2e}), the reference's own autocast loop ({r_max:.2e}, {r_rms:.2e})")
+    assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (e_max, r_max, e_rms, r_rms)
+
+
 def _attn_ref_chunked(q, k, v, heads, rows=1536):
     """fp64 softmax(QK^T d^-1/2)V, one head and a block of query rows at a time (S = 9216 does not fit otherwise)."""
     B, Sq, HD = q.shape
