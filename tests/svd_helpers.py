@@ -98,3 +98,19 @@ VAE_SAMPLE_SEED = 5
 def vae_inputs(seed, T=VAE_T, hw=VAE_HW):
     g = torch.Generator().manual_seed(seed)
     return torch.rand(T, 3, *hw, generator=g) * 2 - 1
+
+
+# FULL-SIZE first stage (configs/test/svd_f_est_ctrl_simp1.yaml:131-159: ch 128, ch_mult [1, 2, 4, 4], 2 ResBlocks per level) at the
+# 576x1024 frame size of configs[3]: the encoder on one frame, the video decoder on FULL_VAE_T latent frames of 72x128 —
+# tests/golden/vae_full.npz (tools/gen_golden_vae_full.py). Outputs recorded subsampled FULL_VAE_SUB plus one dense 32x32 crop.
+FULL_VAE = dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+FULL_VAE_T = 2
+FULL_VAE_HW = (576, 1024)
+FULL_VAE_SUB = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4))
+FULL_VAE_CROP = (slice(None), slice(None), slice(272, 304), slice(496, 528))
+
+
+def vae_full_latent(seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(FULL_VAE_T, 4, FULL_VAE_HW[0] // 8, FULL_VAE_HW[1] // 8, generator=g)

@@ -124,3 +124,14 @@ def test_full_size_parameter_count():
         enc, dec = Encoder(**full), VideoDecoder(**full, video_kernel_size=[3, 1, 1])
     assert sum(p.numel() for p in enc.parameters()) == 34163592
     assert sum(p.numel() for p in dec.parameters()) == 63579183
+
+
+def test_full_size_state_dict_keys_match_the_reference(golden_dir):
+    """The full-size first stage (svd_helpers.FULL_VAE) builds with exactly the reference's parameter names (construction only; the
+    outputs are compared on the GPU, tests/test_vae_gpu.py)."""
+    from sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    from sgm.modules.diffusionmodules.model import Encoder
+    G = np.load(os.path.join(golden_dir, "vae_full.npz"))
+    assert sorted(Encoder(**H.FULL_VAE).state_dict().keys()) == list(G["enc_keys"])
+    assert sorted(VideoDecoder(**H.FULL_VAE, video_kernel_size=[3, 1, 1]).state_dict().keys()) == list(G["vdec_keys"])
+    assert G["vdec_out_sub"].shape == (H.FULL_VAE_T, 3, H.FULL_VAE_HW[0] // 4, H.FULL_VAE_HW[1] // 4)

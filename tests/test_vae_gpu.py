@@ -140,3 +140,52 @@ def test_video_block_on_hip_ops(G):
     with torch.no_grad():
         assert rel(vb(xb, timesteps=H.VAE_T), G["vblock_out"]) < 1e-4
         assert rel(vb(xb, timesteps=H.VAE_T, skip_video=True), G["vblock_out_skip"]) < 1e-4
+
+
+def test_full_size_first_stage_matches_the_reference(golden_dir, ops):
+    """The first stage at its FULL size (configs/test/svd_f_est_ctrl_simp1.yaml:131-159: ch 128, ch_mult [1, 2, 4, 4], 2 ResBlocks per
+    level) on 576x1024 frames against the imported reference's fp32 CPU outputs (tests/golden/vae_full.npz,
+    tools/gen_golden_vae_full.py): the video decoder on two 72x128 latent frames — final frames (subsampled + one dense crop), the
+    mid-block attention output (S = 9216, D = 512: attention_wide's production shape) and the last block of the 288x512 level —
+    and the encoder's moments for one frame. fp32 I/O: 1e-4 relative, the module's bar."""
+    from sgm.util import instantiate_from_config
+    G = np.load(os.path.join(golden_dir, "vae_full.npz"))
+    cfg = {"target": "sgm.models.autoencoder.AutoencodingEngine", "params": {
+        "loss_config": {"target": "torch.nn.Identity"},
+        "regularizer_config": {"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"},
+        "encoder_config": {"target": "sgm.modules.diffusionmodules.model.Encoder", "params": H.FULL_VAE},
+        "decoder_config": {"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder",
+                           "params": dict(H.FULL_VAE, video_kernel_size=[3, 1, 1])}}}
+    eng = instantiate_from_config(cfg).eval()
+    assert sorted(eng.encoder.state_dict().keys()) == list(G["enc_keys"])
+    assert sorted(eng.decoder.state_dict().keys()) == list(G["vdec_keys"])
+    eng.encoder.load_state_dict(H.seeded_state_dict(eng.encoder, 51), strict=True)
+    eng.decoder.load_state_dict(H.seeded_state_dict(eng.decoder, 52), strict=True)
+    eng = eng.to(DEV)
+    acts = {}
+    hooks = [eng.decoder.mid.attn_1.register_forward_hook(lambda m, i, o: acts.__setitem__("mid_attn", o)),
+             eng.decoder.up[1].block[2].register_forward_hook(lambda m, i, o: acts.__setitem__("up1", o))]
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            y = eng.decode(H.vae_full_latent(61).to(DEV), timesteps=H.FULL_VAE_T)
+            m, _ = eng.encode(H.vae_inputs(62, T=1, hw=H.FULL_VAE_HW).to(DEV), unregularized=True)
+        torch.cuda.synchronize()
+        kinds = set(k for k, *_ in ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+        for h in hooks:
+            h.remove()
+    assert tuple(y.shape) == (H.FULL_VAE_T, 3) + H.FULL_VAE_HW
+
+    def rel_to(a, want, absmax):
+        return float((a.detach().double().cpu() - torch.as_tensor(want).double()).abs().max() / absmax)
+    errs = {"mid_attn": rel_to(acts["mid_attn"][:, ::8, ::4, ::4], G["vdec_mid_attn_sub"], float(G["vdec_mid_attn_absmax"])),
+            "up1": rel_to(acts["up1"][:, ::16, ::8, ::8], G["vdec_up1_sub"], float(G["vdec_up1_absmax"])),
+            "out_sub": rel_to(y[H.FULL_VAE_SUB], G["vdec_out_sub"], float(G["vdec_out_absmax"])),
+            "out_crop": rel_to(y[H.FULL_VAE_CROP], G["vdec_out_crop"], float(G["vdec_out_absmax"])),
+            "enc_moments": rel(m, G["enc_moments"])}
+    print("full-size first stage, relative max errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert abs(float(y.double().mean()) - float(G["vdec_out_mean"])) < 1e-4 * float(G["vdec_out_absmax"])
+    assert max(errs.values()) < 1e-4, errs
+    assert {"groupnorm", "bias_residual", "softmax_rows", "tokens_to_planes_add"} <= kinds, kinds
