@@ -4,9 +4,10 @@ the optimizer step): parameter activations -> rasterize -> L1 + DSSIM loss -> ba
   hip_raw: raw parameters straight into the rasterizer (GaussianRasterizer.forward_raw), fused loss, fused Adam
   hip   : multiview_inpaint_amd.train_ops (fused activations, fused loss, fused Adam)
   patched: what an UNCHANGED gs-simp/train.py gets under `python -m multiview_inpaint_amd.dropin.patch_gs_simp train.py ...`:
-          the reference's own activations (exp / normalize / sigmoid / cat), its loss expression
-          (1 - l) * l1_loss(image, gt) + l * (1 - ssim(image, gt)) with the two functions swapped for train_ops' (one fused kernel
-          pair EACH), FusedAdam in place of the torch.optim.Adam its training_setup creates
+          gaussian_renderer.render handing the model's stored parameters to forward_raw (round 4; before: the reference's own
+          exp / normalize / sigmoid / cat), its loss expression (1 - l) * l1_loss(image, gt) + l * (1 - ssim(image, gt)) with the
+          two functions swapped for train_ops' (one fused kernel pair EACH), FusedAdam in place of the torch.optim.Adam its
+          training_setup creates
   torch : the reference's own PyTorch-ROCm formulation (exp / normalize / sigmoid / cat, loss_utils-style SSIM with
           five depthwise convs, torch.optim.Adam)
 Usage (GPU box): python -m multiview_inpaint_amd.bench_train [--steps 20]; bench.py reports the same numbers as
@@ -51,11 +52,18 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
     gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(dev).manual_seed(1))
 
     def step():
-        if variant == "hip_raw":
-            means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
+        if variant in ("hip_raw", "patched"):
+            if variant == "patched":                            # the patched render(): gaussian_renderer/__init__.py:27 as written
+                means2D = torch.zeros_like(prm["xyz"], requires_grad=True) + 0
+                means2D.retain_grad()
+            else:
+                means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
             image, radii, depth = rast.forward_raw(prm["xyz"], means2D, prm["f_dc"], prm["f_rest"], prm["opacity"],
                                                    prm["scaling"], prm["rotation"])
-            loss = T.fused_l1_dssim_loss(image, gt, 0.2)
+            if variant == "patched":                            # gs-simp/train.py:91-92 with the patched names
+                loss = (1.0 - 0.2) * T.l1_loss(image, gt) + 0.2 * (1.0 - T.ssim(image, gt))
+            else:
+                loss = T.fused_l1_dssim_loss(image, gt, 0.2)
             loss.backward()
             opt.step()
             opt.zero_grad(set_to_none=True)
@@ -70,8 +78,6 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
                                    scales=scales, rotations=rots, cov3D_precomp=None)
         if variant == "hip":
             loss = T.fused_l1_dssim_loss(image, gt, 0.2)
-        elif variant == "patched":                          # gs-simp/train.py:91-92 with the patched names
-            loss = (1.0 - 0.2) * T.l1_loss(image, gt) + 0.2 * (1.0 - T.ssim(image, gt))
         else:
             loss = torch_loss(image, gt)
         loss.backward()
@@ -98,8 +104,8 @@ def run_both(steps=20, warmup=3):
                         "sh_degree 3; the HIP rasterizer in both variants, the ops around it fused HIP vs PyTorch-ROCm ops",
             "variants": {"hip_raw": "raw parameters into the rasterizer (activations + SH concat inside the preprocess kernels), "
                                     "fused loss, fused Adam", "hip": "fused activation kernel + standard rasterizer entry, fused "
-                                    "loss, fused Adam", "patched": "an unchanged train.py under dropin.patch_gs_simp: PyTorch activations, "
-                         "l1_loss + ssim swapped for the fused kernels (two calls), FusedAdam", "torch": "PyTorch-ROCm ops for activations, loss and Adam"},
+                                    "loss, fused Adam", "patched": "an unchanged train.py under dropin.patch_gs_simp: render() patched to hand the stored "
+                         "parameters to the rasterizer, l1_loss + ssim swapped for the fused kernels (two calls), FusedAdam", "torch": "PyTorch-ROCm ops for activations, loss and Adam"},
             "results": out, "speedup_of_the_surrounding_ops": round(out[3]["ms_per_iteration"] / out[0]["ms_per_iteration"], 2)}
 
 

@@ -22,6 +22,13 @@ What install() does (each part can be switched off):
               the `torch.optim.Adam(l, lr=0.0, eps=1e-15)` it creates (:163, :653) is replaced by train_ops.FusedAdam over the SAME
               param_groups (names, per-group learning rates) and the same state layout, so update_learning_rate, densification's
               edits of optimizer.state, capture() / restore() run unchanged; one launch per step instead of 6 x 3.
+  * render    gaussian_renderer.render (gaussian_renderer/__init__.py:18-104; imported by name at train.py:16, inpaint_rec.py:16,
+              render.py:17, ...) hands the model's STORED parameters (_xyz, _features_dc, _features_rest, _opacity, _scaling,
+              _rotation) to GaussianRasterizer.forward_raw: exp / sigmoid / normalize / cat of gaussian_model.py:95-115 and their
+              chain rule run inside the preprocess kernels instead of as ~12 PyTorch kernels over the 1.5 M rows (the 288 MB
+              torch.cat of the SH rows alone is 0.15 ms each way). Same arguments, same returned dict. Calls the patched form
+              cannot serve — override_color, pipe.convert_SHs_python, pipe.compute_cov3D_python, a model whose activations or
+              getters are not the stock ones — go to the reference's own render (kept as `_reference_render`).
 Nothing is patched that is not named here; a script that imported the loss functions before install() ran keeps the
 reference's (install() must come first — the runner below guarantees it)."""
 import functools
@@ -50,7 +57,47 @@ def _swap_optimizer(model):
     return True
 
 
-def install(loss=True, optimizer=True):
+def _stock_model(pc, base):
+    """True if `pc` computes what forward_raw computes: the stock activations (gaussian_model.py:33-41) and the stock getters."""
+    import torch
+    if not isinstance(pc, base):
+        return False
+    if (getattr(pc, "scaling_activation", None) is not torch.exp or getattr(pc, "opacity_activation", None) is not torch.sigmoid or
+            getattr(pc, "rotation_activation", None) is not torch.nn.functional.normalize):
+        return False
+    cls = type(pc)
+    return all(getattr(cls, n, None) is getattr(base, n) for n in ("get_xyz", "get_scaling", "get_rotation", "get_opacity", "get_features"))
+
+
+def _make_render(reference_render, base_model):
+    import math
+
+    @functools.wraps(reference_render)
+    def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+        if (override_color is not None or getattr(pipe, "convert_SHs_python", False) or getattr(pipe, "compute_cov3D_python", False)
+                or not _stock_model(pc, base_model) or not pc._xyz.is_cuda):
+            return reference_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+        import torch
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        # the screen-space means exist to carry a gradient back to the caller (train.py:87, :116: add_densification_stats reads its .grad)
+        screenspace_points = torch.zeros_like(pc._xyz, requires_grad=True) + 0
+        if screenspace_points.requires_grad:              # (not under torch.no_grad(): render.py, the evaluation renders)
+            screenspace_points.retain_grad()
+        settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+            scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+            projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+            campos=viewpoint_camera.camera_center, prefiltered=False)
+        image, radii, depth = GaussianRasterizer(raster_settings=settings).forward_raw(
+            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation)
+        return {"render": image, "depth": depth, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii}
+    render._mvi_patched = True
+    return render
+
+
+def install(loss=True, optimizer=True, render=True):
     """Patches the gs-simp modules named above (they must be importable: the script's directory on sys.path). Returns the
     list of what was patched, for logging. Idempotent."""
     if _DROPIN not in sys.path:
@@ -81,6 +128,13 @@ def install(loss=True, optimizer=True):
                 return training_setup
             cls.training_setup = wrap(setup)
             done.append(f"scene.gaussian_model.{name}.training_setup")
+    if render:
+        gr = importlib.import_module("gaussian_renderer")
+        gm = importlib.import_module("scene.gaussian_model")
+        if not getattr(gr.render, "_mvi_patched", False):
+            gr._reference_render = gr.render
+            gr.render = _make_render(gr.render, gm.GaussianModel)
+        done.append("gaussian_renderer.render")
     return done
 
 

@@ -33,16 +33,26 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
         class Untouched:
             pass
     """))
+    (tmp_path / "gaussian_renderer").mkdir()
+    (tmp_path / "gaussian_renderer" / "__init__.py").write_text(textwrap.dedent("""
+        def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+            return ("stand-in render", scaling_modifier, override_color)
+    """))
     (tmp_path / "train_like.py").write_text(textwrap.dedent("""
         import sys
         from utils.loss_utils import l1_loss, ssim
         from scene.gaussian_model import GaussianModel
+        from gaussian_renderer import render
+        import gaussian_renderer as gr
         import utils.loss_utils as lu
         g = GaussianModel()
         assert g.training_setup(2.0) == "set up"
         o = g.optimizer
         print("ARGV", sys.argv[1:])
         print("LOSS", l1_loss.__module__, ssim.__module__, lu._reference_l1_loss(0, 0), lu._reference_ssim(0, 0))
+        # a call the fused form cannot serve (override_color) reaches the script's own render with its arguments
+        print("RENDER", getattr(render, "_mvi_patched", False), render.__name__, gr._reference_render is not render,
+              render(None, g, None, None, 0.5, "colours"))
         print("OPT", type(o).__module__, type(o).__name__, [(pg["name"], pg["lr"], pg["eps"], pg["betas"]) for pg in o.param_groups],
               o.param_groups[0]["params"][0] is g._xyz)
     """))
@@ -55,4 +65,6 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
     assert out["LOSS"] == "multiview_inpaint_amd.train_ops multiview_inpaint_amd.train_ops stand-in l1 stand-in ssim"
     assert out["OPT"] == ("multiview_inpaint_amd.train_ops FusedAdam [('xyz', 1.0, 1e-15, (0.9, 0.999)), "
                           "('opacity', 0.05, 1e-15, (0.9, 0.999))] True")
+    assert out["RENDER"] == "True render True ('stand-in render', 0.5, 'colours')"
     assert "scene.gaussian_model.GaussianModel.training_setup" in p.stderr and "Untouched" not in p.stderr
+    assert "gaussian_renderer.render" in p.stderr

@@ -1,0 +1,157 @@
+"""dropin.patch_gs_simp's render (the model's STORED parameters into GaussianRasterizer.forward_raw) against a stand-in of the
+reference's render() call shape (gaussian_renderer/__init__.py:18-104: PyTorch activations of gaussian_model.py:95-115, then the
+rasterizer's standard entry): same dict, same integers, images / depth / gradients to the tolerance of the device activations, and
+every call the patched form cannot serve lands in the reference's own function."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "multiview_inpaint_amd", "dropin")
+if DROPIN not in sys.path:
+    sys.path.insert(0, DROPIN)
+
+
+class Model:
+    """The attributes and getters render() reads from scene.gaussian_model.GaussianModel (gaussian_model.py:24-115)."""
+
+    def __init__(self, sc, max_deg, active_deg):
+        dev = "cuda"
+        t = {k: torch.tensor(v, device=dev) for k, v in sc.items() if k != "sh_degree"}
+        self.max_sh_degree, self.active_sh_degree = max_deg, active_deg
+        self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+        P = t["means3D"].shape[0]
+        g = torch.Generator(dev).manual_seed(3)
+        self._xyz = torch.nn.Parameter(t["means3D"].clone())
+        self._features_dc = torch.nn.Parameter(t["shs"][:, :1].contiguous())
+        self._features_rest = torch.nn.Parameter(t["shs"][:, 1:].contiguous())
+        self._opacity = torch.nn.Parameter(torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)))
+        self._scaling = torch.nn.Parameter(torch.log(t["scales"]))
+        self._rotation = torch.nn.Parameter(t["rotations"] * (0.5 + torch.rand(P, 1, device=dev, generator=g)))
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: s.scaling_activation(s._scaling))
+    get_rotation = property(lambda s: s.rotation_activation(s._rotation))
+    get_opacity = property(lambda s: s.opacity_activation(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+    def params(self):
+        return dict(xyz=self._xyz, dc=self._features_dc, rest=self._features_rest, o=self._opacity, s=self._scaling, q=self._rotation)
+
+
+class Camera:
+    def __init__(self, cam):
+        self.image_height, self.image_width = cam["H"], cam["W"]
+        self.FoVx, self.FoVy = 2 * math.atan(cam["tanfovx"]), 2 * math.atan(cam["tanfovy"])
+        self.world_view_transform = torch.tensor(cam["viewmatrix"], device="cuda")
+        self.full_proj_transform = torch.tensor(cam["projmatrix"], device="cuda")
+        self.camera_center = torch.tensor(cam["campos"], device="cuda")
+
+
+class Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+CALLS = []
+
+
+def standin_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """The reference's call shape: activations in PyTorch, SH rows concatenated, the rasterizer's standard entry."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    CALLS.append("reference")
+    pts = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+    if pts.requires_grad:
+        pts.retain_grad()
+    rs = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
+        prefiltered=False)
+    kw = dict(shs=pc.get_features, colors_precomp=None) if override_color is None else dict(shs=None, colors_precomp=override_color)
+    img, radii, depth = GaussianRasterizer(raster_settings=rs)(means3D=pc.get_xyz, means2D=pts, opacities=pc.get_opacity,
+                                                               scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None, **kw)
+    return {"render": img, "depth": depth, "viewspace_points": pts, "visibility_filter": radii > 0, "radii": radii}
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("max_deg,active_deg,scale_mod", [(3, 3, 1.0), (3, 1, 1.0), (2, 2, 0.7), (0, 0, 1.0)])
+def test_patched_render_equals_the_reference_call_shape(max_deg, active_deg, scale_mod):
+    from multiview_inpaint_amd.dropin import patch_gs_simp
+    from raster_helpers import small_scene
+    cam, sc, bg = small_scene(33, N=4000, W=208, H=120, deg=max_deg, pose=True, log_scale=np.log(0.05))
+    camera, pipe = Camera(cam), Pipe()
+    bg_t = torch.tensor(bg, device="cuda")
+    patched = patch_gs_simp._make_render(standin_render, Model)
+    g_img = torch.randn(3, cam["H"], cam["W"], device="cuda", generator=torch.Generator("cuda").manual_seed(9))
+
+    def run(fn):
+        pc = Model(sc, max_deg, active_deg)
+        pkg = fn(camera, pc, pipe, bg_t, scale_mod)
+        (pkg["render"] * g_img).sum().backward()
+        return pkg, {k: v.grad for k, v in pc.params().items()}
+
+    CALLS.clear()
+    want, gw = run(standin_render)
+    assert CALLS == ["reference"]
+    got, gg = run(patched)
+    assert CALLS == ["reference"], "the patched render went through the reference's function"
+    assert list(got.keys()) == list(want.keys())
+    assert torch.equal(got["radii"], want["radii"]) and torch.equal(got["visibility_filter"], want["visibility_filter"])
+    assert int(got["visibility_filter"].sum()) > 1000
+    # torch.exp / sigmoid / normalize against the device expressions of the preprocess kernel: a few ulp on the inputs of the projection
+    assert rel(got["render"], want["render"]) < 1e-4
+    finite = torch.isfinite(want["depth"]) & (want["depth"] < 14.9)
+    assert rel(got["depth"][finite], want["depth"][finite]) < 1e-4
+    assert got["viewspace_points"].grad is not None and got["viewspace_points"].shape == want["viewspace_points"].shape
+    assert rel(got["viewspace_points"].grad, want["viewspace_points"].grad) < 1e-3
+    for k in gw:
+        if gw[k] is None or gw[k].numel() == 0:                          # degree 0: features_rest is [P, 0, 3]
+            continue
+        assert gg[k] is not None and rel(gg[k], gw[k]) < 1e-3, k
+
+
+def test_calls_the_patched_render_cannot_serve_go_to_the_reference():
+    from multiview_inpaint_amd.dropin import patch_gs_simp
+    from raster_helpers import small_scene
+    cam, sc, bg = small_scene(34, N=500, W=64, H=48, deg=1, pose=True, log_scale=np.log(0.05))
+    camera, bg_t = Camera(cam), torch.tensor(bg, device="cuda")
+    patched = patch_gs_simp._make_render(standin_render, Model)
+    pc = Model(sc, 1, 1)
+    CALLS.clear()
+    with torch.no_grad():
+        patched(camera, pc, Pipe(), bg_t)
+        assert CALLS == []
+        patched(camera, pc, Pipe(), bg_t, 1.0, torch.rand(500, 3, device="cuda"))            # override_color
+        assert CALLS == ["reference"]
+        p2 = Pipe()
+        p2.convert_SHs_python = True
+        patched(camera, pc, p2, bg_t)
+        assert CALLS == ["reference"] * 2
+
+        class Sub(Model):                                                # a getter of its own: not what forward_raw computes
+            get_opacity = property(lambda s: torch.sigmoid(s._opacity) * 0.5)
+        patched(camera, Sub(sc, 1, 1), Pipe(), bg_t)
+        assert CALLS == ["reference"] * 3
+        pc3 = Model(sc, 1, 1)
+        pc3.scaling_activation = torch.nn.functional.softplus            # another activation
+        patched(camera, pc3, Pipe(), bg_t)
+        assert CALLS == ["reference"] * 4
+
+        class Plain(Model):                                              # subclasses with the stock getters stay on the fused path
+            pass
+        patched(camera, Plain(sc, 1, 1), Pipe(), bg_t)
+        assert CALLS == ["reference"] * 4
