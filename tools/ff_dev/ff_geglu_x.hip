@@ -100,8 +100,7 @@ __device__ __forceinline__ float geglu1(float v, float g) {
 // kGeglu = false: out[r, j] = x . W[j] + b[j], j < inner (= the Linear's out_features); a step = 64 outputs (the same two 32-row
 //                 blocks of a W tile, both plain) — the bias-only projections of level 0 (packed q/k/v, to_out, proj_in / proj_out),
 //                 which the library runs at 0.36 - 0.5 PFLOP/s because at K = 320 they are short loops around a lot of output
-// (the timing ablations and in-kernel stamps this kernel was tuned with — MVI_FFG_EXPERIMENT — live in tools/ff_dev/ff_geglu_x.hip)
-template <typename T, bool kGeglu = true>
+template <typename T, int kX = 0, bool kGeglu = true>        // kX != 0: timing experiments that drop one kind of work (wrong results on purpose)
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                           int64_t rows, int inner, int64_t x_rs, int64_t o_rs, int n_blocks) {
@@ -121,6 +120,7 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     const int64_t row = (int64_t)bid * kRows + wave * 32 + col;
     const bool row_ok = row < rows;
 
+    if (kX == 6 && wave >= kWaves / 2) return;                    // (experiment: one wave per SIMD; s_barrier then counts the live waves only)
     // ---- bias -> LDS (visible after the first barrier of the loop prologue)
     const int n_bias = kGeglu ? 2 * inner : inner;
     for (int i = tid; i < n_bias; i += 64 * kWaves) lbias[i] = bias ? bias[i] : 0.f;
@@ -162,6 +162,7 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
 #pragma unroll
     for (int q = 0; q < 4; ++q) ka[q] = (uint32_t)(col * kRowBytes + ((((2 * q + hh) & 7) ^ ((col >> 1) & 7)) << 4));
     auto wfrag = [&](uint32_t slot_base, int blk, int s) __attribute__((always_inline)) {
+        if (kX == 4) return u32x4{0x3c003c00u, (uint32_t)s, 0, 0};
         // chunk 2 s + hh = 8 (s >> 2) + (2 (s & 3) + hh): the swizzle touches the low three bits only
         return *reinterpret_cast<MVI_AS3 const u32x4*>(lds + slot_base + ka[s & 3] + (s >> 2) * 128 + blk * (32 * kRowBytes));
     };
@@ -200,13 +201,15 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32x4 v = *reinterpret_cast<MVI_AS3 const u32x4*>(lds + ot_r + 1024 * i);
-            *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
+            if (kX != 2 || v[0] == 0x12345678u) *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
         }
     };
     auto store_pair = [&](char* op, int cb, int r, uint32_t pk) __attribute__((always_inline)) {
         const int m = (r & 3) + 8 * (r >> 2);
-        *reinterpret_cast<uint16_t*>(op + cb + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
-        *reinterpret_cast<uint16_t*>(op + cb + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+        if (kX != 2 || pk == 0x12345678u) {
+            *reinterpret_cast<uint16_t*>(op + cb + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
+            *reinterpret_cast<uint16_t*>(op + cb + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+        }
     };
     auto step_fn = [&](auto with_prev_c, uint32_t slot_base, int step, f32x16& av, f32x16& ag, const f32x16& pv, const f32x16& pg)
                        __attribute__((always_inline)) {
@@ -230,7 +233,7 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
             ag = M::mfma(xf[s], as_frag<frag>(fg[s % (kAhead + 1)]), ag);
             if (kPrev && s < 16) {
                 if (kGeglu) {
-                    const float o = geglu1(pv[s], pg[s]);
+                    const float o = kX == 1 ? pv[s] + pg[s] : geglu1(pv[s], pg[s]);
                     if ((s & 1) == 0) held = o;
                     else store_pair(op, 0, s - 1, M::pack2(held, o));
                 } else if ((s & 1) == 1) {                           // plain: both blocks are outputs (bias already inside)
@@ -256,13 +259,27 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
         }
         if (!kGeglu) flush_tile(op);
     };
+#ifdef MVI_FFG_STAMPS
+    uint64_t t_close = 0, t_issue = 0, t_all0 = __builtin_amdgcn_s_memtime();
+#endif
     auto close_step = [&](int step) __attribute__((always_inline)) {
+#ifdef MVI_FFG_STAMPS
+        const uint64_t c0 = __builtin_amdgcn_s_memtime();
+        if (loader) issue_tile(step + 2);
+        const uint64_t c1 = __builtin_amdgcn_s_memtime();
+        if (loader) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        else asm volatile("s_barrier" ::: "memory");
+        const uint64_t c2 = __builtin_amdgcn_s_memtime();
+        t_issue += c1 - c0; t_close += c2 - c1;
+        return;
+#endif
         // loaders: issue the tile two steps ahead (its slot held step - 1, which nobody reads any more), then wait for everything
         // older than those pieces — this wave's pieces of tile step + 1 among them; then the block meets
-        if (loader) {
+        if (loader && kX != 3) {
             issue_tile(step + 2);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
-        } else {
+            if (kX == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesPerLoader) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        } else if (kX != 5) {
             asm volatile("s_barrier" ::: "memory");
         }
     };
@@ -297,6 +314,13 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
         drain(j - 1, va, ga);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // trailing (unused) pieces land before the block releases its LDS
+#ifdef MVI_FFG_STAMPS
+    if (lane == 0 && blockIdx.x == 300 && (wave == 0 || wave == 7)) {
+        const uint64_t tot = __builtin_amdgcn_s_memtime() - t_all0;
+        printf("block 300 wave %d: %d steps, cycles per step: total %llu, DMA issue %llu, wait+barrier %llu\n", wave, n_steps,
+               (unsigned long long)(tot / n_steps), (unsigned long long)(t_issue / n_steps), (unsigned long long)(t_close / n_steps));
+    }
+#endif
 }
 
 }  // namespace ffg
@@ -311,7 +335,17 @@ static int ff_k320_launch(const void* x, const void* w, const float* bias, void*
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &ff_geglu_k320_kernel<T, kGeglu>;
+    auto kern = &ff_geglu_k320_kernel<T, 0, kGeglu>;
+#ifdef MVI_FFG_EXPERIMENTS
+    static const int xp = getenv("MVI_FFG_EXPERIMENT") ? atoi(getenv("MVI_FFG_EXPERIMENT")) : 0;
+    if (xp == 1) kern = &ff_geglu_k320_kernel<T, 1, kGeglu>;
+    if (xp == 2) kern = &ff_geglu_k320_kernel<T, 2, kGeglu>;
+    if (xp == 3) kern = &ff_geglu_k320_kernel<T, 3, kGeglu>;
+    if (xp == 4) kern = &ff_geglu_k320_kernel<T, 4, kGeglu>;
+    if (xp == 5) kern = &ff_geglu_k320_kernel<T, 5, kGeglu>;
+    if (xp == 6) kern = &ff_geglu_k320_kernel<T, 6, kGeglu>;
+    if (xp) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
