@@ -32,7 +32,7 @@ def torch_loss(img, gt, lam=0.2):
     return 0.8 * (img - gt).abs().mean() + 0.2 * (1 - smap.mean())
 
 
-def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
+def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3, extras=None):
     dev = torch.device("cuda")
     cam = syn.make_camera(W, H, 50.0)
     sc = syn.make_scene(N, cam, deg, seed=0)
@@ -51,6 +51,33 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
     rast = R.GaussianRasterizer(rs)
     gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(dev).manual_seed(1))
 
+    # extras: what gs-simp/train.py does per iteration besides the timed region's kernels while it densifies (train.py:96, :113-116):
+    # the loss read back for the progress bar, the max-radii update (boolean-mask indexing, in the script itself) and
+    # add_densification_stats — "masked" = the reference's method, "patched" = dropin.patch_gs_simp's mask-free form
+    stats = None
+    if extras:
+        from .dropin import patch_gs_simp
+
+        class _Stats:
+            def __init__(self):
+                self.xyz_gradient_accum = torch.zeros(N, 1, device=dev)
+                self.denom = torch.zeros(N, 1, device=dev)
+                self.max_radii2D = torch.zeros(N, device=dev)
+
+            def add_densification_stats(self, viewspace_point_tensor, update_filter):      # gaussian_model.py:482-484
+                self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+                self.denom[update_filter] += 1
+        stats = _Stats()
+        add_stats = patch_gs_simp._make_stats(_Stats.add_densification_stats) if extras == "patched" else _Stats.add_densification_stats
+
+    def loop_extras(loss, means2D, radii):
+        if stats is None:
+            return
+        loss.item()
+        vis = radii > 0
+        stats.max_radii2D[vis] = torch.max(stats.max_radii2D[vis], radii[vis].to(stats.max_radii2D.dtype))
+        add_stats(stats, means2D, vis)
+
     def step():
         if variant in ("hip_raw", "patched"):
             if variant == "patched":                            # the patched render(): gaussian_renderer/__init__.py:27 as written
@@ -65,6 +92,7 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
             else:
                 loss = T.fused_l1_dssim_loss(image, gt, 0.2)
             loss.backward()
+            loop_extras(loss, means2D, radii)
             opt.step()
             opt.zero_grad(set_to_none=True)
             return loss
@@ -95,7 +123,10 @@ def run(variant, steps, warmup, N=1_500_000, W=1920, H=1080, deg=3):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / steps
-    return dict(variant=variant, ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 1), loss=round(loss.item(), 5))
+    out = dict(variant=variant, ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 1), loss=round(loss.item(), 5))
+    if extras:
+        out["extras"] = extras
+    return out
 
 
 def run_both(steps=20, warmup=3):
@@ -113,5 +144,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--loop-extras", action="store_true",
+                    help="instead: the patched iteration WITH train.py's per-iteration extras while densifying (loss.item(), max-radii "
+                         "update, add_densification_stats), the reference's masked statistics against the patched mask-free form")
     a = ap.parse_args()
-    print(json.dumps(run_both(a.steps, a.warmup)))
+    if a.loop_extras:
+        print(json.dumps({"workload": "patched training iteration + train.py's per-iteration extras (train.py:96, :113-116)",
+                          "results": [run("patched", a.steps, a.warmup, extras=e) for e in ("masked", "patched")]}))
+    else:
+        print(json.dumps(run_both(a.steps, a.warmup)))

@@ -29,6 +29,11 @@ What install() does (each part can be switched off):
               torch.cat of the SH rows alone is 0.15 ms each way). Same arguments, same returned dict. Calls the patched form
               cannot serve — override_color, pipe.convert_SHs_python, pipe.compute_cov3D_python, a model whose activations or
               getters are not the stock ones — go to the reference's own render (kept as `_reference_render`).
+  * stats     GaussianModel.add_densification_stats (gaussian_model.py:482-484; called every iteration below densify_until_iter,
+              train.py:116) without boolean-mask indexing: `accum[mask] += norm(grad[mask, :2])` and `denom[mask] += 1` are a
+              nonzero() with a host read-back, two gathers and two index_put each; the patched form adds
+              `where(mask, norm(grad[:, :2]), 0)` and `mask` to the whole arrays — the same values, three elementwise kernels, no
+              synchronisation. Other filter types (index tensors) go to the reference's method.
 Nothing is patched that is not named here; a script that imported the loss functions before install() ran keeps the
 reference's (install() must come first — the runner below guarantees it)."""
 import functools
@@ -97,7 +102,25 @@ def _make_render(reference_render, base_model):
     return render
 
 
-def install(loss=True, optimizer=True, render=True):
+def _make_stats(reference_stats):
+    @functools.wraps(reference_stats)
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        import torch
+        g = getattr(viewspace_point_tensor, "grad", None)
+        acc, den = getattr(self, "xyz_gradient_accum", None), getattr(self, "denom", None)
+        if (g is None or not torch.is_tensor(update_filter) or update_filter.dtype != torch.bool or update_filter.ndim != 1
+                or not torch.is_tensor(acc) or not torch.is_tensor(den) or g.ndim != 2 or g.shape[0] != update_filter.shape[0]
+                or tuple(acc.shape) != (g.shape[0], 1) or tuple(den.shape) != (g.shape[0], 1)):
+            return reference_stats(self, viewspace_point_tensor, update_filter)
+        m = update_filter[:, None]
+        n = torch.norm(g[:, :2], dim=-1, keepdim=True)
+        acc += torch.where(m, n, 0.0).to(acc.dtype)
+        den += m.to(den.dtype)
+    add_densification_stats._mvi_patched = True
+    return add_densification_stats
+
+
+def install(loss=True, optimizer=True, render=True, stats=True):
     """Patches the gs-simp modules named above (they must be importable: the script's directory on sys.path). Returns the
     list of what was patched, for logging. Idempotent."""
     if _DROPIN not in sys.path:
@@ -128,6 +151,14 @@ def install(loss=True, optimizer=True, render=True):
                 return training_setup
             cls.training_setup = wrap(setup)
             done.append(f"scene.gaussian_model.{name}.training_setup")
+    if stats:
+        gm = importlib.import_module("scene.gaussian_model")
+        for name, cls in list(vars(gm).items()):
+            fn = isinstance(cls, type) and cls.__dict__.get("add_densification_stats")
+            if not fn or getattr(fn, "_mvi_patched", False):
+                continue
+            cls.add_densification_stats = _make_stats(fn)
+            done.append(f"scene.gaussian_model.{name}.add_densification_stats")
     if render:
         gr = importlib.import_module("gaussian_renderer")
         gm = importlib.import_module("scene.gaussian_model")

@@ -30,6 +30,8 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
                      {'params': [self._opacity], 'lr': 0.05, "name": "opacity"}]
                 self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
                 return "set up"
+            def add_densification_stats(self, viewspace_point_tensor, update_filter):
+                return "stand-in stats"
         class Untouched:
             pass
     """))
@@ -53,6 +55,7 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
         # a call the fused form cannot serve (override_color) reaches the script's own render with its arguments
         print("RENDER", getattr(render, "_mvi_patched", False), render.__name__, gr._reference_render is not render,
               render(None, g, None, None, 0.5, "colours"))
+        print("STATS", getattr(GaussianModel.add_densification_stats, "_mvi_patched", False), g.add_densification_stats(None, [1, 2]))
         print("OPT", type(o).__module__, type(o).__name__, [(pg["name"], pg["lr"], pg["eps"], pg["betas"]) for pg in o.param_groups],
               o.param_groups[0]["params"][0] is g._xyz)
     """))
@@ -68,3 +71,5 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
     assert out["RENDER"] == "True render True ('stand-in render', 0.5, 'colours')"
     assert "scene.gaussian_model.GaussianModel.training_setup" in p.stderr and "Untouched" not in p.stderr
     assert "gaussian_renderer.render" in p.stderr
+    assert out["STATS"] == "True stand-in stats"               # (a filter the mask-free form does not serve: the script's own method ran)
+    assert "scene.gaussian_model.GaussianModel.add_densification_stats" in p.stderr

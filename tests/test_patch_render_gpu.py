@@ -155,3 +155,40 @@ def test_calls_the_patched_render_cannot_serve_go_to_the_reference():
             pass
         patched(camera, Plain(sc, 1, 1), Pipe(), bg_t)
         assert CALLS == ["reference"] * 4
+
+
+def test_patched_densification_stats_equal_the_masked_form():
+    """gaussian_model.py:482-484 restated with boolean-mask indexing against the patched mask-free form, three iterations with
+    different filters; an index-tensor filter goes to the reference's method."""
+    from multiview_inpaint_amd.dropin import patch_gs_simp
+    calls = []
+
+    class M:
+        def __init__(self, P):
+            self.xyz_gradient_accum = torch.zeros(P, 1, device="cuda")
+            self.denom = torch.zeros(P, 1, device="cuda")
+
+        def add_densification_stats(self, viewspace_point_tensor, update_filter):
+            calls.append(1)
+            self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+            self.denom[update_filter] += 1
+
+    P = 100_003
+    patched = patch_gs_simp._make_stats(M.add_densification_stats)
+    a, b = M(P), M(P)
+    g = torch.Generator("cuda").manual_seed(4)
+    for it in range(3):
+        pts = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        pts.grad = torch.randn(P, 3, device="cuda", generator=g) * 10.0 ** (it - 3)
+        filt = torch.rand(P, device="cuda", generator=g) < (0.1, 0.8, 0.0)[it]
+        M.add_densification_stats(a, pts, filt)
+        n = len(calls)
+        patched(b, pts, filt)
+        assert len(calls) == n
+        assert torch.equal(a.denom, b.denom)
+        assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum)
+    assert float(b.denom.sum()) > 0.85 * P
+    idx = torch.arange(0, P, 7, device="cuda")
+    n = len(calls)
+    patched(b, pts, idx)
+    assert len(calls) == n + 1
