@@ -28,6 +28,18 @@ int mvi_photometric_loss(const float* image, const float* gt, const float* weigh
                          float lambda_dssim, float upstream, float* out3, float* dL_dimage, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* The same loss for a caller that COMBINES the two means itself — the reference's own expression
+ * (1 - l) * l1_loss(image, gt) + l * (1 - ssim(image, gt)) (gs-simp/train.py:91-92, utils/loss_utils.py:17-18, :33-41) under autograd:
+ * mvi_photometric_loss_stats is the forward (out3 as above with lambda = 0: out3[0] = out3[1] = mean|x - y|, out3[2] = mean SSIM) and
+ * leaves the SSIM derivative maps in `workspace`, which the caller keeps untouched until the backward;
+ * mvi_photometric_loss_grad2 then writes dL_dimage = weights2[0] * d mean|x - y| / d image + weights2[1] * d mean SSIM / d image, with
+ * weights2 two DEVICE floats (autograd's upstream gradients: not read back). One statistics pass and one gradient pass for the
+ * pair, as in the fused call. */
+int mvi_photometric_loss_stats(const float* image, const float* gt, const float* weight, int32_t H, int32_t W, float* out3,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int mvi_photometric_loss_grad2(const float* image, const float* gt, const float* weight, int32_t H, int32_t W,
+                               const float* weights2, float* dL_dimage, void* workspace, size_t workspace_bytes, void* stream);
+
 /* torch.optim.Adam (weight_decay 0, amsgrad off) over up to MVI_ADAM_MAX_GROUPS tensors in one launch — the optimizer
  * of gs-simp/scene/gaussian_model.py:154-163 (six groups, per-group lr, eps 1e-15), stepped at gs-simp/train.py:126-128.
  * `groups_host` is a HOST array (copied into the kernel arguments); every tensor pointer in it is a device pointer to

@@ -154,6 +154,10 @@ def _bind_train_ops(L):
     L.mvi_photometric_loss_workspace_bytes.argtypes = [i32, i32]
     L.mvi_photometric_loss.restype = C.c_int
     L.mvi_photometric_loss.argtypes = [vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, sz, vp]
+    L.mvi_photometric_loss_stats.restype = C.c_int
+    L.mvi_photometric_loss_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    L.mvi_photometric_loss_grad2.restype = C.c_int
+    L.mvi_photometric_loss_grad2.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
     L.mvi_train_last_error.restype = C.c_char_p
     L.mvi_knn3_mean_dist2.restype = C.c_int
     L.mvi_knn3_mean_dist2.argtypes = [vp, i32, vp, vp]

@@ -6,7 +6,7 @@ the optimizer step): parameter activations -> rasterize -> L1 + DSSIM loss -> ba
   patched: what an UNCHANGED gs-simp/train.py gets under `python -m multiview_inpaint_amd.dropin.patch_gs_simp train.py ...`:
           gaussian_renderer.render handing the model's stored parameters to forward_raw (round 4; before: the reference's own
           exp / normalize / sigmoid / cat), its loss expression (1 - l) * l1_loss(image, gt) + l * (1 - ssim(image, gt)) with the
-          two functions swapped for train_ops' (one fused kernel pair EACH), FusedAdam in place of the torch.optim.Adam its
+          two functions swapped for train_ops' (two calls that share ONE node: one statistics and one gradient pass), FusedAdam in place of the torch.optim.Adam its
           training_setup creates
   torch : the reference's own PyTorch-ROCm formulation (exp / normalize / sigmoid / cat, loss_utils-style SSIM with
           five depthwise convs, torch.optim.Adam)
@@ -136,7 +136,7 @@ def run_both(steps=20, warmup=3):
             "variants": {"hip_raw": "raw parameters into the rasterizer (activations + SH concat inside the preprocess kernels), "
                                     "fused loss, fused Adam", "hip": "fused activation kernel + standard rasterizer entry, fused "
                                     "loss, fused Adam", "patched": "an unchanged train.py under dropin.patch_gs_simp: render() patched to hand the stored "
-                         "parameters to the rasterizer, l1_loss + ssim swapped for the fused kernels (two calls), FusedAdam", "torch": "PyTorch-ROCm ops for activations, loss and Adam"},
+                         "parameters to the rasterizer, l1_loss + ssim swapped for train_ops' (two calls, ONE autograd node), FusedAdam", "torch": "PyTorch-ROCm ops for activations, loss and Adam"},
             "results": out, "speedup_of_the_surrounding_ops": round(out[3]["ms_per_iteration"] / out[0]["ms_per_iteration"], 2)}
 
 
@@ -147,8 +147,11 @@ if __name__ == "__main__":
     ap.add_argument("--loop-extras", action="store_true",
                     help="instead: the patched iteration WITH train.py's per-iteration extras while densifying (loss.item(), max-radii "
                          "update, add_densification_stats), the reference's masked statistics against the patched mask-free form")
+    ap.add_argument("--variants", default="", help="comma-separated subset of hip_raw,hip,patched,torch (for profiling one of them)")
     a = ap.parse_args()
-    if a.loop_extras:
+    if a.variants:
+        print(json.dumps({"results": [run(v, a.steps, a.warmup) for v in a.variants.split(",")]}))
+    elif a.loop_extras:
         print(json.dumps({"workload": "patched training iteration + train.py's per-iteration extras (train.py:96, :113-116)",
                           "results": [run("patched", a.steps, a.warmup, extras=e) for e in ("masked", "patched")]}))
     else:

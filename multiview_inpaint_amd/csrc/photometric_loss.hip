@@ -166,10 +166,14 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const double* __restr
     }
 }
 
+// kTwo = false: dL/dimage of upstream * loss(lambda) (host scalars). kTwo = true: w2[0] * d mean|x - y| + w2[1] * d mean SSIM with the
+// two weights read from DEVICE memory — the backward of a caller that combines the two means itself (train.py:91-92 as written:
+// the upstream gradients of autograd are device scalars; reading them back would stall the loop).
+template <bool kTwo>
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                         const float* __restrict__ wmap, const float* __restrict__ dmaps,
                                                         int H, int W, Win win, float lambda, float upstream,
-                                                        float* __restrict__ dL_dimg) {
+                                                        const float* __restrict__ w2, float* __restrict__ dL_dimg) {
     __shared__ f2 s_d12[kHY][kHX + 1];                     // (D1, D2) of the halo
     __shared__ float s_d3[kHY][kHX + 1];
     __shared__ f2 s_h12[kHY][kLX + 1];
@@ -241,8 +245,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         const float wv = wmap ? wmap[o2] : 1.0f;
         const float x = img[idx] * wv, y = gt[idx] * wv;
         const float sgn = x > y ? 1.0f : (x < y ? -1.0f : 0.0f);
-        const float g = (1.0f - lambda) * inv_n * sgn - lambda * inv_n * (g12[o].x + 2.0f * x * g12[o].y + y * g3[o]);
-        dL_dimg[idx] = upstream * g * wv;
+        const float conv = g12[o].x + 2.0f * x * g12[o].y + y * g3[o];
+        if (kTwo) {
+            dL_dimg[idx] = (w2[0] * inv_n * sgn + w2[1] * inv_n * conv) * wv;
+        } else {
+            const float g = (1.0f - lambda) * inv_n * sgn - lambda * inv_n * conv;
+            dL_dimg[idx] = upstream * g * wv;
+        }
     }
 }
 
@@ -269,11 +278,12 @@ extern "C" size_t mvi_photometric_loss_workspace_bytes(int32_t H, int32_t W) {
     return (size_t)9 * H * W * sizeof(float) + blocks * 2 * sizeof(double) + 256;
 }
 
-extern "C" int mvi_photometric_loss(const float* image, const float* gt, const float* weight, int32_t H, int32_t W,
-                                    float lambda_dssim, float upstream, float* out3, float* dL_dimage, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+// what: 1 = the two forward launches (statistics + reduction), 2 = the gradient launch, 3 = both
+static int photometric_impl(int what, const float* image, const float* gt, const float* weight, int32_t H, int32_t W, float lambda_dssim,
+                            float upstream, const float* w2, float* out3, float* dL_dimage, void* workspace, size_t workspace_bytes,
+                            void* stream) {
     if (H <= 0 || W <= 0) return train_fail(MVI_EINVAL, "photometric_loss: empty image");
-    if (!image || !gt || !out3 || !workspace) return train_fail(MVI_EINVAL, "photometric_loss: NULL pointer");
+    if (!image || !gt || !workspace || ((what & 1) && !out3)) return train_fail(MVI_EINVAL, "photometric_loss: NULL pointer");
     if (workspace_bytes < mvi_photometric_loss_workspace_bytes(H, W))
         return train_fail(MVI_ENOMEM, "photometric_loss: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -284,13 +294,36 @@ extern "C" int mvi_photometric_loss(const float* image, const float* gt, const f
     double* partials = (double*)workspace;
     size_t off = ((size_t)nblocks * 2 * sizeof(double) + 255) / 256 * 256;
     float* dmaps = (float*)((char*)workspace + off);
-    hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(256), 0, st, image, gt, weight, H, W, win, dmaps, partials);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, partials, nblocks, 3.0 * (double)H * (double)W,
-                       lambda_dssim, out3);
-    if (dL_dimage)
-        hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(256), 0, st, image, gt, weight, dmaps, H, W, win, lambda_dssim,
-                           upstream, dL_dimage);
+    if (what & 1) {
+        hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(256), 0, st, image, gt, weight, H, W, win, dmaps, partials);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, partials, nblocks, 3.0 * (double)H * (double)W,
+                           lambda_dssim, out3);
+    }
+    if ((what & 2) && dL_dimage) {
+        if (w2)
+            hipLaunchKernelGGL(loss_grad_kernel<true>, grid, dim3(256), 0, st, image, gt, weight, dmaps, H, W, win, 0.0f, 1.0f, w2, dL_dimage);
+        else
+            hipLaunchKernelGGL(loss_grad_kernel<false>, grid, dim3(256), 0, st, image, gt, weight, dmaps, H, W, win, lambda_dssim,
+                               upstream, (const float*)nullptr, dL_dimage);
+    }
     return hipGetLastError() == hipSuccess ? MVI_OK : train_fail(MVI_EHIP, "photometric_loss: kernel launch failed");
+}
+
+extern "C" int mvi_photometric_loss(const float* image, const float* gt, const float* weight, int32_t H, int32_t W,
+                                    float lambda_dssim, float upstream, float* out3, float* dL_dimage, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return photometric_impl(3, image, gt, weight, H, W, lambda_dssim, upstream, nullptr, out3, dL_dimage, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_photometric_loss_stats(const float* image, const float* gt, const float* weight, int32_t H, int32_t W, float* out3,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    return photometric_impl(1, image, gt, weight, H, W, 0.0f, 1.0f, nullptr, out3, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_photometric_loss_grad2(const float* image, const float* gt, const float* weight, int32_t H, int32_t W,
+                                          const float* weights2, float* dL_dimage, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!weights2 || !dL_dimage) return train_fail(MVI_EINVAL, "photometric_loss_grad2: NULL pointer");
+    return photometric_impl(2, image, gt, weight, H, W, 0.0f, 1.0f, weights2, nullptr, dL_dimage, workspace, workspace_bytes, stream);
 }
 
 static thread_local char g_terr[256] = "";

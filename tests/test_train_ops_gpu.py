@@ -75,6 +75,61 @@ def test_reference_named_functions_are_differentiable(T):
     assert float((img.grad / 3.0 - g_ref).abs().max()) < 1e-4 * float(g_ref.abs().max())
 
 
+def test_l1_loss_then_ssim_on_the_same_tensors_share_one_node(T):
+    """The reference's loss expression (train.py:91-92) through the reference-named functions: ssim(a, b) right after l1_loss(a, b)
+    on the same tensor objects is the other output of ONE node (one statistics pass, one gradient pass weighted by the two upstream
+    gradients on the device). Values identical to the stand-alone calls; gradient equal to the fused loss's; anything that breaks
+    the match (other tensors, an in-place edit in between, a second ssim call) takes the stand-alone path with the same values."""
+    name = "c"
+    gt = torch.tensor(G[f"{name}_gt"]).cuda()
+    img = torch.tensor(G[f"{name}_image"]).cuda().requires_grad_(True)
+    calls = []
+    orig = T._LossPair.apply
+    T._LossPair.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        l1 = T.l1_loss(img, gt)
+        ss = T.ssim(img, gt)
+        assert len(calls) == 1 and ss.grad_fn is l1.grad_fn                       # ONE node
+        loss = 0.8 * l1 + 0.2 * (1.0 - ss)
+        loss.backward()
+        g_pair, img.grad = img.grad.clone(), None
+        fused = T.fused_l1_dssim_loss(img, gt, 0.2)
+        fused.backward()
+        g_fused, img.grad = img.grad.clone(), None
+        assert abs(loss.item() - fused.item()) < 1e-6
+        assert float((g_pair - g_fused).abs().max()) < 2e-6 * float(g_fused.abs().max())
+        # the L1 value dropped before ssim is called (one expression): still one node
+        n = len(calls)
+        loss2 = 0.8 * T.l1_loss(img, gt) + 0.2 * (1.0 - T.ssim(img, gt))
+        assert len(calls) == n + 1 and loss2.item() == loss.item() and T._pending_pair is None
+        # stand-alone values (a second ssim call finds nothing pending)
+        ss2 = T.ssim(img, gt)
+        assert ss2.grad_fn is not l1.grad_fn and ss2.item() == ss.item()
+        # L1 alone: the SSIM half gets no gradient
+        l1b = T.l1_loss(img, gt)
+        assert l1b.item() == l1.item()
+        l1b.backward()
+        want = torch.sign(img.detach() - gt) / img.numel()
+        assert float((img.grad - want).abs().max()) < 1e-9
+        img.grad = None
+        # other tensor objects with the same values: no match, same numbers
+        T.l1_loss(img, gt)
+        ss3 = T.ssim(img * 1.0, gt)
+        assert ss3.grad_fn is not l1.grad_fn and abs(ss3.item() - ss.item()) < 1e-7
+        # an in-place edit between the two calls: no match (the pending values belong to the old contents)
+        buf = img.detach().clone()
+        l1c = T.l1_loss(buf, gt)
+        buf.mul_(0.5)
+        ss4 = T.ssim(buf, gt)
+        assert abs(ss4.item() - ss.item()) > 1e-3 and l1c.item() == l1.item()
+        # under no_grad (training_report, render.py): values only, nothing kept
+        with torch.no_grad():
+            a, b = T.l1_loss(img, gt), T.ssim(img, gt)
+        assert a.item() == l1.item() and b.item() == ss.item() and not a.requires_grad
+    finally:
+        T._LossPair.apply = orig
+
+
 def test_full_size_against_torch_restatement_and_properties(T):
     H, W = 1080, 1920
     g = torch.Generator(device="cuda").manual_seed(0)
