@@ -655,13 +655,8 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
         float* out0 = dL_dshs ? (f.raw ? dL_dshs + 3 * si : dL_dshs + si * M * 3) : nullptr;
         float* out_rest = dL_dshs ? (f.raw ? rawx.dL_dshs_rest + si * (3 * M - 3) - 3 : out0) : nullptr;
         float ddx = 0, ddy = 0, ddz = 0;
-        if (!f.raw && M == 16 && (vec_ok & 1)) {
-            // the common case (sh_degree <= 3 stored with 16 coefficients): the 192-byte row moves as twelve 16-byte
-            // accesses per lane instead of 48 + 48 scattered words
-            float rowv[48];
-            const float4* in4 = reinterpret_cast<const float4*>(in0);
-#pragma unroll
-            for (int v = 0; v < 12; ++v) { const float4 t = in4[v]; rowv[4 * v] = t.x; rowv[4 * v + 1] = t.y; rowv[4 * v + 2] = t.z; rowv[4 * v + 3] = t.w; }
+        // a whole 16-coefficient row held in registers: w = coefficient * dL/dcolour feeds the direction gradient, the row becomes dL/dSH
+        auto row16 = [&](float (&rowv)[48]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
 #pragma unroll
@@ -671,10 +666,45 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
                     ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;      // bx / by / bz are zero above nb
                 }
             }
+        };
+        if (!f.raw && M == 16 && (vec_ok & 1)) {
+            // the common case (sh_degree <= 3 stored with 16 coefficients): the 192-byte row moves as twelve 16-byte
+            // accesses per lane instead of 48 + 48 scattered words
+            float rowv[48];
+            const float4* in4 = reinterpret_cast<const float4*>(in0);
+#pragma unroll
+            for (int v = 0; v < 12; ++v) { const float4 t = in4[v]; rowv[4 * v] = t.x; rowv[4 * v + 1] = t.y; rowv[4 * v + 2] = t.z; rowv[4 * v + 3] = t.w; }
+            row16(rowv);
             if (out0) {
                 float4* out4 = reinterpret_cast<float4*>(out0);
 #pragma unroll
                 for (int v = 0; v < 12; ++v) out4[v] = make_float4(rowv[4 * v], rowv[4 * v + 1], rowv[4 * v + 2], rowv[4 * v + 3]);
+            }
+        } else if (f.raw && M == 16) {
+            // raw mode (features_dc [P,1,3] + features_rest [P,15,3]: 12- and 180-byte rows at 4-byte alignment): one 12-byte access,
+            // eleven 16-byte accesses at dword alignment and one word — the per-word form cost the training iteration 94 us here
+            // against 28 us for the same Gaussians through the [P,16,3] entry. (Its own branch, not a variant of the one above: with
+            // both load sequences feeding one array the compiler merged them into 48 single-word loads from a selected address.)
+            struct W3 { float a, b, c; };
+            struct W4 { float a, b, c, d; };
+            float rowv[48];
+            const float* rp = f.shs_rest + si * 45;
+            const W3 t0 = *reinterpret_cast<const W3*>(in0);
+            rowv[0] = t0.a; rowv[1] = t0.b; rowv[2] = t0.c;
+#pragma unroll
+            for (int v = 0; v < 11; ++v) {
+                const W4 t = *reinterpret_cast<const W4*>(rp + 4 * v);
+                rowv[3 + 4 * v] = t.a; rowv[4 + 4 * v] = t.b; rowv[5 + 4 * v] = t.c; rowv[6 + 4 * v] = t.d;
+            }
+            rowv[47] = rp[44];
+            row16(rowv);
+            if (out0) {
+                float* op = rawx.dL_dshs_rest + si * 45;
+                *reinterpret_cast<W3*>(out0) = W3{rowv[0], rowv[1], rowv[2]};
+#pragma unroll
+                for (int v = 0; v < 11; ++v)
+                    *reinterpret_cast<W4*>(op + 4 * v) = W4{rowv[3 + 4 * v], rowv[4 + 4 * v], rowv[5 + 4 * v], rowv[6 + 4 * v]};
+                op[44] = rowv[47];
             }
         } else {
 #pragma unroll
