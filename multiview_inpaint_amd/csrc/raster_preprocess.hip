@@ -680,6 +680,21 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
 #pragma unroll
                 for (int v = 0; v < 12; ++v) out4[v] = make_float4(rowv[4 * v], rowv[4 * v + 1], rowv[4 * v + 2], rowv[4 * v + 3]);
             }
+        } else if (!f.raw && M == 16) {
+            // the same row at 4-byte alignment only (the caller's arrays inside a larger buffer, e.g. dist.GradBucket): 16-byte accesses
+            // at dword alignment
+            struct W4 { float a, b, c, d; };
+            float rowv[48];
+#pragma unroll
+            for (int v = 0; v < 12; ++v) {
+                const W4 t = *reinterpret_cast<const W4*>(in0 + 4 * v);
+                rowv[4 * v] = t.a; rowv[4 * v + 1] = t.b; rowv[4 * v + 2] = t.c; rowv[4 * v + 3] = t.d;
+            }
+            row16(rowv);
+            if (out0) {
+#pragma unroll
+                for (int v = 0; v < 12; ++v) *reinterpret_cast<W4*>(out0 + 4 * v) = W4{rowv[4 * v], rowv[4 * v + 1], rowv[4 * v + 2], rowv[4 * v + 3]};
+            }
         } else if (f.raw && M == 16) {
             // raw mode (features_dc [P,1,3] + features_rest [P,15,3]: 12- and 180-byte rows at 4-byte alignment): one 12-byte access,
             // eleven 16-byte accesses at dword alignment and one word — the per-word form cost the training iteration 94 us here

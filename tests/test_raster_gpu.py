@@ -889,6 +889,33 @@ def test_sparse_backward_equals_dense_backward_and_the_support_is_a_superset(R, 
     print(f"gradient support: {float(support.float().mean()):.4f} of the Gaussians (visible: {float((radii > 0).float().mean()):.3f})")
 
 
+def test_sparse_backward_with_sh_rows_at_4_byte_alignment(R):
+    """The chain rule's SH rows at dword alignment only — gradients written into dist.GradBucket's views (dL/dSH starts 12 P bytes
+    into the flat buffer: P = 20001 leaves it at 12 mod 16) and the SH input itself one float into a larger buffer: the 16-byte
+    accesses at dword alignment against the same call with 16-byte aligned arrays."""
+    from multiview_inpaint_amd import dist as mdist
+    N, W, H, deg = 20001, 320, 200, 3
+    cam = syn.make_camera(W, H, 50.0)
+    sc = syn.make_scene(N, cam, deg, seed=23, log_scale_mean=np.log(0.03))
+    t = _to_dev(sc)
+    rs = _settings(R, cam, np.array([0.2, 0.1, 0.3], np.float32), deg)
+    big = torch.zeros(N * 48 + 1, device="cuda")
+    shs_off = big[1:].view(N, 16, 3)
+    shs_off.copy_(t["shs"])
+    bucket = mdist.GradBucket(N, 16, torch.device("cuda"))
+    assert shs_off.data_ptr() % 16 == 4 and bucket.views["shs"].data_ptr() % 16 == 12
+    g_img = torch.randn(3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    res = []
+    for shs, out in ((t["shs"], None), (shs_off, bucket.views)):
+        kw = dict(shs=shs, scales=t["scales"], rotations=t["rotations"])
+        color, radii, depth, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], **kw)
+        res.append(R.rasterize_backward(rs, st, g_img, t["means3D"], out=out, **kw))
+    assert int((res[0]["shs"].abs().sum(dim=(1, 2)) > 0).sum()) > 500
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        assert _same_to_summation_order(res[1][k].cpu().numpy(), res[0][k].cpu().numpy()), k
+    assert res[1]["shs"].data_ptr() == bucket.views["shs"].data_ptr()
+
+
 @pytest.mark.parametrize("N,W,H,log_scale,squeeze", [
     (1, 16, 16, np.log(0.3), None), (5, 15, 33, np.log(0.3), None), (70, 4096, 16, np.log(0.05), None),
     (3000, 16, 4096, np.log(0.05), None), (3000, 33, 4090, np.log(0.02), None),
