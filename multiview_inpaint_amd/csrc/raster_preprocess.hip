@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kSparseBlock) void preprocess_backward_sparse_kerne
     const float* __restrict__ grad_rows, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dshs,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales, float* __restrict__ dL_drots, RawBackwardExtra rawx,
-    int vec_ok) {   // bit 0: shs / dL_dshs rows may move as 16-byte accesses, bit 1: rotations (the caller's pointers are 16-byte aligned)
+    int vec_ok) {   // bit 0: the shs / dL_dshs rows are 16-byte aligned, bit 1: the rotations are (else: the same widths at dword alignment / per word)
     // a fixed, moderate grid walks the list with a grid stride: the list's length is only known on the device, and a grid
     // sized for P would be 23 k blocks of which a few hundred find work
     const uint32_t n_touched = *g.touched_count;
