@@ -1,0 +1,40 @@
+"""SURVEY.md §8e on the one GPU the suite gets: TWO ranks of the view-sharded step on cuda:0 over gloo — the device path of
+dist.CompactedGradExchange (union scan, windowed gather / scatter kernels, paging) with world_size > 1. The ranks are forked by a
+forkserver that tests/conftest.py starts before anything in the pytest process can initialise the GPU (a process that has may not
+start programs on this pool); the work and its checks are tests/dist_gpu_worker.py."""
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_on_one_gpu_exchange_equals_the_plain_sum_of_their_views(rank_launcher):
+    if rank_launcher is None:
+        pytest.skip("no forkserver was started for this session (no GPU visible at configure time)")
+    import dist_gpu_worker as W
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    q = rank_launcher.Queue()
+    kwargs = dict(N=60_001, W=480, H=304, forced=(None, None, 2000, None))
+    procs = [rank_launcher.Process(target=W.entry, args=(r, world, port, q, kwargs), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, ok, pages, lines = q.get(timeout=300)
+            results[rank] = (ok, pages, lines)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()                                    # exactly the processes started here
+    for r in range(world):
+        ok, pages, lines = results[r]
+        print("\n".join(lines))
+        assert ok, lines[-3:]
+        assert len(pages) == 4 and pages[2] > 3 and pages[0] == 1, pages      # the forced capacity paged; the first step did not
