@@ -94,3 +94,109 @@ def entry(rank, world, port, queue, kwargs):
     except BaseException as e:       # the parent must hear about it
         import traceback
         queue.put((rank, False, [], lines + [traceback.format_exc(), repr(e)]))
+
+
+# ---- the view-sharded TRAINING step (BASELINE configs[4] at two ranks): render own view -> L1 + DSSIM gradient -> backward into the
+# exchange's views -> compacted exchange -> Adam on the replicated parameters, against ONE process that renders every view of a step,
+# sums the gradients and takes the same Adam step.
+def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=6, say=print):
+    import numpy as np
+    import torch
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multiview_inpaint_amd import dist as md, raster as R, synthetic as syn, train_ops as T
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        M = (deg + 1) ** 2
+        sc = syn.make_scene(N, syn.make_camera(W, H, 50.0), deg, seed=0, log_scale_mean=np.log(0.04))
+        names = ("means3D", "opacities", "scales", "rotations", "shs")
+        lrs = dict(means3D=1.6e-4, opacities=1e-2, scales=1e-3, rotations=1e-3, shs=2.5e-3)
+
+        def settings(k):
+            cam = camera(syn, np, k, W, H)
+            return R.GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
+                scale_modifier=1.0, viewmatrix=torch.tensor(cam["viewmatrix"], device=dev), projmatrix=torch.tensor(cam["projmatrix"], device=dev),
+                sh_degree=deg, campos=torch.tensor(cam["campos"], device=dev), prefiltered=False)
+
+        def fresh():
+            t = {k: torch.tensor(sc[k], device=dev) for k in names}
+            opt = T.FusedAdam([{"params": [t[k]], "lr": lrs[k], "name": k} for k in names], lr=0.0, eps=1e-15)
+            return t, opt
+
+        def target(k):                                    # what the views should look like: the scene with other colours
+            g = torch.Generator(dev).manual_seed(77)
+            shs = torch.tensor(sc["shs"], device=dev)
+            shs[:, 0] += 0.6 * torch.randn(N, 3, device=dev, generator=g)
+            t0 = {k2: torch.tensor(sc[k2], device=dev) for k2 in names}
+            img, _, _, _ = R.rasterize_forward(settings(k), t0["means3D"], t0["opacities"], shs=shs, scales=t0["scales"], rotations=t0["rotations"])
+            return img
+
+        def view_gradient(t, k, out=None, sh_grad="dense"):
+            rs = settings(k)
+            kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+            img, _, _, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **kw)
+            out3, g_img = T.photometric_loss_forward_backward(img, target(k), 0.2)
+            g = R.rasterize_backward(rs, st, g_img, t["means3D"], out=out, sh_grad=sh_grad, **kw)
+            return rs, st, g, out3[0]
+
+        # (1) this rank's share of the sharded run
+        t, opt = fresh()
+        ex = md.CompactedGradExchange(N, M, deg, dev)
+        ex.THRESHOLD, ex.MIN_CAPACITY, ex.ROUND = 1.0, 256, 256
+        shard_losses = []
+        for step in range(steps):
+            rs, st, _, loss = view_gradient(t, (step % 2) * world + rank, out=ex.views, sh_grad="factor")   # 2 x world views, revisited
+            got = ex.exchange_support(t["means3D"], rs.campos, st.tensor("grad_support", (N,), torch.uint8))
+            for k in names:
+                t[k].grad = got[k].view_as(t[k])
+            opt.step()
+            total = loss.detach().clone().cpu()
+            td.all_reduce(total)                          # the step's loss summed over the views (for the comparison only)
+            shard_losses.append(float(total))
+        # (2) one process, every view of a step, summed gradients
+        t1, opt1 = fresh()
+        single_losses = []
+        for step in range(steps):
+            acc, tot = None, 0.0
+            for k in range(world):
+                _, _, g, loss = view_gradient(t1, (step % 2) * world + k)
+                acc = {n: g[n].clone() for n in names} if acc is None else {n: acc[n] + g[n] for n in names}
+                tot += float(loss)
+            for n in names:
+                t1[n].grad = acc[n].view_as(t1[n])
+            opt1.step()
+            single_losses.append(tot)
+        torch.cuda.synchronize()
+        ok = True
+        worst = max(abs(a - b) / abs(b) for a, b in zip(shard_losses, single_losses))
+        ok &= worst < 1e-4 and single_losses[-2] < single_losses[0] and single_losses[-1] < single_losses[1]     # (same views two visits later)
+        rms = {}
+        for n in names:
+            d, ref = (t[n] - t1[n]).double(), (t1[n] - torch.tensor(sc[n], device=dev)).double()     # against the distance travelled
+            rms[n] = float(d.pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-30))
+            ok &= rms[n] < 2e-2
+        digest = torch.stack([t[n].double().sum() for n in names]).cpu()
+        every = [torch.zeros_like(digest) for _ in range(world)]
+        td.all_gather(every, digest)
+        same = all(torch.equal(every[0], e) for e in every)           # the replicas stay bit-identical
+        ok &= same
+        say(f"rank {rank}: loss (sum over {world} views) {single_losses[0]:.5f} -> {single_losses[-2]:.5f} and {single_losses[1]:.5f} -> {single_losses[-1]:.5f}; sharded vs single-process loss curve "
+            f"{worst:.2e}; parameter difference / distance travelled (rms) {max(rms.values()):.2e}; replicas identical: {same}")
+        flag = torch.tensor([1.0 if ok else 0.0])
+        td.all_reduce(flag, op=td.ReduceOp.MIN)
+        return flag.item() == 1.0, []
+    finally:
+        td.destroy_process_group()
+
+
+def entry_training(rank, world, port, queue, kwargs):
+    lines = []
+    try:
+        ok, _ = run_training_rank(rank, world, port, say=lines.append, **kwargs)
+        queue.put((rank, ok, [], lines))
+    except BaseException as e:
+        import traceback
+        queue.put((rank, False, [], lines + [traceback.format_exc(), repr(e)]))

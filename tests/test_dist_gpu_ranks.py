@@ -9,18 +9,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_on_one_gpu_exchange_equals_the_plain_sum_of_their_views(rank_launcher):
+def _run_ranks(rank_launcher, target, world, kwargs):
     if rank_launcher is None:
         pytest.skip("no forkserver was started for this session (no GPU visible at configure time)")
-    import dist_gpu_worker as W
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    world = 2
     q = rank_launcher.Queue()
-    kwargs = dict(N=60_001, W=480, H=304, forced=(None, None, 2000, None))
-    procs = [rank_launcher.Process(target=W.entry, args=(r, world, port, q, kwargs), daemon=True) for r in range(world)]
+    procs = [rank_launcher.Process(target=target, args=(r, world, port, q, kwargs), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -33,8 +30,29 @@ def test_two_ranks_on_one_gpu_exchange_equals_the_plain_sum_of_their_views(rank_
             p.join(timeout=30)
             if p.is_alive():
                 p.terminate()                                    # exactly the processes started here
+    return results
+
+
+def test_two_ranks_on_one_gpu_exchange_equals_the_plain_sum_of_their_views(rank_launcher):
+    import dist_gpu_worker as W
+    world = 2
+    results = _run_ranks(rank_launcher, W.entry, world, dict(N=60_001, W=480, H=304, forced=(None, None, 2000, None)))
     for r in range(world):
         ok, pages, lines = results[r]
         print("\n".join(lines))
         assert ok, lines[-3:]
         assert len(pages) == 4 and pages[2] > 3 and pages[0] == 1, pages      # the forced capacity paged; the first step did not
+
+
+def test_two_rank_view_sharded_training_equals_one_process_over_both_views(rank_launcher):
+    """BASELINE configs[4] (per-GPU rasterize + exchange of the Gaussian gradients) at two ranks: six steps of render own view -> L1 + DSSIM
+    gradient -> backward into the exchange's views -> compacted exchange -> Adam on the replicated parameters, against one process
+    that renders both views of every step, sums the gradients and takes the same Adam step: same loss curve, same parameters (to the
+    summation order of the float atomics, measured against the distance the parameters travelled), replicas bit-identical."""
+    import dist_gpu_worker as W
+    world = 2
+    results = _run_ranks(rank_launcher, W.entry_training, world, dict())
+    for r in range(world):
+        ok, _, lines = results[r]
+        print("\n".join(lines))
+        assert ok, lines[-3:]
