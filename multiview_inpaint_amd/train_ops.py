@@ -142,8 +142,7 @@ _pending_pair = None
 def l1_loss(network_output, gt):
     """gs-simp/utils/loss_utils.py:17-18 (same name and signature)."""
     global _pending_pair
-    _prep(network_output, gt, None)                      # argument checks (shapes, device) before anything is remembered
-    l1, ss = _LossPair.apply(network_output, gt)
+    l1, ss = _LossPair.apply(network_output, gt)         # (raises on bad shapes / devices before anything is remembered)
     _pending_pair = (weakref.ref(network_output), network_output._version, weakref.ref(gt), gt._version, ss)
     return l1
 
