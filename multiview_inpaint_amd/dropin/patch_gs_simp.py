@@ -34,6 +34,11 @@ What install() does (each part can be switched off):
               nonzero() with a host read-back, two gathers and two index_put each; the patched form adds
               `where(mask, norm(grad[:, :2]), 0)` and `mask` to the whole arrays — the same values, three elementwise kernels, no
               synchronisation. Other filter types (index tensors) go to the reference's method.
+  * surgery   GaussianModel.prune_points (gaussian_model.py:351-365, with _prune_optimizer :335-349; twice per densification): the 6
+              parameters, their 12 Adam moments and the 3 per-Gaussian statistics are compacted with ONE scan of the mask and ONE gather
+              launch (train_ops.prune_optimizer_state) instead of 21 boolean-index operations with a nonzero() read-back each —
+              bit-identical tensors, optimizer.state re-keyed the same way. Masks that are not boolean GPU tensors, or an optimizer
+              whose groups are not one parameter each, go to the reference's method.
 Nothing is patched that is not named here; a script that imported the loss functions before install() ran keeps the
 reference's (install() must come first — the runner below guarantees it)."""
 import functools
@@ -120,7 +125,33 @@ def _make_stats(reference_stats):
     return add_densification_stats
 
 
-def install(loss=True, optimizer=True, render=True, stats=True):
+def _make_prune_points(reference_prune_points):
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    attrs = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    stat_names = ("xyz_gradient_accum", "denom", "max_radii2D")
+
+    @functools.wraps(reference_prune_points)
+    def prune_points(self, mask):
+        import torch
+        opt = getattr(self, "optimizer", None)
+        ok = (torch.is_tensor(mask) and mask.dtype == torch.bool and mask.ndim == 1 and mask.is_cuda and opt is not None
+              and all(len(g["params"]) == 1 for g in opt.param_groups)
+              and sorted(g.get("name") for g in opt.param_groups) == sorted(names)
+              and all(torch.is_tensor(getattr(self, n, None)) and getattr(self, n).shape[0] == mask.shape[0]
+                      and getattr(self, n).element_size() == 4 for n in stat_names))
+        if not ok:
+            return reference_prune_points(self, mask)
+        from multiview_inpaint_amd.train_ops import prune_optimizer_state
+        tensors, stats = prune_optimizer_state(opt, ~mask, extra=tuple(getattr(self, n) for n in stat_names))
+        for a, n in zip(attrs, names):
+            setattr(self, a, tensors[n])
+        for n, t in zip(stat_names, stats):
+            setattr(self, n, t)
+    prune_points._mvi_patched = True
+    return prune_points
+
+
+def install(loss=True, optimizer=True, render=True, stats=True, surgery=True):
     """Patches the gs-simp modules named above (they must be importable: the script's directory on sys.path). Returns the
     list of what was patched, for logging. Idempotent."""
     if _DROPIN not in sys.path:
@@ -159,6 +190,14 @@ def install(loss=True, optimizer=True, render=True, stats=True):
                 continue
             cls.add_densification_stats = _make_stats(fn)
             done.append(f"scene.gaussian_model.{name}.add_densification_stats")
+    if surgery:
+        gm = importlib.import_module("scene.gaussian_model")
+        for name, cls in list(vars(gm).items()):
+            fn = isinstance(cls, type) and cls.__dict__.get("prune_points")
+            if not fn or getattr(fn, "_mvi_patched", False):
+                continue
+            cls.prune_points = _make_prune_points(fn)
+            done.append(f"scene.gaussian_model.{name}.prune_points")
     if render:
         gr = importlib.import_module("gaussian_renderer")
         gm = importlib.import_module("scene.gaussian_model")

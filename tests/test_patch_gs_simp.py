@@ -32,6 +32,8 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
                 return "set up"
             def add_densification_stats(self, viewspace_point_tensor, update_filter):
                 return "stand-in stats"
+            def prune_points(self, mask):
+                return "stand-in prune"
         class Untouched:
             pass
     """))
@@ -56,6 +58,7 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
         print("RENDER", getattr(render, "_mvi_patched", False), render.__name__, gr._reference_render is not render,
               render(None, g, None, None, 0.5, "colours"))
         print("STATS", getattr(GaussianModel.add_densification_stats, "_mvi_patched", False), g.add_densification_stats(None, [1, 2]))
+        print("PRUNE", getattr(GaussianModel.prune_points, "_mvi_patched", False), g.prune_points([True, False]))
         print("OPT", type(o).__module__, type(o).__name__, [(pg["name"], pg["lr"], pg["eps"], pg["betas"]) for pg in o.param_groups],
               o.param_groups[0]["params"][0] is g._xyz)
     """))
@@ -73,3 +76,4 @@ def test_runner_patches_loss_functions_and_optimizer_before_the_script_imports_t
     assert "gaussian_renderer.render" in p.stderr
     assert out["STATS"] == "True stand-in stats"               # (a filter the mask-free form does not serve: the script's own method ran)
     assert "scene.gaussian_model.GaussianModel.add_densification_stats" in p.stderr
+    assert out["PRUNE"] == "True stand-in prune" and "scene.gaussian_model.GaussianModel.prune_points" in p.stderr

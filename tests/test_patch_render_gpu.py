@@ -259,3 +259,78 @@ def test_short_training_run_matches_the_pytorch_formulation():
             assert float(d.abs().max()) <= 40 * lrs[k] * 1.01, k
     assert torch.equal(den_a, den_b)
     assert rel(acc_a, acc_b) < 5e-3
+
+
+def test_patched_prune_points_equals_the_boolean_index_form():
+    """gaussian_model.py:335-365 restated (boolean indexing of parameters, Adam moments and statistics, optimizer.state re-keyed)
+    against the patched prune_points (one mask scan + one gather launch): every tensor identical, the optimizer steps on; a mask
+    that is an index tensor goes to the reference's method."""
+    from multiview_inpaint_amd import train_ops as T
+    from multiview_inpaint_amd.dropin import patch_gs_simp
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    attrs = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    shapes = dict(xyz=(3,), f_dc=(1, 3), f_rest=(15, 3), opacity=(1,), scaling=(3,), rotation=(4,))
+    calls = []
+
+    class M:
+        def __init__(self, P, opt_cls):
+            g = torch.Generator("cuda").manual_seed(2)
+            for a, n in zip(attrs, names):
+                setattr(self, a, torch.nn.Parameter(torch.randn(P, *shapes[n], device="cuda", generator=g)))
+            self.optimizer = opt_cls([{"params": [getattr(self, a)], "lr": 1e-2, "name": n} for a, n in zip(attrs, names)], lr=0.0, eps=1e-15)
+            for a in attrs:
+                getattr(self, a).grad = torch.randn(getattr(self, a).shape, device="cuda", generator=g)
+            self.optimizer.step()                                    # non-trivial moments
+            self.xyz_gradient_accum = torch.rand(P, 1, device="cuda", generator=g)
+            self.denom = torch.rand(P, 1, device="cuda", generator=g)
+            self.max_radii2D = torch.rand(P, device="cuda", generator=g)
+
+        def _prune_optimizer(self, mask):                            # gaussian_model.py:335-349
+            out = {}
+            for group in self.optimizer.param_groups:
+                st = self.optimizer.state.get(group["params"][0], None)
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+                del self.optimizer.state[group["params"][0]]
+                group["params"][0] = torch.nn.Parameter(group["params"][0][mask].requires_grad_(True))
+                self.optimizer.state[group["params"][0]] = st
+                out[group["name"]] = group["params"][0]
+            return out
+
+        def prune_points(self, mask):                                # gaussian_model.py:351-365
+            calls.append(1)
+            valid = ~mask
+            t = self._prune_optimizer(valid)
+            for a, n in zip(attrs, names):
+                setattr(self, a, t[n])
+            self.xyz_gradient_accum, self.denom, self.max_radii2D = self.xyz_gradient_accum[valid], self.denom[valid], self.max_radii2D[valid]
+
+    P = 50_001
+    patched = patch_gs_simp._make_prune_points(M.prune_points)
+    a, b = M(P, T.FusedAdam), M(P, T.FusedAdam)
+    mask = torch.rand(P, device="cuda", generator=torch.Generator("cuda").manual_seed(3)) < 0.37
+    M.prune_points(a, mask)
+    n = len(calls)
+    patched(b, mask)
+    assert len(calls) == n, "the patched method went through the reference's"
+    kept = int((~mask).sum())
+    for attr in attrs + ("xyz_gradient_accum", "denom", "max_radii2D"):
+        x, y = getattr(a, attr), getattr(b, attr)
+        assert x.shape[0] == kept and torch.equal(x, y), attr
+    for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert isinstance(pb, torch.nn.Parameter) and pb.requires_grad and gb["name"] == ga["name"]
+        sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
+        assert pb is getattr(b, attrs[names.index(gb["name"])])
+    for m in (a, b):                                                 # and training goes on from the pruned state
+        for attr in attrs:
+            getattr(m, attr).grad = torch.ones_like(getattr(m, attr))
+        m.optimizer.step()
+    assert torch.equal(a._xyz, b._xyz) and torch.equal(a._features_rest, b._features_rest)
+    idx = torch.arange(0, kept, 5, device="cuda")
+    n = len(calls)
+    try:
+        patched(b, idx)                                              # not a boolean mask: the reference's method (which rejects ~idx its own way)
+    except Exception:
+        pass
+    assert len(calls) == n + 1
