@@ -256,7 +256,7 @@ def test_short_training_run_matches_the_pytorch_formulation():
         if pa[k].numel():
             d, ref = (pa[k] - pb[k]).double(), pb[k].double()
             assert float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 5e-3, k
-            assert float(d.abs().max()) <= 40 * lrs[k] * 1.01, k
+            assert float(d.abs().max()) <= 2 * 40 * lrs[k] * 1.01, k           # (each run moves a parameter by about lr per step at most)
     assert torch.equal(den_a, den_b)
     assert rel(acc_a, acc_b) < 5e-3
 
