@@ -103,27 +103,40 @@ def cpu_baseline():
                        f"to this process), {dt:.1f} s")
 
 
+SVD_CHILD_FAILURES = []          # what went wrong in a child that produced no result: kept in the JSON line, never swallowed
+
+
 def _svd_child(two_streams, steps, timeout):
     """The SVD denoise-step benchmark (multiview_inpaint_amd/svd/bench_svd.py) in a child process; None if it failed or did not
-    finish within `timeout` seconds (the child is then killed)."""
+    finish within `timeout` seconds (the child is then killed) — with the reason and the tail of the child's stderr appended to
+    SVD_CHILD_FAILURES."""
     import subprocess
     env = dict(os.environ, MVI_SVD_TWO_STREAMS="1" if two_streams else "0")
+    what = "two streams" if two_streams else "one stream"
+
+    def failed(why, err):
+        tail = (err or "").strip().splitlines()[-12:]
+        SVD_CHILD_FAILURES.append({"child": what, "why": why, "stderr_tail": tail})
+        sys.stderr.write(f"[bench] SVD child ({what}) {why}\n" + "".join(f"    {ln}\n" for ln in tail))
+        return None
+
     try:
         # MVI_BENCH_SVD_WEIGHTS=f16: the reference's own precision (fp16), +1.5 % step time on this chip; default bf16
         p = subprocess.run([sys.executable, "-m", "multiview_inpaint_amd.svd.bench_svd", "--steps", str(steps), "--warmup", "2",
                             "--weights", os.environ.get("MVI_BENCH_SVD_WEIGHTS", "bf16")],
-                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
-    except subprocess.TimeoutExpired:
-        return None
+                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else e.stderr
+        return failed(f"did not finish within {timeout} s and was killed", err)
     if p.returncode != 0:
-        return None
+        return failed(f"exited with code {p.returncode}", p.stderr)
     for line in reversed(p.stdout.strip().splitlines()):
         if line.startswith("{"):
             try:
                 return json.loads(line)
             except ValueError:
-                return None
-    return None
+                return failed("printed a line that is not JSON", p.stderr)
+    return failed("printed no JSON line", p.stderr)
 
 
 def svd_leg(steps):
@@ -359,6 +372,8 @@ def main():
                if backend != "nccl" or "MVI_BENCH_DEVICE" in os.environ else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # the shared library every kernel of this run came from (MVI_HIP_LIB redirects it for same-box A/B runs)
+            "library": os.path.relpath(_lib.LIB_PATH, ROOT) + (" (MVI_HIP_LIB override)" if _lib.LIB_OVERRIDDEN else ""),
             "config": {"workload": f"rasterizer-with-depth fwd+bwd, one {W}x{H} view per GPU per step, "
                                    f"N={N} Gaussians, sh_degree {deg} (BASELINE.json configs[2] size, SURVEY.md §8d scene)",
                        "gaussians": N, "visible": V, "num_rendered_D": D, "tiles": T,
@@ -432,10 +447,25 @@ def main():
                 bench_svd.use_shipped_miopen_db()
                 svd = bench_svd.run_gpu(dev, steps=args.svd_steps, warmup=2)
                 svd["execution"] = "one stream (in-process: the child process could not run)"
+            if SVD_CHILD_FAILURES:
+                svd["child_failures"] = SVD_CHILD_FAILURES
             svd["metric"] = "SVD 14-frame 576x1024 denoise steps/s (ControlNet + ControlledVideoUNet, CFG batch 28)"
             if not args.no_cpu_baseline:
                 svd["cpu_baseline"] = bench_svd.run_cpu_baseline()
             out["svd"] = svd
+            # HBM bytes per launch of the two hand-written contractions at their largest shapes of this step, from the committed
+            # PMC passes (tools/pmc_svd_traffic.sh -> profiles/svd_traffic.json; gfx950 corrections applied there); null if absent
+            svd_traffic = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "svd_traffic.json")) as fh:
+                    svd_traffic = json.load(fh).get("kernels", {})
+            except (OSError, ValueError):
+                pass
+
+            def _traffic(key):
+                k = svd_traffic.get(key)
+                return None if not k else {"hbm_bytes_per_launch": k["hbm_bytes_corrected"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
+                                           "launch": k["shape"], "l2_hit_rate": k.get("l2_hit_rate")}
             am = svd.get("hip_ops", {}).get("attention_mfma")
             if am:
                 # the roofline of path B's hand-written contraction, flat at the top level (attention FLOPs /
@@ -444,7 +474,7 @@ def main():
                     "bound": "mfma", "kernel": "attn_flash8_kernel (+ attn_flash_kernel for S < 1024)",
                     "achieved": am["TFLOPs"], "peak": bench_svd.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": am["frac_of_bf16_mfma_peak"], "calls_per_step": am["calls_per_step"], "ms_per_step": am["ms_per_step"],
-                    "traffic": None}
+                    "traffic": _traffic("attention")}
             cv = svd.get("hip_ops", {}).get("conv3x3_n320")
             if cv:
                 # the other hand-written contraction of path B (round 3): the 3x3 convolutions as implicit GEMMs in
@@ -453,7 +483,7 @@ def main():
                     "bound": "mfma", "kernel": "linear_n320_kernel<kConv> (3x3 convolutions, C_out = 320 g; K split at level 3)",
                     "achieved": cv["TFLOPs"], "peak": bench_svd.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": cv["frac_of_bf16_mfma_peak"], "calls_per_step": cv["calls_per_step"], "ms_per_step": cv["ms_per_step"],
-                    "traffic": None}
+                    "traffic": _traffic("conv3x3_n320")}
             out["svd_steps_per_s"] = svd.get("steps_per_s")
     if world > 1 or force_dist:
         td.destroy_process_group()

@@ -9,6 +9,10 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVI_HIP_LIB: another build of the SAME library for same-box A/B timing (tools/ab_lib.sh); never set by tests or bench defaults
 LIB_PATH = os.environ.get("MVI_HIP_LIB") or os.path.join(_HERE, "csrc", "libmvi_hip.so")
+LIB_OVERRIDDEN = bool(os.environ.get("MVI_HIP_LIB"))
+if LIB_OVERRIDDEN:                                       # an experiment build may compute wrong results on purpose: never silently
+    import sys as _sys
+    _sys.stderr.write(f"[mvi] MVI_HIP_LIB is set: every kernel comes from {LIB_PATH}, not from the in-tree build\n")
 INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
 
 

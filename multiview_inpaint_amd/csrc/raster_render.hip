@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const int rounds = (todo + kBlock - 1) / kBlock;
 
     float T = inside ? 1.0f : 0.0f;                 // 0 = this pixel takes no further contributions
-    float T_out = 1.0f, C2 = 0.f, Dp = kDepthSentinel;
+    float T_out = 1.0f, C2 = 0.f, Dp = kDepthSentinel, Tc = 1.0f;
     f2 C01 = {0.f, 0.f};                            // red, green: one packed fma on the (aligned) first two registers of the colour
     uint32_t last = 0;
 
@@ -173,10 +173,14 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
                 const float w = contrib ? alpha * T : 0.0f;
                 C01 = pk_fma(f2{cd.x, cd.y}, splat(w), C01);
                 C2 = __builtin_fmaf(cd.z, w, C2);
-                // median depth of the w-depth fork = depth of the entry that takes T from above 0.5 to below it. Every
-                // contributing entry met while T > 0.5 overwrites the candidate: the last of them is that entry if T ever gets
-                // below 0.5 (checked once, after the loop), and two instructions per entry cheaper than testing the crossing here
-                Dp = (contrib && T > 0.5f) ? cd.w : Dp;
+                // median depth of the w-depth fork = depth of the entry that takes T from above 0.5 to below it (T > 0.5 and
+                // T (1 - alpha) < 0.5, both strict: oracle/raster_oracle.c orc_render_forward). Every contributing entry met
+                // while T > 0.5 overwrites the candidate and the T it leaves behind (two selects on one condition): the last
+                // of them is the crossing entry iff it left T below 0.5 — checked once, after the loop. An entry that leaves
+                // T at exactly 0.5 is not a crossing, and nothing behind it starts from above 0.5: the sentinel stays.
+                const bool above = contrib && T > 0.5f;
+                Dp = above ? cd.w : Dp;
+                Tc = above ? test_T : Tc;
                 T_out = contrib ? test_T : T_out;
                 last = contrib ? __float_as_uint(a.z) : last;           // 1-based position in the tile's list
                 T = contrib ? test_T : (valid ? 0.0f : T);              // valid but below 1e-4: saturated from here on
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
         out_color[pix] = C01.x + T_out * f.bg[0];
         out_color[hw + pix] = C01.y + T_out * f.bg[1];
         out_color[2 * hw + pix] = C2 + T_out * f.bg[2];
-        out_depth[pix] = T_out < 0.5f ? Dp : kDepthSentinel;          // never crossed 0.5: the sentinel (gs-simp/gen_seq.py:50)
+        out_depth[pix] = Tc < 0.5f ? Dp : kDepthSentinel;             // never crossed 0.5: the sentinel (gs-simp/gen_seq.py:50)
     }
 }
 

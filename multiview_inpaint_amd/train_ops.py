@@ -116,6 +116,9 @@ class _LossPair(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_l1, g_ssim):
+        global _pending_pair
+        if _pending_pair is not None and _pending_pair[-1] is ctx:
+            _pending_pair = None                          # this node's buffers are released with this backward: nothing may join it later
         if not ctx.saved_tensors:
             return None, None
         img, g, ws = ctx.saved_tensors
@@ -133,17 +136,24 @@ class _LossPair(torch.autograd.Function):
 
 
 # l1_loss(a, b) followed by ssim(a, b) on the SAME tensor objects (the reference's loss expression, train.py:91-92): the second call
-# returns the other output of the first call's node. Matched by object identity and in-place version (weak references to a and b). The
-# SSIM half waits in this one slot until the matching ssim() takes it or the next l1_loss() replaces it — the caller may have dropped
-# the L1 value by then (`0.8 * l1_loss(a, b) + 0.2 * (1 - ssim(a, b))` in one expression) — so at most one node is pinned by it.
+# returns the other output of the first call's node. Matched by object identity and in-place version (weak references to a and b), by
+# the autograd state both calls ran under (grad mode and a.requires_grad: an l1_loss under no_grad must not hand a detached SSIM to
+# a differentiated ssim()), and only while the node has not run its backward (which frees its buffers: the slot is cleared there).
+# The SSIM half waits in this one slot until the matching ssim() takes it or the next l1_loss() replaces it — the caller may have
+# dropped the L1 value by then (`0.8 * l1_loss(a, b) + 0.2 * (1 - ssim(a, b))` in one expression) — so at most one node is pinned by it.
 _pending_pair = None
+
+
+def _autograd_state(t):
+    return (torch.is_grad_enabled(), bool(t.requires_grad))
 
 
 def l1_loss(network_output, gt):
     """gs-simp/utils/loss_utils.py:17-18 (same name and signature)."""
     global _pending_pair
     l1, ss = _LossPair.apply(network_output, gt)         # (raises on bad shapes / devices before anything is remembered)
-    _pending_pair = (weakref.ref(network_output), network_output._version, weakref.ref(gt), gt._version, ss)
+    _pending_pair = (weakref.ref(network_output), network_output._version, weakref.ref(gt), gt._version, ss,
+                     _autograd_state(network_output), ss.grad_fn)
     return l1
 
 
@@ -153,7 +163,8 @@ def ssim(img1, img2, window_size=11, size_average=True):
     if window_size != 11 or not size_average:
         raise NotImplementedError("ssim: only window_size=11, size_average=True (the only form the training scripts use)")
     pair, _pending_pair = _pending_pair, None
-    if pair is not None and pair[0]() is img1 and pair[1] == img1._version and pair[2]() is img2 and pair[3] == img2._version:
+    if (pair is not None and pair[0]() is img1 and pair[1] == img1._version and pair[2]() is img2 and pair[3] == img2._version
+            and pair[5] == _autograd_state(img1)):
         return pair[4]
     return _PhotometricLoss.apply(img1, img2, None, 1.0, 2)
 

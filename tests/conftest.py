@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # first of all, before torch is imported or any HIP call can run in this process: the clean parent of the rank tests
+    _start_rank_launcher()
+    # another build of the library (same-box A/B runs, tools/ab_lib.sh) must never be what the tests load
+    if os.environ.pop("MVI_HIP_LIB", None):
+        sys.stderr.write("[mvi] tests ignore MVI_HIP_LIB: the in-tree multiview_inpaint_amd/csrc/libmvi_hip.so is what is tested\n")
     # GPU runs: MIOpen looks its convolution solvers up in the find-db recorded on the MI355X (the kernels the bench uses)
     # instead of choosing by heuristic; must happen before the process first touches MIOpen. Harmless without a GPU.
     try:
@@ -17,20 +22,18 @@ def pytest_configure(config):
         bench_svd.use_shipped_miopen_db()
     except Exception:
         pass
-    _start_rank_launcher()
 
 
 _LAUNCHER = None
 
 
 def _start_rank_launcher():
-    """A multiprocessing forkserver started NOW — at configure time nothing in this process has initialised the GPU, so the server
-    (and every rank it forks later for tests/test_dist_gpu_ranks.py) is clean. Only on a box with a GPU; counting devices does not
-    initialise them."""
+    """A multiprocessing forkserver started NOW — the first thing pytest_configure does, before torch is imported and before any
+    HIP / HSA call can have run in this process — so the server (a fresh fork + exec child) and every rank it forks later for
+    tests/test_dist_gpu_ranks.py are clean. Only on a box with a GPU, told by the driver's device node (no runtime call)."""
     global _LAUNCHER
     try:
-        import torch
-        if torch.cuda.device_count() < 1:
+        if not os.path.exists("/dev/kfd") or os.environ.get("MVI_NO_RANK_LAUNCHER"):
             return
         import multiprocessing as mp
         from multiprocessing import forkserver

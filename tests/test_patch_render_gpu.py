@@ -249,14 +249,18 @@ def test_short_training_run_matches_the_pytorch_formulation():
     assert la[-1] < 0.8 * la[0], (la[0], la[-1])
     worst = max(abs(a - b) / b for a, b in zip(la, lb))
     print(f"loss {la[0]:.5f} -> {la[-1]:.5f}; worst relative difference of the two loss curves {worst:.2e}")
-    assert worst < 2e-3, worst
+    assert worst < 3e-4, worst                               # (measured 3e-5: ten times that)
     # parameters: in rms — with eps = 1e-15 Adam moves a parameter whose gradient is noise by +-lr per step whatever the gradient's size, so a
-    # handful of (occluded) Gaussians legitimately end a few lr apart between two formulations that differ in the last bits
+    # handful of (occluded) Gaussians legitimately end a few lr apart between two formulations that differ in the last bits. What a
+    # wrong update rule would do instead is move MANY elements apart: at most one element in a thousand may end more than 4 lr from
+    # its twin (40 steps could carry it 80 lr away), and the rms distance stays below 5e-3 of the parameters' own rms
     for k in pa:
         if pa[k].numel():
             d, ref = (pa[k] - pb[k]).double(), pb[k].double()
             assert float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 5e-3, k
-            assert float(d.abs().max()) <= 2 * 40 * lrs[k] * 1.01, k           # (each run moves a parameter by about lr per step at most)
+            far = float((d.abs() > 4 * lrs[k]).double().mean())
+            print(f"{k}: fraction of elements more than 4 lr apart {far:.2e}, max distance {float(d.abs().max()) / lrs[k]:.1f} lr")
+            assert far < 1e-3, (k, far)
     assert torch.equal(den_a, den_b)
     assert rel(acc_a, acc_b) < 5e-3
 

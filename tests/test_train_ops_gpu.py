@@ -126,6 +126,23 @@ def test_l1_loss_then_ssim_on_the_same_tensors_share_one_node(T):
         with torch.no_grad():
             a, b = T.l1_loss(img, gt), T.ssim(img, gt)
         assert a.item() == l1.item() and b.item() == ss.item() and not a.requires_grad
+        # l1_loss under no_grad, ssim differentiated: the detached half must not be handed over (the SSIM term would lose its gradient)
+        with torch.no_grad():
+            T.l1_loss(img, gt)
+        ss5 = T.ssim(img, gt)
+        assert ss5.requires_grad and ss5.item() == ss.item()
+        (1.0 - ss5).backward()
+        assert float(img.grad.abs().max()) > 0
+        img.grad = None
+        # the L1 value backpropagated (graph freed) before ssim is called: ssim gets a node of its own instead of the freed one
+        l1d = T.l1_loss(img, gt)
+        l1d.backward()
+        assert T._pending_pair is None
+        img.grad = None
+        ss6 = T.ssim(img, gt)
+        ss6.backward()
+        assert ss6.item() == ss.item() and float(img.grad.abs().max()) > 0
+        img.grad = None
     finally:
         T._LossPair.apply = orig
 
