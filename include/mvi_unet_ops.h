@@ -273,6 +273,18 @@ int mvi_attention_forward_strided(const void* q, const void* k, const void* v, v
 int mvi_attention_temporal_strided(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
                                    int32_t S, int32_t H, int32_t D, float scale, int32_t dtype,
                                    int64_t qkv_token_stride, int64_t out_token_stride, void* stream);
+/* The two strided forms for a q that ALREADY carries D^-1/2 * log2(e): P = exp2(q' . k - m), no scale argument. The caller folds
+ * that constant into the WEIGHTS of the q projection in fp32, before their one rounding to bf16 / f16 (svd/transformer.py,
+ * CrossAttention._packed_qkv_weight): q' = round(x . round(c W_q)^T) carries the same single output rounding as the reference's
+ * q = round(x . W_q^T) (svd_inpaint1/sgm/modules/attention.py:281-300, :332-336), whereas scaling q inside the kernel rounds it a
+ * second time. It takes the scale multiply (one v_mul per score) out of the 8-wave MFMA kernel's softmax — the port that bounds it.
+ * The fp32-math kernels and the temporal MFMA kernel apply ln 2 in its place (same results to 1 ulp of the scores). */
+int mvi_attention_forward_strided_qlog2(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                                        int32_t Sq, int32_t Sk, int32_t D, int32_t dtype, int64_t q_token_stride,
+                                        int64_t kv_token_stride, int64_t out_token_stride, void* stream);
+int mvi_attention_temporal_strided_qlog2(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                                         int32_t S, int32_t H, int32_t D, int32_t dtype, int64_t qkv_token_stride,
+                                         int64_t out_token_stride, void* stream);
 /* Which kernel serves a temporal-attention call of this shape: 1 = the MFMA kernel of csrc/attn_temporal.hip (bf16 / f16, D = 64,
  * T <= 16, 16-byte aligned rows), 0 = the fp32-math kernel of csrc/attn_rowtile.hip. Strides in elements, 0 = H*D. */
 int mvi_attention_temporal_kernel_variant(int32_t T, int32_t H, int32_t D, int32_t dtype, int64_t qkv_token_stride,

@@ -363,9 +363,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVI_ATTN_WP
     }
 }
 
+// scale_log2e: what a score is multiplied by on its way into exp2 (softmax scale * log2 e; 1 for a q that carries it already)
 template <typename T>
 int attn_flash_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
-                      float scale, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
+                      float scale_log2e, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
     const int64_t hd = (int64_t)H * kFD;
     if (q_rs == 0) q_rs = hd;
     if (kv_rs == 0) kv_rs = hd;
@@ -374,7 +375,7 @@ int attn_flash_launch(const void* q, const void* k, const void* v, void* out, in
     const int64_t total = (int64_t)B * H * q_blocks;
     if (total > 0x7FFFFFFFll) return MVI_EINVAL;
     hipLaunchKernelGGL((attn_flash_kernel<T>), dim3((unsigned)total), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
+                       (const T*)v, (T*)out, H, Sq, Sk, scale_log2e, q_blocks, (int)total, q_rs, kv_rs, o_rs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 template int attn_flash_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
@@ -383,7 +384,7 @@ template int attn_flash_launch<__half>(const void*, const void*, const void*, vo
 // 8-wave kernel for long sequences (attn_flash8.hip)
 template <typename T>
 int attn_flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
-                       float scale, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs);
+                       float scale, bool q_log2, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs);
 
 // rowtile kernel (attn_rowtile.hip)
 template <typename T>
@@ -404,9 +405,13 @@ extern "C" int mvi_attention_kernel_variant(int32_t Sq, int32_t Sk, int32_t D, i
     return (forced == 8 || (forced != 4 && Sq >= 1024 && Sk >= 256)) ? 8 : 4;
 }
 
+// q_log2: q carries softmax scale * log2(e) already (mvi_attention_forward_strided_qlog2); `scale` is then ln 2, what the kernels
+// that exponentiate with e must apply, and the exp2 kernels take their scores as they are
+constexpr float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
 static int attention_forward_impl(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Sq,
                                   int32_t Sk, int32_t D, float scale, int32_t dtype, int64_t q_ts, int64_t kv_ts, int64_t o_ts,
-                                  void* stream) {
+                                  void* stream, bool q_log2 = false) {
+    if (q_log2) scale = kLn2;
     if (B < 0 || H <= 0 || Sq < 0 || Sk <= 0 || D <= 0) return mvi::unet_fail(MVI_EINVAL, "attention: bad shape");
     if (B == 0 || Sq == 0) return MVI_OK;
     if (!q || !k || !v || !out) return mvi::unet_fail(MVI_EINVAL, "attention: NULL pointer");
@@ -422,11 +427,13 @@ static int attention_forward_impl(const void* q, const void* k, const void* v, v
     const int variant = mvi_attention_kernel_variant(Sq, Sk, D, dtype);
     if (variant != 0) {
         if (variant == 8)
-            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash8_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
-                                      : mvi::attn_flash8_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
-        else
-            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts)
-                                      : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, st, q_ts, kv_ts, o_ts);
+            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash8_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_ts, kv_ts, o_ts)
+                                      : mvi::attn_flash8_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_ts, kv_ts, o_ts);
+        else {
+            const float sl2 = q_log2 ? 1.0f : scale * kLog2e;
+            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, sl2, st, q_ts, kv_ts, o_ts)
+                                      : mvi::attn_flash_launch<__half>(q, k, v, out, B, H, Sq, Sk, sl2, st, q_ts, kv_ts, o_ts);
+        }
     } else {
         if (D != 16 && D != 32 && D != 64) return mvi::unet_fail(MVI_EINVAL, "attention: head dim must be 16, 32 or 64");
         switch (dtype) {
@@ -450,6 +457,12 @@ extern "C" int mvi_attention_forward_strided(const void* q, const void* k, const
                                              void* stream) {
     return attention_forward_impl(q, k, v, out, B, H, Sq, Sk, D, scale, dtype, q_token_stride, kv_token_stride,
                                   out_token_stride, stream);
+}
+
+extern "C" int mvi_attention_forward_strided_qlog2(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H,
+                                                   int32_t Sq, int32_t Sk, int32_t D, int32_t dtype, int64_t q_token_stride,
+                                                   int64_t kv_token_stride, int64_t out_token_stride, void* stream) {
+    return attention_forward_impl(q, k, v, out, B, H, Sq, Sk, D, kLn2, dtype, q_token_stride, kv_token_stride, out_token_stride, stream, true);
 }
 
 namespace mvi {
@@ -503,4 +516,11 @@ extern "C" int mvi_attention_temporal_strided(const void* q, const void* k, cons
                                               int32_t S, int32_t H, int32_t D, float scale, int32_t dtype,
                                               int64_t qkv_token_stride, int64_t out_token_stride, void* stream) {
     return attention_temporal_impl(q, k, v, out, Bo, T, S, H, D, scale, dtype, qkv_token_stride, out_token_stride, stream);
+}
+
+// q carries D^-1/2 log2(e): these kernels exponentiate with e, so ln 2 is the factor left to apply
+extern "C" int mvi_attention_temporal_strided_qlog2(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
+                                                    int32_t S, int32_t H, int32_t D, int32_t dtype, int64_t qkv_token_stride,
+                                                    int64_t out_token_stride, void* stream) {
+    return attention_temporal_impl(q, k, v, out, Bo, T, S, H, D, kLn2, dtype, qkv_token_stride, out_token_stride, stream);
 }

@@ -5,9 +5,12 @@
 //
 // Why a second kernel: at D = 64 the 4-wave kernel is bound by the SIMD's ISSUE port, not by the matrix pipe
 // (profiles/r01u_pmc_attention.txt: 13.8 VALU per MFMA, pipe 39.7 % busy). This one removes issue slots:
-//   * the softmax scale and the running reference exponent m never touch the VALU: Q is multiplied by
-//     scale*log2(e) once per block (prologue), and -m enters the scores as the C operand of the first MFMA of every
-//     QK^T chain (a 16-register block holding -m), so P = exp2(S') directly — 32 v_fma per wave-tile gone;
+//   * the running reference exponent m never touches the VALU: -m enters the scores as the C operand of the first MFMA of every
+//     QK^T chain (a 16-register block holding -m). The softmax SCALE has two forms (template kExact, below): applied to the fp32
+//     scores (one v_mul per score; the form a caller's own q gets in bf16), or absent from the loop because Q carries
+//     scale * log2(e) — either rounded into Q in the prologue (f16's default: a second rounding of q) or, since round 5, already
+//     inside q from its projection's weights (mvi_attention_forward_strided_qlog2: no second rounding, both types; what the
+//     self-attentions of the SVD modules run) — so P = exp2(S') directly;
 //   * K and V tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, 2 per wave and
 //     tile) instead of through VGPRs (8 loads + 12 LDS stores + 16 pack ops per wave and tile in the 4-wave kernel);
 //   * V stays row-major in LDS and is read transposed by ds_read_b64_tr_b16 (no hand transposition);
@@ -483,7 +486,7 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
 }  // namespace f8
 
 template <typename T>
-static int flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, float scale,
+static int flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, float scale, bool q_log2,
                          hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
     using namespace f8;
     constexpr int kQB = 32 * kWaves;
@@ -498,7 +501,9 @@ static int flash8_launch(const void* q, const void* k, const void* v, void* out,
     // see kExact. Default: exact for bf16; folded for f16, whose 11-bit mantissa makes the second rounding of Q eight times smaller
     // (below the exact bf16 form's own error) — f16 is the reference's precision recipe and the fold is worth 7 % of the kernel
     static const int fold_env = getenv("MVI_ATTN_FOLD_SCALE") ? atoi(getenv("MVI_ATTN_FOLD_SCALE")) : -1;
-    const bool fold = fold_env >= 0 ? fold_env != 0 : std::is_same<T, __half>::value;
+    // q_log2 (mvi_attention_forward_strided_qlog2): q carries scale * log2(e) from its projection's weights — the folded kernel with
+    // nothing left to fold (its prologue multiplies Q by exactly 1), for both types
+    const bool fold = q_log2 || (fold_env >= 0 ? fold_env != 0 : std::is_same<T, __half>::value);
     if (!((attr_set >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash8_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes + 16) != hipSuccess ||
@@ -509,20 +514,20 @@ static int flash8_launch(const void* q, const void* k, const void* v, void* out,
     }
     auto kern = fold ? &attn_flash8_kernel<T, false> : &attn_flash8_kernel<T, true>;
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * kWaves), kLdsBytes + 16, st, (const T*)q, (const T*)k, (const T*)v,
-                       (T*)out, H, Sq, Sk, scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
+                       (T*)out, H, Sq, Sk, q_log2 ? 1.0f : scale * 1.4426950408889634f, q_blocks, (int)total, q_rs, kv_rs, o_rs);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
 template <typename T>
 int attn_flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
-                       float scale, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
+                       float scale, bool q_log2, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs) {
     const int64_t hd = (int64_t)H * f8::kD;
     if (q_rs == 0) q_rs = hd;
     if (kv_rs == 0) kv_rs = hd;
     if (o_rs == 0) o_rs = hd;
-    return flash8_launch<T>(q, k, v, out, B, H, Sq, Sk, scale, st, q_rs, kv_rs, o_rs);
+    return flash8_launch<T>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_rs, kv_rs, o_rs);
 }
-template int attn_flash8_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
-template int attn_flash8_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, hipStream_t, int64_t, int64_t, int64_t);
+template int attn_flash8_launch<__hip_bfloat16>(const void*, const void*, const void*, void*, int, int, int, int, float, bool, hipStream_t, int64_t, int64_t, int64_t);
+template int attn_flash8_launch<__half>(const void*, const void*, const void*, void*, int, int, int, int, float, bool, hipStream_t, int64_t, int64_t, int64_t);
 
 }  // namespace mvi

@@ -197,9 +197,10 @@ def attention(q, k, v, heads):
     return out
 
 
-def attention_packed(qkv, heads):
+def attention_packed(qkv, heads, q_log2=False):
     """Self-attention on ONE packed projection qkv [B, S, 3*H*D] = (q | k | v) -> [B, S, H*D]: the kernels read q, k, v in
-    place with a token stride of 3*H*D (mvi_attention_forward_strided), so the three projections are one GEMM."""
+    place with a token stride of 3*H*D (mvi_attention_forward_strided), so the three projections are one GEMM.
+    q_log2: q carries D^-1/2 log2(e) from its projection's weights (mvi_attention_forward_strided_qlog2)."""
     L = _lib.lib()
     if qkv.dtype not in _DT or not qkv.is_contiguous():
         raise TypeError("attention_packed: contiguous fp32/bf16/f16 [B, S, 3*H*D] expected")
@@ -213,13 +214,17 @@ def attention_packed(qkv, heads):
         ATTN_VARIANTS.append((int(L.mvi_attention_kernel_variant(S, S, D, _DT[qkv.dtype])), S, S))
     p = qkv.data_ptr()
     with torch.cuda.device(qkv.device), _Timed(kind, 4.0 * B * heads * S * S * D, qkv.device):
-        _check(L.mvi_attention_forward_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), B, heads, S, S, D,
-                                               float(D) ** -0.5, _DT[qkv.dtype], C3, C3, HD, _stream(qkv.device)),
-               "attention (packed)")
+        if q_log2:
+            rc = L.mvi_attention_forward_strided_qlog2(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), B, heads, S, S, D, _DT[qkv.dtype],
+                                                       C3, C3, HD, _stream(qkv.device))
+        else:
+            rc = L.mvi_attention_forward_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), B, heads, S, S, D,
+                                                 float(D) ** -0.5, _DT[qkv.dtype], C3, C3, HD, _stream(qkv.device))
+        _check(rc, "attention (packed)")
     return out
 
 
-def attention_temporal_packed(qkv, heads, T):
+def attention_temporal_packed(qkv, heads, T, q_log2=False):
     """attention_temporal on a packed projection qkv [(bo*T), S, 3*H*D] -> [(bo*T), S, H*D]."""
     L = _lib.lib()
     if qkv.dtype not in _DT or not qkv.is_contiguous():
@@ -232,9 +237,13 @@ def attention_temporal_packed(qkv, heads, T):
     p = qkv.data_ptr()
     # HBM-bound (T = 14 keys per query): work = algorithmic bytes, q + k + v read and the output written once
     with torch.cuda.device(qkv.device), _Timed("attention_temporal", 4.0 * BT * S * HD * es, qkv.device):
-        _check(L.mvi_attention_temporal_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), BT // T, T, S, heads, D,
-                                                float(D) ** -0.5, _DT[qkv.dtype], C3, HD, _stream(qkv.device)),
-               "attention_temporal (packed)")
+        if q_log2:
+            rc = L.mvi_attention_temporal_strided_qlog2(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), BT // T, T, S, heads, D,
+                                                        _DT[qkv.dtype], C3, HD, _stream(qkv.device))
+        else:
+            rc = L.mvi_attention_temporal_strided(p, p + HD * es, p + 2 * HD * es, out.data_ptr(), BT // T, T, S, heads, D,
+                                                  float(D) ** -0.5, _DT[qkv.dtype], C3, HD, _stream(qkv.device))
+        _check(rc, "attention_temporal (packed)")
     return out
 
 

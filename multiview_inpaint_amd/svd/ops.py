@@ -144,24 +144,34 @@ def packed_ok(x, heads, dim_head):
     return x.is_cuda and not torch.is_grad_enabled() and dim_head in (16, 32, 64) and (heads * dim_head * x.element_size()) % 16 == 0
 
 
-def attention_packed(qkv, heads):
-    """Self-attention on one packed projection qkv [B, S, 3*H*D] = (q | k | v) -> [B, S, H*D]."""
+def _unfold_q(q, heads, q_log2):
+    """q of a packed projection whose q rows carry dim_head^-1/2 * log2(e) (CrossAttention._packed_qkv_weight), for a consumer that
+    applies the softmax scale itself."""
+    if not q_log2:
+        return q
+    D = q.shape[-1] // heads
+    return (q.float() * (D ** 0.5 * 0.6931471805599453)).to(q.dtype)
+
+
+def attention_packed(qkv, heads, q_log2=False):
+    """Self-attention on one packed projection qkv [B, S, 3*H*D] = (q | k | v) -> [B, S, H*D]. q_log2: the q third already
+    carries dim_head^-1/2 * log2(e) (folded into its projection's weights)."""
     if qkv.is_cuda and not _needs_autograd(qkv):
         from . import hip_ops
-        return hip_ops.attention_packed(qkv.contiguous(), heads)
+        return hip_ops.attention_packed(qkv.contiguous(), heads, q_log2=q_log2)
     _fallback(qkv, "attention_packed", _why(qkv))
     q, k, v = qkv.chunk(3, dim=-1)
-    return attention(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+    return attention(_unfold_q(q, heads, q_log2).contiguous(), k.contiguous(), v.contiguous(), heads)
 
 
-def attention_temporal_packed(qkv, heads, T):
+def attention_temporal_packed(qkv, heads, T, q_log2=False):
     """attention_temporal on a packed projection [(bo*T), S, 3*H*D]."""
     if qkv.is_cuda and not _needs_autograd(qkv):
         from . import hip_ops
-        return hip_ops.attention_temporal_packed(qkv.contiguous(), heads, T)
+        return hip_ops.attention_temporal_packed(qkv.contiguous(), heads, T, q_log2=q_log2)
     _fallback(qkv, "attention_temporal_packed", _why(qkv))
     q, k, v = qkv.chunk(3, dim=-1)
-    return attention_temporal(q.contiguous(), k.contiguous(), v.contiguous(), heads, T)
+    return attention_temporal(_unfold_q(q, heads, q_log2).contiguous(), k.contiguous(), v.contiguous(), heads, T)
 
 
 def attention_wide(q, k, v):

@@ -20,6 +20,13 @@ from . import ops
 from .layers import AlphaBlender, linear, maybe_checkpoint, timestep_embedding, zero_module
 
 
+import os
+
+LOG2E = 1.4426950408889634
+# MVI_ATTN_WEIGHT_FOLD=0: the packed projection keeps to_q.weight as it is and the kernels apply the softmax scale (same-box A/B runs)
+FOLD_SCALE_INTO_WQ = os.environ.get("MVI_ATTN_WEIGHT_FOLD", "1") != "0"
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
@@ -74,7 +81,8 @@ class CrossAttention(nn.Module):
         if context is None and not n_times_crossframe_attn_in_self and not n_extra and ops.packed_ok(x, self.heads, self.dim_head):
             # self-attention at inference: one GEMM [.., C] x [C, 3 H D] instead of three passes over the activations;
             # the attention kernel reads q, k, v out of the packed result in place
-            return ops.linear_module(self.to_out, ops.attention_packed(ops.linear(x, self._packed_qkv_weight()), self.heads))
+            w, q_log2 = self._packed_qkv_weight(x.dtype)
+            return ops.linear_module(self.to_out, ops.attention_packed(ops.linear(x, w), self.heads, q_log2=q_log2))
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if n_times_crossframe_attn_in_self:
             n = n_times_crossframe_attn_in_self
@@ -87,21 +95,32 @@ class CrossAttention(nn.Module):
         return self.to_out(out)
 
 
-    def _packed_qkv_weight(self):
-        """cat(to_q.weight, to_k.weight, to_v.weight) [3 H D, C], rebuilt only when a weight changes (inference weights
-        are static; not a parameter or buffer, so the state-dict keys stay the reference's)."""
+    def _packed_qkv_weight(self, act_dtype=None):
+        """(cat(to_q.weight, to_k.weight, to_v.weight) [3 H D, C], q_log2), rebuilt only when a weight changes (inference weights
+        are static; not a parameter or buffer, so the state-dict keys stay the reference's).
+        q_log2 (reduced precision on the GPU, FOLD_SCALE_INTO_WQ): the q rows are round(dim_head^-1/2 * log2(e) * to_q.weight),
+        the product taken in fp32 and rounded ONCE to the weights' type, so the packed projection's q already is the exponent of
+        2 the softmax needs (attention.py:332-336 `softmax(q k^T * scale)`): q' = round(x . W_q'^T) carries one output rounding,
+        as the reference's q does — scaling q inside the attention kernel would round it a second time, and scaling the fp32
+        scores costs the 8-wave kernel one multiply per score on the port that bounds it."""
         ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
-        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        fold = (FOLD_SCALE_INTO_WQ and ws[0].is_cuda and ws[0].dtype in (torch.bfloat16, torch.float16)
+                and (act_dtype is None or act_dtype == ws[0].dtype) and not torch.is_grad_enabled())
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws) + (fold,)
         hit = getattr(self, "_wqkv", None)
         if hit is None or hit[0] != key:
-            hit = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+            wq = ws[0].detach()
+            if fold:
+                wq = (wq.float() * (self.scale * LOG2E)).to(wq.dtype)
+            hit = (key, torch.cat([wq, ws[1].detach(), ws[2].detach()], dim=0).contiguous(), fold)
             self._wqkv = hit
-        return hit[1]
+        return hit[1], hit[2]
 
     def forward_temporal(self, x, T):
         """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back."""
         if ops.packed_ok(x, self.heads, self.dim_head) and self.to_k.in_features == self.to_q.in_features:
-            return ops.linear_module(self.to_out, ops.attention_temporal_packed(ops.linear(x, self._packed_qkv_weight()), self.heads, T))
+            w, q_log2 = self._packed_qkv_weight(x.dtype)
+            return ops.linear_module(self.to_out, ops.attention_temporal_packed(ops.linear(x, w), self.heads, T, q_log2=q_log2))
         return self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
 
     def single_token(self, ctx):

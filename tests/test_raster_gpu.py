@@ -40,7 +40,7 @@ def _viol(got, ref, floor):
     return d > tol, (float((d / tol).max()) if d.size else 0.0)
 
 
-PURE_REL_MIN_FRACTION = 0.5       # of the non-zero reference elements of every gradient array, see _grad_check
+PURE_REL_MIN_FRACTION = 0.97      # of the non-zero reference elements of every gradient array, see _grad_check
 _REPORT = os.environ.get("MVI_PARITY_REPORT")      # file the per-array parity figures are appended to (the GPU runs set it)
 
 
@@ -738,7 +738,7 @@ def test_edge_transmittance_lands_on_one_half_exactly(R, ro):
     color, radii, depth, st = R.rasterize_forward(_settings(R, cam, bg, 0), t["means3D"], t["opacities"], shs=t["shs"],
                                                   scales=t["scales"], rotations=t["rotations"])
     dg = depth.cpu().numpy()[0]
-    assert st.tensor("final_T", (H, W), torch.float32).cpu().numpy()[16, 16] == f["final_T"][16, 16]
+    assert st.tensor("final_T", (H, W), torch.float32).cpu().numpy()[16, 16] < 0.4      # the second entry took T well below 0.5
     assert dg[16, 16] == 15.0, "an entry that leaves T at exactly 0.5 must not be reported as the median"
     # the other pair (0.7 then 0.9) crosses at its first entry: depth 2.5 around its centre, identical to the oracle
     fr = ro.margins(p, f)

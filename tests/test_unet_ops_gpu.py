@@ -761,14 +761,68 @@ def test_self_attention_module_takes_the_packed_path_and_matches(ops):
         q, k, v = m.to_q(x), m.to_k(x), m.to_v(x)
         want = m.to_out(ops.attention(q, k, v, 2))
         assert rel(got, want) < 1e-5
-        w1 = m._packed_qkv_weight()
-        assert m._packed_qkv_weight() is w1                 # cached
+        w1, folded = m._packed_qkv_weight()
+        assert not folded                                   # fp32 weights keep to_q.weight as it is
+        assert m._packed_qkv_weight()[0] is w1              # cached
         m.to_k.weight.mul_(2.0)
-        assert m._packed_qkv_weight() is not w1             # rebuilt after an in-place weight update
+        assert m._packed_qkv_weight()[0] is not w1          # rebuilt after an in-place weight update
         assert "_wqkv" not in m.state_dict() and len(m.state_dict()) == 5
         got_t = m.forward_temporal(x, 2)
         want_t = m.to_out(ops.attention_temporal(m.to_q(x), m.to_k(x), m.to_v(x), 2, 2))
         assert rel(got_t, want_t) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S", [320, 1280])
+def test_softmax_scale_folded_into_the_q_weights(ops, dtype, S):
+    """Reduced precision: the packed projection's q rows are round(dim_head^-1/2 log2(e) to_q.weight) and the kernels are told
+    (mvi_attention_forward_strided_qlog2 / mvi_attention_temporal_strided_qlog2). Against an fp64 evaluation of the module's
+    formula from the SAME stored weights and input (attention.py:281-344), the folded path's error is no larger than 1.25 x the
+    error of the unfolded path (to_q.weight as it is, scale inside the kernel) — measured, both printed: the fold trades the
+    rounding of 320 weights per output for no second rounding of q. S = 320 runs the 4-wave kernel, S = 1280 the 8-wave kernel,
+    the temporal form the 16x16 MFMA kernel."""
+    from multiview_inpaint_amd.svd import transformer as TR
+    from multiview_inpaint_amd.svd.transformer import CrossAttention
+    torch.manual_seed(11)
+    m = CrossAttention(query_dim=320, heads=5, dim_head=64).eval()
+    with torch.no_grad():
+        for lin in (m.to_q, m.to_k, m.to_v):
+            lin.weight.mul_(3.0)                            # logits of a few units: a softmax that is neither flat nor one-hot
+    m = m.cuda().to(dtype)
+    x = torch.randn(2, S, 320, device="cuda").to(dtype)
+
+    def ref(regroup_T=None):
+        xd = x.double()
+        q, k, v = (xd @ w.weight.double().t() for w in (m.to_q, m.to_k, m.to_v))
+        if regroup_T:
+            B, T = x.shape[0] // regroup_T, regroup_T
+            q, k, v = (t.reshape(B, T, S, 5, 64).permute(0, 2, 3, 1, 4) for t in (q, k, v))       # b s h t d
+            o = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v
+            o = o.permute(0, 3, 1, 2, 4).reshape(x.shape[0], S, 320)
+        else:
+            q, k, v = (t.reshape(-1, S, 5, 64).transpose(1, 2) for t in (q, k, v))
+            o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(-1, S, 320)
+        return o @ m.to_out[0].weight.double().t() + m.to_out[0].bias.double()
+
+    res = {}
+    for fold in (True, False):
+        old = TR.FOLD_SCALE_INTO_WQ
+        TR.FOLD_SCALE_INTO_WQ = fold
+        try:
+            with torch.no_grad():
+                w, q_log2 = m._packed_qkv_weight(dtype)
+                assert q_log2 == fold
+                if fold:
+                    want_q = (m.to_q.weight.float() * (0.125 * 1.4426950408889634)).to(dtype)
+                    assert torch.equal(w[:320], want_q) and torch.equal(w[320:640], m.to_k.weight)
+                res[fold] = (m(x), m.forward_temporal(x, 2))
+        finally:
+            TR.FOLD_SCALE_INTO_WQ = old
+    e = {f: (rel(res[f][0], ref()), rel(res[f][1], ref(2))) for f in res}
+    print(f"{dtype} S={S}: error of the module vs fp64, spatial / temporal: folded {e[True][0]:.2e} / {e[True][1]:.2e}, "
+          f"unfolded {e[False][0]:.2e} / {e[False][1]:.2e}")
+    for i in range(2):
+        assert e[True][i] <= 1.25 * e[False][i] + 1e-4, e
 
 
 def test_temporal_conv_on_channel_stacked_input():
