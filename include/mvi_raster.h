@@ -136,6 +136,17 @@ int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, 
                             float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
                             float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch, 
                             int32_t grad_rows_prezeroed, void* stream);
+/* mvi_raster_backward_raw with the SH gradient left in FACTORED form: dL_dsh_color_factor [P,3] (what mvi_raster_backward
+ * writes into dL_dcolors for an SH input: dL/dcolour with the clamp mask applied) instead of dL_dfeatures_dc / dL_dfeatures_rest —
+ * the form view-parallel training exchanges (multiview_inpaint_amd/train_views.py on the model's STORED parameters; the summed
+ * dL/dSH is rebuilt by mvi_raster_sh_backward_views). The other gradients are those of mvi_raster_backward_raw, bit for bit. */
+int mvi_raster_backward_raw_factor(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t num_rendered, const float* xyz,
+                                   const float* features_dc, const float* features_rest, const float* raw_opacity,
+                                   const float* raw_scaling, const float* raw_rotation, const int32_t* radii, const void* geom,
+                                   const void* binning, const void* image, const float* dL_dout_color, float* dL_dxyz,
+                                   float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dsh_color_factor,
+                                   float* dL_draw_scaling, float* dL_draw_rotation, float* grad_rows_scratch,
+                                   int32_t grad_rows_prezeroed, void* stream);
 
 /* View-parallel training (no counterpart in the reference, which is single-GPU: gs-simp/train.sh:1):
  * dL_dshs[g,k,c] = sum over views v of Y_k(normalize(means3D[g] - campos[v])) * dL_dcolors[v,g,c] for k < (deg+1)^2,

@@ -89,6 +89,10 @@ typedef struct mvi_compact_tensor {
     const void* in;   /* [P, width] */
     void* out;        /* [n_keep, width] */
     int32_t width;
+    int32_t packed_stride;   /* window forms only: words between consecutive rows of the COMPACT side (the gather's out, the scatter's
+                              * in), >= width; 0 = width (contiguous rows). Lets one compact array [capacity, 3 M] be scattered into
+                              * two full-size tensors (features_dc [P, 3] | features_rest [P, 3 M - 3]) by two entries whose `in`
+                              * pointers are 0 and 3 words into its rows. mvi_compact_gather ignores it (its outputs are contiguous). */
 } mvi_compact_tensor;
 size_t mvi_compact_workspace_bytes(int32_t P);
 int mvi_compact_plan(const uint8_t* keep_mask, int32_t P, void* workspace, size_t workspace_bytes,
@@ -108,6 +112,13 @@ int mvi_compact_gather_window(const mvi_compact_tensor* tensors_host, int32_t n_
 int mvi_compact_scatter_window(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P,
                                const uint32_t* n_keep_device, uint32_t first, uint32_t capacity, const void* workspace,
                                void* stream);
+
+/* Gradient supports as bit masks, for the one small collective in front of the compacted exchange: pack bits[w] bit b =
+ * (flags[32 w + b] != 0) for the (P + 31) / 32 words of one rank's support; union: mask[i] = 1 if any of the n_ranks gathered bit
+ * arrays bits_all [n_ranks][(P + 31) / 32] has bit i set, else 0 (the keep-mask mvi_compact_plan takes). P / 8 bytes per rank in
+ * ONE all-gather instead of a P-byte all-reduce(MAX). No counterpart in the reference (single GPU). */
+int mvi_support_pack_bits(const uint8_t* flags, int32_t P, uint32_t* bits, void* stream);
+int mvi_support_union_bits(const uint32_t* bits_all, int32_t n_ranks, int32_t P, uint8_t* mask, void* stream);
 
 const char* mvi_train_last_error(void);
 

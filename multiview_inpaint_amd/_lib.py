@@ -42,7 +42,7 @@ class AdamGroup(C.Structure):
 
 class CompactTensor(C.Structure):
     """struct mvi_compact_tensor (include/mvi_train_ops.h)"""
-    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("width", C.c_int32)]
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("width", C.c_int32), ("packed_stride", C.c_int32)]
 
 
 def declared_symbols():
@@ -112,6 +112,8 @@ def lib():
     L.mvi_raster_forward_geom_raw.argtypes = [C.POINTER(RasterSettings), i32, i32] + [vp] * 6 + [vp, sz, vp, C.POINTER(i64), vp]
     L.mvi_raster_backward_raw.restype = C.c_int
     L.mvi_raster_backward_raw.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 19 + [i32, vp]
+    L.mvi_raster_backward_raw_factor.restype = C.c_int
+    L.mvi_raster_backward_raw_factor.argtypes = [C.POINTER(RasterSettings), i32, i32, i64] + [vp] * 18 + [i32, vp]
     L.mvi_raster_sh_backward_views.restype = C.c_int
     L.mvi_raster_sh_backward_views.argtypes = [i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp]
     L.mvi_raster_mark_visible.restype = C.c_int
@@ -173,6 +175,10 @@ def _bind_train_ops(L):
     L.mvi_compact_plan.argtypes = [vp, i32, vp, sz, vp, vp]
     L.mvi_compact_gather.restype = C.c_int
     L.mvi_compact_gather.argtypes = [C.POINTER(CompactTensor), i32, i32, C.c_uint32, vp, vp]
+    L.mvi_support_pack_bits.restype = C.c_int
+    L.mvi_support_pack_bits.argtypes = [vp, i32, vp, vp]
+    L.mvi_support_union_bits.restype = C.c_int
+    L.mvi_support_union_bits.argtypes = [vp, i32, i32, vp, vp]
     for f in (L.mvi_compact_gather_window, L.mvi_compact_scatter_window):
         f.restype = C.c_int
         f.argtypes = [C.POINTER(CompactTensor), i32, i32, vp, C.c_uint32, C.c_uint32, vp, vp]

@@ -80,6 +80,47 @@ __global__ __launch_bounds__(kCpBlock) void compact_fill_kernel(const uint8_t* _
     if (keep) src_rows[off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)i;
 }
 
+// Gradient supports as BIT masks (view-parallel training: what the ranks tell each other about their views before the compacted
+// exchange — P / 8 bytes per rank in one all-gather instead of a P-byte all-reduce(MAX)).
+// pack: bits[w] bit b = flags[32 w + b] != 0, one word per thread from two 16-byte loads; union: mask[i] = 1 if any of the W
+// gathered bit arrays has bit i set, one word (32 flags, two 16-byte stores) per thread.
+__global__ __launch_bounds__(256) void support_pack_kernel(const uint8_t* __restrict__ flags, int P, uint32_t* __restrict__ bits, int words) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= words) return;
+    const int i0 = 32 * w;
+    uint32_t r = 0;
+    if (i0 + 32 <= P && ((uintptr_t)flags & 15u) == 0) {
+        const uint4 a = *reinterpret_cast<const uint4*>(flags + i0), b = *reinterpret_cast<const uint4*>(flags + i0 + 16);
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r |= (((v[q] >> (8 * k)) & 0xFFu) ? 1u : 0u) << (4 * q + k);
+    } else {
+        for (int k = 0; k < 32 && i0 + k < P; ++k) r |= (flags[i0 + k] ? 1u : 0u) << k;
+    }
+    bits[w] = r;
+}
+
+__global__ __launch_bounds__(256) void support_union_kernel(const uint32_t* __restrict__ bits_all, int W, int words, int P,
+                                                            uint8_t* __restrict__ mask) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= words) return;
+    uint32_t r = 0;
+    for (int k = 0; k < W; ++k) r |= bits_all[(size_t)k * words + w];
+    const int i0 = 32 * w;
+    if (i0 + 32 <= P && ((uintptr_t)mask & 15u) == 0) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = ((r >> (4 * q)) & 1u) | (((r >> (4 * q + 1)) & 1u) << 8) | (((r >> (4 * q + 2)) & 1u) << 16) | (((r >> (4 * q + 3)) & 1u) << 24);
+        *reinterpret_cast<uint4*>(mask + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint4*>(mask + i0 + 16) = make_uint4(v[4], v[5], v[6], v[7]);
+    } else {
+        for (int k = 0; k < 32 && i0 + k < P; ++k) mask[i0 + k] = (uint8_t)((r >> k) & 1u);
+    }
+}
+
 struct GatherTable {
     mvi_compact_tensor t[MVI_COMPACT_MAX_TENSORS];
 };
@@ -124,6 +165,7 @@ __global__ __launch_bounds__(256) void compact_window_kernel(GatherTable tab, co
     const uint32_t n = n_all > first ? min(capacity, n_all - first) : 0u;
     const mvi_compact_tensor t = tab.t[blockIdx.y];
     const uint32_t w = (uint32_t)t.width;
+    const uint32_t ps = t.packed_stride > 0 ? (uint32_t)t.packed_stride : w;       // words between rows of the compact side
     const uint32_t* __restrict__ in = (const uint32_t*)t.in;
     uint32_t* __restrict__ out = (uint32_t*)t.out;
     const float inv = 1.0f / (float)w;
@@ -135,7 +177,7 @@ __global__ __launch_bounds__(256) void compact_window_kernel(GatherTable tab, co
         const uint32_t words = rows * w;
         for (uint32_t e = threadIdx.x; e < words; e += 256u) {
             const uint32_t j = (uint32_t)(((float)e + 0.5f) * inv);
-            const uint64_t full = (uint64_t)s_src[j] * w + (e - j * w), packed = (uint64_t)row0 * w + e;
+            const uint64_t full = (uint64_t)s_src[j] * w + (e - j * w), packed = (uint64_t)(row0 + j) * ps + (e - j * w);
             if (kScatter) out[full] = in ? in[packed] : 0u;
             else out[packed] = in[full];
         }
@@ -181,6 +223,24 @@ extern "C" int mvi_compact_plan(const uint8_t* keep_mask, int32_t P, void* works
     return MVI_OK;
 }
 
+extern "C" int mvi_support_pack_bits(const uint8_t* flags, int32_t P, uint32_t* bits, void* stream) {
+    if (P < 0) return mvi::train_fail(MVI_EINVAL, "support_pack_bits: P < 0");
+    if (P == 0) return MVI_OK;
+    if (!flags || !bits) return mvi::train_fail(MVI_EINVAL, "support_pack_bits: NULL pointer");
+    const int words = (P + 31) / 32;
+    hipLaunchKernelGGL(mvi::support_pack_kernel, dim3((words + 255) / 256), dim3(256), 0, (hipStream_t)stream, flags, P, bits, words);
+    return hipGetLastError() == hipSuccess ? MVI_OK : mvi::train_fail(MVI_EHIP, "support_pack_bits: kernel launch failed");
+}
+
+extern "C" int mvi_support_union_bits(const uint32_t* bits_all, int32_t n_ranks, int32_t P, uint8_t* mask, void* stream) {
+    if (P < 0 || n_ranks < 1) return mvi::train_fail(MVI_EINVAL, "support_union_bits: bad argument");
+    if (P == 0) return MVI_OK;
+    if (!bits_all || !mask) return mvi::train_fail(MVI_EINVAL, "support_union_bits: NULL pointer");
+    const int words = (P + 31) / 32;
+    hipLaunchKernelGGL(mvi::support_union_kernel, dim3((words + 255) / 256), dim3(256), 0, (hipStream_t)stream, bits_all, n_ranks, words, P, mask);
+    return hipGetLastError() == hipSuccess ? MVI_OK : mvi::train_fail(MVI_EHIP, "support_union_bits: kernel launch failed");
+}
+
 extern "C" int mvi_compact_gather(const mvi_compact_tensor* tensors_host, int32_t n_tensors, int32_t P, uint32_t n_keep,
                                   const void* workspace, void* stream) {
     using namespace mvi;
@@ -212,7 +272,8 @@ static int compact_window(bool scatter, const mvi_compact_tensor* tensors_host, 
     for (int i = 0; i < n_tensors; ++i) {
         tab.t[i] = tensors_host[i];
         // a scatter may have no input (zero fill); every other pointer is needed; 256 * width must stay below 2^22 (fp32 row index)
-        if ((!tab.t[i].in && !scatter) || !tab.t[i].out || tab.t[i].width <= 0 || tab.t[i].width > 8192) return train_fail(MVI_EINVAL, who);
+        if ((!tab.t[i].in && !scatter) || !tab.t[i].out || tab.t[i].width <= 0 || tab.t[i].width > 8192 ||
+            (tab.t[i].packed_stride != 0 && tab.t[i].packed_stride < tab.t[i].width)) return train_fail(MVI_EINVAL, who);
     }
     uint32_t blocks = (capacity + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;

@@ -347,6 +347,27 @@ int mvi_raster_backward_raw(const mvi_raster_settings* s, int32_t P, int32_t M, 
                          dL_draw_rotation, nullptr, grad_rows_scratch, stream, rawx);
 }
 
+int mvi_raster_backward_raw_factor(const mvi_raster_settings* s, int32_t P, int32_t M, int64_t D, const float* xyz,
+                                   const float* features_dc, const float* features_rest, const float* raw_opacity,
+                                   const float* raw_scaling, const float* raw_rotation, const int32_t* radii, const void* geom,
+                                   const void* binning, const void* image, const float* dL_dout_color, float* dL_dxyz,
+                                   float* dL_dmeans2D, float* dL_draw_opacity, float* dL_dsh_color_factor, float* dL_draw_scaling,
+                                   float* dL_draw_rotation, float* grad_rows_scratch, int32_t grad_rows_prezeroed, void* stream) {
+    mvi::Frame f;
+    if (int rc = make_frame(s, P, M, f)) return rc;
+    if (P > 0 && (!features_dc || (M > 1 && !features_rest) || !raw_opacity || !dL_dsh_color_factor))
+        return fail(MVI_EINVAL, "NULL raw parameter / colour factor pointer%s");
+    f.raw = 1;
+    f.shs_rest = features_rest;
+    mvi::RawBackwardExtra rawx;
+    rawx.raw_opacity = raw_opacity;
+    rawx.dL_dshs_rest = nullptr;                 // no dense SH gradient: every kernel tests dL_dshs before it touches either half
+    rawx.rows_prezeroed = grad_rows_prezeroed;
+    return backward_impl(f, P, D, xyz, features_dc, nullptr, raw_scaling, raw_rotation, nullptr, radii, geom, binning, image,
+                         dL_dout_color, dL_dxyz, dL_dmeans2D, dL_draw_opacity, nullptr, dL_dsh_color_factor, dL_draw_scaling,
+                         dL_draw_rotation, nullptr, grad_rows_scratch, stream, rawx);
+}
+
 static int backward_impl(mvi::Frame& f, int32_t P, int64_t D, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* scales, const float* rotations,
                          const float* cov3D_precomp, const int32_t* radii, const void* geom, const void* binning,

@@ -207,7 +207,8 @@ class CompactedGradExchange(FactoredGradExchange):
     1920 x 1080 view is 3 % of the 1.5 M Gaussians (87 % are "visible" in the radii > 0 sense, but the first ~240 entries of a
     tile's list saturate its pixels), so the union over 8 views is at most a quarter of the rows.
 
-        1. all-reduce(MAX) of the per-rank support bytes [P] (1.5 MB at P = 1.5 M) -> the union, identical on all ranks
+        1. the per-rank supports travel as BIT masks in one all-gather (P / 8 bytes per rank: 188 KB at P = 1.5 M; round 4:
+           an all-reduce(MAX) of P bytes) and are OR-ed locally -> the union, identical on all ranks
         2. one scan of the union into a row list (csrc/compact_rows.hip); its length n stays on the device and is copied to
            pinned host memory on the side
         3. ONE gather launch packs the union rows of the four small gradients, the colour factors and the positions into
@@ -229,8 +230,16 @@ class CompactedGradExchange(FactoredGradExchange):
     MIN_CAPACITY = 16384
     ROUND = 4096
 
-    def __init__(self, P: int, M: int, sh_degree: int, device, group=None):
+    def __init__(self, P: int, M: int, sh_degree: int, device, group=None, split_sh: bool = False):
+        """split_sh: the summed SH gradient is delivered as two tensors, "shs_dc" [P, 1, 3] and "shs_rest" [P, M - 1, 3] — the
+        shapes of the reference's _features_dc / _features_rest parameters (gaussian_model.py:108-111), which the optimizer steps
+        separately — instead of one "shs" [P, M, 3]; the scatter kernel writes both from the one compact array."""
         super().__init__(P, M, sh_degree, device, group=group)
+        self.split_sh = bool(split_sh)
+        if self.split_sh:
+            f32 = dict(dtype=torch.float32, device=device)
+            self.shs = None                                        # (allocated on demand by the full-size fallback)
+            self.shs_dc, self.shs_rest = torch.zeros(P, 1, 3, **f32), torch.zeros(P, max(M - 1, 0), 3, **f32)
         self.last_union_fraction = None
         self.last_compacted = None
         self.last_pages = None
@@ -265,14 +274,72 @@ class CompactedGradExchange(FactoredGradExchange):
         from . import _lib
         L = _lib.lib()
         tab = (_lib.CompactTensor * len(pairs))()
-        for e, (full, comp) in zip(tab, pairs):
+        for e, pair in zip(tab, pairs):
+            full, comp = pair[0], pair[1]
+            off, stride = (pair[2], pair[3]) if len(pair) > 2 else (0, 0)      # words into a row of the compact side / between its rows
             src, dst = (comp, full) if scatter else (full, comp)
-            e.in_, e.out, e.width = (src.data_ptr() if src is not None else None), dst.data_ptr(), full[0].numel()
+            addr = lambda t, is_comp: None if t is None else t.data_ptr() + (4 * off if is_comp else 0)
+            e.in_, e.out, e.width, e.packed_stride = addr(src, scatter), addr(dst, not scatter), full[0].numel(), stride
         dev = self.small.device
         fn = L.mvi_compact_scatter_window if scatter else L.mvi_compact_gather_window
         with torch.cuda.device(dev):
             _lib.check(fn(tab, len(pairs), self.P, C.c_void_p(ws.data_ptr() + self._ws_bytes), first, cap, C.c_void_p(ws.data_ptr()),
                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "compact window")
+
+    def _sh_pairs(self, sh_c, cap):
+        """(full, compact[, offset, stride]) entries that scatter the compact dL/dSH rows [cap, M, 3] into the full-size output(s);
+        sh_c = None: entries that zero those rows."""
+        M3 = 3 * self.M
+        if not self.split_sh:
+            return [(self.shs.view(self.P, M3), None if sh_c is None else sh_c.view(cap, M3))]
+        out = [(self.shs_dc.view(self.P, 3), None if sh_c is None else sh_c.view(cap, M3), 0, M3)]
+        if self.M > 1:
+            out.append((self.shs_rest.view(self.P, M3 - 3), None if sh_c is None else sh_c.view(cap, M3), 3, M3))
+        return out
+
+    def _result(self):
+        g = {name: self.views[name] for name, _ in self.SMALL}
+        if self.split_sh:
+            g["shs_dc"], g["shs_rest"] = self.shs_dc, self.shs_rest
+        else:
+            g["shs"] = self.shs
+        return g
+
+    def _full_size(self, means3D, campos):
+        """The base class's full-size exchange; split_sh: its [P, M, 3] result copied into the two outputs."""
+        if self.split_sh and self.shs is None:
+            self.shs = torch.zeros(self.P, self.M, 3, dtype=torch.float32, device=self.small.device)
+        FactoredGradExchange.exchange(self, means3D, campos)
+        if self.split_sh:
+            self.shs_dc.copy_(self.shs[:, :1])
+            self.shs_rest.copy_(self.shs[:, 1:])
+        return self._result()
+
+    def _union_mask(self, visible):
+        """self._mask <- the union over ranks of the supports (GPU path). One all-gather of bit masks (MVI_DIST_BYTE_MASK=1: the
+        round-4 form, an all-reduce(MAX) of the byte mask, for A/B runs)."""
+        import ctypes as C
+        import os
+        from . import _lib
+        P, dev = self.P, self.small.device
+        flags = visible.to(torch.uint8).reshape(-1)
+        if os.environ.get("MVI_DIST_BYTE_MASK") == "1":
+            self._mask.copy_(flags)
+            td.all_reduce(self._mask, op=td.ReduceOp.MAX, group=self.group)
+            return
+        if getattr(self, "_bits", None) is None:
+            words = (P + 31) // 32
+            self._bits = torch.zeros(words, dtype=torch.int32, device=dev)
+            self._bits_all = torch.zeros(self.world * words, dtype=torch.int32, device=dev)
+        flags = flags if flags.is_contiguous() else flags.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mvi_support_pack_bits(C.c_void_p(flags.data_ptr()), P, C.c_void_p(self._bits.data_ptr()), st), "support_pack_bits")
+        td.all_gather_into_tensor(self._bits_all, self._bits, group=self.group)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mvi_support_union_bits(C.c_void_p(self._bits_all.data_ptr()), self.world, P,
+                                                         C.c_void_p(self._mask.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "support_union_bits")
 
     def _page(self, means3D, campos, ws, first: int, cap: int):
         """Rows [first, first + cap) of the union list: gather, exchange, rebuild dL/dSH, scatter back. Buffers are cut to `cap`
@@ -293,8 +360,7 @@ class CompactedGradExchange(FactoredGradExchange):
         td.all_reduce(self._small_c[:11 * cap], op=td.ReduceOp.SUM, group=self.group)
         h.wait()
         sh_grad_from_factors(means_c, recv[:, 3 * cap:], recv[:, :3 * cap].view(self.world, cap, 3), self.M, self.deg, out=sh_c)
-        self._window(True, [(self.views[nm], sg) for nm, sg in zip(names, segs)] + [(self.shs.view(self.P, 3 * self.M), sh_c.view(cap, 3 * self.M))],
-                     ws, first, cap)
+        self._window(True, [(self.views[nm], sg) for nm, sg in zip(names, segs)] + self._sh_pairs(sh_c, cap), ws, first, cap)
 
     def _exchange_device(self, means3D: torch.Tensor, campos: torch.Tensor, visible: torch.Tensor):
         import ctypes as C
@@ -305,8 +371,7 @@ class CompactedGradExchange(FactoredGradExchange):
             self._alloc(cap)
         self._cur ^= 1
         ws, ws_prev = self._ws[self._cur], self._ws[self._cur ^ 1]
-        self._mask.copy_(visible.to(torch.uint8).reshape(-1))
-        td.all_reduce(self._mask, op=td.ReduceOp.MAX, group=self.group)
+        self._union_mask(visible)
         cnt = ws[self._ws_bytes:self._ws_bytes + 4].view(torch.int32)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mvi_compact_plan(C.c_void_p(self._mask.data_ptr()), P, C.c_void_p(ws.data_ptr()), self._ws_bytes,
@@ -316,9 +381,10 @@ class CompactedGradExchange(FactoredGradExchange):
         self._count_ev.record()
         # dL/dSH is zero outside the rows this step writes: clear what the previous step wrote (its row list is still in ws_prev)
         if self._shs_rows == "plan":
-            self._window(True, [(self.shs.view(P, 3 * self.M), None)], ws_prev, 0, P)
+            self._window(True, self._sh_pairs(None, P), ws_prev, 0, P)
         elif self._shs_rows is not None:
-            self.shs.zero_()
+            for t in ((self.shs_dc, self.shs_rest) if self.split_sh else (self.shs,)):
+                t.zero_()
         self._page(means3D, campos, ws, 0, cap)
         self._count_ev.synchronize()                             # upstream of everything queued above: the device is not idle
         n = int(self._count_pin.item())
@@ -328,9 +394,7 @@ class CompactedGradExchange(FactoredGradExchange):
         self._shs_rows = "plan"
         self.last_union_fraction, self.last_compacted, self.last_pages, self.last_capacity = (n / P if P else 0.0), True, pages, cap
         self._next_cap = min(P, max(self.MIN_CAPACITY, -(-int(self.HEADROOM * n) // self.ROUND) * self.ROUND))
-        g = {name: self.views[name] for name, _ in self.SMALL}
-        g["shs"] = self.shs
-        return g
+        return self._result()
 
     def exchange_visible(self, means3D: torch.Tensor, campos: torch.Tensor, visible: torch.Tensor):
         """visible [P] bool / uint8: any superset of this rank's gradient support — RasterState.tensor("grad_support", ...)
@@ -342,10 +406,11 @@ class CompactedGradExchange(FactoredGradExchange):
         if visible.is_cuda:
             if self.last_union_fraction is not None and self.last_union_fraction > self.THRESHOLD:
                 # full-size exchange; the union is still measured (on the side) so that a later step can compact again
-                m = visible.to(torch.uint8).reshape(-1).clone()
-                td.all_reduce(m, op=td.ReduceOp.MAX, group=self.group)
-                frac = m.float().mean()
-                out = self.exchange(means3D, campos)
+                if getattr(self, "_mask", None) is None:
+                    self._alloc(max(1, self.MIN_CAPACITY))
+                self._union_mask(visible)
+                frac = self._mask.float().mean()
+                out = self._full_size(means3D, campos)
                 self._shs_rows = "all"
                 self.last_union_fraction, self.last_compacted, self.last_pages = float(frac.item()), False, 0
                 self._next_cap = P
@@ -362,7 +427,7 @@ class CompactedGradExchange(FactoredGradExchange):
         self.last_compacted = bool(P) and n <= self.THRESHOLD * P
         if not self.last_compacted:
             self._shs_rows = "all"
-            return self.exchange(means3D, campos)
+            return self._full_size(means3D, campos)
         widths = [w for _, w in self.SMALL]
         rows = torch.cat(parts, 1).contiguous()                                                       # [n, 11]
         send = torch.cat([fac_c.reshape(-1), campos.reshape(3).to(rows.dtype)])
@@ -374,11 +439,17 @@ class CompactedGradExchange(FactoredGradExchange):
                                     recv[:, :3 * n].reshape(self.world, n, 3).contiguous(), self.M, self.deg)
         # the full-size outputs are zero outside the rows written here: the small arrays are the backward's own outputs
         # (zero outside this rank's support, which the union contains), self.shs is cleared where the last step wrote it
-        if isinstance(self._shs_rows, str):
-            self.shs.zero_()
-        elif self._shs_rows is not None:
-            self.shs[self._shs_rows] = 0
-        self.shs[idx] = sh_c
+        outs = (self.shs_dc, self.shs_rest) if self.split_sh else (self.shs,)
+        for t in outs:
+            if isinstance(self._shs_rows, str):
+                t.zero_()
+            elif self._shs_rows is not None:
+                t[self._shs_rows] = 0
+        if self.split_sh:
+            self.shs_dc[idx] = sh_c[:, :1]
+            self.shs_rest[idx] = sh_c[:, 1:]
+        else:
+            self.shs[idx] = sh_c
         self._shs_rows = idx
         g, o = {}, 0
         for (name, w) in self.SMALL:
@@ -387,8 +458,7 @@ class CompactedGradExchange(FactoredGradExchange):
             g[name] = v
             o += w
         assert o == sum(widths)
-        g["shs"] = self.shs
-        return g
+        return self._result()
 
     exchange_support = exchange_visible
 

@@ -741,5 +741,10 @@ def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=No
     return y
 
 
+def attention_kernel_variant(Sq, Sk, D, dtype):
+    """0 = fp32-math rowtile kernel, 4 / 8 = the 4- / 8-wave MFMA kernel (the function the C dispatch itself uses)."""
+    return int(_lib.lib().mvi_attention_kernel_variant(int(Sq), int(Sk), int(D), _DT[dtype]))
+
+
 def attention_kernel_kind(Sq, Sk, D, dtype):
     return int(_lib.lib().mvi_attention_kernel_kind(Sq, Sk, D, _DT[dtype]))

@@ -144,6 +144,16 @@ def packed_ok(x, heads, dim_head):
     return x.is_cuda and not torch.is_grad_enabled() and dim_head in (16, 32, 64) and (heads * dim_head * x.element_size()) % 16 == 0
 
 
+def attention_scale_fold_pays(x, dim_head):
+    """Whether the self-attention of x [B, S, C] runs the 8-wave MFMA kernel (csrc/attn_flash8.hip), whose softmax is bound by
+    vector issue: the only kernel for which a q that carries the softmax scale (CrossAttention._packed_qkv_weight(fold=True))
+    is faster."""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 3):
+        return False
+    from . import hip_ops
+    return hip_ops.attention_kernel_variant(x.shape[1], x.shape[1], dim_head, x.dtype) == 8
+
+
 def _unfold_q(q, heads, q_log2):
     """q of a packed projection whose q rows carry dim_head^-1/2 * log2(e) (CrossAttention._packed_qkv_weight), for a consumer that
     applies the softmax scale itself."""

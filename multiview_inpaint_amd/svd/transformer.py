@@ -81,7 +81,8 @@ class CrossAttention(nn.Module):
         if context is None and not n_times_crossframe_attn_in_self and not n_extra and ops.packed_ok(x, self.heads, self.dim_head):
             # self-attention at inference: one GEMM [.., C] x [C, 3 H D] instead of three passes over the activations;
             # the attention kernel reads q, k, v out of the packed result in place
-            w, q_log2 = self._packed_qkv_weight(x.dtype)
+            # the softmax scale rides in the q weights exactly where it buys speed: sequences the 8-wave kernel serves
+            w, q_log2 = self._packed_qkv_weight(x.dtype, fold=ops.attention_scale_fold_pays(x, self.dim_head))
             return ops.linear_module(self.to_out, ops.attention_packed(ops.linear(x, w), self.heads, q_log2=q_log2))
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if n_times_crossframe_attn_in_self:
@@ -95,31 +96,34 @@ class CrossAttention(nn.Module):
         return self.to_out(out)
 
 
-    def _packed_qkv_weight(self, act_dtype=None):
+    def _packed_qkv_weight(self, act_dtype=None, fold=False):
         """(cat(to_q.weight, to_k.weight, to_v.weight) [3 H D, C], q_log2), rebuilt only when a weight changes (inference weights
         are static; not a parameter or buffer, so the state-dict keys stay the reference's).
-        q_log2 (reduced precision on the GPU, FOLD_SCALE_INTO_WQ): the q rows are round(dim_head^-1/2 * log2(e) * to_q.weight),
-        the product taken in fp32 and rounded ONCE to the weights' type, so the packed projection's q already is the exponent of
-        2 the softmax needs (attention.py:332-336 `softmax(q k^T * scale)`): q' = round(x . W_q'^T) carries one output rounding,
-        as the reference's q does — scaling q inside the attention kernel would round it a second time, and scaling the fp32
-        scores costs the 8-wave kernel one multiply per score on the port that bounds it."""
+        fold (reduced precision on the GPU, FOLD_SCALE_INTO_WQ; asked for by the spatial self-attentions the 8-wave MFMA kernel
+        serves, S >= 1024): the q rows are round(dim_head^-1/2 * log2(e) * to_q.weight), the product taken in fp32 and rounded
+        once to the weights' type, so the packed projection's q already is the exponent of 2 the softmax needs (attention.py:332-336
+        `softmax(q k^T * scale)`) and the kernel's softmax loses its one multiply per score — the port that bounds it. Price: the
+        320 .. 1280 weights behind a q element are rounded a second time (the in-kernel alternative rounds q itself a second
+        time: the same size of perturbation); measured on the op (tests/test_unet_ops_gpu.py::test_softmax_scale_folded_...) and
+        inside the reference-pinned graphs at full size. Two cached forms per module at most (folded / plain)."""
         ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
-        fold = (FOLD_SCALE_INTO_WQ and ws[0].is_cuda and ws[0].dtype in (torch.bfloat16, torch.float16)
-                and (act_dtype is None or act_dtype == ws[0].dtype) and not torch.is_grad_enabled())
-        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws) + (fold,)
-        hit = getattr(self, "_wqkv", None)
+        fold = bool(fold and FOLD_SCALE_INTO_WQ and ws[0].is_cuda and ws[0].dtype in (torch.bfloat16, torch.float16)
+                    and (act_dtype is None or act_dtype == ws[0].dtype) and not torch.is_grad_enabled())
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        slot = "_wqkv_folded" if fold else "_wqkv"
+        hit = getattr(self, slot, None)
         if hit is None or hit[0] != key:
             wq = ws[0].detach()
             if fold:
                 wq = (wq.float() * (self.scale * LOG2E)).to(wq.dtype)
             hit = (key, torch.cat([wq, ws[1].detach(), ws[2].detach()], dim=0).contiguous(), fold)
-            self._wqkv = hit
+            setattr(self, slot, hit)
         return hit[1], hit[2]
 
     def forward_temporal(self, x, T):
         """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back."""
         if ops.packed_ok(x, self.heads, self.dim_head) and self.to_k.in_features == self.to_q.in_features:
-            w, q_log2 = self._packed_qkv_weight(x.dtype)
+            w, q_log2 = self._packed_qkv_weight(x.dtype)      # (plain: T keys per softmax, nothing to gain from the fold)
             return ops.linear_module(self.to_out, ops.attention_temporal_packed(ops.linear(x, w), self.heads, T, q_log2=q_log2))
         return self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
 
