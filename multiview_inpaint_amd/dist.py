@@ -83,9 +83,10 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.T
     """Multi-view counterpart of add_densification_stats (gaussian_model.py:482-484) + the max-radii
     update (train.py:115): each rank contributes the norm of ITS view's screen-space gradient where
     ITS view saw the Gaussian; sums / max are taken over ranks so every rank holds identical stats."""
-    norm = torch.zeros_like(xyz_gradient_accum)
-    norm[visibility] = torch.norm(viewspace_grad[visibility, :2], dim=-1, keepdim=True)
-    cnt = visibility.to(denom.dtype).view_as(denom).clone()
+    # mask-free (no nonzero() read-back): where(mask, norm, 0) over the whole arrays — the same values as the indexed form
+    vis = visibility.view_as(xyz_gradient_accum)
+    norm = torch.where(vis, torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True).to(xyz_gradient_accum.dtype), 0.0)
+    cnt = visibility.to(denom.dtype).view_as(denom)
     rad = torch.where(visibility, radii.to(max_radii2D.dtype), torch.zeros_like(max_radii2D))
     pack = torch.cat([norm.reshape(-1), cnt.reshape(-1)])
     td.all_reduce(pack, op=td.ReduceOp.SUM, group=group)

@@ -38,7 +38,11 @@ What install() does (each part can be switched off):
               parameters, their 12 Adam moments and the 3 per-Gaussian statistics are compacted with ONE scan of the mask and ONE gather
               launch (train_ops.prune_optimizer_state) instead of 21 boolean-index operations with a nonzero() read-back each —
               bit-identical tensors, optimizer.state re-keyed the same way. Masks that are not boolean GPU tensors, or an optimizer
-              whose groups are not one parameter each, go to the reference's method.
+              whose groups are not one parameter each, go to the reference's method. GaussianModel.cat_tensors_to_optimizer
+              (gaussian_model.py:384-404; behind densification_postfix, twice per densification) grows the 6 parameters and their
+              12 moments through train_ops.extend_optimizer_state (moments: allocate + copy + memset of the new rows instead of a
+              zeros_like temporary and a concatenation each) — identical tensors, optimizer.state re-keyed the same way; a dict or an
+              optimizer of another shape goes to the reference's method.
 Nothing is patched that is not named here; a script that imported the loss functions before install() ran keeps the
 reference's (install() must come first — the runner below guarantees it)."""
 import functools
@@ -151,6 +155,26 @@ def _make_prune_points(reference_prune_points):
     return prune_points
 
 
+def _make_cat_tensors(reference_cat_tensors):
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+    @functools.wraps(reference_cat_tensors)
+    def cat_tensors_to_optimizer(self, tensors_dict):
+        import torch
+        opt = getattr(self, "optimizer", None)
+        ok = (opt is not None and isinstance(tensors_dict, dict) and all(len(g["params"]) == 1 for g in opt.param_groups)
+              and sorted(g.get("name") for g in opt.param_groups) == sorted(names)
+              and all(torch.is_tensor(tensors_dict.get(n)) and tensors_dict[n].device == g["params"][0].device
+                      and tensors_dict[n].dtype == g["params"][0].dtype and tensors_dict[n].shape[1:] == g["params"][0].shape[1:]
+                      for g in opt.param_groups for n in (g["name"],)))
+        if not ok:
+            return reference_cat_tensors(self, tensors_dict)
+        from multiview_inpaint_amd.train_ops import extend_optimizer_state
+        return extend_optimizer_state(opt, tensors_dict)
+    cat_tensors_to_optimizer._mvi_patched = True
+    return cat_tensors_to_optimizer
+
+
 def install(loss=True, optimizer=True, render=True, stats=True, surgery=True):
     """Patches the gs-simp modules named above (they must be importable: the script's directory on sys.path). Returns the
     list of what was patched, for logging. Idempotent."""
@@ -198,6 +222,12 @@ def install(loss=True, optimizer=True, render=True, stats=True, surgery=True):
                 continue
             cls.prune_points = _make_prune_points(fn)
             done.append(f"scene.gaussian_model.{name}.prune_points")
+        for name, cls in list(vars(gm).items()):
+            fn = isinstance(cls, type) and cls.__dict__.get("cat_tensors_to_optimizer")
+            if not fn or getattr(fn, "_mvi_patched", False):
+                continue
+            cls.cat_tensors_to_optimizer = _make_cat_tensors(fn)
+            done.append(f"scene.gaussian_model.{name}.cat_tensors_to_optimizer")
     if render:
         gr = importlib.import_module("gaussian_renderer")
         gm = importlib.import_module("scene.gaussian_model")

@@ -360,20 +360,42 @@ def rasterize_forward_raw(rs: GaussianRasterizationSettings, xyz, features_dc, f
 
 
 def rasterize_backward_raw(rs: GaussianRasterizationSettings, st: RasterState, grad_color, xyz, features_dc, features_rest,
-                           raw_opacity, raw_scaling, raw_rotation):
+                           raw_opacity, raw_scaling, raw_rotation, out=None, sh_grad="dense"):
     """HIP backward with respect to the raw parameters. Returns dict(xyz, means2D, features_dc, features_rest,
-    opacity, scaling, rotation)."""
+    opacity, scaling, rotation). `out` may hold preallocated contiguous fp32 tensors to write into (same keys).
+    sh_grad="factor" (view-parallel training, train_views.py): dict(xyz, means2D, opacity, scaling, rotation,
+    sh_color_factor [P,3]) — the SH gradient stays in the factored form the exchange moves (dist.FactoredGradExchange) and
+    features_dc / features_rest are None (mvi_raster_backward_raw_factor)."""
+    if sh_grad not in ("dense", "factor"):
+        raise ValueError(f"sh_grad must be 'dense' or 'factor', got {sh_grad!r}")
     L = _lib.lib()
     fr = _Frame(rs)
     dev, P, M = xyz.device, st.P, st.M
     f32 = dict(dtype=torch.float32, device=dev)
-    g = dict(xyz=torch.empty(P, 3, **f32), means2D=torch.empty(P, 3, **f32), opacity=torch.empty(P, 1, **f32),
-             features_dc=torch.empty(P, 1, 3, **f32), features_rest=torch.empty(P, M - 1, 3, **f32),
-             scaling=torch.empty(P, 3, **f32), rotation=torch.empty(P, 4, **f32))
+    out = out or {}
+
+    def buf(name, *shape):
+        t = out.get(name)
+        if t is None:
+            return torch.empty(*shape, **f32)
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"out[{name!r}] must be a contiguous fp32 {shape} tensor on {dev}")
+        return t
+    g = dict(xyz=buf("xyz", P, 3), means2D=buf("means2D", P, 3), opacity=buf("opacity", P, 1), features_dc=None, features_rest=None,
+             scaling=buf("scaling", P, 3), rotation=buf("rotation", P, 4))
     scratch, clean = st.take_rows(dev)
     grad_color = grad_color.to(torch.float32).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
+        if sh_grad == "factor":
+            g["sh_color_factor"] = buf("sh_color_factor", P, 3)
+            _lib.check(L.mvi_raster_backward_raw_factor(
+                C.byref(fr.c), P, M, st.D, _ptr(xyz), _ptr(features_dc), _ptr(features_rest), _ptr(raw_opacity), _ptr(raw_scaling),
+                _ptr(raw_rotation), _ptr(st.radii), _ptr(st.geom), _ptr(st.binning), _ptr(st.image), _ptr(grad_color),
+                _ptr(g["xyz"]), _ptr(g["means2D"]), _ptr(g["opacity"]), _ptr(g["sh_color_factor"]),
+                _ptr(g["scaling"]), _ptr(g["rotation"]), _ptr(scratch), clean, stream), "rasterize backward raw (factor)")
+            return g
+        g["features_dc"], g["features_rest"] = buf("features_dc", P, 1, 3), buf("features_rest", P, M - 1, 3)
         _lib.check(L.mvi_raster_backward_raw(
             C.byref(fr.c), P, M, st.D, _ptr(xyz), _ptr(features_dc), _ptr(features_rest), _ptr(raw_opacity), _ptr(raw_scaling),
             _ptr(raw_rotation), _ptr(st.radii), _ptr(st.geom), _ptr(st.binning), _ptr(st.image), _ptr(grad_color),

@@ -372,9 +372,16 @@ def extend_optimizer_state(optimizer, tensors_dict):
     """cat_tensors_to_optimizer (gs-simp/scene/gaussian_model.py:384-404) for torch.optim.Adam / FusedAdam whose groups hold
     one named parameter each: every parameter gets the new rows of tensors_dict[group name] appended, its Adam moments get
     zero rows, optimizer.state is re-keyed like the reference does. Appending is a device-to-device copy per tensor (nothing
-    to fuse); this helper exists so densify_and_clone / densify_and_split run against FusedAdam unchanged.
-    Returns {group name: new nn.Parameter}."""
+    to fuse): the moments are grown as allocate + copy + memset of the tail (the reference materialises a zeros_like per moment
+    and concatenates: two more passes over the new rows and a temporary each). dropin.patch_gs_simp puts it behind the model's
+    cat_tensors_to_optimizer. Returns {group name: new nn.Parameter}."""
     new = {}
+
+    def grow(t, n_new):
+        out = t.new_empty((t.shape[0] + n_new,) + tuple(t.shape[1:]))
+        out[:t.shape[0]].copy_(t)
+        out[t.shape[0]:].zero_()
+        return out
     for g in optimizer.param_groups:
         assert len(g["params"]) == 1
         old = g["params"][0]
@@ -382,8 +389,7 @@ def extend_optimizer_state(optimizer, tensors_dict):
         stt = optimizer.state.get(old, None)
         if stt is not None:
             if "exp_avg" in stt:
-                stt["exp_avg"] = torch.cat((stt["exp_avg"], torch.zeros_like(ext)), dim=0)
-                stt["exp_avg_sq"] = torch.cat((stt["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+                stt["exp_avg"], stt["exp_avg_sq"] = grow(stt["exp_avg"], ext.shape[0]), grow(stt["exp_avg_sq"], ext.shape[0])
             del optimizer.state[old]
         g["params"][0] = torch.nn.Parameter(torch.cat((old.data, ext), dim=0).requires_grad_(True))
         if stt is not None:

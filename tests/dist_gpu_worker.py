@@ -96,95 +96,105 @@ def entry(rank, world, port, queue, kwargs):
         queue.put((rank, False, [], lines + [traceback.format_exc(), repr(e)]))
 
 
-# ---- the view-sharded TRAINING step (BASELINE configs[4] at two ranks): render own view -> L1 + DSSIM gradient -> backward into the
-# exchange's views -> compacted exchange -> Adam on the replicated parameters, against ONE process that renders every view of a step,
-# sums the gradients and takes the same Adam step.
-def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=6, say=print):
+# ---- the view-sharded TRAINING loop (BASELINE configs[4] at two ranks) through the SHIPPED module, multiview_inpaint_amd.train_views:
+# ViewShardedTrainer on a stand-in of the reference's GaussianModel (tests/gs_standin.py) with dropin.patch_gs_simp's surgery hooks
+# installed on it — stored parameters into the raw-parameter rasterizer, fused L1 + DSSIM incl. the mask of the non-inpainted views,
+# backward into the exchange's buffers, bit-mask all-gather + compacted exchange, reduced densification statistics, densify_and_prune
+# on every rank with an identically seeded generator, FusedAdam — against ONE process that renders every view of a step with the same
+# pieces (world = 1), sums the gradients and runs the same tail.
+def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=14, say=print):
     import numpy as np
     import torch
     import torch.distributed as td
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from multiview_inpaint_amd import dist as md, raster as R, synthetic as syn, train_ops as T
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from multiview_inpaint_amd import raster as R, synthetic as syn, train_ops as T, train_views as TV
+        from multiview_inpaint_amd.dropin import patch_gs_simp
+        import gs_standin as GS
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
-        M = (deg + 1) ** 2
         sc = syn.make_scene(N, syn.make_camera(W, H, 50.0), deg, seed=0, log_scale_mean=np.log(0.04))
-        names = ("means3D", "opacities", "scales", "rotations", "shs")
-        lrs = dict(means3D=1.6e-4, opacities=1e-2, scales=1e-3, rotations=1e-3, shs=2.5e-3)
 
-        def settings(k):
-            cam = camera(syn, np, k, W, H)
-            return R.GaussianRasterizationSettings(
-                image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
-                scale_modifier=1.0, viewmatrix=torch.tensor(cam["viewmatrix"], device=dev), projmatrix=torch.tensor(cam["projmatrix"], device=dev),
-                sh_degree=deg, campos=torch.tensor(cam["campos"], device=dev), prefiltered=False)
+        class Model(GS.StandinGaussianModel):                        # the hooks an unchanged script gets (patch_gs_simp.install)
+            prune_points = patch_gs_simp._make_prune_points(GS.StandinGaussianModel.prune_points)
+            cat_tensors_to_optimizer = patch_gs_simp._make_cat_tensors(GS.StandinGaussianModel.cat_tensors_to_optimizer)
 
-        def fresh():
-            t = {k: torch.tensor(sc[k], device=dev) for k in names}
-            opt = T.FusedAdam([{"params": [t[k]], "lr": lrs[k], "name": k} for k in names], lr=0.0, eps=1e-15)
-            return t, opt
-
-        def target(k):                                    # what the views should look like: the scene with other colours
+        def target_image(k):                                         # what view k should look like: the scene with other colours
             g = torch.Generator(dev).manual_seed(77)
             shs = torch.tensor(sc["shs"], device=dev)
             shs[:, 0] += 0.6 * torch.randn(N, 3, device=dev, generator=g)
-            t0 = {k2: torch.tensor(sc[k2], device=dev) for k2 in names}
-            img, _, _, _ = R.rasterize_forward(settings(k), t0["means3D"], t0["opacities"], shs=shs, scales=t0["scales"], rotations=t0["rotations"])
+            t0 = {k2: torch.tensor(sc[k2], device=dev) for k2 in ("means3D", "opacities", "scales", "rotations")}
+            cam = camera(syn, np, k, W, H)
+            rs = R.GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
+                scale_modifier=1.0, viewmatrix=torch.tensor(cam["viewmatrix"], device=dev), projmatrix=torch.tensor(cam["projmatrix"], device=dev),
+                sh_degree=deg, campos=torch.tensor(cam["campos"], device=dev), prefiltered=False)
+            img, _, _, _ = R.rasterize_forward(rs, t0["means3D"], t0["opacities"], shs=shs, scales=t0["scales"], rotations=t0["rotations"])
             return img
 
-        def view_gradient(t, k, out=None, sh_grad="dense"):
-            rs = settings(k)
-            kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
-            img, _, _, st = R.rasterize_forward(rs, t["means3D"], t["opacities"], prepare_backward=True, **kw)
-            out3, g_img = T.photometric_loss_forward_backward(img, target(k), 0.2)
-            g = R.rasterize_backward(rs, st, g_img, t["means3D"], out=out, sh_grad=sh_grad, **kw)
-            return rs, st, g, out3[0]
+        cams = []
+        for k in range(6):                                           # six views; every third one is a NON-inpainted view with a mask
+            mask = None
+            if k % 3 == 2:
+                mask = torch.zeros(1, H, W, device=dev)
+                mask[:, H // 4:H // 2, W // 3:2 * W // 3] = 1.0
+            cams.append(GS.StandinCamera(camera(syn, np, k, W, H), target_image(k), mask=mask, inpainted=mask is None, name=f"v{k}"))
+        opt_args = GS.StandinOpt(iterations=steps + 1, densify_from_iter=3, densify_until_iter=steps + 1, densification_interval=5,
+                                 densify_grad_threshold=2e-5)      # one densification inside the run (iteration 5 and 10)
+        bg = torch.zeros(3, device=dev)
+        extent = 6.0
 
         # (1) this rank's share of the sharded run
-        t, opt = fresh()
-        ex = md.CompactedGradExchange(N, M, deg, dev)
-        ex.THRESHOLD, ex.MIN_CAPACITY, ex.ROUND = 1.0, 256, 256
-        shard_losses = []
-        for step in range(steps):
-            rs, st, _, loss = view_gradient(t, (step % 2) * world + rank, out=ex.views, sh_grad="factor")   # 2 x world views, revisited
-            got = ex.exchange_support(t["means3D"], rs.campos, st.tensor("grad_support", (N,), torch.uint8))
-            for k in names:
-                t[k].grad = got[k].view_as(t[k])
-            opt.step()
-            total = loss.detach().clone().cpu()
-            td.all_reduce(total)                          # the step's loss summed over the views (for the comparison only)
-            shard_losses.append(float(total))
-        # (2) one process, every view of a step, summed gradients
-        t1, opt1 = fresh()
-        single_losses = []
-        for step in range(steps):
+        m = Model(sc, deg, optimizer_cls=T.FusedAdam)
+        tr = TV.ViewShardedTrainer(m, opt_args, lambda: list(cams), bg, extent, seed=3)
+        assert tr.world == world and tr.rank == rank
+        shard_losses, shard_P = [], []
+        for it in range(1, steps + 1):
+            loss3 = tr.step(it)
+            tot = loss3[:1].detach().clone().cpu()
+            td.all_reduce(tot)                                       # the step's loss summed over the views (for the comparison only)
+            shard_losses.append(float(tot))
+            shard_P.append(int(m._xyz.shape[0]))
+        same = tr.replicas_identical()
+        # (2) one process, every view of a step, summed gradients, the same tail
+        m1 = Model(sc, deg, optimizer_cls=T.FusedAdam)
+        t1 = TV.ViewShardedTrainer(m1, opt_args, lambda: list(cams), bg, extent, seed=3, world=1)
+        stack = TV.ViewStack(lambda: list(cams), world, 0, seed=3)     # the draws of the sharded run
+        names = [n for n, _ in TV.PARAMS]
+        key = dict(xyz="xyz", opacity="opacity", scaling="scaling", rotation="rotation", f_dc="features_dc", f_rest="features_rest")
+        single_losses, single_P = [], []
+        for it in range(1, steps + 1):
+            m1.update_learning_rate(it)
+            p = t1.params()
             acc, tot = None, 0.0
-            for k in range(world):
-                _, _, g, loss = view_gradient(t1, (step % 2) * world + k)
-                acc = {n: g[n].clone() for n in names} if acc is None else {n: acc[n] + g[n] for n in names}
-                tot += float(loss)
-            for n in names:
-                t1[n].grad = acc[n].view_as(t1[n])
-            opt1.step()
+            for cam in stack.next_views():
+                st, rs, radii, loss3, g = t1.view_gradients(cam, it)
+                acc = {n: g[key[n]].clone() for n in names} if acc is None else {n: acc[n] + g[key[n]] for n in names}
+                tot += float(loss3[0])
+                if it < opt_args.densify_until_iter:
+                    t1._densification_stats(g["means2D"], radii)
+            t1.finish_step(it, p, acc)
             single_losses.append(tot)
+            single_P.append(int(m1._xyz.shape[0]))
         torch.cuda.synchronize()
-        ok = True
-        worst = max(abs(a - b) / abs(b) for a, b in zip(shard_losses, single_losses))
-        ok &= worst < 1e-4 and single_losses[-2] < single_losses[0] and single_losses[-1] < single_losses[1]     # (same views two visits later)
-        rms = {}
-        for n in names:
-            d, ref = (t[n] - t1[n]).double(), (t1[n] - torch.tensor(sc[n], device=dev)).double()     # against the distance travelled
-            rms[n] = float(d.pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-30))
-            ok &= rms[n] < 2e-2
-        digest = torch.stack([t[n].double().sum() for n in names]).cpu()
-        every = [torch.zeros_like(digest) for _ in range(world)]
-        td.all_gather(every, digest)
-        same = all(torch.equal(every[0], e) for e in every)           # the replicas stay bit-identical
-        ok &= same
-        say(f"rank {rank}: loss (sum over {world} views) {single_losses[0]:.5f} -> {single_losses[-2]:.5f} and {single_losses[1]:.5f} -> {single_losses[-1]:.5f}; sharded vs single-process loss curve "
-            f"{worst:.2e}; parameter difference / distance travelled (rms) {max(rms.values()):.2e}; replicas identical: {same}")
+        ok = same
+        first_change = next((i for i in range(steps) if single_P[i] != N), steps)
+        # before the first change of P the two runs see the same rows: loss curves to fp32 summation order; after it a Gaussian
+        # whose accumulated statistic sits on the densification threshold may be split in one run and not in the other
+        worst_pre = max(abs(a - b) / abs(b) for a, b in zip(shard_losses[:first_change + 1], single_losses[:first_change + 1]))
+        worst_post = max([abs(a - b) / abs(b) for a, b in zip(shard_losses[first_change + 1:], single_losses[first_change + 1:])] or [0.0])
+        ok &= worst_pre < 1e-4 and worst_post < 2e-2
+        ok &= first_change < steps and shard_P[-1] != N                       # the densification happened, in both runs
+        ok &= all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(shard_P, single_P))
+        ok &= shard_losses[-1] < shard_losses[0]
+        every = [None] * world
+        td.all_gather_object(every, shard_P)
+        ok &= all(e == every[0] for e in every)                               # every rank went through the same sizes
+        say(f"rank {rank}: loss (sum over {world} views) {shard_losses[0]:.5f} -> {shard_losses[-1]:.5f}; P {N} -> {shard_P[-1]} (single process "
+            f"{single_P[-1]}), first change at iteration {first_change + 1}; sharded vs single-process loss curve {worst_pre:.2e} before it, "
+            f"{worst_post:.2e} after; replicas identical after {steps} steps incl. densify + prune: {same}")
         flag = torch.tensor([1.0 if ok else 0.0])
         td.all_reduce(flag, op=td.ReduceOp.MIN)
         return flag.item() == 1.0, []

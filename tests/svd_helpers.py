@@ -2,7 +2,19 @@
 the small network configuration, seeded weights and seeded inputs. Weights are regenerated from the
 seed on both sides (same state-dict keys and shapes by construction), so fixtures hold only inputs'
 seeds and the reference's outputs."""
+import os
+
 import torch
+
+
+def report(line):
+    """print + append to the file named by MVI_PARITY_REPORT (the GPU runs set it: pytest -q shows no output of passing tests)."""
+    print(line)
+    path = os.environ.get("MVI_PARITY_REPORT")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + " | " + line + "\n")
+
 
 SMALL_UNET = dict(in_channels=8, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[2, 1],
                   channel_mult=[1, 2], num_head_channels=16, transformer_depth=1, context_dim=24, adm_in_channels=12,

@@ -45,10 +45,12 @@ def test_two_ranks_on_one_gpu_exchange_equals_the_plain_sum_of_their_views(rank_
 
 
 def test_two_rank_view_sharded_training_equals_one_process_over_both_views(rank_launcher):
-    """BASELINE configs[4] (per-GPU rasterize + exchange of the Gaussian gradients) at two ranks: six steps of render own view -> L1 + DSSIM
-    gradient -> backward into the exchange's views -> compacted exchange -> Adam on the replicated parameters, against one process
-    that renders both views of every step, sums the gradients and takes the same Adam step: same loss curve, same parameters (to the
-    summation order of the float atomics, measured against the distance the parameters travelled), replicas bit-identical."""
+    """BASELINE configs[4] (per-GPU rasterize + exchange of the Gaussian gradients) at two ranks THROUGH THE SHIPPED MODULE
+    (multiview_inpaint_amd.train_views.ViewShardedTrainer): fourteen iterations of the loop body of inpaint_rec.py:96-163 — own view of
+    the step's two, fused L1 + DSSIM (masked for the non-inpainted views), backward on the stored parameters into the exchange's
+    buffers, bit-mask all-gather + compacted exchange, reduced densification statistics, densify_and_prune twice (identically seeded
+    torch.normal, surgery through patch_gs_simp's hooks), FusedAdam — against one process that renders both views of every step with
+    the same pieces: same loss curve up to the first change of P (1e-4), close after it, same sizes, replicas bit-identical at the end."""
     import dist_gpu_worker as W
     world = 2
     results = _run_ranks(rank_launcher, W.entry_training, world, dict())

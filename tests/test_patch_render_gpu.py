@@ -338,3 +338,66 @@ def test_patched_prune_points_equals_the_boolean_index_form():
     except Exception:
         pass
     assert len(calls) == n + 1
+
+
+def test_patched_densification_equals_the_reference_recipe():
+    """The densify half behind the hook: densify_and_prune of the stand-in model (tests/gs_standin.py: the
+    reference's recipe, gaussian_model.py:384-480 — clone, split with torch.normal, cat_tensors_to_optimizer through
+    densification_postfix, prune) run twice from identical states and identical generator seeds, once as written and once with
+    dropin.patch_gs_simp's cat_tensors_to_optimizer + prune_points on the class: every parameter, both Adam moments and the
+    statistics identical, optimizer.state re-keyed to the new parameters, and training steps on identically. A dict the hook does
+    not serve (a missing group) lands in the reference's method."""
+    from multiview_inpaint_amd import train_ops as T
+    from multiview_inpaint_amd.dropin import patch_gs_simp
+    from raster_helpers import small_scene
+    import gs_standin as GS
+    cam, sc, bg = small_scene(41, N=30_000, W=64, H=64, deg=2, pose=False, log_scale=np.log(0.05))
+    calls = []
+
+    class Ref(GS.StandinGaussianModel):
+        def cat_tensors_to_optimizer(self, d):
+            calls.append("cat")
+            return GS.StandinGaussianModel.cat_tensors_to_optimizer(self, d)
+
+    class Hooked(Ref):
+        cat_tensors_to_optimizer = patch_gs_simp._make_cat_tensors(Ref.cat_tensors_to_optimizer)
+        prune_points = patch_gs_simp._make_prune_points(GS.StandinGaussianModel.prune_points)
+
+    def prepared(cls):
+        m = cls(sc, 2, optimizer_cls=T.FusedAdam)
+        g = torch.Generator("cuda").manual_seed(4)
+        for p in m.params().values():                                # non-trivial moments
+            p.grad = torch.randn(p.shape, device="cuda", generator=g)
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+        P = m._xyz.shape[0]
+        m.xyz_gradient_accum = torch.rand(P, 1, device="cuda", generator=g) * 6e-4      # about a third above the threshold
+        m.denom = torch.ones(P, 1, device="cuda")
+        m.max_radii2D = torch.rand(P, device="cuda", generator=g) * 30
+        return m
+    a, b = prepared(Ref), prepared(Hooked)
+    for m in (a, b):
+        torch.manual_seed(9)
+        torch.cuda.manual_seed(9)
+        m.densify_and_prune(0.0002, 0.005, 6.0, 20)
+    assert calls.count("cat") == 2, calls                          # clone + split of the reference run only: the hook served its own
+    P2 = a._xyz.shape[0]
+    assert P2 != 30_000 and b._xyz.shape[0] == P2
+    for attr in GS.StandinGaussianModel.ATTRS + ("xyz_gradient_accum", "denom", "max_radii2D"):
+        assert torch.equal(getattr(a, attr), getattr(b, attr)), attr
+    for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert isinstance(pb, torch.nn.Parameter) and pb.requires_grad and pb is getattr(b, GS.StandinGaussianModel.ATTRS[GS.StandinGaussianModel.NAMES.index(gb["name"])])
+        sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
+    for m in (a, b):
+        for p in m.params().values():
+            p.grad = torch.ones_like(p)
+        m.optimizer.step()
+    assert torch.equal(a._xyz, b._xyz) and torch.equal(a._features_rest, b._features_rest) and torch.equal(a._opacity, b._opacity)
+    n = len(calls)
+    try:
+        Hooked.cat_tensors_to_optimizer(b, {"xyz": b._xyz[:2].detach()})          # not the six groups: the reference's method (which raises its own way)
+    except Exception:
+        pass
+    assert len(calls) == n + 1

@@ -819,7 +819,7 @@ def test_softmax_scale_folded_into_the_q_weights(ops, dtype):
         else:
             want = ref(x)
             e_f, e_p = rel(res[S, True][0], want), rel(res[S, False][0], want)
-            print(f"{dtype} S={S}: error of the module vs fp64: q weights carrying the scale {e_f:.2e}, plain {e_p:.2e} ({e_f / e_p:.2f} x)")
+            H.report(f"{dtype} S={S}: error of the module vs fp64: q weights carrying the scale {e_f:.2e}, plain {e_p:.2e} ({e_f / e_p:.2f} x)")
             assert e_f <= 1.15 * e_p, (e_f, e_p)
 
 
@@ -915,7 +915,7 @@ def test_hd64_nets_in_bf16_run_the_mfma_kernel_within_the_reference_autocast_bud
         r_max, r_rms = _err(torch.tensor(G64[name + "_bf16ac"]), ref)
         worst = max(worst, e_max / r_max, e_rms / r_rms)
         assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
-    print(f"bf16 HIP path vs reference fp32: worst error ratio to the reference's own bf16-autocast error = {worst:.2f}")
+    H.report(f"bf16 HIP path vs reference fp32: worst error ratio to the reference's own bf16-autocast error = {worst:.2f}")
 
 
 @pytest.mark.parametrize("dtype,tag", [(torch.bfloat16, "bf16ac"), (torch.float16, "f16ac")])
@@ -968,7 +968,7 @@ def test_hd64_nets_on_a_32x32_latent_run_the_8_wave_kernel_within_the_reference_
         r_max, r_rms = _err(torch.tensor(G64[name + "_" + tag]), ref)
         worst = max(worst, e_max / r_max, e_rms / r_rms)
         assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
-    print(f"{dtype}: 8-wave kernel x{len(eight)}, 4-wave x{len(four)}; worst error ratio to the reference's own autocast "
+    H.report(f"{dtype}: 8-wave kernel x{len(eight)}, 4-wave x{len(four)}; worst error ratio to the reference's own autocast "
           f"error = {worst:.2f}")
 
 
@@ -1044,7 +1044,7 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
         r_max, r_rms = _err(torch.tensor(G[name + "_" + tag]), ref)
         worst = max(worst, e_max / r_max, e_rms / r_rms)
         assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
-    print(f"{dtype}: {n_vrb} token-major VideoResBlocks, {count('conv3x3_n320')} 3x3 + {count('conv3t_n320')} frame convolutions in the "
+    H.report(f"{dtype}: {n_vrb} token-major VideoResBlocks, {count('conv3x3_n320')} 3x3 + {count('conv3t_n320')} frame convolutions in the "
           f"implicit-GEMM kernel; worst error ratio to the reference's own autocast error = {worst:.2f}")
 
 
@@ -1107,7 +1107,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
         r_max, r_rms = (float(v) for v in G[budget + name])          # the reference's own autocast error in this type against the same fp32 tensor
         worst = max(worst, e_max / r_max, e_rms / r_rms)
         assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
-    print(f"full-size step in {dt} vs the reference: worst error ratio to the reference's own autocast error in that type = {worst:.2f}")
+    H.report(f"full-size step in {dt} vs the reference: worst error ratio to the reference's own autocast error in that type = {worst:.2f}")
 
 
 @pytest.mark.parametrize("dt,budget", [(torch.bfloat16, "budget_"), (torch.float16, "budget_f16_")])
@@ -1155,7 +1155,7 @@ def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, bu
     assert xs.dtype == torch.float32 and torch.isfinite(xs).all()
     e_max, e_rms = _err(xs[:, :, ::2, ::2], G["sample_final_f32"])
     r_max, r_rms = (float(v) for v in G[budget + "sample_final"])
-    print(f"two sampling steps at full size in {dt}: error (max, rms) = ({e_max:.2e}, {e_rms:.2e}), the reference's own autocast loop ({r_max:.2e}, {r_rms:.2e})")
+    H.report(f"two sampling steps at full size in {dt}: error (max, rms) = ({e_max:.2e}, {e_rms:.2e}), the reference's own autocast loop ({r_max:.2e}, {r_rms:.2e})")
     assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (e_max, r_max, e_rms, r_rms)
 
 
