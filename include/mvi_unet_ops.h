@@ -273,6 +273,45 @@ int mvi_attention_forward_strided(const void* q, const void* k, const void* v, v
 int mvi_attention_temporal_strided(const void* q, const void* k, const void* v, void* out, int32_t Bo, int32_t T,
                                    int32_t S, int32_t H, int32_t D, float scale, int32_t dtype,
                                    int64_t qkv_token_stride, int64_t out_token_stride, void* stream);
+/* Order of the contraction index of mvi_conv3x3_n320's weight: 1 (default) = [C_out][C_in / 64][9 taps][64 channels] — the nine
+ * taps of a 64-channel chunk are consecutive, so a block's re-reads of its activation rows hit the XCD's L2 —, 0 = [C_out][9][C_in]
+ * (tap-major, rounds 3 - 4; MVI_CONV_K_ORDER=0). set = 0 / 1 selects, anything else only queries; returns the order in force. The
+ * weight handed to mvi_conv3x3_n320* must be packed in that order. */
+int mvi_conv3x3_n320_k_order(int32_t set);
+
+/* mvi_ff_geglu for a LONG contraction (round 5): the GEGLU projection of the level-1 / level-2 FeedForward layers of the 576 x 1024
+ * step ([64512, 640] x [640, 2 * 2560], [16128, 1280] x [1280, 2 * 5120]; sgm/modules/attention.py:87-95), in csrc/linear_n320.hip's
+ * frame: a block's 320 accumulator columns are 160 value columns and the gate columns of the same 160 outputs, gated in registers
+ * (exact-erf GELU as mvi_ff_geglu). K a multiple of 64 (>= 128), inner a multiple of 160, bf16 / f16; out as mvi_ff_geglu's
+ * (room for mvi_ff_geglu_out_rows(rows) rows), rows 16-byte aligned. */
+int mvi_ff_geglu_n320_supported(int32_t K, int32_t inner, int32_t dtype);
+int mvi_ff_geglu_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
+                      int32_t K, int32_t inner, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
+
+/* GroupNorm statistics from the PRODUCER of the normalised tensor (round 5). The ResBlock's second norm and its temporal twin read
+ * what a convolution of this library has just written (openaimodel.py:292-305, :339-343; video_model.py:41-54):
+ * mvi_conv3x3_n320_gnstats / mvi_conv3t_n320_gnstats are mvi_conv3x3_n320 (stride 1) / mvi_conv3t_n320 whose blocks also leave, in
+ * gn_part [samples * (spatial / 256) * gn_groups][3], (count, mean, M2) of every GroupNorm group of their 256 rows — of the ROUNDED
+ * outputs plus gn_chan_bias [samples, C_out] (the timestep-embedding bias the norm adds first; NULL: none) — and
+ * mvi_groupnorm_silu_tok2tok_pre is mvi_groupnorm_silu_tok2tok_frames without its statistics pass, merging those partials
+ * (chunks_per_sample = spatial / 256): the tensor is read once instead of twice. A sample is an image (3x3) or a frame (3-tap:
+ * spatial = pixels of a frame); `frames` > 1 merges the frames of a video as in the _frames form. Only shapes for which
+ * mvi_conv_n320_gnstats_supported answers 1 (stride 1, no K split, spatial a multiple of 256, groups of <= 40 channels that tile 320);
+ * bf16 / f16. gn_part: mvi_conv_n320_gnstats_bytes(samples, spatial, groups); workspace of _pre: N * C * 2 floats. */
+int mvi_conv_n320_gnstats_supported(int64_t rows, int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t spatial,
+                                    int32_t groups);
+size_t mvi_conv_n320_gnstats_bytes(int64_t samples, int64_t spatial, int32_t groups);
+int mvi_conv3x3_n320_gnstats(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
+                             int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                             const float* gn_chan_bias, int32_t gn_groups, float* gn_part, size_t gn_part_bytes, void* stream);
+int mvi_conv3t_n320_gnstats(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels,
+                            int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                            const float* gn_chan_bias, int32_t gn_groups, float* gn_part, size_t gn_part_bytes, void* stream);
+int mvi_groupnorm_silu_tok2tok_pre(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                   int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps,
+                                   int32_t fuse_silu, int32_t dtype, const float* part, int32_t chunks_per_sample,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* The two strided forms for a q that ALREADY carries D^-1/2 * log2(e): P = exp2(q' . k - m), no scale argument. The caller folds
  * that constant into the WEIGHTS of the q projection in fp32, before their one rounding to bf16 / f16 (svd/transformer.py,
  * CrossAttention._packed_qkv_weight): q' = round(x . round(c W_q)^T) carries the same single output rounding as the reference's

@@ -225,6 +225,21 @@ static int gt_launch(const void* x, void* y, const float* w, const float* b, con
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
+// merge + apply with the statistics ALREADY in `part` [N * chunks_per_sample * G][3] — left there by the producer of x (the
+// implicit-GEMM convolution's epilogue, csrc/linear_n320.hip kStats): x is read once, y written once
+template <typename T>
+static int gt_launch_pre(const void* x, void* y, const float* w, const float* b, const float* cb, int64_t N, int C, int64_t S, int G, float eps,
+                         int silu, const float* part, int chunks_per_sample, float* ws, hipStream_t st, int frames) {
+    constexpr int V = Io<T>::kVec;
+    const int vpr = C / V, rp = gt_rows_per_pass(vpr);
+    const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
+    float* ss = ws;                                               // [N, C, 2]
+    const dim3 grid((unsigned)chunks, (unsigned)N), block((unsigned)(vpr * rp));
+    hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)N), dim3(kGtMergeThreads), 0, st, part, w, b, cb, ss, C, G, chunks_per_sample, eps, frames);
+    hipLaunchKernelGGL((gt_apply_kernel<T>), grid, block, 0, st, (const T*)x, (T*)y, ss, C, S, vpr, rp, silu);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
 }  // namespace mvi
 
 static int gt_geometry_ok(int64_t N, int32_t C, int64_t S, int32_t G, int32_t dtype) {
@@ -264,6 +279,24 @@ static int tok2tok_impl(const void* x, void* y, const float* weight, const float
         default: return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok: unknown dtype");
     }
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok: kernel launch failed") : MVI_OK;
+}
+
+extern "C" int mvi_groupnorm_silu_tok2tok_pre(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,
+                                              int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps,
+                                              int32_t fuse_silu, int32_t dtype, const float* part, int32_t chunks_per_sample,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!gt_geometry_ok(N, C, spatial, groups, dtype) || dtype == MVI_DT_F32)
+        return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_pre: bf16 / f16, C a multiple of groups (<= 64) and of the 16-byte vector width");
+    if (frames < 1 || N % frames || chunks_per_sample < 1) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_pre: bad frames / chunks");
+    if (!x || !y || !weight || !bias || !part || !workspace) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_pre: NULL pointer");
+    if (((uintptr_t)x | (uintptr_t)y) % 16) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_pre: x / y must be 16-byte aligned");
+    if (workspace_bytes < (size_t)N * C * 2 * sizeof(float)) return mvi::unet_fail(MVI_ENOMEM, "groupnorm_tok2tok_pre: workspace too small (N C 2 floats)");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::gt_launch_pre<__hip_bfloat16>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, part, chunks_per_sample, (float*)workspace, st, frames)
+                       : mvi::gt_launch_pre<__half>(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, part, chunks_per_sample, (float*)workspace, st, frames);
+    return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok_pre: kernel launch failed") : MVI_OK;
 }
 
 extern "C" int mvi_groupnorm_silu_tok2tok(const void* x, void* y, const float* weight, const float* bias, const float* chan_bias,

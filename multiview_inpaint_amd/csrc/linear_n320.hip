@@ -71,6 +71,8 @@ template <> struct Mma<__hip_bfloat16> {
         bf16x2 r = __builtin_convertvector(f, bf16x2);
         return *reinterpret_cast<uint32_t*>(&r);
     }
+    __device__ static float lo(uint32_t w) { return __uint_as_float(w << 16); }
+    __device__ static float hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 };
 template <> struct Mma<__half> {
     using frag = f16x8;
@@ -80,6 +82,8 @@ template <> struct Mma<__half> {
         f16x2 r = __builtin_convertvector(f, f16x2);
         return *reinterpret_cast<uint32_t*>(&r);
     }
+    __device__ static float lo(uint32_t w) { f16x2 h = *reinterpret_cast<f16x2*>(&w); return (float)h[0]; }
+    __device__ static float hi(uint32_t w) { f16x2 h = *reinterpret_cast<f16x2*>(&w); return (float)h[1]; }
 };
 template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
@@ -106,12 +110,45 @@ __device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) 
 struct ConvGeom {
     int H, W, cpc, taps, groups, ksplit;             // INPUT image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
     int stride, Ho, Wo;                              // 1 or 2 (3x3 only); output height / width (= H, W at stride 1)
+    int cc_major;                                    // K ordered (channel chunk, tap, 64 channels) instead of (tap, channel): see conv_k_order
 };
 
-template <typename T, bool kConv, bool kSplit = false>
+// kStats: the GroupNorm that FOLLOWS this convolution gets its statistics from here (ResBlock out_layers[0] behind in_layers[2],
+// openaimodel.py:292-305, :339-343; the temporal twin, video_model.py:41-54): every block leaves, per GroupNorm group inside its 320
+// output channels, (count, mean, M2) of its 256 rows x C_g channels of the ROUNDED outputs (what the norm will read) + the norm's
+// per-(sample, channel) bias (the timestep embedding rides inside the norm), in the layout gt_merge_kernel of
+// csrc/groupnorm_tokens.hip takes: part[(sample * chunks + chunk) * G + group][3], chunk = the block's place among the S / 256 blocks
+// of its sample (the host only takes this form when S % 256 == 0). The separate statistics pass over the tensor disappears.
+struct GnStats {
+    float* part;                                     // [samples * (S / 256) * G][3]; NULL: no statistics
+    const float* chan_bias;                          // [samples, C_out] or NULL
+    int G, S;                                        // GroupNorm groups over all C_out channels; rows (pixels) per sample
+};
+
+// kGeglu (round 5): the GEGLU projection of the level-1 / level-2 FeedForward layers (K = 640 / 1280; attention.py:87-95,
+// `x, gate = self.proj(x).chunk(2, dim=-1); x * F.gelu(gate)`) in this kernel's frame: a block's 320 accumulator columns are 160
+// value columns and the 160 gate columns of the SAME outputs (W rows 160 g .. and inner + 160 g ..: five column tiles each, value
+// tile t and gate tile t + 5 meet in the same lane and register), the epilogue gates in registers and stores 160 outputs per row.
+// The [rows, 2 inner] intermediate the library GEMM writes and geglu_kernel reads back (1 GB per call at level 1) never exists.
+// cg.groups = inner / 160 column groups; W is [2 inner][K], bias [2 inner] or NULL.
+// v * gelu(g), exact-erf GELU by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): the arithmetic of csrc/ff_geglu.hip's geglu1
+__device__ __forceinline__ float geglu1(float v, float g) {
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(g), 0.3275911f * 0.70710678118654752f, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(g * g * (-0.5f * 1.4426950408889634f));
+    const float erf_abs = __builtin_fmaf(-p, e, 1.0f);
+    const float hg = 0.5f * g;
+    return v * __builtin_fmaf(__builtin_fabsf(hg), erf_abs, hg);
+}
+
+template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part) {
+                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part, GnStats gn) {
     using M = Mma<T>;
     using frag = typename M::frag;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -124,6 +161,14 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     int bid = blockIdx.x;
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
     int part_col0 = 0, ks = 0;
+    int gg = 0;                                      // kGeglu: the block's column group (160 outputs)
+    constexpr int kHalf = kN / 2;                    // 160
+    const int inner = kGeglu ? cg.groups * kHalf : 0;
+    if (kGeglu) {
+        gg = bid % cg.groups;
+        bid /= cg.groups;
+        out += gg * kHalf;
+    }
     if (kConv && cg.groups > 1) {                    // (row block, column group): the groups of one row block run side by side
         const int g = bid % cg.groups;
         bid /= cg.groups;
@@ -146,7 +191,8 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     f32x16 acc[kNT];
 #pragma unroll
     for (int j = 0; j < kNT; ++j) {
-        const float b = bias && !kSplit ? bias[32 * j + col] : 0.f;      // (kSplit: the reduction adds it)
+        const float b = bias && !kSplit ? (kGeglu ? bias[(j < kNT / 2 ? 0 : inner - kHalf) + gg * kHalf + 32 * j + col] : bias[32 * j + col])
+                                        : 0.f;                           // (kSplit: the reduction adds it)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = b;
     }
@@ -175,7 +221,8 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             if (py == cg.H - 1) tap_ok &= ~0x4u;
         }
     }
-    int ld_tap = kConv ? c0 / cg.cpc : 0, ld_cc = kConv ? c0 - ld_tap * cg.cpc : 0;   // kConv: (tap, channel chunk) of the next load_x call — they come in chunk order
+    // kConv: (tap, channel chunk) of the next load_x call — they come in chunk order: chunk c = tap * cpc + cc, or cc * taps + tap (cc_major)
+    int ld_tap = kConv ? (cg.cc_major ? c0 % cg.taps : c0 / cg.cpc) : 0, ld_cc = kConv ? (cg.cc_major ? c0 / cg.taps : c0 - ld_tap * cg.cpc) : 0;
     // returns the lane's keep mask for the fragment (all ones unless kConv and the tap is outside the image)
     auto load_x = [&](int c, u32x4 (&xr)[4]) __attribute__((always_inline)) -> uint32_t {
         if (!kConv) {
@@ -184,15 +231,18 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, x_voff);
             return ~0u;
         }
-        const int dy = cg.taps == 9 ? ld_tap / 3 - 1 : ld_tap - 1, dx = cg.taps == 9 ? ld_tap - 3 * (ld_tap / 3) - 1 : 0;
+        // (both counters are wave-uniform by construction; said explicitly: the base below is a scalar operand of the loads)
+        const int tap_u = __builtin_amdgcn_readfirstlane(ld_tap), cc_u = __builtin_amdgcn_readfirstlane(ld_cc);
+        const int dy = cg.taps == 9 ? tap_u / 3 - 1 : tap_u - 1, dx = cg.taps == 9 ? tap_u - 3 * (tap_u / 3) - 1 : 0;
         const int delta = (dy * cg.W + dx) * (int)(x_rs * 2);
-        const bool ok = (tap_ok >> ld_tap) & 1u;
+        const bool ok = (tap_ok >> tap_u) & 1u;
         const uint32_t voff = ok ? x_voff + (uint32_t)delta : x_voff;
-        const char* const base = xbase + ld_cc * (kKC * 2);
+        const char* const base = xbase + cc_u * (kKC * 2);
 #pragma unroll
         for (int s = 0; s < 4; ++s) xr[s] = load16_async(base + 32 * s, voff);
         if (c + 1 < n_chunks) {                      // (the calls past the end repeat the last chunk)
-            if (++ld_cc == cg.cpc) { ld_cc = 0; ++ld_tap; }
+            if (cg.cc_major) { if (++ld_tap == cg.taps) { ld_tap = 0; ++ld_cc; } }
+            else if (++ld_cc == cg.cpc) { ld_cc = 0; ++ld_tap; }
         }
         return ok ? ~0u : 0u;
     };
@@ -206,7 +256,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     for (int i = 0; i < kPiecesPerLoader; ++i) {
         const uint32_t pc = (uint32_t)(wave + i * kLoaders);         // (meaningless for a wave that loads nothing)
         const uint32_t r = 8u * pc + (uint32_t)(lane >> 3), slot = (uint32_t)(lane & 7);
-        p_voff[i] = r * w_row_bytes + 16u * (slot ^ ((r >> 1) & 7u));
+        // kGeglu: rows 0 .. 159 of the chunk image are W rows 160 g + r (values), rows 160 .. 319 W rows inner + 160 g + (r - 160) (gates)
+        const uint32_t wr = kGeglu ? (r < (uint32_t)kHalf ? (uint32_t)(gg * kHalf) + r : (uint32_t)(inner + gg * kHalf) + (r - (uint32_t)kHalf)) : r;
+        p_voff[i] = wr * w_row_bytes + 16u * (slot ^ ((r >> 1) & 7u));
     }
     const char* const wbase = reinterpret_cast<const char*>(w) + (int64_t)c0 * (kKC * 2);
     auto issue_chunk = [&](int c) __attribute__((always_inline)) {
@@ -309,6 +361,40 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             for (int i = 0; i < 16; ++i) pbase[((i & 3) + 8 * (i >> 2)) * c_tot + 32 * j] = acc[j][i];
         return;
     }
+    if (kGeglu) {
+        // value tile t (columns 32 t ..) and gate tile t + 5 sit in the same lane and register: gate in place, then the five tiles
+        // leave like the plain form's — two tiles (one 128-byte run per row) per flush, the fifth alone (64 bytes per row)
+        char* const gbase = reinterpret_cast<char*>(out + row0 * o_rs);
+        const int64_t grow_bytes = o_rs * 2;
+        const uint32_t gtile = (uint32_t)(kRing * kChunkBytes + wave * 4096);
+        const uint32_t gt_w = gtile + (uint32_t)(4 * hh * 128 + col * 2);
+        const uint32_t gt_r = gtile + (uint32_t)((lane >> 3) * 128 + (lane & 7) * 16);
+        const int64_t gst_off = (int64_t)(lane >> 3) * grow_bytes + (lane & 7) * 16;
+#pragma unroll
+        for (int t0 = 0; t0 < kNT / 2; t0 += 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t0 + t < kNT / 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const uint32_t pk = M::pack2(geglu1(acc[t0 + t][r], acc[t0 + t + kNT / 2][r]),
+                                                     geglu1(acc[t0 + t][r + 1], acc[t0 + t + kNT / 2][r + 1]));
+                        const int m = (r & 3) + 8 * (r >> 2);
+                        *reinterpret_cast<MVI_AS3 uint16_t*>(lds + gt_w + 64 * t + m * 128) = (uint16_t)(pk & 0xFFFFu);
+                        *reinterpret_cast<MVI_AS3 uint16_t*>(lds + gt_w + 64 * t + (m + 1) * 128) = (uint16_t)(pk >> 16);
+                    }
+                }
+            }
+            char* const op = gbase + (t0 / 2) * 128;
+            const bool one = t0 + 1 >= kNT / 2;                   // the last flush holds one tile: lanes of the upper 64 bytes have nothing
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = *reinterpret_cast<MVI_AS3 const u32x4*>(lds + gt_r + 1024 * i);
+                if (!one || (lane & 7) < 4) *reinterpret_cast<u32x4*>(op + (8 * i) * grow_bytes + gst_off) = v;
+            }
+        }
+        return;
+    }
     // ---- outputs: two column tiles at a time through the wave's LDS tile [32 rows][64 columns], then four 16-byte stores per lane
     char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
     const int64_t orow_bytes = o_rs * 2;
@@ -316,6 +402,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     const uint32_t ot_w = otile + (uint32_t)(4 * hh * 128 + col * 2);              // + 128 * row of the register (+ 64 for the second tile)
     const uint32_t ot_r = otile + (uint32_t)((lane >> 3) * 128 + (lane & 7) * 16);  // + 1024 i: rows 8 i + lane / 8
     const int64_t st_off = (int64_t)(lane >> 3) * orow_bytes + (lane & 7) * 16;
+    float cs1[kStats ? kNT : 1], cs2[kStats ? kNT : 1];          // kStats: per column tile, sum and sum of squares of this lane's 16 rows
+#pragma unroll
+    for (int j = 0; j < (kStats ? kNT : 1); ++j) cs1[j] = cs2[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < kNT; j += 2) {
 #pragma unroll
@@ -323,6 +412,11 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const uint32_t pk = M::pack2(acc[j + t][r], acc[j + t][r + 1]);
+                if (kStats) {                                    // of the values as stored (the norm reads the rounded tensor)
+                    const float a = M::lo(pk), b = M::hi(pk);
+                    cs1[j + t] += a + b;
+                    cs2[j + t] = __builtin_fmaf(a, a, __builtin_fmaf(b, b, cs2[j + t]));
+                }
                 const int m = (r & 3) + 8 * (r >> 2);
                 *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + 64 * t + m * 128) = (uint16_t)(pk & 0xFFFFu);
                 *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + 64 * t + (m + 1) * 128) = (uint16_t)(pk >> 16);
@@ -333,6 +427,51 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         for (int i = 0; i < 4; ++i) {
             const u32x4 v = *reinterpret_cast<MVI_AS3 const u32x4*>(lds + ot_r + 1024 * i);
             *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
+        }
+    }
+    if (kStats && gn.part) {
+        // wave partials -> the wave's own 4 KiB output tile (its flush reads are issued: LDS operations of one wave execute in order):
+        // [320 channels][2] floats = 2560 bytes; the two lane halves hold different rows of a column
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            cs1[j] += __shfl_xor(cs1[j], 32);
+            cs2[j] += __shfl_xor(cs2[j], 32);
+        }
+        MVI_AS3 float* const wp = (MVI_AS3 float*)(lds + otile);
+        if (hh == 0) {
+#pragma unroll
+            for (int j = 0; j < kNT; ++j) { wp[2 * (32 * j + col)] = cs1[j]; wp[2 * (32 * j + col) + 1] = cs2[j]; }
+        }
+        __syncthreads();
+        // channel totals over the block's 256 rows -> the spare 1536 bytes behind the partials of tile (channel / 40)
+        MVI_AS3 float* const tiles = (MVI_AS3 float*)(lds + kRing * kChunkBytes);
+        if (tid < kN) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < kWaves; ++wv) { a += tiles[wv * 1024 + 2 * tid]; b += tiles[wv * 1024 + 2 * tid + 1]; }
+            MVI_AS3 float* const tot = tiles + (tid / 40) * 1024 + 640 + 2 * (tid % 40);
+            tot[0] = a; tot[1] = b;
+        }
+        __syncthreads();
+        const int c_tot = cg.groups * kN, Cg = c_tot / gn.G, n_g = kN / Cg;      // groups inside this block's 320 channels
+        if (tid < n_g) {
+            const int64_t r0 = (int64_t)bid * kRows;                              // the block's first row: all 256 belong to one sample
+            const int64_t n = r0 / gn.S;
+            const int chunk = (int)((r0 - n * gn.S) / kRows), chunks = gn.S / kRows;
+            const float* cb = gn.chan_bias ? gn.chan_bias + n * c_tot + part_col0 : nullptr;
+            const float rws = (float)kRows;
+            float tot = 0.f;
+            for (int c = tid * Cg; c < (tid + 1) * Cg; ++c)
+                tot += tiles[(c / 40) * 1024 + 640 + 2 * (c % 40)] + rws * (cb ? cb[c] : 0.f);
+            const float mean = tot / (rws * Cg);
+            float m2 = 0.f;
+            for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) {
+                const float s1 = tiles[(c / 40) * 1024 + 640 + 2 * (c % 40)], s2 = tiles[(c / 40) * 1024 + 640 + 2 * (c % 40) + 1];
+                const float d = mean - (cb ? cb[c] : 0.f);                       // the group mean seen from this channel's own offset
+                m2 += s2 - 2.f * d * s1 + rws * d * d;
+            }
+            float* p = gn.part + ((n * chunks + chunk) * gn.G + part_col0 / Cg + tid) * 3;
+            p[0] = rws * Cg; p[1] = mean; p[2] = m2 > 0.f ? m2 : 0.f;
         }
     }
 }
@@ -362,23 +501,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace ln3
 
-template <typename T, bool kConv = false, bool kSplit = false>
+template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
-                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0}, float* part = nullptr) {
+                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0}, float* part = nullptr,
+                              ln3::GnStats gn = {nullptr, nullptr, 0, 0}) {
     using namespace ln3;
     const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups * cg.ksplit;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T, kConv, kSplit>;
+    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu>;
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
-                       o_rs, (int)n_blocks, cg, part);
+                       o_rs, (int)n_blocks, cg, part, gn);
     if (kSplit) {
         const int c_tot = cg.groups * kN;
         const int64_t threads = rows * (c_tot / 8), rows_pad = (rows + kRows - 1) / kRows * kRows;
@@ -414,6 +554,32 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
     return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
 }
 
+// GEGLU projection with a long contraction (the level-1 / level-2 FeedForward layers): see kGeglu at the kernel
+extern "C" int mvi_ff_geglu_n320_supported(int32_t K, int32_t inner, int32_t dtype) {
+    return K >= 2 * mvi::ln3::kKC && K % mvi::ln3::kKC == 0 && inner > 0 && inner % (mvi::ln3::kN / 2) == 0 &&
+           (int64_t)2 * inner * K * 2 <= 0xFFFFFFFFll && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+extern "C" int mvi_ff_geglu_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
+                                 int32_t K, int32_t inner, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream) {
+    if (rows < 0 || !mvi_ff_geglu_n320_supported(K, inner, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: needs K a multiple of 64 (>= 128), inner a multiple of 160, bf16 or f16");
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: NULL pointer");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: out needs room for mvi_ff_geglu_out_rows(rows) rows (whole 256-row blocks are stored)");
+    if (x_row_stride < K || out_row_stride < inner || x_row_stride % 8 || out_row_stride % 8 ||
+        ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
+        return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: x, weight and out rows must be 16-byte aligned");
+    if (256 * x_row_stride * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: row block exceeds 32-bit byte offsets");
+    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, inner / (mvi::ln3::kN / 2), 1, 1, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
+                       : mvi::linear_n320_launch<__half, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
+    return rc ? mvi::unet_fail(rc, "ff_geglu_n320: kernel launch failed") : MVI_OK;
+}
+
 // Convolutions of token-major activations with C_out a multiple of 320 (all four levels of both networks):
 //   * 3x3 / stride 1 / padding 1 (ResBlock in_layers[2] / out_layers[3], svd_inpaint1/sgm/modules/diffusionmodules/openaimodel.py:256-275,
 //     :301-318; Upsample.conv :118-134): x [N, H, W, C_in], weight [C_out][9 C_in] = conv.weight.permute(0, 2, 3, 1) flattened;
@@ -423,6 +589,19 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
 extern "C" int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t dtype) {
     return C_out > 0 && C_out % mvi::ln3::kN == 0 && C_in >= mvi::ln3::kKC && C_in % mvi::ln3::kKC == 0 &&
            (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+}
+
+// Order of the 3x3 convolution's contraction (round 5). 0: (tap, channel) — weight [C_out][9][C_in], the form of rounds 3 - 4.
+// 1 (default): (64-channel chunk, tap, channel) — weight [C_out][C_in / 64][9][64]: the nine taps of one channel chunk follow each
+// other, and they read the SAME 128-byte slices of the block's four image rows shifted by a pixel or a row — 64 KB per block and
+// chunk, which stays in the XCD's L2 — where the tap-major order came back to a pixel after 10 - 40 chunks of other data and found it
+// evicted: the counters showed the 330 MB activation of a level-0 convolution fetched nine times (3.06 GB per launch at
+// 28 x 72x128, 640 -> 320: profiles/r5d_pmc_svd_traffic.txt). The caller packs the weight in the same order
+// (svd/hip_ops.py conv3x3_n320_weight reads mvi_conv3x3_n320_k_order()); the (3,1,1) form keeps (tap, channel).
+static int g_conv_k_order = [] { const char* e = getenv("MVI_CONV_K_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int mvi_conv3x3_n320_k_order(int32_t set) {
+    if (set == 0 || set == 1) g_conv_k_order = set;
+    return g_conv_k_order;
 }
 
 // K split of a convolution launch: 1 (none) when the (row block, column group) grid already covers half the chip; otherwise enough
@@ -444,9 +623,19 @@ static size_t conv_workspace_bytes(int64_t rows, int32_t taps, int32_t C_in, int
     return ks == 1 ? 0 : (size_t)ks * (size_t)mvi_ff_geglu_out_rows(rows) * (size_t)C_out * sizeof(float);
 }
 
+// Can a convolution launch of this shape leave the statistics of the GroupNorm behind it (kStats)? Unsplit launches whose 256-row
+// blocks never straddle two samples, GroupNorm groups that tile the 320 channels of a block.
+static int conv_gnstats_ok(int64_t rows, int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t spatial, int32_t groups) {
+    if (stride != 1 || spatial <= 0 || spatial % mvi::ln3::kRows || rows % spatial || groups <= 0 || C_out % groups) return 0;
+    const int Cg = C_out / groups;
+    if (Cg > 40 || mvi::ln3::kN % Cg) return 0;                   // (the block's per-channel totals sit 40 to an LDS tile)
+    return conv_ksplit(rows, taps, C_in, C_out) == 1;
+}
+
 static int conv_taps_n320(const char* what, const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
                           int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride,
-                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream,
+                          mvi::ln3::GnStats gn = {nullptr, nullptr, 0, 0}) {
     char msg[160];
     auto fail = [&](const char* m) {
         snprintf(msg, sizeof msg, "%s: %s", what, m);
@@ -468,9 +657,13 @@ static int conv_taps_n320(const char* what, const void* x, const void* weight, c
     // the K split is taken when the caller brought its workspace (mvi_conv3x3_n320_workspace_bytes); without one the launch is unsplit
     int ks = conv_ksplit(rows, taps, C_in, C_out);
     if (ks > 1 && (!workspace || workspace_bytes < conv_workspace_bytes(rows, taps, C_in, C_out) || (uintptr_t)workspace % 16)) ks = 1;
-    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo};
+    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo, taps == 9 ? g_conv_k_order : 0};
     int rc;
-    if (ks > 1)
+    if (gn.part) {
+        if (!conv_gnstats_ok(rows, taps, stride, C_in, C_out, gn.S, gn.G)) return fail("this shape cannot leave GroupNorm statistics (mvi_conv_n320_gnstats_supported)");
+        rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16, true, false, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg, nullptr, gn)
+                                  : mvi::linear_n320_launch<__half, true, false, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg, nullptr, gn);
+    } else if (ks > 1)
         rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16, true, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st,
                                                                                         cg, (float*)workspace)
                                   : mvi::linear_n320_launch<__half, true, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg,
@@ -499,6 +692,34 @@ extern "C" int mvi_conv3x3_n320(const void* x, const void* weight, const float* 
                                 void* workspace, size_t workspace_bytes, void* stream) {
     return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, stride, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvi_conv_n320_gnstats_supported(int64_t rows, int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t spatial,
+                                               int32_t groups) {
+    return (taps == 9 || taps == 3) && C_out > 0 && C_out % mvi::ln3::kN == 0 && C_in >= mvi::ln3::kKC && C_in % mvi::ln3::kKC == 0
+           ? conv_gnstats_ok(rows, taps, stride, C_in, C_out, spatial, groups) : 0;
+}
+
+extern "C" size_t mvi_conv_n320_gnstats_bytes(int64_t samples, int64_t spatial, int32_t groups) {
+    return samples <= 0 || spatial <= 0 || groups <= 0 ? 0 : (size_t)samples * (size_t)(spatial / mvi::ln3::kRows) * (size_t)groups * 3 * sizeof(float);
+}
+
+extern "C" int mvi_conv3x3_n320_gnstats(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
+                                        int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                                        const float* gn_chan_bias, int32_t gn_groups, float* gn_part, size_t gn_part_bytes, void* stream) {
+    if (!gn_part || gn_part_bytes < mvi_conv_n320_gnstats_bytes(N, (int64_t)H * W, gn_groups))
+        return mvi::unet_fail(MVI_EINVAL, "conv3x3_n320_gnstats: statistics buffer missing or too small (mvi_conv_n320_gnstats_bytes)");
+    return conv_taps_n320("conv3x3_n320_gnstats", x, weight, bias, out, N, H, W, 9, 1, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
+                          nullptr, 0, stream, mvi::ln3::GnStats{gn_part, gn_chan_bias, gn_groups, H * W});
+}
+
+extern "C" int mvi_conv3t_n320_gnstats(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels,
+                                       int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                                       const float* gn_chan_bias, int32_t gn_groups, float* gn_part, size_t gn_part_bytes, void* stream) {
+    if (!gn_part || gn_part_bytes < mvi_conv_n320_gnstats_bytes(B * T, pixels, gn_groups))
+        return mvi::unet_fail(MVI_EINVAL, "conv3t_n320_gnstats: statistics buffer missing or too small (mvi_conv_n320_gnstats_bytes)");
+    return conv_taps_n320("conv3t_n320_gnstats", x, weight, bias, out, B, T, pixels, 3, 1, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
+                          nullptr, 0, stream, mvi::ln3::GnStats{gn_part, gn_chan_bias, gn_groups, pixels});
 }
 
 extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels,

@@ -331,6 +331,29 @@ def ff_geglu(x, weight, bias):
     return out.reshape(*x.shape[:-1], inner)
 
 
+def ff_geglu_n320_supported(K, inner, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_ff_geglu_n320_supported(int(K), int(inner), _DT[dtype]))
+
+
+def ff_geglu_n320(x, weight, bias):
+    """ff_geglu for a long contraction (K = 640 / 1280: the level-1 / level-2 FeedForward layers) on csrc/linear_n320.hip's GEGLU
+    form (mvi_ff_geglu_n320): x [..., K], weight [2 inner, K], bias [2 inner] or None."""
+    L = _lib.lib()
+    K, inner = x.shape[-1], weight.shape[0] // 2
+    xc = x.reshape(-1, K)
+    if xc.stride(1) != 1 or xc.stride(0) % 8 or xc.data_ptr() % 16:
+        xc = xc.contiguous()
+    wc = weight if weight.is_contiguous() and weight.data_ptr() % 16 == 0 else weight.contiguous().clone()
+    rows = xc.shape[0]
+    cap = int(L.mvi_ff_geglu_out_rows(rows))
+    full = torch.empty(cap, inner, dtype=x.dtype, device=x.device)
+    b = None if bias is None else _f32(bias)
+    with torch.cuda.device(x.device), _Timed("ff_geglu_n320", 4.0 * rows * K * inner, x.device):
+        _check(L.mvi_ff_geglu_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), rows, cap, K, inner,
+                                   xc.stride(0), full.stride(0), _DT[x.dtype], _stream(x.device)), "ff_geglu_n320")
+    return full[:rows].reshape(*x.shape[:-1], inner)
+
+
 def linear_k320_supported(K, out_features, dtype):
     return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_linear_k320_supported(int(K), int(out_features), _DT[dtype]))
 
@@ -380,8 +403,13 @@ def conv3x3_n320_supported(C_in, C_out, dtype):
 
 
 def conv3x3_n320_weight(weight):
-    """conv.weight [C_out, C_in, 3, 3] in the kernel's order: [C_out][9 C_in], tap-major (ky, kx, c)."""
-    return weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()
+    """conv.weight [C_out, C_in, 3, 3] in the kernel's order (mvi_conv3x3_n320_k_order): [C_out][C_in / 64][9 taps (ky, kx)][64
+    channels] — or, order 0, [C_out][9][C_in], tap-major."""
+    Co, Ci = weight.shape[0], weight.shape[1]
+    taps = weight.permute(0, 2, 3, 1).reshape(Co, 9, Ci)                       # [Co, tap, c]
+    if _lib.lib().mvi_conv3x3_n320_k_order(-1) == 1 and Ci % 64 == 0:
+        return taps.reshape(Co, 9, Ci // 64, 64).permute(0, 2, 1, 3).reshape(Co, -1).contiguous()
+    return taps.reshape(Co, -1).contiguous()
 
 
 def conv3t_n320_weight(weight):
@@ -389,8 +417,24 @@ def conv3t_n320_weight(weight):
     return weight[:, :, :, 0, 0].permute(0, 2, 1).reshape(weight.shape[0], -1).contiguous()
 
 
-def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split=True):
-    """tok: token-major activations of N images of H x W pixels (or, taps = 3, N videos of H frames of W pixels)."""
+class GnPartials:
+    """Statistics a producer kernel left for the GroupNorm behind it: `part` [samples * chunks * groups, 3] fp32 (count, mean, M2),
+    `chunks` per sample, for `groups` groups and the per-sample channel bias `chan_bias` (the object, or None) they were taken with."""
+    __slots__ = ("part", "chunks", "groups", "chan_bias")
+
+    def __init__(self, part, chunks, groups, chan_bias):
+        self.part, self.chunks, self.groups, self.chan_bias = part, int(chunks), int(groups), chan_bias
+
+
+def conv_n320_gnstats_supported(rows, taps, C_in, C_out, spatial, groups, stride=1):
+    return bool(_lib.lib().mvi_conv_n320_gnstats_supported(int(rows), int(taps), int(stride), int(C_in), int(C_out), int(spatial), int(groups)))
+
+
+def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split=True, gn=None):
+    """tok: token-major activations of N images of H x W pixels (or, taps = 3, N videos of H frames of W pixels).
+    gn = (groups, chan_bias [samples, C_out] fp32 or None): also leave the statistics of the GroupNorm that follows
+    (mvi_conv3x3_n320_gnstats / mvi_conv3t_n320_gnstats) — returns (out, GnPartials); the caller asked
+    conv_n320_gnstats_supported first."""
     L = _lib.lib()
     C = tok.shape[-1]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -408,6 +452,18 @@ def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split
                                        else L.mvi_conv3t_n320_workspace_bytes(N, H, W, C, Co))
     ws = _workspace(tok.device, ws_bytes) if ws_bytes else None
     wsp = None if ws is None else ws.data_ptr()
+    if gn is not None:
+        groups, cb = gn
+        samples, spatial = (N, H * W) if taps == 9 else (N * H, W)
+        if cb is not None and (cb.dtype != torch.float32 or not cb.is_contiguous() or tuple(cb.shape) != (samples, Co)):
+            raise ValueError(f"{kind}: gn chan_bias must be contiguous fp32 [{samples}, {Co}]")
+        nb = int(L.mvi_conv_n320_gnstats_bytes(samples, spatial, int(groups)))
+        part = torch.empty(nb // 4, dtype=torch.float32, device=tok.device)
+        fn = L.mvi_conv3x3_n320_gnstats if taps == 9 else L.mvi_conv3t_n320_gnstats
+        with torch.cuda.device(tok.device), _Timed(kind, 2.0 * rows * taps * C * Co, tok.device):
+            _check(fn(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, cap, full.stride(0),
+                      _DT[tok.dtype], None if cb is None else cb.data_ptr(), int(groups), part.data_ptr(), nb, _stream(tok.device)), kind + " (gn stats)")
+        return full[:rows], GnPartials(part, spatial // 256, groups, cb)
     with torch.cuda.device(tok.device), _Timed(kind, 2.0 * rows * taps * C * Co, tok.device):
         if taps == 9:
             rc = L.mvi_conv3x3_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, stride,
@@ -432,22 +488,29 @@ def conv3t_n320_fills_chip(B, T, S, C_in, C_out, min_blocks):
     return blocks >= min_blocks or int(_lib.lib().mvi_conv3t_n320_workspace_bytes(B, T, S, C_in, C_out)) > 0
 
 
-def conv3x3_n320(tok, weight_taps, bias, H, W, stride=1, split=True):
+def conv3x3_n320(tok, weight_taps, bias, H, W, stride=1, split=True, gn=None):
     """3x3 / padding 1 convolution (stride 1 or 2) to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
-    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, Ho Wo, C_out]; weight_taps from conv3x3_n320_weight."""
+    (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, Ho Wo, C_out]; weight_taps from conv3x3_n320_weight.
+    gn = (groups, chan_bias): -> (out, GnPartials) for the GroupNorm that follows (see _conv_taps_n320)."""
     N, S, C = tok.shape
     if S != H * W:
         raise ValueError("conv3x3_n320: tok [N, H W, C_in] expected")
-    return _conv_taps_n320("conv3x3_n320", tok, weight_taps, bias, N, H, W, 9, stride, split).view(N, -1, weight_taps.shape[0])
+    r = _conv_taps_n320("conv3x3_n320", tok, weight_taps, bias, N, H, W, 9, stride, split, gn=gn)
+    if gn is not None:
+        return r[0].view(N, -1, weight_taps.shape[0]), r[1]
+    return r.view(N, -1, weight_taps.shape[0])
 
 
-def conv3t_n320(tok, weight_taps, bias, T, split=True):
+def conv3t_n320(tok, weight_taps, bias, T, split=True, gn=None):
     """(3, 1, 1) / padding (1, 0, 0) convolution over the frame axis of token-major activations tok [(b T), S, C_in] (frames of a video
-    consecutive) -> [(b T), S, C_out]; weight_taps from conv3t_n320_weight."""
+    consecutive) -> [(b T), S, C_out]; weight_taps from conv3t_n320_weight. gn: as conv3x3_n320 (a sample = a frame)."""
     BT, S, C = tok.shape
     if BT % T:
         raise ValueError("conv3t_n320: tok [(b T), S, C_in] expected")
-    return _conv_taps_n320("conv3t_n320", tok, weight_taps, bias, BT // T, T, S, 3, 1, split).view(BT, S, -1)
+    r = _conv_taps_n320("conv3t_n320", tok, weight_taps, bias, BT // T, T, S, 3, 1, split, gn=gn)
+    if gn is not None:
+        return r[0].view(BT, S, -1), r[1]
+    return r.view(BT, S, -1)
 
 
 def stem_conv3x3_supported(conv, x):
@@ -713,9 +776,10 @@ def planes_to_tokens(x, upsample=1):
     return out
 
 
-def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=None, frames=1):
+def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=None, frames=1, partials=None):
     """GroupNorm(+SiLU) of token-major t [N, S, C] -> [N, S, C] (csrc/groupnorm_tokens.hip); frames > 1: statistics over the `frames`
-    consecutive samples of a video (the temporal ResBlock's norm), chan_bias still per sample."""
+    consecutive samples of a video (the temporal ResBlock's norm), chan_bias still per sample. partials (GnPartials): the statistics
+    the producer of t left (same groups, same chan_bias object) — no statistics pass (mvi_groupnorm_silu_tok2tok_pre)."""
     L = _lib.lib()
     if t.dtype not in _DT:
         raise TypeError(f"group_norm_tok2tok: unsupported dtype {t.dtype}")
@@ -733,6 +797,16 @@ def group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=No
     ws = _workspace(tc.device, nbytes)
     if frames < 1 or N % frames:
         raise ValueError(f"group_norm_tok2tok: {N} samples are not whole videos of {frames} frames")
+    if partials is not None:
+        if partials.groups != num_groups or (partials.chan_bias is None) != (chan_bias is None) or \
+                partials.part.numel() != N * partials.chunks * num_groups * 3:
+            raise ValueError("group_norm_tok2tok: the producer's statistics do not belong to this norm")
+        with torch.cuda.device(tc.device), _Timed("groupnorm_tok2tok", 2.0 * tc.numel() * tc.element_size(), tc.device):
+            _check(L.mvi_groupnorm_silu_tok2tok_pre(tc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
+                                                    None if cb is None else cb.data_ptr(), N, int(frames), Cc, S, num_groups, float(eps),
+                                                    int(bool(silu)), _DT[t.dtype], partials.part.data_ptr(), partials.chunks,
+                                                    ws.data_ptr(), ws.numel(), _stream(tc.device)), "group_norm_tok2tok (pre)")
+        return y
     with torch.cuda.device(tc.device), _Timed("groupnorm_tok2tok", 2.0 * tc.numel() * tc.element_size(), tc.device):
         _check(L.mvi_groupnorm_silu_tok2tok_frames(tc.data_ptr(), y.data_ptr(), _f32(weight).data_ptr(), _f32(bias).data_ptr(),
                                                    None if cb is None else cb.data_ptr(), N, int(frames), Cc, S, num_groups, float(eps),

@@ -537,22 +537,31 @@ def conv3x3_planes_via_tokens(conv, x, upsample=1):
 TIME_STACK_TOKENS = os.environ.get("MVI_SVD_TIME_STACK_TOKENS", "1") != "0"
 
 
-def _conv_tokens(conv, tok, H, W):
+GN_STATS_FROM_CONV = os.environ.get("MVI_SVD_GN_STATS_FROM_CONV", "1") != "0"      # 0: every token GroupNorm runs its own statistics pass (A/B)
+
+
+def _conv_tokens(conv, tok, H, W, gn=None):
     """3x3 convolution of token-major activations [N, H W, C_in] -> [N, H W, C_out], bias withheld. Output channels in multiples
     of 320 (every ResBlock convolution of the SVD networks) go to the hand-written implicit GEMM; anything else is handed to the
     library as a channels-last view, so MIOpen's NHWC kernel runs without the transposes it wraps
-    around NCHW tensors."""
+    around NCHW tensors.
+    gn = (groups, chan_bias): the GroupNorm that follows; returns (out, partials) — partials (hip_ops.GnPartials) when the
+    implicit-GEMM launch could leave that norm's statistics behind (levels 0 and 1 of the 576 x 1024 step), else None."""
     N, S, C = tok.shape
     if CONV_N320:
         from . import hip_ops
         if (hip_ops.conv3x3_n320_supported(C, conv.out_channels, tok.dtype) and N * S * C * 2 < 2 ** 32
                 and hip_ops.conv3x3_n320_fills_chip(N, H, W, C, conv.out_channels, CONV_N320_MIN_BLOCKS)):
-            return hip_ops.conv3x3_n320(tok, _tap_major_weight(conv.weight), None, H, W)
+            if gn is not None and GN_STATS_FROM_CONV and hip_ops.conv_n320_gnstats_supported(N * S, 9, C, conv.out_channels, S, gn[0]):
+                return hip_ops.conv3x3_n320(tok, _tap_major_weight(conv.weight), None, H, W, gn=gn)
+            y = hip_ops.conv3x3_n320(tok, _tap_major_weight(conv.weight), None, H, W)
+            return (y, None) if gn is not None else y
     x = tok.view(N, H, W, C).permute(0, 3, 1, 2)                  # [N, C, H, W] with channels-last strides: no copy
     y = F.conv2d(x, _channels_last_weight(conv.weight), None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not y.is_contiguous(memory_format=torch.channels_last):     # (the library answered in NCHW: still correct, one copy)
         y = y.contiguous(memory_format=torch.channels_last)
-    return y.permute(0, 2, 3, 1).reshape(N, y.shape[2] * y.shape[3], y.shape[1])
+    y = y.permute(0, 2, 3, 1).reshape(N, y.shape[2] * y.shape[3], y.shape[1])
+    return (y, None) if gn is not None else y
 
 
 def _nhwc_path_ok(self, x):
@@ -589,9 +598,10 @@ def _resblock_forward_fused(self, x, emb, tokens_out=False):
         g1, g2 = self.in_layers[0], self.out_layers[0]
         H, W = x.shape[2], x.shape[3]
         t = ops.group_norm_tokens(x, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True)
-        t = _conv_tokens(conv1, t, H, W)
         e = _emb_chan_bias(self.emb_layers, emb, conv1)
-        t = ops.group_norm_tok2tok(t, g2.num_groups, g2.weight, g2.bias, g2.eps, silu=True, chan_bias=e)
+        e = e if e.is_contiguous() else e.contiguous()
+        t, stats = _conv_tokens(conv1, t, H, W, gn=(g2.num_groups, e))      # (the second norm's statistics ride in the convolution's epilogue)
+        t = ops.group_norm_tok2tok(t, g2.num_groups, g2.weight, g2.bias, g2.eps, silu=True, chan_bias=e, partials=stats)
         t = _conv_tokens(conv2, self.out_layers[2](t), H, W)
         # tokens_out (VideoResBlock with a token-major temporal ResBlock behind): the same add with the result left token-major
         last_add = _planes_add_to_tokens if tokens_out else ops.tokens_to_planes_add
@@ -683,9 +693,15 @@ class VideoResBlock(ResBlock):
         g0, g1 = ts.in_layers[0], ts.out_layers[0]
         c1, c2 = ts.in_layers[2], ts.out_layers[3]
         h = ops.group_norm_tok2tok(xt, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, frames=T)
-        h = hip_ops.conv3t_n320(h, _tap_major_weight(c1.weight), None, T)
         e = _emb_chan_bias(ts.emb_layers, emb, c1)                 # [(b T), c] fp32 incl. the first convolution's bias
-        h = ops.group_norm_tok2tok(h, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, frames=T)
+        e = e if e.is_contiguous() else e.contiguous()
+        stats = None
+        BT, S, C = h.shape
+        if GN_STATS_FROM_CONV and hip_ops.conv_n320_gnstats_supported(BT * S, 3, C, c1.out_channels, S, g1.num_groups):
+            h, stats = hip_ops.conv3t_n320(h, _tap_major_weight(c1.weight), None, T, gn=(g1.num_groups, e))
+        else:
+            h = hip_ops.conv3t_n320(h, _tap_major_weight(c1.weight), None, T)
+        h = ops.group_norm_tok2tok(h, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, frames=T, partials=stats)
         h = hip_ops.conv3t_n320(ts.out_layers[2](h), _tap_major_weight(c2.weight), None, T)
         return hip_ops.tokens_blend_to_planes(h, xt, c2.bias, blend, hw)
 

@@ -89,13 +89,13 @@ def group_norm_tokens(x, num_groups, weight, bias, eps, silu=False, chan_bias=No
     return group_norm(x, num_groups, weight, bias, eps, silu=silu, chan_bias=chan_bias).flatten(2).transpose(1, 2).contiguous()
 
 
-def group_norm_tok2tok(t, num_groups, weight, bias, eps, silu=False, chan_bias=None, frames=1):
+def group_norm_tok2tok(t, num_groups, weight, bias, eps, silu=False, chan_bias=None, frames=1, partials=None):
     """GroupNorm(+SiLU) of token-major t [N, S, C] with token-major output (statistics per sample and group over (S, C/G));
     chan_bias [N, C] is added first. The norm between two convolutions that run on channels-last tensors. frames > 1: the temporal
     layers' norm — statistics over the `frames` consecutive samples of a video (video_model.py:71-75), chan_bias still per sample."""
     if t.is_cuda and not _needs_autograd(t, weight, bias, chan_bias):
         from . import hip_ops
-        return hip_ops.group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, frames=frames)
+        return hip_ops.group_norm_silu_tok2tok(t, num_groups, weight, bias, eps, silu, chan_bias=chan_bias, frames=frames, partials=partials)
     _fallback(t, "group_norm_tok2tok", _why(t, weight, bias, chan_bias))
     N, S, C = t.shape
     tf = t.float() if chan_bias is None else t.float() + chan_bias.float().reshape(N, 1, C)
@@ -229,6 +229,11 @@ FF_GEGLU_MIN_ROWS = 32768       # below, the fused kernel's 256-row blocks do no
 K320_KERNELS = os.environ.get("MVI_K320", "1") != "0"      # MVI_K320=0: library GEMMs everywhere (same-box A/B runs)
 
 
+FF_GEGLU_N320 = os.environ.get("MVI_FF_GEGLU_N320", "1") != "0"
+FF_GEGLU_N320_K = (640, 1280)
+FF_GEGLU_N320_MIN_ROWS = 32768
+
+
 def linear_geglu(x, weight, bias=None):
     """GEGLU of the reference (sgm/modules/attention.py:87-95): `x, gate = F.linear(x, weight, bias).chunk(2, -1); x * F.gelu(gate)`.
     On the GPU, for the shapes csrc/ff_geglu.hip covers (K = 320 in bf16 / f16: the level-0 FeedForward layers) and enough rows,
@@ -239,6 +244,11 @@ def linear_geglu(x, weight, bias=None):
         from . import hip_ops
         if hip_ops.ff_geglu_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
             return hip_ops.ff_geglu(x, weight, bias)
+        # K = 640 / 1280 (levels 1 and 2): csrc/linear_n320.hip's GEGLU form, where it was measured faster than the library
+        # GEMM + geglu_kernel (FF_GEGLU_N320_MIN_ROWS; MVI_FF_GEGLU_N320=0: library everywhere)
+        if FF_GEGLU_N320 and x.shape[-1] in FF_GEGLU_N320_K and x.numel() // x.shape[-1] >= FF_GEGLU_N320_MIN_ROWS \
+                and hip_ops.ff_geglu_n320_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
+            return hip_ops.ff_geglu_n320(x, weight, bias)
     return geglu(F.linear(x, weight, bias))
 
 

@@ -188,7 +188,8 @@ def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=14
         ok &= worst_pre < 1e-4 and worst_post < 2e-2
         ok &= first_change < steps and shard_P[-1] != N                       # the densification happened, in both runs
         ok &= all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(shard_P, single_P))
-        ok &= shard_losses[-1] < shard_losses[0]
+        # (no "the loss goes down" check: cloning 12 k Gaussians with their full opacity raises the loss of the next steps — it is the
+        # single-process run doing exactly the same that is asserted)
         every = [None] * world
         td.all_gather_object(every, shard_P)
         ok &= all(e == every[0] for e in every)                               # every rank went through the same sizes

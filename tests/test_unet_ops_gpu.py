@@ -441,6 +441,42 @@ def test_ff_geglu_fused_projection(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_ff_geglu_long_contraction(ops, dtype, tol):
+    """mvi_ff_geglu_n320 (round 5): the GEGLU projection at K = 640 / 1280 in csrc/linear_n320.hip's frame (160 value + 160 gate
+    columns per block, gated in registers) against fp64 on the rounded inputs — ragged row counts, one to sixteen column groups, no
+    bias, a strided x, gates deep in both GELU tails — and never less accurate than the library GEMM + geglu it replaces (which
+    rounds the [rows, 2 inner] intermediate); the dispatch of ops.linear_geglu takes it for enough rows at those K only."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(43)
+    for rows, K, inner, with_bias, strided in [(1000, 640, 2560, True, False), (777, 640, 160, False, False), (4099, 1280, 320, True, True),
+                                               (256, 128, 480, True, False), (33, 1280, 5120, False, False)]:
+        wide = (torch.randn(rows, 2 * K if strided else K, generator=g) * 1.2).to(dtype)
+        x = wide[:, :K]
+        w = (torch.randn(2 * inner, K, generator=g) * K ** -0.5).to(dtype)
+        w[inner:inner + 4] *= 6.0                                    # gates of +-10 and beyond: gelu(g) -> g and -> -0
+        b = (torch.randn(2 * inner, generator=g) * 0.3).to(dtype) if with_bias else None
+        h = F.linear(x.double(), w.double(), None if b is None else b.double())
+        ref = h[:, :inner] * F.gelu(h[:, inner:])
+        xs = wide.cuda()[:, :K]
+        assert ops.ff_geglu_n320_supported(K, inner, dtype) and xs.is_contiguous() != strided
+        y = ops.ff_geglu_n320(xs, w.cuda(), None if b is None else b.cuda())
+        assert y.shape == (rows, inner) and y.dtype == dtype and torch.isfinite(y).all()
+        e_fused = rel(y, ref)
+        e_lib = rel(ops.geglu(F.linear(xs, w.cuda(), None if b is None else b.cuda())), ref)
+        assert e_fused < tol and e_fused <= 1.05 * e_lib + 1e-4, (rows, K, inner, e_fused, e_lib)
+    assert not ops.ff_geglu_n320_supported(640, 100, dtype) and not ops.ff_geglu_n320_supported(96, 160, dtype)
+    x = torch.randn(2, dev_ops.FF_GEGLU_N320_MIN_ROWS // 2, 640, generator=g).to(dtype).cuda()
+    w = (torch.randn(640, 640, generator=g) * 640 ** -0.5).to(dtype).cuda()
+    ops.PROFILE = []
+    big = dev_ops.linear_geglu(x, w, None)
+    small = dev_ops.linear_geglu(x[:, :100], w, None)
+    kinds = [e[0] for e in ops.PROFILE]
+    ops.PROFILE = None
+    assert big.shape == (2, dev_ops.FF_GEGLU_N320_MIN_ROWS // 2, 320) and kinds == ["ff_geglu_n320", "geglu"], kinds
+    assert rel(big[:, :100], small.double()) < 2 * tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
     """silu(conv2d(x, w, b, padding=1)) for 16 output channels and <= 16 input channels on the MFMA kernel of csrc/stem_conv.hip
     (the stride-1 layers of the ControlNet hint stem at its two finest resolutions): against fp64 on the rounded inputs, 7 / 16 / 3 / 9
@@ -1605,6 +1641,52 @@ def test_groupnorm_tok2tok_with_temporal_statistics(ops, dtype, tol, b, T, S, C)
         assert y.dtype == dtype and (y.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
     with pytest.raises(ValueError):
         ops.group_norm_silu_tok2tok(x.cuda(), 32, w.cuda(), bb.cuda(), 1e-5, True, frames=T + 1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 64), (torch.float16, 1.0 / 512)])
+@pytest.mark.parametrize("taps,N,H,W,C,Co,frames", [(9, 8, 64, 64, 320, 320, 1), (9, 4, 64, 64, 640, 640, 1), (9, 2, 128, 128, 1280, 1280, 1),
+                                                    (3, 4, 4, 8192, 320, 320, 4), (3, 2, 4, 8192, 640, 640, 4)])
+def test_groupnorm_statistics_from_the_convolution_epilogue(ops, dtype, tol, taps, N, H, W, C, Co, frames):
+    """mvi_conv3x3_n320_gnstats / mvi_conv3t_n320_gnstats + mvi_groupnorm_silu_tok2tok_pre (round 5): the convolution that feeds a
+    ResBlock's second GroupNorm (openaimodel.py:292-305, :339-343; the temporal twin video_model.py:41-54) leaves that norm's
+    (count, mean, M2) partials behind, and the norm merges them instead of reading the tensor a second time. The convolution's
+    output is bit-identical to the plain launch; the norm's output equals the three-launch form's to the type's rounding and meets
+    the fp64 GroupNorm of the stored tensor (+ the per-sample channel bias, statistics over `frames` frames for the 3-tap form) at
+    the bar of the other token-norm tests. Group widths 10 / 20 / 40 channels (C_out 320 / 640 / 1280), one to four column groups."""
+    g = torch.Generator().manual_seed(C + taps)
+    if taps == 9:
+        samples, S = N, H * W
+        tok = (torch.randn(N, S, C, generator=g) * 0.7).to(dtype).cuda()
+        wt = ops.conv3x3_n320_weight((torch.randn(Co, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(dtype).cuda())
+        run = lambda gn: ops.conv3x3_n320(tok, wt, None, H, W, gn=gn)
+    else:                                                            # N videos of H frames of W pixels
+        samples, S = N * H, W
+        tok = (torch.randn(samples, S, C, generator=g) * 0.7).to(dtype).cuda()
+        wt = ops.conv3t_n320_weight((torch.randn(Co, C, 3, 1, 1, generator=g) / (1.7 * C ** 0.5)).to(dtype).cuda())
+        run = lambda gn: ops.conv3t_n320(tok, wt, None, H, gn=gn)
+    assert ops.conv_n320_gnstats_supported(samples * S, taps, C, Co, S, 32)
+    w, bb = (1.0 + 0.1 * torch.randn(Co, generator=g)).cuda(), (0.1 * torch.randn(Co, generator=g)).cuda()
+    cb = (0.5 * torch.randn(samples, Co, generator=g)).cuda()
+    plain = run(None)
+    for chan_bias in (cb, None):
+        out, stats = run((32, chan_bias))
+        assert torch.equal(out, plain) and stats.chunks == S // 256 and stats.part.numel() == samples * (S // 256) * 32 * 3
+        y = ops.group_norm_silu_tok2tok(out, 32, w, bb, 1e-5, True, chan_bias=chan_bias, frames=frames, partials=stats)
+        y3 = ops.group_norm_silu_tok2tok(out, 32, w, bb, 1e-5, True, chan_bias=chan_bias, frames=frames)
+        xf = out.double().cpu() if chan_bias is None else out.double().cpu() + chan_bias.double().cpu()[:, None, :]
+        x5 = xf.reshape(samples // frames, frames * S, Co).transpose(1, 2)
+        ref = F.silu(F.group_norm(x5, 32, w.double().cpu(), bb.double().cpu(), 1e-5)).transpose(1, 2).reshape(samples, S, Co)
+        scale = max(1.0, ref.abs().max().item())
+        e_pre, e_3 = (y.double().cpu() - ref).abs().max().item() / scale, (y3.double().cpu() - ref).abs().max().item() / scale
+        assert e_pre <= tol and e_pre <= 1.5 * e_3 + 1e-6, (e_pre, e_3)
+        # the statistics themselves: merged per (sample, group) they are the fp64 moments of the stored tensor
+        part = stats.part.view(samples, S // 256, 32, 3).double().cpu()
+        cnt, mean = part[..., 0], part[..., 1]
+        gmean = (cnt * mean).sum(1) / cnt.sum(1)
+        want = xf.reshape(samples, S, 32, Co // 32).mean(dim=(1, 3))
+        assert (gmean - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.group_norm_silu_tok2tok(plain, 16, w, bb, 1e-5, True, partials=stats)      # another norm's groups
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
