@@ -457,6 +457,10 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
 
     MVI_AS3 uint32_t* const redo_flag = (MVI_AS3 uint32_t*)(lds + kLdsBytes);
     if (tid == 0) *redo_flag = 0u;                               // ordered before any read by the barriers of run()
+#ifdef MVI_ATTN_YOUNG_PRIO
+    // (A/B build, HISTORY.md round 5) static priority for the second-dispatched half: the loser of the SIMD's VALU arbitration
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 64 * kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     run(std::false_type{});
     // block-wide vote (the waves share the K / V ring and its barriers, so they repeat together or not at all)
     // (f16: P itself is packed to f16, which ends at 65504 — a row sum of at most 2^15 proves that no P of the row was larger)

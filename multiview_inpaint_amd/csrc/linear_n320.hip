@@ -111,6 +111,7 @@ struct ConvGeom {
     int H, W, cpc, taps, groups, ksplit;             // INPUT image height / width, 64-channel chunks per tap (C_in / 64), 9 or 3, C_out / 320
     int stride, Ho, Wo;                              // 1 or 2 (3x3 only); output height / width (= H, W at stride 1)
     int cc_major;                                    // K ordered (channel chunk, tap, 64 channels) instead of (tap, channel): see conv_k_order
+    int frame_major;                                 // taps == 3: row blocks walked (pixel block, frame) instead of (frame, pixel block)
 };
 
 // kStats: the GroupNorm that FOLLOWS this convolution gets its statistics from here (ResBlock out_layers[0] behind in_layers[2],
@@ -180,6 +181,16 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     if (kSplit) {
         ks = bid % cg.ksplit;
         bid /= cg.ksplit;
+    }
+    if (kConv && cg.taps == 3 && cg.frame_major) {
+        // (3,1,1) form: the three taps of a block read the SAME 256 pixels of frames t - 1, t, t + 1, i.e. every activation row is read by
+        // the blocks of three consecutive frames. In row order those blocks are S / 256 launches apart and each finds the rows evicted
+        // from L2; walked (pixel block, frame) instead, they are neighbours — dispatched back to back, on one XCD (the remap above) —
+        // and two of the three reads hit. Only the order of the row blocks changes (the host allows it when S % 256 == 0).
+        const int bpf = cg.W / kRows, per_video = cg.H * bpf;                    // cg.H frames of cg.W pixels
+        const int v = bid / per_video, j = bid - v * per_video;
+        const int pb = j / cg.H, f = j - pb * cg.H;
+        bid = v * per_video + f * bpf + pb;
     }
     const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
     const int64_t row = row0 + col;
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
-                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0}, float* part = nullptr,
+                              hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0}, float* part = nullptr,
                               ln3::GnStats gn = {nullptr, nullptr, 0, 0}) {
     using namespace ln3;
     const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups * cg.ksplit;
@@ -572,7 +583,7 @@ extern "C" int mvi_ff_geglu_n320(const void* x, const void* weight, const float*
         ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
         return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: x, weight and out rows must be 16-byte aligned");
     if (256 * x_row_stride * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: row block exceeds 32-bit byte offsets");
-    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, inner / (mvi::ln3::kN / 2), 1, 1, 0, 0, 0};
+    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, inner / (mvi::ln3::kN / 2), 1, 1, 0, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == MVI_DT_BF16
                        ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
@@ -596,7 +607,7 @@ extern "C" int mvi_conv3x3_n320_supported(int32_t C_in, int32_t C_out, int32_t d
 // other, and they read the SAME 128-byte slices of the block's four image rows shifted by a pixel or a row — 64 KB per block and
 // chunk, which stays in the XCD's L2 — where the tap-major order came back to a pixel after 10 - 40 chunks of other data and found it
 // evicted: the counters showed the 330 MB activation of a level-0 convolution fetched nine times (3.06 GB per launch at
-// 28 x 72x128, 640 -> 320: profiles/r5d_pmc_svd_traffic.txt). The caller packs the weight in the same order
+// 28 x 72x128, 640 -> 320: profiles/round5_pmc_svd_traffic_tap_major.txt). The caller packs the weight in the same order
 // (svd/hip_ops.py conv3x3_n320_weight reads mvi_conv3x3_n320_k_order()); the (3,1,1) form keeps (tap, channel).
 static int g_conv_k_order = [] { const char* e = getenv("MVI_CONV_K_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
 extern "C" int mvi_conv3x3_n320_k_order(int32_t set) {
@@ -657,7 +668,8 @@ static int conv_taps_n320(const char* what, const void* x, const void* weight, c
     // the K split is taken when the caller brought its workspace (mvi_conv3x3_n320_workspace_bytes); without one the launch is unsplit
     int ks = conv_ksplit(rows, taps, C_in, C_out);
     if (ks > 1 && (!workspace || workspace_bytes < conv_workspace_bytes(rows, taps, C_in, C_out) || (uintptr_t)workspace % 16)) ks = 1;
-    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo, taps == 9 ? g_conv_k_order : 0};
+    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo, taps == 9 ? g_conv_k_order : 0,
+                                   (taps == 3 && g_conv_k_order && W % mvi::ln3::kRows == 0) ? 1 : 0};
     int rc;
     if (gn.part) {
         if (!conv_gnstats_ok(rows, taps, stride, C_in, C_out, gn.S, gn.G)) return fail("this shape cannot leave GroupNorm statistics (mvi_conv_n320_gnstats_supported)");

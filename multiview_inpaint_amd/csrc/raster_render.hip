@@ -304,7 +304,10 @@ int launch_zero_regions(const ZeroRegions& z, hipStream_t st) {
 // run at the 64-B-request rate. Row layout of grad_rows [P][16]:
 //   0 mean2D.x  1 mean2D.y  2 conic A  3 conic B  4 conic C  5 opacity  6 r  7 g  8 b  9..15 unused
 constexpr int kRow = 16;
-constexpr int kSlabG = 3;          // Gaussians parked per wave before a row-sum pass (3 x 9 = 27 rows)
+#ifndef MVI_RB_SLAB
+#define MVI_RB_SLAB 3
+#endif
+constexpr int kSlabG = MVI_RB_SLAB;   // Gaussians parked per wave before a row-sum pass (3 x 9 = 27 rows; <= 7: one lane per row)
 constexpr int kSlabStride = 20;    // floats per slab row (16 used; 80-byte rows keep b128 reads conflict-free)
 
 
@@ -342,7 +345,10 @@ __device__ __forceinline__ void quad_sum9(float& a, float& b, float& c, float& d
 // pixels are summed in the lane before the quad reduction, and the reduction/slab cost is paid once per 128 pixels.
 // Block = 128 threads = one tile; 128 list entries are staged per round. Decisions (alpha, active) use the same
 // operation order as the forward kernel (products rounded, one fma per sum), element-wise.
-__global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_backward_kernel(
+#ifndef MVI_RB_WAVES
+#define MVI_RB_WAVES 5             // waves per SIMD the register allocation aims at (A/B builds: -DMVI_RB_WAVES=4; HISTORY.md round 5)
+#endif
+__global__ __launch_bounds__(kB2) __attribute__((amdgpu_waves_per_eu(MVI_RB_WAVES, MVI_RB_WAVES))) void render_backward_kernel(
     Frame f, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ xy, const float4* __restrict__ rgbd, const float4* __restrict__ conic_opacity,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,

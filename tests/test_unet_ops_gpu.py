@@ -30,6 +30,19 @@ if DROPIN not in sys.path:
     sys.path.insert(0, DROPIN)
 
 
+# Reduced-precision bars of the reference-pinned graphs: the build's error against the reference's fp32 output as a multiple of
+# the reference's OWN autocast error in the same type (max norm and rms, per recorded tensor).
+#   * at the full size of configs[3] (28 x 72x128 latents, millions of elements per tensor): 1.3 x. Observed in round 5, with the
+#     softmax scale folded into the q weights: 1.10 x (bf16) / 1.14 x (f16) on the networks, 1.06 x / 0.89 x after two sampling steps.
+#   * on the 16x16 / 32x32 latents of the small fixtures: 1.6 x. There the max norm over a few thousand elements is a noisy
+#     statistic: swapping ONE kernel family for the library's moves the f16 multiple of the production-width fixture between 1.26 and
+#     1.53 with no family standing out (tools/diag_c320_precision.py -> profiles/round5_diag_c320_f16.txt: shipped 1.27, library
+#     convolutions 1.53, NCHW ResBlocks 1.46, exact-scale attention 1.34; rms multiples 0.94 - 1.25) — the "1.56 x in f16" of round 4
+#     was that noise, not an op. Observed this round: 0.97 - 1.47.
+FULL_SIZE_BAR = 1.3
+SMALL_LATENT_BAR = 1.6
+
+
 def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
@@ -910,7 +923,7 @@ def _err(a, b):
 def test_hd64_nets_in_bf16_run_the_mfma_kernel_within_the_reference_autocast_budget(golden_dir, strict):
     """num_head_channels = 64 (configs/test/svd_f_est_ctrl_simp1.yaml:31), latent 16x16: every spatial self-attention has
     D = 64, S_k = 256 or 64 and — in bf16 — runs attn_flash_kernel INSIDE the module graph (asserted from the op log).
-    Bar: the build's bf16 error against the reference's fp32 output is at most 2x the error of the reference's OWN
+    Bar: the build's bf16 error against the reference's fp32 output is at most SMALL_LATENT_BAR (1.6) x the error of the reference's OWN
     reduced-precision recipe (autocast over fp32 weights, csvd.py:27-31; bf16 on the CPU) against the same fp32 output,
     per tensor, in max norm and in rms (fixture tests/golden/sgm_hd64.npz, generated from the imported reference)."""
     from sgm.modules.diffusionmodules.video_model import VideoUNet
@@ -950,7 +963,7 @@ def test_hd64_nets_in_bf16_run_the_mfma_kernel_within_the_reference_autocast_bud
         e_max, e_rms = _err(got.float(), ref)
         r_max, r_rms = _err(torch.tensor(G64[name + "_bf16ac"]), ref)
         worst = max(worst, e_max / r_max, e_rms / r_rms)
-        assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
+        assert e_max <= SMALL_LATENT_BAR * r_max and e_rms <= SMALL_LATENT_BAR * r_rms, (name, e_max, r_max, e_rms, r_rms)
     H.report(f"bf16 HIP path vs reference fp32: worst error ratio to the reference's own bf16-autocast error = {worst:.2f}")
 
 
@@ -1003,7 +1016,7 @@ def test_hd64_nets_on_a_32x32_latent_run_the_8_wave_kernel_within_the_reference_
         e_max, e_rms = _err(got.float(), ref)
         r_max, r_rms = _err(torch.tensor(G64[name + "_" + tag]), ref)
         worst = max(worst, e_max / r_max, e_rms / r_rms)
-        assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
+        assert e_max <= SMALL_LATENT_BAR * r_max and e_rms <= SMALL_LATENT_BAR * r_rms, (name, e_max, r_max, e_rms, r_rms)
     H.report(f"{dtype}: 8-wave kernel x{len(eight)}, 4-wave x{len(four)}; worst error ratio to the reference's own autocast "
           f"error = {worst:.2f}")
 
@@ -1017,7 +1030,7 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     runs on tokens, and the temporal attention (T = 3, D = 64, H = 5 / 10) runs csrc/attn_temporal.hip. Which kernels ran is read
     from the op profile and from mvi_attention_temporal_kernel_variant (the function the C dispatch uses). Reference semantics:
     openaimodel.py:256-354, video_model.py:12-81, video_attention.py:110-141; precision recipe models/csvd.py:27-31.
-    Bar, in bf16 and in f16 (the reference's own GPU recipe): the build's error against the reference's fp32 output is at most 2x the
+    Bar, in bf16 and in f16 (the reference's own GPU recipe): the build's error against the reference's fp32 output is at most SMALL_LATENT_BAR (1.6) x the
     error of the reference's OWN autocast run in that type, per tensor, in max norm and in rms (fixture tests/golden/sgm_c320.npz,
     generated from the imported reference by tools/gen_golden_sgm_c320.py) — for the three final tensors AND for four
     intermediate block outputs of the UNet (first level-0 block, first level-1 block, middle block, an output block; round 4)."""
@@ -1079,7 +1092,7 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
         e_max, e_rms = _err(got.float(), ref)
         r_max, r_rms = _err(torch.tensor(G[name + "_" + tag]), ref)
         worst = max(worst, e_max / r_max, e_rms / r_rms)
-        assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
+        assert e_max <= SMALL_LATENT_BAR * r_max and e_rms <= SMALL_LATENT_BAR * r_rms, (name, e_max, r_max, e_rms, r_rms)
     H.report(f"{dtype}: {n_vrb} token-major VideoResBlocks, {count('conv3x3_n320')} 3x3 + {count('conv3t_n320')} frame convolutions in the "
           f"implicit-GEMM kernel; worst error ratio to the reference's own autocast error = {worst:.2f}")
 
@@ -1093,7 +1106,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     fp32, plus the same evaluation under the reference's own bf16 autocast — and under f16 autocast, the reference's GPU recipe
     (yaml :214), for the f16 run of this test — as the error budget (tools/gen_golden_sgm_full.py; seeded weights and inputs,
     regenerated here bit for bit). Bar as at the production widths: error against the reference's
-    fp32 output <= 2 x the reference's own autocast error, in max norm and in rms, for the network output, the last control
+    fp32 output <= FULL_SIZE_BAR (1.3) x the reference's own autocast error, in max norm and in rms, for the network output, the last control
     residual and four intermediate block outputs (subsampled in the fixture)."""
     from models.csvd import ControlNet, ControlledVideoUNet
     from multiview_inpaint_amd.svd import bench_svd, hip_ops
@@ -1142,7 +1155,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
         e_max, e_rms = _err(got, ref)
         r_max, r_rms = (float(v) for v in G[budget + name])          # the reference's own autocast error in this type against the same fp32 tensor
         worst = max(worst, e_max / r_max, e_rms / r_rms)
-        assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (name, e_max, r_max, e_rms, r_rms)
+        assert e_max <= FULL_SIZE_BAR * r_max and e_rms <= FULL_SIZE_BAR * r_rms, (name, e_max, r_max, e_rms, r_rms)
     H.report(f"full-size step in {dt} vs the reference: worst error ratio to the reference's own autocast error in that type = {worst:.2f}")
 
 
@@ -1154,7 +1167,7 @@ def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, bu
     VScalingWithEDMcNoise) over SVDInpaintEngine.apply_model (ControlNet with the hint-stem cache -> ControlledVideoUNet) on
     the HIP path, sampler state in fp32, networks in bf16 / f16 — against the same loop of the imported reference on the CPU in
     fp32 (tools/gen_golden_sgm_full_sample.py -> tests/golden/sgm_full.npz `sample_final_f32`, subsampled [:, :, ::2, ::2]),
-    with the error of the reference's own bf16 / f16 autocast loop as the budget (bar: 2x, max norm and rms)."""
+    with the error of the reference's own bf16 / f16 autocast loop as the budget (bar: FULL_SIZE_BAR = 1.3 x, max norm and rms)."""
     from models.csvd import ControlNet, ControlledVideoUNet, SVDInpaintEngine
     from sgm.modules.diffusionmodules.denoiser import Denoiser
     from sgm.util import instantiate_from_config
@@ -1192,7 +1205,7 @@ def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, bu
     e_max, e_rms = _err(xs[:, :, ::2, ::2], G["sample_final_f32"])
     r_max, r_rms = (float(v) for v in G[budget + "sample_final"])
     H.report(f"two sampling steps at full size in {dt}: error (max, rms) = ({e_max:.2e}, {e_rms:.2e}), the reference's own autocast loop ({r_max:.2e}, {r_rms:.2e})")
-    assert e_max <= 2.0 * r_max and e_rms <= 2.0 * r_rms, (e_max, r_max, e_rms, r_rms)
+    assert e_max <= FULL_SIZE_BAR * r_max and e_rms <= FULL_SIZE_BAR * r_rms, (e_max, r_max, e_rms, r_rms)
 
 
 def _attn_ref_chunked(q, k, v, heads, rows=1536):

@@ -189,3 +189,41 @@ def test_full_size_first_stage_matches_the_reference(golden_dir, ops):
     assert abs(float(y.double().mean()) - float(G["vdec_out_mean"])) < 1e-4 * float(G["vdec_out_absmax"])
     assert max(errs.values()) < 1e-4, errs
     assert {"groupnorm", "bias_residual", "softmax_rows", "tokens_to_planes_add"} <= kinds, kinds
+
+
+@pytest.mark.parametrize("dt,bar", [(torch.bfloat16, 1.3), (torch.float16, 0.5)])
+def test_full_size_first_stage_reduced_precision_decode_within_the_reference_autocast_budget(golden_dir, ops, dt, bar):
+    """decode_first_stage(dtype=...) — the opt-in reduced-precision decode (round 5: the fp32 decode of 14 frames is 1.26 s, bound by
+    the fp32 matrix rate) — at the full size of configs[3], two 72x128 latent frames -> 576x1024 frames, against the imported
+    reference's fp32 frames (tests/golden/vae_full.npz). Budget: the error of the reference's OWN bf16-autocast decode of the same
+    weights and latents against its fp32 decode (tools/gen_golden_vae_full_bf16.py; max 1.07e-2, rms 1.8e-3 of the largest output):
+    bf16 within 1.3 x of it in max norm and rms, f16 (11-bit mantissa) within half of it. GroupNorm statistics and the softmax stay
+    fp32; the fp32 default is untouched (test_full_size_first_stage_matches_the_reference)."""
+    import svd_helpers as H
+    from sgm.util import instantiate_from_config
+    from multiview_inpaint_amd.svd import vae
+    G = np.load(os.path.join(golden_dir, "vae_full.npz"))
+    assert "budget_bf16_out_sub" in G.files, "run tools/gen_golden_vae_full_bf16.py (build container only)"
+    cfg = {"target": "sgm.models.autoencoder.AutoencodingEngine", "params": {
+        "loss_config": {"target": "torch.nn.Identity"},
+        "regularizer_config": {"target": "sgm.modules.autoencoding.regularizers.DiagonalGaussianRegularizer"},
+        "encoder_config": {"target": "sgm.modules.diffusionmodules.model.Encoder", "params": H.FULL_VAE},
+        "decoder_config": {"target": "sgm.modules.autoencoding.temporal_ae.VideoDecoder",
+                           "params": dict(H.FULL_VAE, video_kernel_size=[3, 1, 1])}}}
+    eng = instantiate_from_config(cfg).eval()
+    eng.decoder.load_state_dict(H.seeded_state_dict(eng.decoder, 52), strict=True)
+    eng = eng.to(DEV)
+    z = H.vae_full_latent(61).to(DEV)
+    y = vae.decode_first_stage(eng, z * 0.18215, dtype=dt)              # (decode_first_stage unscales by 1 / 0.18215)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float32 and tuple(y.shape) == (H.FULL_VAE_T, 3) + H.FULL_VAE_HW
+    assert next(eng.decoder.parameters()).dtype == torch.float32        # the model itself stays fp32
+    amax = float(G["vdec_out_absmax"])
+    worst = 0.0
+    for name, sl in (("out_sub", H.FULL_VAE_SUB), ("out_crop", H.FULL_VAE_CROP)):
+        d = (y[sl].double().cpu() - torch.as_tensor(G["vdec_" + name]).double()).abs()
+        e_max, e_rms = float(d.max()) / amax, float(d.pow(2).mean().sqrt()) / amax
+        b_max, b_rms = (float(v) for v in G["budget_bf16_" + name])
+        worst = max(worst, e_max / b_max, e_rms / b_rms)
+        assert e_max <= bar * b_max and e_rms <= bar * b_rms, (name, e_max, b_max, e_rms, b_rms)
+    H.report(f"first-stage decode at full size in {dt}: worst ratio of its error to the reference's own bf16-autocast decode error = {worst:.2f}")
