@@ -529,7 +529,16 @@ def _decoder_in(first_stage_model, dtype):
     key = tuple((p.data_ptr(), p._version) for p in dec.parameters())
     hit = first_stage_model.__dict__.get("_mvi_decoder_copies", {}).get(dtype)
     if hit is None or hit[0] != key:
-        hit = (key, copy.deepcopy(dec).to(dtype).eval())
+        red = copy.deepcopy(dec).to(dtype).eval()
+        # what an autocast run keeps in fp32 stays in fp32 here: the affine parameters of the norms (a rounded per-channel gain is a
+        # systematic error that no spatial average removes: 1.7 x the reference's bf16-autocast error with them rounded) and the
+        # blending factors; the norm kernels take fp32 parameters beside reduced-precision activations anyway
+        src = dict(dec.named_parameters())
+        for name, p in red.named_parameters():
+            mod = red.get_submodule(name.rsplit(".", 1)[0]) if "." in name else red
+            if isinstance(mod, nn.GroupNorm) or name.endswith("mix_factor"):
+                p.data = src[name].detach().float().clone()
+        hit = (key, red)
         first_stage_model.__dict__.setdefault("_mvi_decoder_copies", {})[dtype] = hit
     return hit[1]
 
