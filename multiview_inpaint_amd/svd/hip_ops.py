@@ -269,13 +269,23 @@ def attention_wide(q, k, v):
     B, Sq, D = q.shape
     Sk = k.shape[1]
     out = torch.empty_like(q)
-    per = Sq * Sk * q.element_size()
+    # Reduced-precision I/O (the opt-in bf16 / f16 first-stage decode): the scores and the probabilities stay fp32 — a D = 512 logit
+    # rounded to bf16 before the softmax carries an error of |logit| 2^-9, which alone put the bf16 decode at 1.7 x the reference's own
+    # bf16-autocast error (its scaled_dot_product_attention keeps the scores in fp32). 2 x 2 B Sq Sk D FLOPs on the fp32 matrix path:
+    # ~25 ms of a 270 ms decode at 14 x 576x1024.
+    wide = q.dtype != torch.float32
+    per = Sq * Sk * (4 if wide else q.element_size())
     step = max(1, min(B, _WIDE_SCORE_BYTES // max(per, 1)))
     kt = k.transpose(1, 2)
     for b0 in range(0, B, step):
-        s = torch.bmm(q[b0:b0 + step], kt[b0:b0 + step])
-        softmax_rows_(s, float(D) ** -0.5)
-        torch.bmm(s, v[b0:b0 + step], out=out[b0:b0 + step])
+        if wide:
+            s = torch.bmm(q[b0:b0 + step].float(), kt[b0:b0 + step].float())
+            softmax_rows_(s, float(D) ** -0.5)
+            out[b0:b0 + step] = torch.bmm(s, v[b0:b0 + step].float())
+        else:
+            s = torch.bmm(q[b0:b0 + step], kt[b0:b0 + step])
+            softmax_rows_(s, float(D) ** -0.5)
+            torch.bmm(s, v[b0:b0 + step], out=out[b0:b0 + step])
     return out
 
 
