@@ -108,7 +108,10 @@ template <int N> __device__ __forceinline__ void wait_vm_then_barrier() {
 // |logit| * 2^-9 in the exponent, i.e. a few per cent on P where two keys with logits of ~60 compete (2.7e-2 of the
 // output scale on the adversarial rows of tests/test_unet_ops_gpu.py, against 5e-3 with the exact form).
 constexpr int kWaves = 8;
-constexpr int kLoaders = 4;
+#ifndef MVI_ATTN_NLOADERS
+#define MVI_ATTN_NLOADERS 4
+#endif
+constexpr int kLoaders = MVI_ATTN_NLOADERS;
 
 template <typename T, bool kExact>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -194,6 +197,20 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                 r = r < Sk ? r : Sk - 1;
                 dma_piece(base, (uint32_t)r * row_bytes + 16u * p_chunk[i], p_dst[i] + ring_off);
             }
+        }
+    };
+    // one piece of tile tt (A/B build MVI_ATTN_SPREAD_DMA: the four pieces of a loader leave one per quarter instead of together at the
+    // end of the tile)
+    auto issue_piece = [&](int tt, int i) __attribute__((always_inline)) {
+        if (i >= n_pieces) return;
+        const uint32_t ring_off = (uint32_t)((tt & (kRing - 1)) * kTileBytes);
+        const char* const base = p_is_v[i] ? vbase : kbase;
+        if (tt < n_full) {
+            dma_piece(base + (int64_t)tt * kKT * row_bytes, p_voff[i], p_dst[i] + ring_off);
+        } else {
+            int r = tt * kKT + p_row[i];
+            r = r < Sk ? r : Sk - 1;
+            dma_piece(base, (uint32_t)r * row_bytes + 16u * p_chunk[i], p_dst[i] + ring_off);
         }
     };
     // counted waits: "at most `tiles_in_flight` tiles' worth of this wave's own pieces still outstanding", then the barrier
@@ -412,9 +429,15 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             Frags f2 = load_frags(next, 0, 0, has_next, slot, 32);
             quarter(pipe_c, fq0, true, 0, s1, 0, s0, pend, t > 0);          // (before tile 0 nothing is pending)
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MVI_ATTN_SPREAD_DMA
+            if (has_next) issue_piece(t + 3, 0);
+#endif
             Frags f3 = load_frags(next, 0, 3, has_next, slot, 48);
             quarter(pipe_c, fq1, true, 3, s1, 1, s0, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MVI_ATTN_SPREAD_DMA
+            if (has_next) issue_piece(t + 3, 1);
+#endif
             if (ragged) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -424,12 +447,19 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             if (has_next) fq0 = load_frags(next, 1, 0, true, next, 0);
             quarter(pipe_c, f2, has_next, 0, s0, 0, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MVI_ATTN_SPREAD_DMA
+            if (has_next) issue_piece(t + 3, 2);
+#endif
             if (has_next) fq1 = load_frags(next, 1, 3, true, next, 16);
             quarter(pipe_c, f3, has_next, 3, s0, 1, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) {
                 // slot (t + 3) % 4 held tile t - 1: nobody reads it after the barrier that opened this tile
+#ifdef MVI_ATTN_SPREAD_DMA
+                issue_piece(t + 3, 3);
+#else
                 issue_tile(t + 3);
+#endif
                 wait_tiles_then_barrier(std::integral_constant<int, 1>{});   // own pieces of tile t + 2 (and everything older) landed
             }
         };

@@ -33,7 +33,7 @@ def main():
     from multiview_inpaint_amd.svd import hip_ops, vae
     import svd_helpers as H
     dev = "cuda:0"
-    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[a.dtype]
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     torch.backends.cudnn.benchmark = a.search
     eng = vae.AutoencodingEngine(encoder_config=vae.Encoder(**FULL),
                                  decoder_config=vae.VideoDecoder(**FULL, video_kernel_size=[3, 1, 1])).eval()
