@@ -58,6 +58,9 @@ constexpr int kRing = 3;
 #ifndef LN3_SGB
 #define LN3_SGB 1
 #endif
+#ifndef LN3_FAKE16
+#define LN3_FAKE16 0
+#endif
 constexpr int kLoaders = LN3_LOADERS;
 constexpr int kPiecesPerLoader = kPieces / kLoaders; // 10
 constexpr int kLdsBytes = kRing * kChunkBytes + kWaves * 4096;
@@ -66,6 +69,9 @@ template <typename T> struct Mma;
 template <> struct Mma<__hip_bfloat16> {
     using frag = bf16x8;
     __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static __attribute__((ext_vector_type(4))) float mfma16(frag a, frag b, __attribute__((ext_vector_type(4))) float c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
     __device__ static uint32_t pack2(float lo, float hi) {
         f32x2 f = {lo, hi};
         bf16x2 r = __builtin_convertvector(f, bf16x2);
@@ -77,6 +83,9 @@ template <> struct Mma<__hip_bfloat16> {
 template <> struct Mma<__half> {
     using frag = f16x8;
     __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static __attribute__((ext_vector_type(4))) float mfma16(frag a, frag b, __attribute__((ext_vector_type(4))) float c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
     __device__ static uint32_t pack2(float lo, float hi) {
         f32x2 f = {lo, hi};
         f16x2 r = __builtin_convertvector(f, f16x2);
@@ -207,6 +216,14 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = b;
     }
+#if LN3_FAKE16
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 acc4[kNT][4];
+#pragma unroll
+    for (int j = 0; j < kNT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc4[j][i >> 2][i & 3] = acc[j][i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the compiler's own loads are done before the hand-counted ones start
 
     // ---- x: A operand, element e of lane (col, hh), k-step s of chunk c: x[row][64 c + 16 s + 8 hh + e]; rows past the end read the last row
@@ -306,7 +323,17 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 #pragma unroll
         for (int q = 0; q < 4 * kNT; ++q) {
             if (q + kAhead < 4 * kNT) wf[(q + kAhead) % (kAhead + 1)] = wfrag(slot_base, q + kAhead);
+#if LN3_FAKE16
+            // TIMING ONLY (results are garbage): the same chunk as two v_mfma_f32_16x16x32 per fragment pair — the FLOPs, LDS reads and
+            // accumulator count of a 16x16x32 tiling — to see what clock the chip holds on that shape before the layouts are rewritten
+            {
+                const int j = q % kNT, h = 2 * ((q / kNT) & 1);
+                acc4[j][h] = M::mfma16(as_frag<frag>(xr[q / kNT]), as_frag<frag>(wf[q % (kAhead + 1)]), acc4[j][h]);
+                acc4[j][h + 1] = M::mfma16(as_frag<frag>(xr[q / kNT]), as_frag<frag>(wf[q % (kAhead + 1)]), acc4[j][h + 1]);
+            }
+#else
             acc[q % kNT] = M::mfma(as_frag<frag>(xr[q / kNT]), as_frag<frag>(wf[q % (kAhead + 1)]), acc[q % kNT]);
+#endif
         }
         // the order above is the order wanted: left alone, the scheduler sinks every read to just before its MFMA (ds_read, wait
         // lgkmcnt(0), MFMA, 40 times per chunk) and the LDS latency is exposed: 1.13-1.24 PFLOP/s instead of 1.23-1.32
@@ -314,7 +341,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
 #pragma unroll
         for (int q = 0; q < 4 * kNT; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, LN3_FAKE16 ? 2 : 1, 0);
             if (q + kAhead < 4 * kNT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
 #endif
@@ -361,6 +388,12 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     }
     if (c < n_chunks) chunk_fn(slot, xa, ka_keep);                   // K / 64 odd: one chunk left
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // trailing (unused) pieces and rows land before the block ends
+#if LN3_FAKE16
+#pragma unroll
+    for (int j = 0; j < kNT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = acc4[j][i >> 2][i & 3];
+#endif
 
     if (kSplit) {
         // fp32 partial sums straight from the accumulators: register i of column tile j = row (i & 3) + 8 (i >> 2) + 4 hh, column 32 j + col
