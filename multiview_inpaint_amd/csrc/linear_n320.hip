@@ -36,6 +36,18 @@ namespace mvi {
 int unet_fail(int code, const char* msg);
 namespace ln3 {
 
+#ifndef LN3_STAMPS
+#define LN3_STAMPS 0
+#endif
+#if LN3_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/build_variant.sh ... -DLN3_STAMPS=1): wave 0 of every block leaves s_memrealtime (100 MHz) at four places
+// and its hardware id in a buffer of its own; the launcher prints the mean phase lengths and the per-CU gaps between blocks to stderr.
+__device__ unsigned long long* g_stamps;
+#define LN3_STAMP(k) do { if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LN3_STAMP(k) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -163,6 +175,14 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;       // the lane's row / column inside a 16 x 16 tile, its 8-element group of a 32-deep k-step
     int bid = blockIdx.x;
+    LN3_STAMP(0);
+#if LN3_STAMPS
+    if (tid == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        g_stamps[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
     int part_col0 = 0, ks = 0;
     int gg = 0;                                      // kGeglu: the block's column group (160 outputs)
@@ -295,7 +315,8 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         const uint32_t slot_off = (uint32_t)((c % kRing) * kChunkBytes);
         const char* const base = wbase + (int64_t)cc * (kKC * 2);
 #pragma unroll
-        for (int i = 0; i < kPiecesPerLoader; ++i) dma_piece(base, p_voff[i], lds0 + slot_off + 1024u * (uint32_t)(wave + i * kLoaders));
+        for (int i = 0; i < kPiecesPerLoader; ++i)
+            dma_piece(base, p_voff[i], __builtin_amdgcn_readfirstlane(lds0 + slot_off + 1024u * (uint32_t)(wave + i * kLoaders)));
     };
 
     // ---- LDS read addressing: B operand = W rows; lane (n16, kg), column tile j, k-step s reads row 16 j + n16, 16-byte slot 4 s + kg
@@ -335,6 +356,11 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     };
     // Loaders issue the chunk two ahead (its slot held chunk c - 1, which nobody reads any more), then every wave waits for
     // everything older than those pieces — the next chunk's W pieces and its own next x rows among them — and the block meets.
+    // Round 5, tried and not kept: the eight waves as two groups half a chunk apart (the barrier at the END of a chunk for waves 0 - 3,
+    // in the MIDDLE for waves 4 - 7), so that a SIMD's matrix pipe always has one wave in mid-chunk while the other sits at the barrier
+    // and waits for its first fragments. Correct, and 2 - 3 % SLOWER on every shape (profiles/round5_n320_phased_ab.txt): the loop
+    // spends 3620 cycles per chunk on 2560 cycles of MFMAs at 1.89 GHz (in-kernel stamps, LN3_STAMPS) — the chip trades the idle
+    // cycles for clock, and filling them returns as a lower clock, not as time.
     // (The x registers are NOT operands of the wait: tied operands made the allocator copy them in front of it, i.e. before the
     // loads had landed. Nothing that uses them can move above the wait anyway: every MFMA also takes a W fragment read from LDS
     // after it, and LDS reads do not cross a statement that clobbers memory.)
@@ -360,6 +386,10 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
+    LN3_STAMP(1);
+#if LN3_STAMPS
+    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
+#endif
 
     auto next_slot = [&](uint32_t s) __attribute__((always_inline)) { return s + kChunkBytes == (uint32_t)(kRing * kChunkBytes) ? 0u : s + kChunkBytes; };
     uint32_t slot = 0;
@@ -378,6 +408,10 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     // trailing (unused) pieces and rows land before the block ends; mfma_settle: the last matrix instructions (8 passes each) have
     // written their accumulators before anything the compiler schedules reads one
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    LN3_STAMP(2);
+#if LN3_STAMPS
+    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -472,6 +506,11 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
         }
     }
+    LN3_STAMP(3);
+#if LN3_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();      // this wave's stores acknowledged
+#endif
     if (kStats && gn.part) {
         // wave partials -> the wave's own 4 KiB output tile (its flush reads are issued: LDS operations of one wave execute in order):
         // [320 channels][2] floats = 2560 bytes; the four kg hold different rows of a column
@@ -562,8 +601,54 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
+#if LN3_STAMPS
+    unsigned long long* dbg = nullptr;
+    hipMalloc(&dbg, (size_t)n_blocks * 64);
+    hipMemset(dbg, 0, (size_t)n_blocks * 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dbg, sizeof dbg);
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
                        o_rs, (int)n_blocks, cg, part, gn);
+#if LN3_STAMPS
+    {
+        hipStreamSynchronize(st);
+        unsigned long long* h = (unsigned long long*)malloc((size_t)n_blocks * 64);
+        hipMemcpy(h, dbg, (size_t)n_blocks * 64, hipMemcpyDeviceToHost);
+        hipFree(dbg);
+        double cyc = 0;
+        for (int64_t b = 0; b < n_blocks; ++b) cyc += (double)(h[b * 8 + 7] - h[b * 8 + 6]);
+        fprintf(stderr, "[ln3 stamps] loop: %.0f shader cycles per chunk, clock %.3f GHz\n", cyc / n_blocks / (K / kKC),
+                cyc / n_blocks / 1e3 / ([&] { double t = 0; for (int64_t b = 0; b < n_blocks; ++b) t += (double)(h[b * 8 + 2] - h[b * 8 + 1]); return t / n_blocks * 10; }()));
+        double ph[4] = {0, 0, 0, 0};
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            const unsigned long long* q = h + b * 8;
+            ph[0] += (double)(q[1] - q[0]); ph[1] += (double)(q[2] - q[1]); ph[2] += (double)(q[3] - q[2]); ph[3] += (double)(q[5] - q[3]);
+            if (q[0] < t0) t0 = q[0];
+            if (q[5] > t1) t1 = q[5];
+        }
+        // per CU (xcc, se, sh, cu from the hardware id): blocks in start order, the gap between one block's last stamp and the next one's first
+        struct Ev { unsigned long long key, s, e; };
+        Ev* ev = (Ev*)malloc((size_t)n_blocks * sizeof(Ev));
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            const unsigned long long id = h[b * 8 + 4];
+            ev[b] = {((id >> 32) << 16) | ((id >> 8) & 0xFFu) | (((id >> 13) & 7u) << 8) | (((id >> 12) & 1u) << 11), h[b * 8], h[b * 8 + 5]};
+        }
+        qsort(ev, (size_t)n_blocks, sizeof(Ev), [](const void* a, const void* b) {
+            const Ev *x = (const Ev*)a, *y = (const Ev*)b;
+            return x->key != y->key ? (x->key < y->key ? -1 : 1) : (x->s < y->s ? -1 : (x->s > y->s));
+        });
+        double gap = 0; int64_t gaps = 0, cus = n_blocks ? 1 : 0;
+        for (int64_t b = 1; b < n_blocks; ++b) {
+            if (ev[b].key == ev[b - 1].key) { gap += (double)ev[b].s - (double)ev[b - 1].e; ++gaps; } else ++cus;
+        }
+        fprintf(stderr, "[ln3 stamps] blocks %lld on %lld CUs, chunks %d: prologue %.2f us, loop %.2f us, epilogue issue %.2f us, store ack %.2f us; "
+                        "gap to the next block on the CU %.2f us (%lld gaps); first stamp to last %.1f us\n",
+                (long long)n_blocks, (long long)cus, K / kKC, ph[0] / n_blocks / 100, ph[1] / n_blocks / 100, ph[2] / n_blocks / 100,
+                ph[3] / n_blocks / 100, gaps ? gap / gaps / 100 : 0.0, (long long)gaps, (double)(t1 - t0) / 100);
+        free(ev); free(h);
+    }
+#endif
     if (kSplit) {
         const int c_tot = cg.groups * kN;
         const int64_t threads = rows * (c_tot / 8), rows_pad = (rows + kRows - 1) / kRows * kRows;
