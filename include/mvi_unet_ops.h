@@ -136,10 +136,12 @@ int mvi_linear_k320_supported(int32_t K, int32_t out_features, int32_t dtype);
 int mvi_linear_k320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
                     int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
 
-/* nn.Linear with 320 outputs and a long contraction (csrc/linear_n320.hip): out[r, n] = x[r, :] . weight[n, :] + bias[n], n < 320,
- * K a multiple of 64 (>= 128), bf16 / f16 — the second projection of the level-0 FeedForward layers (`FeedForward.net[2]`,
- * sgm/modules/attention.py:98-115: [258048, 1280] x [1280, 320]), where the library's 256-wide macro-tiles cover 320 columns with
- * 37 % padding. A block keeps all 320 outputs of its 256 rows in accumulators; same padded-output contract as mvi_ff_geglu
+/* nn.Linear with 320 g outputs and a long contraction (csrc/linear_n320.hip): out[r, n] = x[r, :] . weight[n, :] + bias[n],
+ * n < out_features = 320 g, K a multiple of 64 (>= 128), bf16 / f16 — the second projection of the FeedForward layers
+ * (`FeedForward.net[2]`, sgm/modules/attention.py:98-115: [258048, 1280] x [1280, 320] at level 0, where the library's 256-wide
+ * macro-tiles cover 320 columns with 37 % padding; round 5: [64512, 2560] x [2560, 640] and [16128, 5120] x [5120, 1280] at levels
+ * 1 and 2, and the attention output projections 640 -> 640 / 1280 -> 1280). A block keeps 320 outputs of its 256 rows in
+ * accumulators, the g column groups of a row block are neighbours in the grid; same padded-output contract as mvi_ff_geglu
  * (`out` has room for mvi_ff_geglu_out_rows(rows) rows; rows of x, weight and out 16-byte aligned). */
 int mvi_linear_n320_supported(int32_t K, int32_t out_features, int32_t dtype);
 int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,

@@ -193,7 +193,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         bid /= cg.groups;
         out += gg * kHalf;
     }
-    if (kConv && cg.groups > 1) {                    // (row block, column group): the groups of one row block run side by side
+    if (!kGeglu && cg.groups > 1) {                  // (row block, column group): the groups of one row block run side by side
         const int g = bid % cg.groups;
         bid /= cg.groups;
         w += (int64_t)g * kN * K;
@@ -661,14 +661,15 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
 }  // namespace mvi
 
 extern "C" int mvi_linear_n320_supported(int32_t K, int32_t out_features, int32_t dtype) {
-    return out_features == mvi::ln3::kN && K >= 2 * mvi::ln3::kKC && K % mvi::ln3::kKC == 0 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
+    return out_features > 0 && out_features % mvi::ln3::kN == 0 && K >= 2 * mvi::ln3::kKC && K % mvi::ln3::kKC == 0 &&
+           (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16);
 }
 
 extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity,
                                int32_t K, int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype,
                                void* stream) {
     if (rows < 0 || !mvi_linear_n320_supported(K, out_features, dtype))
-        return mvi::unet_fail(MVI_EINVAL, "linear_n320: needs out_features = 320, K a multiple of 64 (>= 128), bf16 or f16");
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320: needs out_features a multiple of 320, K a multiple of 64 (>= 128), bf16 or f16");
     if (rows == 0) return MVI_OK;
     if (!x || !weight || !out) return mvi::unet_fail(MVI_EINVAL, "linear_n320: NULL pointer");
     if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
@@ -676,11 +677,14 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
     if (x_row_stride < K || out_row_stride < out_features || x_row_stride % 8 || out_row_stride % 8 ||
         ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
         return mvi::unet_fail(MVI_EINVAL, "linear_n320: x, weight and out rows must be 16-byte aligned");
-    if ((int64_t)out_features * K * 2 > 0xFFFFFFFFll || 256 * x_row_stride * 2 > 0xFFFFFFFFll)
+    if ((int64_t)mvi::ln3::kN * K * 2 > 0xFFFFFFFFll || 256 * x_row_stride * 2 > 0xFFFFFFFFll)
         return mvi::unet_fail(MVI_EINVAL, "linear_n320: weight / row block exceeds 32-bit byte offsets");
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st)
-                                        : mvi::linear_n320_launch<__half>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st);
+    // out_features = 320 g (round 5): g column groups per row block, neighbours in the grid — the blocks of one row block read the same
+    // x rows, the first from HBM and the others from L2 (the convolutions' column groups)
+    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, out_features / mvi::ln3::kN, 1, 1, 0, 0, 0, 0};
+    const int rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
+                                        : mvi::linear_n320_launch<__half>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
     return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
 }
 

@@ -253,17 +253,32 @@ def linear_geglu(x, weight, bias=None):
 
 
 N320_KERNEL = os.environ.get("MVI_N320", "1") != "0"          # csrc/linear_n320.hip for [rows, K] x [K, 320] with rows >= FF_GEGLU_MIN_ROWS
+# Round 5: the same kernel with 320 g outputs (g column groups per row block) for the projections of levels 1 and 2 INTO 640 / 1280
+# channels — FeedForward.net[2] (K = 2560 / 5120) and the attention output projections (K = 640 / 1280) — where it was measured faster
+# than the tuned library GEMM (180 / 165 / 55 / 46 us against 215 / 189 / 80 / 57: profiles/round5_n320_groups.txt); the packed q/k/v
+# projections (1920 / 3840 outputs) tie and stay with the library, and so does everything whose grid would not fill the chip (level 3).
+N320_GROUPS = os.environ.get("MVI_N320_GROUPS", "1") != "0"
+N320_GROUP_WIDTHS = (640, 1280)
+N320_GROUP_MIN_BLOCKS = 200
 
 
 def linear(x, weight, bias=None):
     """F.linear(x, weight, bias). On the GPU, the K = 320 projections of the level-0 transformer blocks (packed q/k/v, to_out,
     proj_in / proj_out: output-bound GEMMs around a 20-step loop) take csrc/ff_geglu.hip's plain-epilogue kernel
-    (mvi_linear_k320), and the level-0 projections INTO 320 channels with a long contraction (FeedForward.net[2], K = 1280) take
-    csrc/linear_n320.hip (mvi_linear_n320); everything else is the library GEMM."""
+    (mvi_linear_k320), the level-0 projections INTO 320 channels with a long contraction (FeedForward.net[2], K = 1280) take
+    csrc/linear_n320.hip (mvi_linear_n320), and so do the projections into 640 / 1280 channels of levels 1 and 2 (N320_GROUPS above);
+    everything else is the library GEMM."""
+    if K320_KERNELS and N320_KERNEL and N320_GROUPS and x.is_cuda and weight.shape[0] in N320_GROUP_WIDTHS and x.dtype == weight.dtype \
+            and not _needs_autograd(x, weight, bias):
+        rows = x.numel() // max(x.shape[-1], 1)
+        if (rows + 255) // 256 * (weight.shape[0] // 320) >= N320_GROUP_MIN_BLOCKS:
+            from . import hip_ops
+            if hip_ops.linear_n320_supported(x.shape[-1], weight.shape[0], x.dtype):
+                return hip_ops.linear_n320(x, weight, bias)
     if K320_KERNELS and x.is_cuda and not _needs_autograd(x, weight, bias) and x.dtype == weight.dtype \
             and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
         from . import hip_ops
-        n320 = N320_KERNEL and hip_ops.linear_n320_supported(x.shape[-1], weight.shape[0], x.dtype)
+        n320 = N320_KERNEL and weight.shape[0] == 320 and hip_ops.linear_n320_supported(x.shape[-1], weight.shape[0], x.dtype)
         if n320 and x.shape[-1] == 320:            # 320 -> 320 (to_out, proj_in / proj_out): both kernels apply, this one is 6 % faster (93 / 99 us)
             return hip_ops.linear_n320(x, weight, bias)
         if hip_ops.linear_k320_supported(x.shape[-1], weight.shape[0], x.dtype):

@@ -534,8 +534,9 @@ def test_linear_n320_kernel(ops, dtype, tol):
     strided x; the dispatcher takes it only for enough rows; the library keeps every other shape."""
     from multiview_inpaint_amd.svd import ops as dev_ops
     g = torch.Generator().manual_seed(47)
-    for rows, K, with_bias, strided in [(1000, 1280, True, False), (70001, 128, False, True), (300, 192, True, False), (2561, 704, True, True)]:
-        N = 320
+    for rows, K, with_bias, strided, N in [(1000, 1280, True, False, 320), (70001, 128, False, True, 320), (300, 192, True, False, 320),
+                                           (2561, 704, True, True, 320), (1300, 640, True, False, 640), (513, 2560, True, True, 640),
+                                           (700, 1280, False, False, 1280), (257, 192, True, False, 1920)]:      # 320 g outputs: column groups
         wide = (torch.randn(rows, K + 64 if strided else K, generator=g) * 1.2).to(dtype)
         w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
         b = (torch.randn(N, generator=g) * 0.3).to(dtype) if with_bias else None
@@ -551,12 +552,21 @@ def test_linear_n320_kernel(ops, dtype, tol):
     ops.PROFILE = []
     big = dev_ops.linear(x, w)
     small = dev_ops.linear(x[:100], w)                               # too few rows: library
-    other = dev_ops.linear(x, torch.cat([w, w]))                     # 640 outputs: library
+    other = dev_ops.linear(x, torch.cat([w, w, w]))                  # 960 outputs: library (the column-group form is taken for 640 / 1280)
+    kinds = [e[0] for e in ops.PROFILE]
+    assert kinds == ["linear_n320"] and other.shape[-1] == 960
+    assert rel(big[:100], small.double()) < tol
+    # 640 outputs: the column-group form once its grid fills the chip (N320_GROUP_MIN_BLOCKS row blocks x groups), the library below
+    w2 = torch.cat([w, w])
+    ops.PROFILE = []
+    wide_grid = dev_ops.linear(x[:256 * 100], w2)                    # 100 row blocks x 2 groups
+    thin_grid = dev_ops.linear(x[:256 * 99], w2)                     # 198 blocks: library
     kinds = [e[0] for e in ops.PROFILE]
     ops.PROFILE = None
-    assert kinds == ["linear_n320"] and other.shape[-1] == 640
-    assert rel(big[:100], small.double()) < tol
-    assert not ops.linear_n320_supported(1280, 640, dtype) and not ops.linear_n320_supported(1000, 320, dtype) and not ops.linear_n320_supported(64, 320, dtype)
+    assert kinds == ["linear_n320"] and rel(wide_grid[:256 * 99], thin_grid.double()) < tol
+    assert rel(wide_grid[:, :320], big[:256 * 100].double()) < tol and rel(wide_grid[:, 320:], big[:256 * 100].double()) < tol
+    assert ops.linear_n320_supported(1280, 640, dtype) and not ops.linear_n320_supported(1280, 600, dtype)
+    assert not ops.linear_n320_supported(1000, 320, dtype) and not ops.linear_n320_supported(64, 320, dtype)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])

@@ -48,6 +48,16 @@ for (rows, K, calls) in [(BT * 9216, 1280, 21), (BT * 9216, 320, 28)]:
     ms = timed(lambda: hip_ops.linear_n320(x, w, None))
     total += ms * calls
     print(f"linear {rows} x {K} -> 320: {ms * 1e3:.0f} us {2.0 * rows * K * 320 / ms / 1e9:.0f} TF", flush=True)
+for (rows, K, N, calls) in [(BT * 2304, 2560, 640, 21), (BT * 576, 5120, 1280, 21), (BT * 2304, 640, 640, 28), (BT * 576, 1280, 1280, 28),
+                            (BT * 2304, 640, 1920, 14), (BT * 576, 1280, 3840, 14), (BT * 144, 5120, 1280, 6), (BT * 144, 1280, 1280, 8)]:
+    x = torch.randn(rows, K, device=dev, dtype=torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    b = torch.randn(N, device=dev)
+    if hip_ops.linear_n320_supported(K, N, x.dtype):
+        ms = timed(lambda: hip_ops.linear_n320(x, w, b))
+        ms_l = timed(lambda: torch.nn.functional.linear(x, w, b.bfloat16()))
+        print(f"linear {rows} x {K} -> {N}: {ms * 1e3:.0f} us {2.0 * rows * K * N / ms / 1e9:.0f} TF   | library {ms_l * 1e3:.0f} us "
+              f"{2.0 * rows * K * N / ms_l / 1e9:.0f} TF  ({calls} calls per step: {(ms_l - ms) * calls:+.2f} ms)", flush=True)
 for (rows, K, calls) in [(BT * 2304, 640, 21)]:
     x = torch.randn(rows, K, device=dev, dtype=torch.bfloat16)
     w = (torch.randn(8 * K, K, device=dev) * 0.02).bfloat16()
