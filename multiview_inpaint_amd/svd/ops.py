@@ -231,7 +231,7 @@ K320_KERNELS = os.environ.get("MVI_K320", "1") != "0"      # MVI_K320=0: library
 
 FF_GEGLU_N320 = os.environ.get("MVI_FF_GEGLU_N320", "1") != "0"
 FF_GEGLU_N320_K = (640, 1280)
-FF_GEGLU_N320_MIN_ROWS = 32768
+FF_GEGLU_N320_MIN_ROWS = int(os.environ.get("MVI_FF_GEGLU_N320_MIN_ROWS", "16000"))     # (level 2: 16 128 rows; round 5, with the 16x16x32 kernel: 385 us against 329 + 84)
 
 
 def linear_geglu(x, weight, bias=None):
@@ -239,14 +239,14 @@ def linear_geglu(x, weight, bias=None):
     On the GPU, for the shapes csrc/ff_geglu.hip covers (K = 320 in bf16 / f16: the level-0 FeedForward layers) and enough rows,
     projection and gating run as ONE kernel and the [rows, 2 inner] intermediate never exists; everything else is the library
     GEMM followed by geglu()."""
-    if K320_KERNELS and x.is_cuda and not _needs_autograd(x, weight, bias) and x.dtype == weight.dtype \
-            and x.numel() // max(x.shape[-1], 1) >= FF_GEGLU_MIN_ROWS:
+    if K320_KERNELS and x.is_cuda and not _needs_autograd(x, weight, bias) and x.dtype == weight.dtype:
         from . import hip_ops
-        if hip_ops.ff_geglu_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
+        rows = x.numel() // max(x.shape[-1], 1)
+        if rows >= FF_GEGLU_MIN_ROWS and hip_ops.ff_geglu_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
             return hip_ops.ff_geglu(x, weight, bias)
         # K = 640 / 1280 (levels 1 and 2): csrc/linear_n320.hip's GEGLU form, where it was measured faster than the library
         # GEMM + geglu_kernel (FF_GEGLU_N320_MIN_ROWS; MVI_FF_GEGLU_N320=0: library everywhere)
-        if FF_GEGLU_N320 and x.shape[-1] in FF_GEGLU_N320_K and x.numel() // x.shape[-1] >= FF_GEGLU_N320_MIN_ROWS \
+        if FF_GEGLU_N320 and x.shape[-1] in FF_GEGLU_N320_K and rows >= FF_GEGLU_N320_MIN_ROWS \
                 and hip_ops.ff_geglu_n320_supported(x.shape[-1], weight.shape[0] // 2, x.dtype):
             return hip_ops.ff_geglu_n320(x, weight, bias)
     return geglu(F.linear(x, weight, bias))
