@@ -144,6 +144,16 @@ int mvi_linear_k320(const void* x, const void* weight, const float* bias, void* 
  * accumulators, the g column groups of a row block are neighbours in the grid; same padded-output contract as mvi_ff_geglu
  * (`out` has room for mvi_ff_geglu_out_rows(rows) rows; rows of x, weight and out 16-byte aligned). */
 int mvi_linear_n320_supported(int32_t K, int32_t out_features, int32_t dtype);
+/* The same projection into 320 channels with the residual add(s) and the LayerNorm that follow it in the transformer blocks run in
+ * the epilogue (sgm/modules/attention.py:544-572 `x = attn1(norm1(x)) + x; ... self.ff(self.norm3(x))`, video_attention.py:110-141):
+ *     h = round(x W^T + bias);  s_pre = round(resid + h);  s = round(s_pre + row[r / row_div]);  y = LayerNorm(s) * ln_weight + ln_bias
+ * — the arithmetic and rounding points of mvi_add_layernorm behind mvi_linear_n320, without h, and without the read-back of resid + h.
+ * resid [rows, 320] or NULL (then s_pre = h); row [G, 320] or NULL; s_pre / s [capacity, 320] or NULL (not stored); y [capacity, 320].
+ * resid, s_pre, s and y have rows of out_row_stride elements; the outputs are padded to whole 256-row blocks like mvi_linear_n320's. */
+int mvi_linear_n320_add_layernorm(const void* x, const void* weight, const float* bias, int64_t rows, int64_t out_rows_capacity, int32_t K,
+                                  int64_t x_row_stride, const void* resid, const void* row, int64_t row_div, const float* ln_weight,
+                                  const float* ln_bias, float eps, void* s_pre, void* s, void* y, int64_t out_row_stride, int32_t dtype,
+                                  void* stream);
 int mvi_linear_n320(const void* x, const void* weight, const float* bias, void* out, int64_t rows, int64_t out_rows_capacity, int32_t K,
                     int32_t out_features, int64_t x_row_stride, int64_t out_row_stride, int32_t dtype, void* stream);
 

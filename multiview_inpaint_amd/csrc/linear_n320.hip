@@ -162,10 +162,25 @@ __device__ __forceinline__ float geglu1(float v, float g) {
     return v * __builtin_fmaf(__builtin_fabsf(hg), erf_abs, hg);
 }
 
-template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false>
+// kLn (round 5): the projection's output never reaches memory — the residual add(s) and the LayerNorm that FOLLOW it in the transformer
+// blocks (attention.py:544-572 `x = attn1(norm1(x)) + x; ... norm3(x)`, video_attention.py:110-141) run in the epilogue, on the
+// arithmetic of csrc/token_rows.hip's add_layernorm (which this replaces at level 0, where a block holds whole rows of 320):
+//     h = round(x W^T + bias);  s_pre = round(resid + h);  s = round(s_pre + row[r / row_div]);  y = LayerNorm(s) * ln_w + ln_b
+// resid / row optional (without resid: s_pre = h); s_pre / s are stored when asked for, y always (`out`). All of resid, s_pre, s, y
+// are [rows, 320] in rows of o_rs elements (the outputs padded to whole blocks like `out`).
+struct LnEpi {
+    const void *resid, *row;                         // [rows, 320] or NULL; [G, 320] or NULL (row r takes row[r / row_div])
+    int64_t row_div;
+    const float *w, *b;                              // LayerNorm weight / bias [320]
+    void *s_pre, *s;                                 // optional outputs
+    float eps;
+};
+
+template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part, GnStats gn) {
+                        int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part, GnStats gn,
+                        LnEpi ln = {nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, 0.f}) {
     using M = Mma<T>;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
@@ -478,6 +493,94 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
     const int64_t orow_bytes = o_rs * 2;
     const int64_t st_off = (int64_t)(lane >> 3) * orow_bytes + (lane & 7) * 16;
+    if constexpr (kLn) {
+        // In the STORE layout: after a flush's four column tiles went through the LDS tile, lane (lr = lane / 8, lc = lane % 8) reads
+        // columns 64 f + 8 lc .. + 7 of rows 8 i + lr (i < 4) as 16 bytes — the layout a coalesced load of the residual has too.
+        // The row's 320 values stay in registers packed (5 flushes x 4 rows x 4 dwords, while the accumulators they came from die);
+        // a row is spread over the 8 lanes of equal lr: mean and centred sum of squares by xor shuffles, two passes over registers as
+        // in add_layernorm_kernel.
+        const int lr = lane >> 3, lc = lane & 7;
+        const T* const resid = (const T*)ln.resid;
+        const T* const rowv = (const T*)ln.row;
+        int64_t rd[4], rw[4];                                    // element offsets of the lane's rows in resid (clamped) and in row[]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = row0 + 8 * i + lr, rc = r < rows ? r : rows - 1;
+            rd[i] = rc * o_rs + 8 * lc;
+            rw[i] = rowv ? (rc / ln.row_div) * kN + 8 * lc : 0;
+        }
+        u32x4 sv[kNT / 4][4];
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < kNT / 4; ++f) {
+            // (asking for flush f + 1's pieces a flush ahead, and for all LayerNorm weights before the statistics, was measured 5 %
+            // SLOWER: the epilogue is bound by the bytes — all 256 blocks of a round reach it together — not by latency)
+            u32x4 rx[4], rr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (resid) rx[i] = *reinterpret_cast<const u32x4*>(resid + rd[i] + 64 * f);
+                if (rowv) rr[i] = *reinterpret_cast<const u32x4*>(rowv + rw[i] + 64 * f);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) tile_put(t, jj, r, M::pack2(acc[t][4 * f + jj][r], acc[t][4 * f + jj][r + 1]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4 v = *reinterpret_cast<MVI_AS3 const u32x4*>(lds + ot_r(i));         // h, rounded
+                const int64_t o_off = (8 * i) * orow_bytes + st_off + f * 128;
+                if (resid) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = M::pack2(M::lo(rx[i][k]) + M::lo(v[k]), M::hi(rx[i][k]) + M::hi(v[k]));
+                }
+                if (ln.s_pre) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>((T*)ln.s_pre + row0 * o_rs) + o_off) = v;
+                if (rowv) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = M::pack2(M::lo(v[k]) + M::lo(rr[i][k]), M::hi(v[k]) + M::hi(rr[i][k]));
+                }
+                if (ln.s) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>((T*)ln.s + row0 * o_rs) + o_off) = v;
+                sv[f][i] = v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sum[i] += M::lo(v[k]) + M::hi(v[k]);
+            }
+        }
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = sum[i];
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+            mean[i] = t / (float)kN;
+            float m2 = 0.f;
+#pragma unroll
+            for (int f = 0; f < kNT / 4; ++f)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d0 = M::lo(sv[f][i][k]) - mean[i], d1 = M::hi(sv[f][i][k]) - mean[i];
+                    m2 = __builtin_fmaf(d0, d0, __builtin_fmaf(d1, d1, m2));
+                }
+            m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 4);
+            rstd[i] = rsqrtf(m2 / (float)kN + ln.eps);
+        }
+#pragma unroll
+        for (int f = 0; f < kNT / 4; ++f) {
+            const float4* const wp = reinterpret_cast<const float4*>(ln.w + 64 * f + 8 * lc);
+            const float4* const bp = reinterpret_cast<const float4*>(ln.b + 64 * f + 8 * lc);
+            const float4 w0 = wp[0], w1 = wp[1], b0 = bp[0], b1 = bp[1];
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = M::pack2((M::lo(sv[f][i][k]) - mean[i]) * rstd[i] * wv[2 * k] + bv[2 * k],
+                                    (M::hi(sv[f][i][k]) - mean[i]) * rstd[i] * wv[2 * k + 1] + bv[2 * k + 1]);
+                *reinterpret_cast<u32x4*>(obase + (8 * i) * orow_bytes + st_off + f * 128) = o;
+            }
+        }
+        return;
+    }
     float cs1[kStats ? kNT : 1], cs2[kStats ? kNT : 1];          // kStats: per column tile, sum and sum of squares of this lane's 8 rows
 #pragma unroll
     for (int j = 0; j < (kStats ? kNT : 1); ++j) cs1[j] = cs2[j] = 0.f;
@@ -585,17 +688,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace ln3
 
-template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false>
+template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
                               hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0}, float* part = nullptr,
-                              ln3::GnStats gn = {nullptr, nullptr, 0, 0}) {
+                              ln3::GnStats gn = {nullptr, nullptr, 0, 0},
+                              ln3::LnEpi ln = {nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, 0.f}) {
     using namespace ln3;
     const int64_t n_blocks = (rows + kRows - 1) / kRows * cg.groups * cg.ksplit;
     if (n_blocks > 0x7FFFFFFFll) return MVI_EINVAL;
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu>;
+    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn>;
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
@@ -608,7 +712,7 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dbg, sizeof dbg);
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
-                       o_rs, (int)n_blocks, cg, part, gn);
+                       o_rs, (int)n_blocks, cg, part, gn, ln);
 #if LN3_STAMPS
     {
         hipStreamSynchronize(st);
@@ -686,6 +790,35 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
     const int rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
                                         : mvi::linear_n320_launch<__half>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
     return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
+}
+
+// Projection into 320 channels + residual add(s) + LayerNorm in one kernel: see kLn at the kernel
+extern "C" int mvi_linear_n320_add_layernorm(const void* x, const void* weight, const float* bias, int64_t rows, int64_t out_rows_capacity,
+                                             int32_t K, int64_t x_row_stride, const void* resid, const void* row, int64_t row_div,
+                                             const float* ln_weight, const float* ln_bias, float eps, void* s_pre, void* s, void* y,
+                                             int64_t out_row_stride, int32_t dtype, void* stream) {
+    if (rows < 0 || !mvi_linear_n320_supported(K, mvi::ln3::kN, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320_add_layernorm: needs K a multiple of 64 (>= 128), bf16 or f16 (320 outputs)");
+    if (rows == 0) return MVI_OK;
+    if (!x || !weight || !y || !ln_weight || !ln_bias) return mvi::unet_fail(MVI_EINVAL, "linear_n320_add_layernorm: NULL pointer");
+    if (row && row_div <= 0) return mvi::unet_fail(MVI_EINVAL, "linear_n320_add_layernorm: row_div must be positive");
+    if (out_rows_capacity < mvi_ff_geglu_out_rows(rows))
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320_add_layernorm: the outputs need room for mvi_ff_geglu_out_rows(rows) rows");
+    if (x_row_stride < K || out_row_stride < mvi::ln3::kN || x_row_stride % 8 || out_row_stride % 8 ||
+        ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)row | (uintptr_t)s_pre | (uintptr_t)s |
+         (uintptr_t)ln_weight | (uintptr_t)ln_bias) % 16)
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320_add_layernorm: every row (and the LayerNorm vectors) must be 16-byte aligned");
+    if ((int64_t)mvi::ln3::kN * K * 2 > 0xFFFFFFFFll || 256 * x_row_stride * 2 > 0xFFFFFFFFll)
+        return mvi::unet_fail(MVI_EINVAL, "linear_n320_add_layernorm: weight / row block exceeds 32-bit byte offsets");
+    const mvi::ln3::LnEpi ln = {resid, row, row ? row_div : 1, ln_weight, ln_bias, s_pre, s, eps};
+    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == MVI_DT_BF16
+                       ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, false, true>(x, weight, bias, y, rows, K, x_row_stride,
+                                                                                                   out_row_stride, st, cg, nullptr, {nullptr, nullptr, 0, 0}, ln)
+                       : mvi::linear_n320_launch<__half, false, false, false, false, true>(x, weight, bias, y, rows, K, x_row_stride, out_row_stride, st,
+                                                                                           cg, nullptr, {nullptr, nullptr, 0, 0}, ln);
+    return rc ? mvi::unet_fail(rc, "linear_n320_add_layernorm: kernel launch failed") : MVI_OK;
 }
 
 // GEGLU projection with a long contraction (the level-1 / level-2 FeedForward layers): see kGeglu at the kernel

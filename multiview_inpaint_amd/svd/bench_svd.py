@@ -243,7 +243,7 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     ops = {}
     for kind, (calls, ms, work) in prof.items():
         per_step_ms = ms / steps
-        if kind in ("attention_mfma", "attention_rowtile", "ff_geglu", "ff_geglu_n320", "linear_n320", "conv3x3_n320", "conv3t_n320"):   # MFMA kernels: work = FLOPs
+        if kind in ("attention_mfma", "attention_rowtile", "ff_geglu", "ff_geglu_n320", "linear_n320", "linear_n320_ln", "conv3x3_n320", "conv3t_n320"):   # MFMA kernels: work = FLOPs
             tf = work / (ms * 1e-3) / 1e12
             ops[kind] = dict(calls_per_step=calls // steps, ms_per_step=round(per_step_ms, 3), TFLOPs=round(tf, 1),
                              frac_of_bf16_mfma_peak=round(tf / MFMA_BF16_PEAK_TFLOPS, 4))

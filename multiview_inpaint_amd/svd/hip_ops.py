@@ -408,6 +408,51 @@ def linear_n320(x, weight, bias):
     return full[:rows].reshape(*x.shape[:-1], N)
 
 
+def linear_n320_add_layer_norm(x, weight, bias, ln_weight, ln_bias, eps, resid=None, row=None, ret_pre=False):
+    """add_layer_norm(resid, h=F.linear(x, weight, bias), row=row) with the projection in the same kernel (mvi_linear_n320_add_layernorm):
+    x [..., K], weight [320, K]; resid [..., 320] or None (then the sum starts from h); row [G, 320] / [G, 1, 320] or None.
+    Returns (y, s, s_pre) like add_layer_norm: s the residual stream after the adds (h itself without resid and row), s_pre = resid + h
+    only with ret_pre."""
+    L = _lib.lib()
+    K, N = x.shape[-1], weight.shape[0]
+    xc = x.reshape(-1, K)
+    if xc.stride(1) != 1 or xc.stride(0) % 8 or xc.data_ptr() % 16:
+        xc = xc.contiguous()
+    wc = weight if weight.is_contiguous() else weight.contiguous()
+    rows = xc.shape[0]
+    cap = int(L.mvi_ff_geglu_out_rows(rows))
+    rc, rowc, row_div = None, None, 1
+    if resid is not None:
+        if resid.shape[-1] != N or resid.numel() != rows * N or resid.dtype != x.dtype:
+            raise ValueError("linear_n320_add_layer_norm: resid must be [rows, 320] of x's dtype")
+        rc = resid.reshape(rows, N)
+        rc = rc if rc.is_contiguous() and rc.data_ptr() % 16 == 0 else rc.contiguous()
+    if row is not None:
+        if row.dtype != x.dtype or row.shape[-1] != N:
+            raise ValueError("linear_n320_add_layer_norm: row must be [G, 320] / [G, 1, 320] of x's dtype")
+        rowc = row.reshape(-1, N)
+        rowc = rowc if rowc.is_contiguous() and rowc.data_ptr() % 16 == 0 else rowc.contiguous().clone()
+        G = rowc.shape[0]
+        if G == 0 or rows % G:
+            raise ValueError(f"linear_n320_add_layer_norm: {rows} rows do not split into {G} equal runs")
+        row_div = rows // G
+    y = torch.empty(cap, N, dtype=x.dtype, device=x.device)
+    s = torch.empty(cap, N, dtype=x.dtype, device=x.device)
+    s_pre = torch.empty(cap, N, dtype=x.dtype, device=x.device) if (ret_pre and rowc is not None) else None
+    b = None if bias is None else _f32(bias)
+    with torch.cuda.device(x.device), _Timed("linear_n320_ln", 2.0 * rows * K * N, x.device):
+        _check(L.mvi_linear_n320_add_layernorm(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), rows, cap, K, xc.stride(0),
+                                               None if rc is None else rc.data_ptr(), None if rowc is None else rowc.data_ptr(), row_div,
+                                               _f32(ln_weight).data_ptr(), _f32(ln_bias).data_ptr(), float(eps),
+                                               None if s_pre is None else s_pre.data_ptr(), s.data_ptr(), y.data_ptr(), N, _DT[x.dtype],
+                                               _stream(x.device)), "linear_n320_add_layer_norm")
+    shape = (*x.shape[:-1], N)
+    s = s[:rows].reshape(shape)
+    if ret_pre:
+        s_pre = s if s_pre is None else s_pre[:rows].reshape(shape)
+    return y[:rows].reshape(shape), s, s_pre
+
+
 def conv3x3_n320_supported(C_in, C_out, dtype):
     return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().mvi_conv3x3_n320_supported(int(C_in), int(C_out), _DT[dtype]))
 

@@ -367,6 +367,43 @@ def add_layer_norm(x, norm, h=None, row=None, ret_pre=False):
     return norm(s), s, (s_pre if ret_pre else None)
 
 
+LN_EPILOGUE = os.environ.get("MVI_LN_EPILOGUE", "1") != "0"    # MVI_LN_EPILOGUE=0: projection and add + LayerNorm as two kernels (same-box A/B)
+
+
+def _plain_linear(mod):
+    if isinstance(mod, torch.nn.Sequential) and len(mod) == 2 and isinstance(mod[0], torch.nn.Linear) \
+            and isinstance(mod[1], torch.nn.Dropout) and not (mod[1].training and mod[1].p > 0):
+        return mod[0]
+    return mod if type(mod) is torch.nn.Linear else None
+
+
+def linear_add_layer_norm(lin_in, lin_mod, resid, norm, row=None, ret_pre=False):
+    """add_layer_norm(resid, norm, h=lin_mod(lin_in), row=row, ret_pre=ret_pre) — the projection that ends an attention / FeedForward
+    layer, the residual add(s) behind it and the LayerNorm of the NEXT layer (attention.py:544-572, video_attention.py:110-141).
+    With resid None the sum starts from the projection itself (proj_in followed by norm1). On the GPU at the level-0 width (320
+    outputs: a block of csrc/linear_n320.hip holds whole rows) all of it is ONE kernel: the projection's result and its read-back
+    never touch memory (hip_ops.linear_n320_add_layer_norm); everywhere else it is linear_module + add_layer_norm."""
+    lin = _plain_linear(lin_mod)
+    if LN_EPILOGUE and K320_KERNELS and N320_KERNEL and lin is not None and lin_in.is_cuda and lin.out_features == 320 \
+            and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and tuple(norm.normalized_shape) == (320,) \
+            and lin_in.dtype == lin.weight.dtype and lin_in.numel() // max(lin_in.shape[-1], 1) >= FF_GEGLU_MIN_ROWS \
+            and not _needs_autograd(lin_in, lin.weight, lin.bias, resid, row, norm.weight, norm.bias):
+        from . import hip_ops
+        if hip_ops.linear_n320_supported(lin_in.shape[-1], 320, lin_in.dtype) and (resid is None or resid.dtype == lin_in.dtype) \
+                and (row is None or row.dtype == lin_in.dtype):
+            return hip_ops.linear_n320_add_layer_norm(lin_in, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, resid=resid, row=row,
+                                                      ret_pre=ret_pre)
+    return finish_add_layer_norm(linear_module(lin_mod, lin_in), dict(resid=resid, norm=norm, row=row, ret_pre=ret_pre))
+
+
+def finish_add_layer_norm(h, fuse):
+    """The unfused form of a `fuse` request ({resid, norm, row, ret_pre}) for a layer output h that already exists."""
+    resid, row, ret_pre = fuse.get("resid"), fuse.get("row"), fuse.get("ret_pre", False)
+    if resid is None:
+        return add_layer_norm(h, fuse["norm"], row=row, ret_pre=ret_pre)
+    return add_layer_norm(resid, fuse["norm"], h=h, row=row, ret_pre=ret_pre)
+
+
 def add_lerp(x, h, base, alpha):
     """lerp(x + h, base, alpha): alpha * base + (1 - alpha) * (x + h) with alpha [G] broadcast over equal runs of
     the rows of x [B, S, C] (AlphaBlender after the temporal block's last residual add)."""

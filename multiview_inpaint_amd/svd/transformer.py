@@ -43,11 +43,17 @@ class FeedForward(nn.Module):
         first = GEGLU(dim, inner) if glu else nn.Sequential(nn.Linear(dim, inner), nn.GELU())
         self.net = nn.Sequential(first, nn.Dropout(dropout), nn.Linear(inner, dim if dim_out is None else dim_out))
 
-    def forward(self, x):
+    def forward(self, x, fuse=None):
         # (Dropout is the identity at inference; the output projection goes through ops.linear, which takes the MFMA kernel of
         # csrc/linear_n320.hip for the level-0 shape [258048, 1280] x [1280, 320] and is F.linear everywhere else)
+        # fuse = {resid, norm, row, ret_pre}: the residual add(s) and the LayerNorm that follow this layer ride on its output projection
+        # (ops.linear_add_layer_norm); the result is then add_layer_norm's (y, s, s_pre)
         if self.training and self.net[1].p > 0:
-            return self.net(x)
+            h = self.net(x)
+            return h if fuse is None else ops.finish_add_layer_norm(h, fuse)
+        if fuse is not None:
+            return ops.linear_add_layer_norm(self.net[0](x), self.net[2], fuse.get("resid"), fuse["norm"], row=fuse.get("row"),
+                                             ret_pre=fuse.get("ret_pre", False))
         return ops.linear_module(self.net[2], self.net[0](x))
 
 
@@ -63,7 +69,15 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
         self.backend = backend
 
-    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
+    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0, fuse=None):
+        """fuse = {resid, norm, row, ret_pre} (FeedForward.forward): the result is add_layer_norm's (y, s, s_pre) instead of the layer output."""
+        if fuse is not None:
+            if context is None and not n_times_crossframe_attn_in_self and additional_tokens is None and mask is None \
+                    and ops.packed_ok(x, self.heads, self.dim_head):
+                w, q_log2 = self._packed_qkv_weight(x.dtype, fold=ops.attention_scale_fold_pays(x, self.dim_head))
+                return ops.linear_add_layer_norm(ops.attention_packed(ops.linear(x, w), self.heads, q_log2=q_log2), self.to_out,
+                                                 fuse.get("resid"), fuse["norm"], row=fuse.get("row"), ret_pre=fuse.get("ret_pre", False))
+            return ops.finish_add_layer_norm(self.forward(x, context, mask, additional_tokens, n_times_crossframe_attn_in_self), fuse)
         if mask is not None:
             raise NotImplementedError("attention masks are not part of the SVD denoise path")
         n_extra = 0
@@ -120,12 +134,17 @@ class CrossAttention(nn.Module):
             setattr(self, slot, hit)
         return hit[1], hit[2]
 
-    def forward_temporal(self, x, T):
-        """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back."""
+    def forward_temporal(self, x, T, fuse=None):
+        """Self-attention over frames for x [(b t), s, c] in place of regroup -> forward -> regroup back (fuse: see forward)."""
         if ops.packed_ok(x, self.heads, self.dim_head) and self.to_k.in_features == self.to_q.in_features:
             w, q_log2 = self._packed_qkv_weight(x.dtype)      # (plain: T keys per softmax, nothing to gain from the fold)
-            return ops.linear_module(self.to_out, ops.attention_temporal_packed(ops.linear(x, w), self.heads, T, q_log2=q_log2))
-        return self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
+            o = ops.attention_temporal_packed(ops.linear(x, w), self.heads, T, q_log2=q_log2)
+            if fuse is not None:
+                return ops.linear_add_layer_norm(o, self.to_out, fuse.get("resid"), fuse["norm"], row=fuse.get("row"),
+                                                 ret_pre=fuse.get("ret_pre", False))
+            return ops.linear_module(self.to_out, o)
+        h = self.to_out(ops.attention_temporal(self.to_q(x), self.to_k(x), self.to_v(x), self.heads, T))
+        return h if fuse is None else ops.finish_add_layer_norm(h, fuse)
 
     def single_token(self, ctx):
         """Cross-attention to ONE context token: the projected value row (see forward)."""
@@ -168,19 +187,26 @@ class BasicTransformerBlock(nn.Module):
         h, skip = self.forward_deferred(x, context)
         return h + skip
 
-    def forward_deferred(self, x, context=None):
+    def forward_deferred(self, x, context=None, n1=None, ff_fuse=None):
         """The block with its last residual add left to the caller: returns (h, skip), block output = h + skip.
-        Every inner residual add is fused with the LayerNorm that follows it (ops.add_layer_norm). With a
-        single context token the cross-attention output is one row per image (CrossAttention.forward), norm2
-        cannot influence it and is not evaluated, and both inner adds collapse into one pass."""
-        n1, _, _ = ops.add_layer_norm(x, self.norm1)
-        a = self.attn1(n1, context=context if self.disable_self_attn else None)
+        Every inner residual add is fused with the LayerNorm that follows it — and both ride on the output projection of the layer
+        that produced the addend (CrossAttention / FeedForward `fuse`: one kernel at the level-0 width, linear + add_layer_norm
+        elsewhere). With a single context token the cross-attention output is one row per image (CrossAttention.forward), norm2
+        cannot influence it and is not evaluated, and both inner adds collapse into one pass.
+        n1: norm1(x) when the caller already has it (the stem's proj_in carries it). ff_fuse = {norm, row, ret_pre}: the caller's NEXT
+        add + LayerNorm (the temporal block's entry) rides on this block's FeedForward; the return value is then
+        add_layer_norm(skip, norm, h=h, row=row, ret_pre=ret_pre)'s (y, s, s_pre) instead of (h, skip)."""
+        if n1 is None:
+            n1, _, _ = ops.add_layer_norm(x, self.norm1)
         ctx = x if context is None else context
+        self_ctx = context if self.disable_self_attn else None
         if context is not None and ctx.shape[1] == 1:
-            n3, x, _ = ops.add_layer_norm(x, self.norm3, h=a, row=self.attn2.single_token(ctx))
+            n3, x, _ = self.attn1(n1, context=self_ctx, fuse=dict(resid=x, norm=self.norm3, row=self.attn2.single_token(ctx)))
         else:
-            n2, x, _ = ops.add_layer_norm(x, self.norm2, h=a)
-            n3, x, _ = ops.add_layer_norm(x, self.norm3, h=self.attn2(n2, context=context))
+            n2, x, _ = self.attn1(n1, context=self_ctx, fuse=dict(resid=x, norm=self.norm2))
+            n3, x, _ = self.attn2(n2, context=context, fuse=dict(resid=x, norm=self.norm3))
+        if ff_fuse is not None:
+            return self.ff(n3, fuse=dict(ff_fuse, resid=x))
         return self.ff(n3), x
 
 
@@ -275,7 +301,7 @@ class VideoTransformerBlock(nn.Module):
     def forward(self, x, context=None, timesteps=None):
         return maybe_checkpoint(lambda a, c: self._forward(a, c, timesteps), self.checkpoint, x, context)
 
-    def forward_in_place_layout(self, h, skip, emb, frame_context, timesteps):
+    def forward_in_place_layout(self, h, skip, emb, frame_context, timesteps, entry=None):
         """Same block on tokens [(b t), s, c] WITHOUT regrouping to (b s) t c: LayerNorm, the feed-forwards
         and the projections are per-token, the frame self-attention reads its T rows with a stride
         (ops.attention_temporal), and the cross-attention sees one context token per video (`frame_context`
@@ -288,20 +314,23 @@ class VideoTransformerBlock(nn.Module):
         Every residual / broadcast add rides on the LayerNorm that follows it."""
         assert not self.disable_self_attn and not self.switch_temporal_ca_to_sa
         T = int(self.timesteps or timesteps)
+        # entry: (norm(s), s, x_spatial) with x_spatial = h + skip, s = x_spatial + emb — from the spatial block's FeedForward when the
+        # caller had it carry them (`entry`: BasicTransformerBlock.forward_deferred(ff_fuse=...) with self.entry_norm)
+        if entry is None:
+            entry = ops.add_layer_norm(skip, self.entry_norm, h=h, row=emb, ret_pre=True)
         if self.ff_in:
-            ni, x, x_spatial = ops.add_layer_norm(skip, self.norm_in, h=h, row=emb, ret_pre=True)
-            fi = self.ff_in(ni)
-            if self.is_res:
-                n1, x, _ = ops.add_layer_norm(x, self.norm1, h=fi)
-            else:
-                x = fi
-                n1, _, _ = ops.add_layer_norm(x, self.norm1)
+            ni, x, x_spatial = entry
+            n1, x, _ = self.ff_in(ni, fuse=dict(resid=x if self.is_res else None, norm=self.norm1))
         else:
-            n1, x, x_spatial = ops.add_layer_norm(skip, self.norm1, h=h, row=emb, ret_pre=True)
-        a = self.attn1.forward_temporal(n1, T)
+            n1, x, x_spatial = entry
         row = self.attn2.single_token(frame_context) if self.attn2 is not None else None     # [b, 1, c]
-        n3, x, _ = ops.add_layer_norm(x, self.norm3, h=a, row=row)
+        n3, x, _ = self.attn1.forward_temporal(n1, T, fuse=dict(resid=x, norm=self.norm3, row=row))
         return x_spatial, self.ff(n3), (x if self.is_res else None)
+
+    @property
+    def entry_norm(self):
+        """The LayerNorm the block's input meets first (norm_in in front of ff_in, else norm1)."""
+        return self.norm_in if self.ff_in else self.norm1
 
     def _forward(self, x, context=None, timesteps=None):
         assert self.timesteps or timesteps
@@ -384,13 +413,20 @@ class SpatialVideoTransformer(SpatialTransformer):
             time_context = time_context.repeat_interleave(h * w, dim=0)
             if time_context.ndim == 2:
                 time_context = time_context[:, None]
-        t = self._tokens_in(x)
+        n1 = None
+        if in_place and self.use_linear:
+            # the stem's projection carries the first block's norm1 (one kernel at the level-0 width)
+            n1, t, _ = ops.linear_add_layer_norm(self.norm.forward_tokens(x), self.proj_in, None, self.transformer_blocks[0].norm1)
+        else:
+            t = self._tokens_in(x)
         emb = self.time_pos_embed(self._frame_embedding(T, x.shape[0] // T, x.device))[:, None, :]
         alpha = None
         for blk, mix in zip(self.transformer_blocks, self.time_stack):
             if in_place:
-                h_sp, skip = blk.forward_deferred(t, context)
-                x_spatial, f, x_t = mix.forward_in_place_layout(h_sp, skip, emb, frame_context, T)
+                # the spatial block's FeedForward carries the temporal block's entry: + skip, + frame embedding, LayerNorm
+                entry = blk.forward_deferred(t, context, n1=n1, ff_fuse=dict(norm=mix.entry_norm, row=emb, ret_pre=True))
+                n1 = None
+                x_spatial, f, x_t = mix.forward_in_place_layout(None, None, emb, frame_context, T, entry=entry)
                 if alpha is None:
                     alpha = self.time_mixer.get_alpha(image_only_indicator)
                     if alpha.numel() > 1 and alpha.size(0) != t.size(0):

@@ -527,6 +527,76 @@ def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_linear_n320_with_the_add_and_layernorm_behind_it_in_the_epilogue(ops, dtype, tol):
+    """mvi_linear_n320_add_layernorm — the projection that ends an attention / FeedForward layer with the residual add(s) and the NEXT
+    LayerNorm in its epilogue (attention.py:544-572, video_attention.py:110-141) — against the two kernels it replaces
+    (linear_n320 + add_layernorm: the residual stream s and s_pre BIT-EQUAL, the same rounding points; y within two ulps of the
+    storage type, the row sums are taken in another order) and against fp64 on the same rounded inputs: with residual + broadcast
+    row + s_pre (the temporal block's entry), residual only, residual + row, neither (proj_in -> norm1); ragged rows (a last block
+    of 232 rows / 1 row), K = 320 and 1280, a strided x. Then through the dispatcher (ops.linear_add_layer_norm): one kernel for
+    enough rows, the two-kernel form below, MVI_LN_EPILOGUE's switch."""
+    from multiview_inpaint_amd.svd import ops as dev_ops
+    g = torch.Generator().manual_seed(53)
+    N = 320
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for rows, K, G, with_resid, ret_pre, strided in [(1000, 1280, 4, True, True, False), (2561, 320, 0, True, False, True),
+                                                     (512, 320, 2, True, False, False), (769, 1280, 0, False, False, False),
+                                                     (768, 192, 3, False, True, False)]:
+        wide = (torch.randn(rows, K + 64 if strided else K, generator=g) * 1.1).to(dtype)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+        b = (torch.randn(N, generator=g) * 0.3).to(dtype)
+        lw, lb = torch.randn(N, generator=g) * 0.5 + 1.0, torch.randn(N, generator=g) * 0.2
+        resid = (torch.randn(rows, N, generator=g) * 1.5).to(dtype) if with_resid else None
+        row = (torch.randn(G, 1, N, generator=g)).to(dtype) if G else None
+        xs = wide.cuda()[:, :K]
+        args = dict(resid=None if resid is None else resid.cuda(), row=None if row is None else row.cuda(), ret_pre=ret_pre)
+        y, s_, sp = ops.linear_n320_add_layer_norm(xs, w.cuda(), b.cuda(), lw.cuda(), lb.cuda(), 1e-5, **args)
+        h = ops.linear_n320(xs, w.cuda(), b.cuda())
+        if with_resid:
+            y2, s2, sp2 = ops.add_layer_norm(args["resid"], lw.cuda(), lb.cuda(), 1e-5, h=h, row=args["row"], ret_pre=ret_pre)
+        else:
+            y2, s2, sp2 = ops.add_layer_norm(h, lw.cuda(), lb.cuda(), 1e-5, row=args["row"], ret_pre=ret_pre)
+            s2 = h if s2 is None else s2
+        assert y.shape == (rows, N) and y.dtype == dtype and s_.shape == (rows, N)
+        assert torch.equal(s_, s2), (rows, K, G)
+        if ret_pre:
+            assert torch.equal(sp, sp2), (rows, K, G)
+        else:
+            assert sp is None
+        scale = y2.float().abs().max().item()
+        assert (y.float() - y2.float()).abs().max().item() <= 2 * ulp * scale, (rows, K, G)
+        # fp64 on the same rounded inputs, the sums rounded where the storage type rounds them
+        hd = F.linear(wide[:, :K].double(), w.double(), b.double()).to(dtype).double()
+        sd = hd if resid is None else (resid.double() + hd).to(dtype).double()
+        if row is not None:
+            sd = (sd.reshape(G, rows // G, N) + row.double().reshape(G, 1, N)).reshape(rows, N).to(dtype).double()
+        ref = F.layer_norm(sd, (N,), lw.double(), lb.double(), 1e-5)
+        assert rel(y, ref) < tol
+    # the dispatcher
+    lin = torch.nn.Linear(1280, 320).to(dtype).cuda()
+    norm = torch.nn.LayerNorm(320).to(dtype).cuda()
+    x = torch.randn(dev_ops.FF_GEGLU_MIN_ROWS, 1280, generator=g).to(dtype).cuda()
+    r = torch.randn(dev_ops.FF_GEGLU_MIN_ROWS, 320, generator=g).to(dtype).cuda()
+    with torch.no_grad():
+        ops.PROFILE = []
+        y, s_, _ = dev_ops.linear_add_layer_norm(x, lin, r, norm)
+        y3, s3, _ = dev_ops.linear_add_layer_norm(x[:1000], lin, r[:1000], norm)           # too few rows: two kernels
+        kinds = [e[0] for e in ops.PROFILE]
+        assert kinds == ["linear_n320_ln", "add_layernorm"], kinds
+        assert rel(s_[:1000], s3.double()) < tol and rel(y[:1000], y3.double()) < tol       # (the library GEMM behind s3 sums in another order)
+        dev_ops.LN_EPILOGUE = False
+        try:
+            ops.PROFILE = []
+            y4, s4, _ = dev_ops.linear_add_layer_norm(x, lin, r, norm)
+            kinds = [e[0] for e in ops.PROFILE]
+        finally:
+            dev_ops.LN_EPILOGUE = True
+            ops.PROFILE = None
+        assert kinds == ["linear_n320", "add_layernorm"], kinds
+        assert torch.equal(s_, s4) and (y.float() - y4.float()).abs().max().item() <= 2 * ulp * y4.float().abs().max().item()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_linear_n320_kernel(ops, dtype, tol):
     """nn.Linear INTO 320 channels with a long contraction (csrc/linear_n320.hip: outputs stationary in accumulators, K streamed
     in chunks of 64 through an LDS ring): against fp64 and against the library GEMM, ragged rows (a last block of 232 / 1 / 44
