@@ -34,7 +34,6 @@ namespace mvi {
 int unet_fail(int code, const char* msg);
 namespace ffg {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -46,7 +45,7 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define MVI_AS3 __attribute__((address_space(3)))
 
 constexpr int kK = 320;                              // contraction length
-constexpr int kKS = kK / 16;                         // MFMA k-steps
+constexpr int kKS = kK / 32;                         // MFMA k-steps (v_mfma_f32_16x16x32)
 constexpr int kWaves = 8;
 constexpr int kRows = 32 * kWaves;                   // x rows per block
 constexpr int kStep = 32;                            // outputs per step
@@ -58,9 +57,10 @@ constexpr int kLoaders = 4;
 constexpr int kPiecesPerLoader = kPieces / kLoaders; // 10
 
 template <typename T> struct Mma;
+// c += A B on v_mfma_f32_16x16x32, IN PLACE and in program order (tied inline assembly: csrc/linear_n320.hip, Mma, says why). The compiler
+// does not know these are matrix instructions: the wait states around ordinary reads / writes of an accumulator are written out below.
 template <> struct Mma<__hip_bfloat16> {
-    using frag = bf16x8;
-    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    __device__ static void mfma(f32x4& c, u32x4 a, u32x4 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
     __device__ static uint32_t pack2(float lo, float hi) {
         f32x2 f = {lo, hi};
         bf16x2 r = __builtin_convertvector(f, bf16x2);
@@ -68,15 +68,13 @@ template <> struct Mma<__hip_bfloat16> {
     }
 };
 template <> struct Mma<__half> {
-    using frag = f16x8;
-    __device__ static f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    __device__ static void mfma(f32x4& c, u32x4 a, u32x4 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
     __device__ static uint32_t pack2(float lo, float hi) {
         f32x2 f = {lo, hi};
         f16x2 r = __builtin_convertvector(f, f16x2);
         return *reinterpret_cast<uint32_t*>(&r);
     }
 };
-template <typename F> __device__ __forceinline__ F as_frag(u32x4 v) { return *reinterpret_cast<F*>(&v); }
 
 __device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
@@ -107,7 +105,6 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
                           int64_t rows, int inner, int64_t x_rs, int64_t o_rs, int n_blocks) {
     constexpr int kOutStep = kGeglu ? kStep : 2 * kStep;         // outputs (and W rows of the first block) a step advances by
     using M = Mma<T>;
-    using frag = typename M::frag;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -115,26 +112,29 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, hh = lane >> 5;
+    const int n16 = lane & 15, kg = lane >> 4;       // the lane's row / column inside a 16 x 16 tile, its 8-element group of a 32-deep k-step
     int bid = blockIdx.x;
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
-    const int64_t row = (int64_t)bid * kRows + wave * 32 + col;
-    const bool row_ok = row < rows;
+    const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
 
     // ---- bias -> LDS (visible after the first barrier of the loop prologue)
     const int n_bias = kGeglu ? 2 * inner : inner;
     for (int i = tid; i < n_bias; i += 64 * kWaves) lbias[i] = bias ? bias[i] : 0.f;
 
-    // ---- x rows: B operand, element j of lane (col, hh), k-step s: x[row][16 s + 8 hh + j]
-    frag xf[kKS];
-    {
-        const T* xp = x + (row_ok ? row : rows - 1) * x_rs + 8 * hh;
+    // ---- x rows: A operand of row tile t, k-step s: element j of lane (n16, kg) = x[row0 + 16 t + n16][32 s + 8 kg + j]
+    u32x4 xf[2][kKS];
 #pragma unroll
-        for (int s = 0; s < kKS; ++s) xf[s] = as_frag<frag>(*reinterpret_cast<const u32x4*>(xp + 16 * s));
+    for (int t = 0; t < 2; ++t) {
+        const int64_t row = row0 + 16 * t + n16;
+        const T* xp = x + (row < rows ? row : rows - 1) * x_rs + 8 * kg;
+#pragma unroll
+        for (int s = 0; s < kKS; ++s) xf[t][s] = *reinterpret_cast<const u32x4*>(xp + 32 * s);
     }
 
     // ---- LDS-DMA source addressing: piece p of a tile fills LDS bytes [1024 p, 1024 p + 1024) lane-linearly; the lane's 16 bytes are
-    // (tile row r, slot c) and receive source chunk c ^ ((r >> 1) & 7) (low three bits) of W row (step * 32 + r) or (inner + step * 32 + r - 32)
+    // (tile row r, slot c) and receive source chunk c ^ ((r >> 1) & 7) (low three bits) of the W row tile row r stands for. Round 5
+    // (16 x 16 tiles): inside each 32-row block, tile row 16 ct + n is output column 2 n + ct of the step's 32 — column tile 0 holds the
+    // even columns and tile 1 the odd ones, so a lane ends up with two ADJACENT outputs of a row and stores them as one dword.
     const bool loader = wave < kLoaders;
     uint32_t p_voff[kPiecesPerLoader];
 #pragma unroll
@@ -143,7 +143,8 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
         const uint32_t off = 1024u * pc + 16u * lane;
         const uint32_t r = off / kRowBytes, c = (off - r * kRowBytes) >> 4;
         const uint32_t cs = (c & ~7u) | ((c & 7u) ^ ((r >> 1) & 7u));
-        const uint32_t wrow = r < 32 ? r : (kGeglu ? (uint32_t)inner + (r - 32) : r);
+        const uint32_t col = 2u * (r & 15u) + ((r >> 4) & 1u);       // output column within the block's 32
+        const uint32_t wrow = r < 32 ? col : (kGeglu ? (uint32_t)inner + col : 32u + col);
         p_voff[i] = wrow * kRowBytes + 16u * cs;
     }
     const char* const wbase = reinterpret_cast<const char*>(w);
@@ -157,44 +158,42 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
         for (int i = 0; i < kPiecesPerLoader; ++i) dma_piece(base, p_voff[i], lds0 + slot_off + 1024u * (wave + i * kLoaders));
     };
 
-    // ---- LDS read addressing: A operand = W rows; lane (col, hh), k-step s reads row col (+32 for the gate block), chunk 2 s + hh
-    uint32_t ka[4];
+    // ---- LDS read addressing: B operand = W rows; lane (n16, kg), block blk, column tile ct, k-step s reads tile row 32 blk + 16 ct + n16,
+    // 16-byte chunk 4 s + kg = 8 (s >> 1) + (4 (s & 1) + kg), the low three bits swizzled by (row >> 1) & 7 = n16 >> 1. 640-byte rows
+    // alternate between the two halves of the 64 banks like 128-byte ones: the 16 lanes the LDS serves together (four n16 of one kg,
+    // eight of the next) land on 16 different 4-bank groups.
+    uint32_t ka[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ka[q] = (uint32_t)(col * kRowBytes + ((((2 * q + hh) & 7) ^ ((col >> 1) & 7)) << 4));
-    auto wfrag = [&](uint32_t slot_base, int blk, int s) __attribute__((always_inline)) {
-        // chunk 2 s + hh = 8 (s >> 2) + (2 (s & 3) + hh): the swizzle touches the low three bits only
-        return *reinterpret_cast<MVI_AS3 const u32x4*>(lds + slot_base + ka[s & 3] + (s >> 2) * 128 + blk * (32 * kRowBytes));
+    for (int q = 0; q < 2; ++q) ka[q] = (uint32_t)(n16 * kRowBytes + (((4 * q + kg) ^ (n16 >> 1)) << 4));
+    auto wfrag = [&](uint32_t slot_base, int blk, int ct, int s) __attribute__((always_inline)) {
+        return *reinterpret_cast<MVI_AS3 const u32x4*>(lds + slot_base + ka[s & 1] + (s >> 1) * 128 + (32 * blk + 16 * ct) * kRowBytes);
     };
 
-    // Output addressing. A operand = x rows, B operand = W rows, so the OUTPUT COLUMN sits on the lane (column step * 32 + col)
-    // and accumulator register r is x row (r & 3) + 8 (r >> 2) + 4 hh of the wave's 32: one bias pair per lane, and a store
-    // instruction writes two runs of 32 consecutive outputs (64 bytes). (With W as the A operand a lane held 4 consecutive columns
-    // of ONE row and every 8-byte store of a wave went to 64 different rows.) Stores are not predicated: the caller provides an
-    // output with room for the rows of whole blocks (include/mvi_unet_ops.h).
-    const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
+    // Output addressing. A operand = x rows, B operand = W rows: the OUTPUT COLUMN sits on the lane — columns 2 n16 and 2 n16 + 1 of the
+    // step's 32 (column tiles 0 and 1) — and accumulator register r of row tile t is x row 16 t + 4 kg + r of the wave's 32: one bias
+    // pair per lane and block, and a store instruction writes four rows x 16 dwords (64 bytes each). Stores are not predicated: the
+    // caller provides an output with room for the rows of whole blocks (include/mvi_unet_ops.h).
     char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
-    const uint32_t lane_off = (uint32_t)((4 * hh * o_rs + col) * 2);             // + row (r & 3) + 8 (r >> 2): scalar arithmetic on the base
     const int64_t orow_bytes = o_rs * 2;
+    const uint32_t lane_off = (uint32_t)(4 * kg * orow_bytes + 4 * n16);         // + (16 t + r) rows
 
-    // One step = the 40 MFMAs of this step's 32 outputs (value block and gate block: two accumulator chains, W fragments requested
-    // kAhead k-steps ahead) with the EPILOGUE OF THE PREVIOUS STEP cut into 16 slices between them: k-step s carries output register
-    // s of the previous step (bias is already in the accumulator: its chain starts from it), and every second slice packs and stores
-    // a pair. Scheduling fences keep the slices where they are — left alone, the scheduler issues the 40 MFMAs back to back and
-    // the ~300 VALU instructions of the epilogue behind them, and the step takes the sum of both (measured: 637 us per call).
-    constexpr int kAhead = 2;
-    // stores rows m, m + 1 (registers r, r + 1) of one 32-column block at byte offset `cb` of the step's output columns
-    // Plain form: a step is 64 output columns = one full 128-byte line per row. The two 32 x 32 tiles go through a wave-private
-    // 4 KiB LDS tile [32 rows][64 columns] and leave as four 16-byte stores per lane, each instruction covering 8 rows x 128
-    // contiguous bytes — with 32 two-byte store instructions per step the stores, not the MFMAs, set the step time (6600
-    // cycles per step against 5700 for the GEGLU form, which stores half as much and computes an erf per output on top).
+    // One step = the 80 MFMAs of this step's outputs (first block and second block — value and gate — x two column tiles x two row tiles:
+    // eight accumulator chains; every W fragment feeds the two row tiles; fragments requested kAhead reads ahead) with the EPILOGUE OF
+    // THE PREVIOUS STEP cut into 8 slices between them: k-step s carries rows (t, r) = (s / 4, s % 4) of the previous step (bias is
+    // already in the accumulator: its chain starts from it). Scheduling fences keep the slices where they are — left alone, the
+    // scheduler issues the MFMAs back to back and the ~300 VALU instructions of the epilogue behind them, and the step takes the sum
+    // of both (measured on the 32x32 form: 637 us per call).
+    constexpr int kAhead = 3;
+    // Plain form: a step is 64 output columns = one full 128-byte line per row. The tiles go through a wave-private 4 KiB LDS tile
+    // [32 rows][64 columns] as dwords (two adjacent columns) and leave as four 16-byte stores per lane, each instruction covering
+    // 8 rows x 128 contiguous bytes. A dword store's four kg sit 4 rows = 512 bytes apart, in the same banks: rows with odd kg keep
+    // their two 64-byte halves swapped, and the reader undoes it.
     const uint32_t otile = (uint32_t)(kRing * kTileBytes + n_bias * (int)sizeof(float) + wave * 4096);
-    const uint32_t ot_w = otile + (uint32_t)(4 * hh * 128 + col * 2);              // + 128 * row of the register (+ 64 for the second tile)
-    const uint32_t ot_r = otile + (uint32_t)((lane >> 3) * 128 + (lane & 7) * 16);  // + 1024 i: rows 8 i + lane / 8
+    const uint32_t ot_w = otile + (uint32_t)(4 * kg * 128 + 4 * n16);              // + 128 (16 t + r); first block at 0, second at 64, ^ 64 (kg & 1)
+    const uint32_t ot_r = otile + (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (4 * ((lane >> 5) & 1))) << 4));   // + 1024 i: rows 8 i + lane / 8
     const uint32_t st_off = (uint32_t)((lane >> 3) * orow_bytes + (lane & 7) * 16);
-    auto put_pair = [&](int cb, int r, uint32_t pk) __attribute__((always_inline)) {
-        const int m = (r & 3) + 8 * (r >> 2);
-        *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + cb + m * 128) = (uint16_t)(pk & 0xFFFFu);
-        *reinterpret_cast<MVI_AS3 uint16_t*>(lds + ot_w + cb + (m + 1) * 128) = (uint16_t)(pk >> 16);
+    auto put_dword = [&](int blk, int t, int r, uint32_t pk) __attribute__((always_inline)) {
+        *reinterpret_cast<MVI_AS3 uint32_t*>(lds + ot_w + 128 * (16 * t + r) + ((64 * blk) ^ (64 * (kg & 1)))) = pk;
     };
     auto flush_tile = [&](char* op) __attribute__((always_inline)) {
 #pragma unroll
@@ -203,68 +202,69 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
             *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
         }
     };
-    auto store_pair = [&](char* op, int cb, int r, uint32_t pk) __attribute__((always_inline)) {
-        const int m = (r & 3) + 8 * (r >> 2);
-        *reinterpret_cast<uint16_t*>(op + cb + m * orow_bytes + lane_off) = (uint16_t)(pk & 0xFFFFu);
-        *reinterpret_cast<uint16_t*>(op + cb + (m + 1) * orow_bytes + lane_off) = (uint16_t)(pk >> 16);
+    // rows (t, r) of the previous step: GEGLU — gate the two adjacent columns and store them as one dword; plain — both blocks to the tile
+    auto out_rows = [&](char* op, int t, int r, const f32x4 (&pv)[2][2], const f32x4 (&pg)[2][2]) __attribute__((always_inline)) {
+        if (kGeglu) {
+            const uint32_t pk = M::pack2(geglu1(pv[0][t][r], pg[0][t][r]), geglu1(pv[1][t][r], pg[1][t][r]));
+            *reinterpret_cast<uint32_t*>(op + (16 * t + r) * orow_bytes + lane_off) = pk;
+        } else {
+            put_dword(0, t, r, M::pack2(pv[0][t][r], pv[1][t][r]));
+            put_dword(1, t, r, M::pack2(pg[0][t][r], pg[1][t][r]));
+        }
     };
-    auto step_fn = [&](auto with_prev_c, uint32_t slot_base, int step, f32x16& av, f32x16& ag, const f32x16& pv, const f32x16& pg)
-                       __attribute__((always_inline)) {
+    auto step_fn = [&](auto with_prev_c, uint32_t slot_base, int step, f32x4 (&av)[2][2], f32x4 (&ag)[2][2], const f32x4 (&pv)[2][2],
+                       const f32x4 (&pg)[2][2]) __attribute__((always_inline)) {
         constexpr bool kPrev = decltype(with_prev_c)::value;
-        const int n = step * kOutStep + col;
-        const float bv = lbias[n], bg = lbias[(kGeglu ? inner : kStep) + n];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { av[i] = bv; ag[i] = bg; }
+        for (int ct = 0; ct < 2; ++ct) {
+            const int n = step * kOutStep + 2 * n16 + ct;
+            const float bv = lbias[n], bg = lbias[(kGeglu ? inner : kStep) + n];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { av[ct][t][i] = bv; ag[ct][t][i] = bg; }
+        }
+        // (vector write -> matrix read of the accumulators, by hand)
+        asm volatile("s_nop 4" : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[1][0]), "+v"(av[1][1]), "+v"(ag[0][0]), "+v"(ag[0][1]), "+v"(ag[1][0]),
+                     "+v"(ag[1][1]));
         char* const op = obase + (step - 1) * (kOutStep * 2);        // the previous step's output columns
-        u32x4 fv[kAhead + 1], fg[kAhead + 1];
+        // fragment q = 4 s + 2 blk + ct
+        u32x4 wf[kAhead + 1];
 #pragma unroll
-        for (int s = 0; s < kAhead; ++s) { fv[s] = wfrag(slot_base, 0, s); fg[s] = wfrag(slot_base, 1, s); }
-        float held = 0.f;
+        for (int q = 0; q < kAhead; ++q) wf[q] = wfrag(slot_base, (q >> 1) & 1, q & 1, q >> 2);
 #pragma unroll
         for (int s = 0; s < kKS; ++s) {
-            if (s + kAhead < kKS) {
-                fv[(s + kAhead) % (kAhead + 1)] = wfrag(slot_base, 0, s + kAhead);
-                fg[(s + kAhead) % (kAhead + 1)] = wfrag(slot_base, 1, s + kAhead);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int q = 4 * s + h, blk = h >> 1, ct = h & 1;
+                if (q + kAhead < 4 * kKS) wf[(q + kAhead) % (kAhead + 1)] = wfrag(slot_base, ((q + kAhead) >> 1) & 1, (q + kAhead) & 1, (q + kAhead) >> 2);
+                f32x4 (&a)[2][2] = blk ? ag : av;
+                M::mfma(a[ct][0], xf[0][s], wf[q % (kAhead + 1)]);
+                M::mfma(a[ct][1], xf[1][s], wf[q % (kAhead + 1)]);
             }
-            av = M::mfma(xf[s], as_frag<frag>(fv[s % (kAhead + 1)]), av);
-            ag = M::mfma(xf[s], as_frag<frag>(fg[s % (kAhead + 1)]), ag);
-            if (kPrev && s < 16) {
-                if (kGeglu) {
-                    const float o = geglu1(pv[s], pg[s]);
-                    if ((s & 1) == 0) held = o;
-                    else store_pair(op, 0, s - 1, M::pack2(held, o));
-                } else if ((s & 1) == 1) {                           // plain: both blocks are outputs (bias already inside)
-                    put_pair(0, s - 1, M::pack2(pv[s - 1], pv[s]));
-                    put_pair(kStep * 2, s - 1, M::pack2(pg[s - 1], pg[s]));
-                }
-            }
-            if (kPrev && !kGeglu && s == 18) flush_tile(op);
+            if (kPrev && s < 8) out_rows(op, s >> 2, s & 3, pv, pg);
+            if (kPrev && !kGeglu && s == 8) flush_tile(op);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     // the last step's outputs, with nothing left to hide behind
-    auto drain = [&](int step, const f32x16& pv, const f32x16& pg) __attribute__((always_inline)) {
+    auto drain = [&](int step, const f32x4 (&pv)[2][2], const f32x4 (&pg)[2][2]) __attribute__((always_inline)) {
         char* const op = obase + step * (kOutStep * 2);
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            if (kGeglu) {
-                store_pair(op, 0, r, M::pack2(geglu1(pv[r], pg[r]), geglu1(pv[r + 1], pg[r + 1])));
-            } else {
-                put_pair(0, r, M::pack2(pv[r], pv[r + 1]));
-                put_pair(kStep * 2, r, M::pack2(pg[r], pg[r + 1]));
-            }
-        }
+        for (int u = 0; u < 8; ++u) out_rows(op, u >> 2, u & 3, pv, pg);
         if (!kGeglu) flush_tile(op);
     };
     auto close_step = [&](int step) __attribute__((always_inline)) {
         // loaders: issue the tile two steps ahead (its slot held step - 1, which nobody reads any more), then wait for everything
-        // older than those pieces — this wave's pieces of tile step + 1 among them; then the block meets
+        // older than those pieces — this wave's pieces of tile step + 1 among them; then the block meets. (The s_nops: the step's last
+        // matrix instructions have written their accumulators before the next step's epilogue slices read them.)
         if (loader) {
             issue_tile(step + 2);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_nop 7\n\ts_nop 7\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
         } else {
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_barrier" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);                           // (nothing of the next step's epilogue slices moves above the wait states)
     };
 
     // ---- prologue: tiles 0 and 1 in flight, tile 0 landed
@@ -275,8 +275,12 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     }
     __syncthreads();                                             // tile 0 and the bias vector are in LDS
 
-    f32x16 va, ga, vb, gb;                                       // accumulator sets A (even steps) and B (odd steps)
+    f32x4 va[2][2], ga[2][2], vb[2][2], gb[2][2];                // accumulator sets A (even steps) and B (odd steps): [column tile][row tile]
     auto next_slot = [&](uint32_t s) __attribute__((always_inline)) { return s + kTileBytes == (uint32_t)(kRing * kTileBytes) ? 0u : s + kTileBytes; };
+    auto settle = [&](f32x4 (&v)[2][2], f32x4 (&g)[2][2]) __attribute__((always_inline)) {
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[1][0]),
+                     "+v"(g[1][1]));
+    };
     int j = 0;
     uint32_t slot = 0;                                           // byte offset of step j's ring slot
     step_fn(std::false_type{}, slot, 0, va, ga, va, ga);
@@ -292,8 +296,10 @@ void ff_geglu_k320_kernel(const T* __restrict__ x, const T* __restrict__ w, cons
     }
     if (j < n_steps) {                                           // one step left (n_steps even): it is an odd step
         step_fn(std::true_type{}, slot, j, vb, gb, va, ga);
+        settle(vb, gb);
         drain(j, vb, gb);
     } else {
+        settle(va, ga);
         drain(j - 1, va, ga);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // trailing (unused) pieces land before the block releases its LDS
