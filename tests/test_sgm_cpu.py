@@ -224,6 +224,42 @@ def test_single_key_cross_attention_shortcut_is_exact():
         att(x, context=ctx, mask=torch.ones(3, 10, 1, dtype=torch.bool))
 
 
+def test_residual_and_layernorm_riding_on_the_projections_equal_the_reference_block_order():
+    """Round 5: every inner residual add + the LayerNorm behind it is asked for through the output projection of the layer that
+    produced the addend (CrossAttention / FeedForward `fuse=`, one kernel on the GPU at the level-0 width; here the two-step fallback),
+    the stem's proj_in carries norm1 and the spatial FeedForward carries the temporal block's entry. The composed result equals the
+    reference's own order of operations (attention.py:544-572 `x = attn1(norm1(x)) + x; x = attn2(norm2(x)) + x; ff(norm3(x)) + x`;
+    video_attention.py:278-296 spatial block, + frame embedding, temporal block, blend) on the CPU: one and several context tokens."""
+    from multiview_inpaint_amd.svd import transformer as T
+    torch.manual_seed(0)
+    blk = T.BasicTransformerBlock(64, 2, 32, context_dim=48).eval()
+    x = torch.randn(4, 10, 64)
+    with torch.no_grad():
+        for ctx in (torch.randn(4, 1, 48), torch.randn(4, 3, 48)):
+            h, skip = blk.forward_deferred(x, ctx)
+            ref = blk.attn1(blk.norm1(x)) + x
+            ref = blk.attn2(blk.norm2(ref), context=ctx) + ref
+            ref = blk.ff(blk.norm3(ref)) + ref
+            assert torch.allclose(h + skip, ref, atol=1e-6)
+            # the caller's next add + norm on the FeedForward, the caller's norm1 handed in
+            nxt = torch.nn.LayerNorm(64)
+            emb = torch.randn(4, 1, 64)
+            y, s, s_pre = blk.forward_deferred(x, ctx, n1=blk.norm1(x), ff_fuse=dict(norm=nxt, row=emb, ret_pre=True))
+            assert torch.allclose(s_pre, ref, atol=1e-6) and torch.allclose(s, ref + emb, atol=1e-6) and torch.allclose(y, nxt(ref + emb), atol=1e-5)
+        vt = T.SpatialVideoTransformer(64, 2, 32, depth=1, use_linear=True, context_dim=48, use_spatial_context=True, timesteps=2,
+                                       merge_strategy="learned_with_images", ff_in=True, time_depth=1).eval()
+        for p_ in vt.parameters():
+            torch.nn.init.normal_(p_, std=0.1)
+        xv, ind, ctx = torch.randn(4, 64, 4, 4), torch.zeros(2, 2), torch.randn(4, 1, 48)
+        got = vt(xv, context=ctx, timesteps=2, image_only_indicator=ind)          # the in-place route with every fuse request
+        t = vt._tokens_in(xv)
+        emb = vt.time_pos_embed(vt._frame_embedding(2, 2, xv.device))[:, None, :]
+        t1 = vt.transformer_blocks[0](t, context=ctx)
+        tt = vt.time_stack[0](t1 + emb, context=ctx[::2].repeat_interleave(16, dim=0), timesteps=2)
+        ref = vt._tokens_out(vt.time_mixer(x_spatial=t1, x_temporal=tt, image_only_indicator=ind), xv)
+        assert torch.allclose(got, ref, atol=2e-6)
+
+
 def test_step_invariant_caches_follow_their_inputs():
     """The per-step tensors that depend only on shapes or on rarely-changing inputs are cached (blend factors of
     AlphaBlender, the sinusoidal frequency table, the frame-index embedding): the cached values equal the uncached
