@@ -1875,3 +1875,44 @@ def test_round3_kernels_at_the_full_size_of_the_step():
     q, k, v = (t.float().contiguous() for t in qkv.chunk(3, dim=-1))                              # fp32 I/O: the fp32-math kernel
     ref = hip_ops.attention_temporal(q, k, v, Hh, T)
     assert (out.float() - ref).abs().max().item() <= 1.0 / 64 and (out.float() - ref).pow(2).mean().sqrt().item() <= 1.0 / 512
+
+
+def test_round5_kernels_at_the_full_size_of_the_step():
+    """The round-5 forms of csrc/linear_n320.hip at the shapes of the 14-frame 576x1024 step (BASELINE configs[3]): the column-group
+    projections of levels 1 - 2 and the level-2 GEGLU against the library on the same bf16 tensors (two roundings apart), linearity
+    where the arithmetic is exact (x -> 2 x), and the projection with the add + LayerNorm epilogue at the level-0 row count against
+    the two kernels it replaces (the residual stream bit-equal, the norm within two ulps of bf16)."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator(device="cuda").manual_seed(91)
+    for (rows, K, N) in [(28 * 2304, 2560, 640), (28 * 576, 5120, 1280), (28 * 2304, 640, 640)]:
+        x = torch.randn(rows, K, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+        b = torch.randn(N, device="cuda", generator=g).bfloat16()
+        mine = hip_ops.linear_n320(x, w, b)
+        lib = F.linear(x, w, b)
+        scale = lib.float().abs().max().item()
+        assert (mine.float() - lib.float()).abs().max().item() <= scale / 64
+        assert (mine.float() - lib.float()).pow(2).mean().sqrt().item() <= scale / 1024
+        assert torch.equal(hip_ops.linear_n320(x * 2, w, None), hip_ops.linear_n320(x, w, None) * 2)
+        del x, w, mine, lib
+    rows, K, inner = 28 * 576, 1280, 5120                                  # level-2 FeedForward: GEGLU through the n320 form
+    x = torch.randn(rows, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(2 * inner, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(2 * inner, device="cuda", generator=g).bfloat16()
+    mine = hip_ops.ff_geglu_n320(x, w, b)
+    h = F.linear(x, w, b).float()
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    scale = ref.abs().max().item()
+    assert (mine.float() - ref).abs().max().item() <= scale / 64 and (mine.float() - ref).pow(2).mean().sqrt().item() <= scale / 1024
+    del x, w, h, ref, mine
+    rows, K = 28 * 9216, 1280                                              # level-0 FeedForward.net[2] + skip + frame embedding + norm_in
+    x = torch.randn(rows, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(320, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(320, device="cuda", generator=g).bfloat16()
+    resid = torch.randn(rows, 320, device="cuda", generator=g).bfloat16()
+    emb = torch.randn(28, 1, 320, device="cuda", generator=g).bfloat16()
+    lw, lb = torch.randn(320, device="cuda", generator=g) * 0.5 + 1.0, torch.randn(320, device="cuda", generator=g) * 0.2
+    y, s, s_pre = hip_ops.linear_n320_add_layer_norm(x, w, b, lw, lb, 1e-5, resid=resid, row=emb, ret_pre=True)
+    y2, s2, s_pre2 = hip_ops.add_layer_norm(resid, lw, lb, 1e-5, h=hip_ops.linear_n320(x, w, b), row=emb, ret_pre=True)
+    assert torch.equal(s, s2) and torch.equal(s_pre, s_pre2)
+    assert (y.float() - y2.float()).abs().max().item() <= 2 * 2.0 ** -7 * y2.float().abs().max().item()
