@@ -248,6 +248,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             for (int r = 0; r < 4; ++r) acc[t][j][r] = b;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the compiler's own loads are done before the hand-counted ones start
+#if LN3_STAMPS
+    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();      // (diagnostic: kernel arguments + bias have landed)
+#endif
 
     // ---- x: A operand of row tile t, k-step s (32 deep) of chunk c: element e of lane (n16, kg) = x[row0 + 16 t + n16][64 c + 32 s + 8 kg + e];
     // rows past the end read the last row (kConv: the base is the tensor and the lane offset absolute — a tap's row may lie before the
@@ -609,7 +612,6 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
         }
     }
-    LN3_STAMP(3);
 #if LN3_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();      // this wave's stores acknowledged
@@ -727,7 +729,7 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int64_t b = 0; b < n_blocks; ++b) {
             const unsigned long long* q = h + b * 8;
-            ph[0] += (double)(q[1] - q[0]); ph[1] += (double)(q[2] - q[1]); ph[2] += (double)(q[3] - q[2]); ph[3] += (double)(q[5] - q[3]);
+            ph[0] += (double)(q[3] - q[0]); ph[1] += (double)(q[2] - q[1]); ph[2] += (double)(q[1] - q[3]); ph[3] += (double)(q[5] - q[2]);
             if (q[0] < t0) t0 = q[0];
             if (q[5] > t1) t1 = q[5];
         }
@@ -746,7 +748,7 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
         for (int64_t b = 1; b < n_blocks; ++b) {
             if (ev[b].key == ev[b - 1].key) { gap += (double)ev[b].s - (double)ev[b - 1].e; ++gaps; } else ++cus;
         }
-        fprintf(stderr, "[ln3 stamps] blocks %lld on %lld CUs, chunks %d: prologue %.2f us, loop %.2f us, epilogue issue %.2f us, store ack %.2f us; "
+        fprintf(stderr, "[ln3 stamps] blocks %lld on %lld CUs, chunks %d: arguments + bias %.2f us, loop %.2f us, first x / W chunk + barrier %.2f us, epilogue + store ack %.2f us; "
                         "gap to the next block on the CU %.2f us (%lld gaps); first stamp to last %.1f us\n",
                 (long long)n_blocks, (long long)cus, K / kKC, ph[0] / n_blocks / 100, ph[1] / n_blocks / 100, ph[2] / n_blocks / 100,
                 ph[3] / n_blocks / 100, gaps ? gap / gaps / 100 : 0.0, (long long)gaps, (double)(t1 - t0) / 100);
