@@ -143,7 +143,7 @@ def svd_leg(steps):
     """Second half of the BASELINE.json metric, measured in child processes started before this process initialises the GPU (a
     child may not be exec'd from a process that has). The HEADLINE is the step on ONE stream — the library's default
     (engine.TWO_STREAMS off). The opt-in mode with the ControlNet on a side stream beside the UNet encoder
-    (MVI_SVD_TWO_STREAMS=1; 4 - 5 % faster, but only safe when the GEMM set is pinned: DESIGN.md) is measured as well, under a
+    (MVI_SVD_TWO_STREAMS=1; 1 - 3 % faster at the end of round 5 — 133.4 against 134.8 ms, 137.5 against 142.1 on a slower box — and only safe when the GEMM set is pinned: DESIGN.md) is measured as well, under a
     time-out, and reported NEXT to the headline as `two_streams`. MVI_BENCH_TWO_STREAMS=0 skips it."""
     one = _svd_child(False, steps, 900)
     if one is None:
