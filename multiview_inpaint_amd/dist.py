@@ -79,13 +79,18 @@ def all_reduce_param_grads(params: Iterable[torch.Tensor], group=None, average: 
 
 def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.Tensor, radii: torch.Tensor,
                                xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
-                               group=None):
+                               group=None, norm_scale: float = 1.0):
     """Multi-view counterpart of add_densification_stats (gaussian_model.py:482-484) + the max-radii
     update (train.py:115): each rank contributes the norm of ITS view's screen-space gradient where
-    ITS view saw the Gaussian; sums / max are taken over ranks so every rank holds identical stats."""
+    ITS view saw the Gaussian; sums / max are taken over ranks so every rank holds identical stats.
+    norm_scale undoes a scaling of the loss the caller applied for the optimizer's sake (reduce="mean": upstream = 1 / world):
+    the statistic the reference thresholds (densify_grad_threshold, gaussian_model.py:467-470) is the per-view norm of the
+    gradient of the UNSCALED loss, averaged over the views that saw the Gaussian."""
     # mask-free (no nonzero() read-back): where(mask, norm, 0) over the whole arrays — the same values as the indexed form
     vis = visibility.view_as(xyz_gradient_accum)
     norm = torch.where(vis, torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True).to(xyz_gradient_accum.dtype), 0.0)
+    if norm_scale != 1.0:
+        norm = norm * norm_scale
     cnt = visibility.to(denom.dtype).view_as(denom)
     rad = torch.where(visibility, radii.to(max_radii2D.dtype), torch.zeros_like(max_radii2D))
     pack = torch.cat([norm.reshape(-1), cnt.reshape(-1)])

@@ -502,10 +502,13 @@ def _tap_major_weight(w):
     from . import hip_ops
     key = id(w)
     hit = _tap_weights.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version, w.dtype, w.device):
+    # the packing order of the 3x3 weights is a process-global switch of the kernel (mvi_conv3x3_n320_k_order, read again at every
+    # launch): part of the version, so a switch after the first forward re-packs instead of silently mis-convolving
+    ver = (w.data_ptr(), w._version, w.dtype, w.device, int(hip_ops._lib.lib().mvi_conv3x3_n320_k_order(-1)) if w.dim() == 4 else -1)
+    if hit is None or hit[0]() is not w or hit[1] != ver:
         import weakref
         build = hip_ops.conv3t_n320_weight if w.dim() == 5 else hip_ops.conv3x3_n320_weight
-        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights.pop(k, None)), (w.data_ptr(), w._version, w.dtype, w.device), build(w.detach()))
+        hit = (weakref.ref(w, lambda _r, k=key: _tap_weights.pop(k, None)), ver, build(w.detach()))
         _tap_weights[key] = hit
     return hit[2]
 

@@ -155,8 +155,10 @@ class ViewShardedTrainer:
             self.g.xyz_gradient_accum += torch.where(vis[:, None], n, 0.0).to(self.g.xyz_gradient_accum.dtype)
             self.g.denom += vis[:, None].to(self.g.denom.dtype)
             return
+        # reduce="mean" ran the backward with upstream = 1 / world: the statistic is the norm of the UNSCALED view gradient
+        # (gaussian_model.py:482-484 against densify_grad_threshold), whatever the optimizer steps on
         md.reduce_densification_stats(means2D_grad, vis, radii, self.g.xyz_gradient_accum, self.g.denom, self.g.max_radii2D,
-                                      group=self.group)
+                                      group=self.group, norm_scale=float(self.world) if self.reduce == "mean" else 1.0)
 
     def _seed_densification(self, iteration: int):
         """torch.normal of densify_and_split (gaussian_model.py:437) must draw the same samples on every rank."""
@@ -240,14 +242,19 @@ def _pin_device():
     """Before ANY GPU call: make this process see exactly its GPU, so the reference's 87 hard-coded "cuda" / .cuda() land on it
     (gaussian_renderer/__init__.py:26, gaussian_model.py:126-152, general_utils.py:135 `cuda:0`)."""
     lr = os.environ.get("LOCAL_RANK")
-    if lr is not None and "MVI_TRAIN_VIEWS_NO_PIN" not in os.environ:
-        for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-            vis = os.environ.get(var)
-            if vis:                                           # a restricted list: take this rank's entry of it
-                ids = [v for v in vis.split(",") if v != ""]
-                os.environ[var] = ids[int(lr) % len(ids)]
-            else:
-                os.environ[var] = lr
+    if lr is None or "MVI_TRAIN_VIEWS_NO_PIN" in os.environ:
+        return
+    # ONE device id, derived from whichever list the job was given (HIP's wins when both are set), written to both variables:
+    # two independently derived values could name different GPUs
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if vis:                                                   # a restricted list: this rank's entry of it
+        ids = [v for v in vis.split(",") if v != ""]
+        if int(lr) >= len(ids):
+            raise RuntimeError(f"train_views: LOCAL_RANK {lr} but only {len(ids)} visible device(s) ({vis}): two ranks would share a GPU")
+        dev = ids[int(lr)]
+    else:
+        dev = lr
+    os.environ["HIP_VISIBLE_DEVICES"] = os.environ["CUDA_VISIBLE_DEVICES"] = dev
 
 
 def main(argv=None):

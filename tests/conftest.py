@@ -10,11 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # first of all, before torch is imported or any HIP call can run in this process: the clean parent of the rank tests
-    _start_rank_launcher()
-    # another build of the library (same-box A/B runs, tools/ab_lib.sh) must never be what the tests load
+    # another build of the library (same-box A/B runs, tools/ab_lib.sh) must never be what the tests load — popped FIRST (a pure
+    # os.environ operation), so the forkserver below and every rank it forks inherit an environment without it
     if os.environ.pop("MVI_HIP_LIB", None):
         sys.stderr.write("[mvi] tests ignore MVI_HIP_LIB: the in-tree multiview_inpaint_amd/csrc/libmvi_hip.so is what is tested\n")
+    # then, before torch is imported or any HIP call can run in this process: the clean parent of the rank tests
+    _start_rank_launcher()
     # GPU runs: MIOpen looks its convolution solvers up in the find-db recorded on the MI355X (the kernels the bench uses)
     # instead of choosing by heuristic; must happen before the process first touches MIOpen. Harmless without a GPU.
     try:

@@ -151,13 +151,29 @@ def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=14
         tr = TV.ViewShardedTrainer(m, opt_args, lambda: list(cams), bg, extent, seed=3)
         assert tr.world == world and tr.rank == rank
         shard_losses, shard_P = [], []
+        stat_sum = None
         for it in range(1, steps + 1):
             loss3 = tr.step(it)
             tot = loss3[:1].detach().clone().cpu()
             td.all_reduce(tot)                                       # the step's loss summed over the views (for the comparison only)
             shard_losses.append(float(tot))
             shard_P.append(int(m._xyz.shape[0]))
+            if it == 4:                                              # the statistic the first densification (iteration 5) will threshold
+                stat_sum = (m.xyz_gradient_accum / m.denom.clamp_min(1)).clone()
         same = tr.replicas_identical()
+        # (1b) the same run with reduce="mean" (ADVICE r5): the optimizer steps on the MEAN of the view gradients (Adam: the same
+        # step up to eps), but the densification statistic must stay the per-view norm of the UNSCALED gradient — otherwise
+        # densify_grad_threshold is silently multiplied by world and densification all but stops
+        mm = Model(sc, deg, optimizer_cls=T.FusedAdam)
+        trm = TV.ViewShardedTrainer(mm, opt_args, lambda: list(cams), bg, extent, seed=3, reduce="mean")
+        mean_P, stat_mean = [], None
+        for it in range(1, steps + 1):
+            trm.step(it)
+            mean_P.append(int(mm._xyz.shape[0]))
+            if it == 4:
+                stat_mean = (mm.xyz_gradient_accum / mm.denom.clamp_min(1)).clone()
+        stat_err = float((stat_mean - stat_sum).abs().max() / stat_sum.abs().max())
+        mean_ok = stat_err < 1e-3 and all(abs(a - b) <= max(2, 0.01 * b) for a, b in zip(mean_P, shard_P)) and trm.replicas_identical()
         # (2) one process, every view of a step, summed gradients, the same tail
         m1 = Model(sc, deg, optimizer_cls=T.FusedAdam)
         t1 = TV.ViewShardedTrainer(m1, opt_args, lambda: list(cams), bg, extent, seed=3, world=1)
@@ -179,7 +195,7 @@ def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=14
             single_losses.append(tot)
             single_P.append(int(m1._xyz.shape[0]))
         torch.cuda.synchronize()
-        ok = same
+        ok = same and mean_ok
         first_change = next((i for i in range(steps) if single_P[i] != N), steps)
         # before the first change of P the two runs see the same rows: loss curves to fp32 summation order; after it a Gaussian
         # whose accumulated statistic sits on the densification threshold may be split in one run and not in the other
@@ -195,7 +211,8 @@ def run_training_rank(rank, world, port, N=20_000, W=320, H=208, deg=2, steps=14
         ok &= all(e == every[0] for e in every)                               # every rank went through the same sizes
         say(f"rank {rank}: loss (sum over {world} views) {shard_losses[0]:.5f} -> {shard_losses[-1]:.5f}; P {N} -> {shard_P[-1]} (single process "
             f"{single_P[-1]}), first change at iteration {first_change + 1}; sharded vs single-process loss curve {worst_pre:.2e} before it, "
-            f"{worst_post:.2e} after; replicas identical after {steps} steps incl. densify + prune: {same}")
+            f"{worst_post:.2e} after; replicas identical after {steps} steps incl. densify + prune: {same}; reduce='mean': densification "
+            f"statistic before the first densification equals reduce='sum' to {stat_err:.1e}, P {N} -> {mean_P[-1]}: {mean_ok}")
         flag = torch.tensor([1.0 if ok else 0.0])
         td.all_reduce(flag, op=td.ReduceOp.MIN)
         return flag.item() == 1.0, []

@@ -62,6 +62,11 @@ def _worker(rank, world, port, out_dir):
     want_d = sum(vis[r].float()[:, None] for r in range(world))
     want_m = torch.stack([torch.where(vis[r], rad[r].float(), torch.zeros(P)) for r in range(world)]).max(0).values
     assert torch.allclose(accum, want_a, atol=1e-6) and torch.equal(denom, want_d) and torch.equal(mx, want_m)
+    # ... and with reduce="mean" (the backward ran on loss / world): norm_scale = world restores the per-view norm of the
+    # UNSCALED gradient, the statistic densify_grad_threshold is compared with (gaussian_model.py:467-470, :482-484)
+    accum2, denom2, mx2 = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+    md.reduce_densification_stats(vg[rank] / world, vis[rank], rad[rank], accum2, denom2, mx2, norm_scale=float(world))
+    assert torch.allclose(accum2, want_a, atol=1e-5) and torch.equal(denom2, want_d) and torch.equal(mx2, want_m)
     # 4. factored SH exchange == all-reduce of the dense gradients (SH part rebuilt from 3 floats per view)
     for Mx, deg in ((16, 3), (16, 1), (4, 1)):
         g4 = [torch.Generator().manual_seed(400 + 10 * Mx + r) for r in range(world)]

@@ -40,11 +40,14 @@ def _viol(got, ref, floor):
     return d > tol, (float((d / tol).max()) if d.size else 0.0)
 
 
-PURE_REL_MIN_FRACTION = 0.97      # of the non-zero reference elements of every gradient array, see _grad_check
+PURE_REL_MIN_FRACTION = 0.985     # of the non-zero reference elements of every gradient array, see _grad_check (round 6: was 0.97;
+                                  # observed 0.9918 - 0.9989 in every test but the one below)
+PURE_REL_MIN_FRACTION_HUGE_SPLATS = 0.97   # test_parity_with_more_than_65536_tiles: 600 Gaussians that each cover thousands of
+                                  # pixels, every element a sum of thousands of cancelling atomic terms (observed 0.9757 - 0.992)
 _REPORT = os.environ.get("MVI_PARITY_REPORT")      # file the per-array parity figures are appended to (the GPU runs set it)
 
 
-def _grad_check(name, got, ref, n_flips_allowed):
+def _grad_check(name, got, ref, n_flips_allowed, pure_min=None):
     """A gradient array against the oracle's: rows (Gaussians) with any element outside the elementwise bar are counted
     against the flip allowance (a flipped pair changes that Gaussian's gradient and little else); nothing may be off by
     more than 1e-2 of the array's scale.
@@ -70,7 +73,7 @@ def _grad_check(name, got, ref, n_flips_allowed):
             fh.write(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + " | " + line + "\n")
     assert rows <= 2 * n_flips_allowed, (name, int(rows), worst)
     assert np.abs(got - ref).max() <= 1e-2 * scale, (name, float(np.abs(got - ref).max() / scale))
-    assert frac_pure >= PURE_REL_MIN_FRACTION, (name, frac_pure)
+    assert frac_pure >= (PURE_REL_MIN_FRACTION if pure_min is None else pure_min), (name, frac_pure)
     return worst
 
 
@@ -215,7 +218,7 @@ def test_parity_with_more_than_65536_tiles(R, ro):
                              rotations=t["rotations"])
     torch.cuda.synchronize()
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
-        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"])
+        _grad_check(k, g[k].cpu().numpy(), b[k], f["_flips_allowed"], pure_min=PURE_REL_MIN_FRACTION_HUGE_SPLATS)
 
 
 @pytest.mark.parametrize("seed,deg,mode", [(0, 3, "sh"), (4, 1, "sh"), (5, 2, "precomp"), (6, 0, "sh")])

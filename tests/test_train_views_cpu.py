@@ -39,7 +39,16 @@ def test_launcher_pins_each_rank_to_its_own_gpu(monkeypatch):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")        # a restricted list: rank 3 takes its entry
     monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "4,5,6,7")
     TV._pin_device()
-    assert os.environ["HIP_VISIBLE_DEVICES"] == "7"
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "7" and os.environ["CUDA_VISIBLE_DEVICES"] == "7"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")        # only ONE of the two preset: both end on the same device
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+    TV._pin_device()
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "7" and os.environ["CUDA_VISIBLE_DEVICES"] == "7"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5")            # a list shorter than the local world: refuse, never share a GPU silently
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "4,5")
+    import pytest
+    with pytest.raises(RuntimeError):
+        TV._pin_device()
     monkeypatch.delenv("LOCAL_RANK")
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
     TV._pin_device()

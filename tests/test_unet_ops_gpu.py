@@ -1177,8 +1177,46 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
           f"implicit-GEMM kernel; worst error ratio to the reference's own autocast error = {worst:.2f}")
 
 
+
+class _FullNets:
+    """ControlledVideoUNet + ControlNet of configs[3] (1.52 B + 0.68 B parameters) with the seeded weights of
+    tests/golden/sgm_full.npz: the 2.2 B seeded values are drawn ONCE per module (they took a fifth of the suite when every
+    full-size test drew them again) and kept on the GPU in fp32; get(dtype) builds the modules over copies in that type."""
+
+    def __init__(self):
+        from models.csvd import ControlNet, ControlledVideoUNet
+        self.specs = ((ControlledVideoUNet, H.FULL_UNET, 71), (ControlNet, H.FULL_CTRL, 72))
+        self.master = None
+
+    def _draw(self):
+        if self.master is None:
+            self.master = []
+            for cls, cfg, seed in self.specs:
+                with torch.device("meta"):
+                    m = cls(**cfg)
+                self.master.append({k: v.cuda() for k, v in H.seeded_state_dict(m, seed).items()})
+
+    def get(self, dt):
+        """(cunet, cnet) in dtype dt, eval mode, on the GPU: fresh modules every call (no cached derived weights carried over)."""
+        self._draw()
+        nets = []
+        for (cls, cfg, _), sd in zip(self.specs, self.master):
+            with torch.device("meta"):
+                m = cls(**cfg)
+            m.load_state_dict({k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}, strict=True, assign=True)
+            nets.append(m.eval())
+        return nets
+
+
+@pytest.fixture(scope="module")
+def full_nets():
+    holder = _FullNets()
+    yield holder
+    holder.master = None
+    torch.cuda.empty_cache()
+
 @pytest.mark.parametrize("dt,budget", [(torch.bfloat16, "budget_"), (torch.float16, "budget_f16_")])
-def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, strict, dt, budget):
+def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, strict, full_nets, dt, budget):
     """BASELINE.json configs[3] at its REAL size against the reference itself (round 4): ControlNet + ControlledVideoUNet of
     configs/test/svd_f_est_ctrl_simp1.yaml (1.52 B + 0.68 B parameters), 14 frames on the 72 x 128 latent, CFG batch 28, bf16 on the
     HIP path (8-wave MFMA attention at S = 9216 and 2304, implicit-GEMM convolutions at every level, token-major VideoResBlocks,
@@ -1196,13 +1234,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     assert budget + "cunet_out" in G.files, f"the fixture holds no {budget}* entries (tools/gen_golden_sgm_full.py --add-f16)"
     torch.backends.cudnn.benchmark = False
     bench_svd.use_shipped_miopen_db()
-    nets = []
-    for cls, cfg, seed in ((ControlledVideoUNet, H.FULL_UNET, 71), (ControlNet, H.FULL_CTRL, 72)):
-        with torch.device("meta"):
-            m = cls(**cfg)
-        m.load_state_dict(H.seeded_state_dict(m, seed), strict=True, assign=True)      # the seeded tensors become the parameters
-        nets.append(m.eval().cuda().to(dt))
-    cunet, cnet = nets
+    cunet, cnet = full_nets.get(dt)
     T = H.FULL_T
     inp = H.seeded_inputs(73, T=T, hw=H.FULL_HW, cfg=H.FULL_UNET)
     inp["image_only_indicator"][0, 1] = 1.0
@@ -1240,7 +1272,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
 
 
 @pytest.mark.parametrize("dt,budget", [(torch.bfloat16, "budget_"), (torch.float16, "budget_f16_")])
-def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, budget):
+def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, full_nets, dt, budget):
     """The first two steps of the reference's sampling loop at the full size of BASELINE.json configs[3] ("SVD-xt 14-frame
     576x1024 masked-inpaint sampling"): EulerEDMSampler(num_steps = 2, sigma_max 700) + LinearPredictionGuider (1 -> 2.5,
     control_hint as an additional condition key; the guider doubles the 14 frames to the CFG batch of 28) + Denoiser(
@@ -1257,13 +1289,7 @@ def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, bu
     assert "sample_final_f32" in G.files and budget + "sample_final" in G.files, "run tools/gen_golden_sgm_full_sample.py (build container only)"
     torch.backends.cudnn.benchmark = False
     bench_svd.use_shipped_miopen_db()
-    nets = []
-    for cls, cfg, seed in ((ControlledVideoUNet, H.FULL_UNET, 71), (ControlNet, H.FULL_CTRL, 72)):
-        with torch.device("meta"):
-            m = cls(**cfg)
-        m.load_state_dict(H.seeded_state_dict(m, seed), strict=True, assign=True)
-        nets.append(m.eval().cuda().to(dt))
-    cunet, cnet = nets
+    cunet, cnet = full_nets.get(dt)
     T = H.FULL_T
     one = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(74, T=T, hw=H.FULL_HW, cfg=H.FULL_UNET, cfg_doubled=False).items()}
     sampler = instantiate_from_config({
@@ -1286,6 +1312,59 @@ def test_full_size_sampling_steps_match_the_reference(golden_dir, strict, dt, bu
     r_max, r_rms = (float(v) for v in G[budget + "sample_final"])
     H.report(f"two sampling steps at full size in {dt}: error (max, rms) = ({e_max:.2e}, {e_rms:.2e}), the reference's own autocast loop ({r_max:.2e}, {r_rms:.2e})")
     assert e_max <= FULL_SIZE_BAR * r_max and e_rms <= FULL_SIZE_BAR * r_rms, (e_max, r_max, e_rms, r_rms)
+
+
+def test_full_size_networks_in_fp32_meet_the_north_star_tolerance(golden_dir, strict, full_nets):
+    """north_star's bar itself — "within 1e-4 rel on ... UNet activations" — at the REAL size of configs[3] on the GPU (round 6;
+    the 16-bit runs above are held to the reference's own autocast error, ~1e-2, under which a mis-wired block of small effect
+    could hide): ControlNet + ControlledVideoUNet in fp32 on the HIP path against the fp32 tensors of tests/golden/sgm_full.npz
+    (ONE evaluation of the imported reference on the CPU, models/csvd.py:34-115, :434-498) — the network output, the last control
+    residual and the four intermediate block outputs, each to 1e-4 of its own scale in max norm (and in rms).
+    What runs in fp32 (read from the op profile and asserted): this library's GroupNorm(+SiLU) kernels (NCHW, frames and token
+    forms), LayerNorm / residual / blend / concat passes, the fp32-math attention kernels (row-tile at S = 9216 / 2304, the
+    temporal kernel) — and the vendor libraries for every GEMM and convolution (the MFMA kernels of this library are 16-bit by
+    construction and their dtype gates decline fp32; that is a gate, not a fallback: strict mode stays on)."""
+    from multiview_inpaint_amd.svd import bench_svd, hip_ops
+    G = np.load(os.path.join(golden_dir, "sgm_full.npz"))
+    torch.backends.cudnn.benchmark = False
+    bench_svd.use_shipped_miopen_db()
+    old_tf32 = torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = torch.backends.cudnn.allow_tf32 = False
+    cunet, cnet = full_nets.get(torch.float32)
+    T = H.FULL_T
+    inp = H.seeded_inputs(73, T=T, hw=H.FULL_HW, cfg=H.FULL_UNET)
+    inp["image_only_indicator"][0, 1] = 1.0
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    kw = dict(num_video_frames=T, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1)
+    tt = 0.25 * inp["sigma"].log()
+    probes, handles = {}, []
+    for name in H.FULL_PROBES:
+        handles.append(cunet.get_submodule(name).register_forward_hook(
+            lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[H.FULL_SUB].contiguous())))
+    hip_ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            ctrls = cnet(xin, inp["control_hint"], tt, inp["crossattn"], inp["vector"], **kw)
+            yc = cunet(xin, tt, inp["crossattn"], inp["vector"], control=list(ctrls), **kw)
+        torch.cuda.synchronize()
+        kinds = [rec[0] for rec in hip_ops.PROFILE]
+    finally:
+        hip_ops.PROFILE = None
+        torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.allow_tf32 = old_tf32
+        for hd in handles:
+            hd.remove()
+    assert yc.dtype == torch.float32 and torch.isfinite(yc).all() and len(ctrls) == int(G["n_ctrl"])
+    count = lambda k: sum(1 for x in kinds if x == k)
+    assert count("attention_mfma") == 0 and count("conv3x3_n320") == 0 and count("ff_geglu") == 0, sorted(set(kinds))
+    assert count("attention_rowtile") > 0 and count("attention_temporal") > 0 and count("groupnorm") + count("groupnorm_tokens") > 0, sorted(set(kinds))
+    worst = 0.0
+    for name, got in [("cunet_out", yc), ("ctrl_last", ctrls[-1][H.FULL_SUB])] + [("probe_" + k, probes[k]) for k in H.FULL_PROBES]:
+        e_max, e_rms = _err(got, G[name + "_f32"])
+        worst = max(worst, e_max, e_rms)
+        assert e_max <= 1e-4 and e_rms <= 1e-4, (name, e_max, e_rms)
+    H.report(f"full-size step in fp32 on the GPU vs the reference's fp32 CPU evaluation: worst relative error over 6 tensors = {worst:.2e} "
+             f"(bar 1e-4); kernels of this library that ran: {sorted(set(kinds))}")
 
 
 def _attn_ref_chunked(q, k, v, heads, rows=1536):
