@@ -24,7 +24,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 _ATTN = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"] + os.environ.get("MVI_ATTN_FLAGS", "").split()
 # -fno-slp-vectorize: the SLP vectoriser packs the softmax row sums into v_pk_add_f32, which issue slower beside MFMAs
 # than the scalar adds they replace (MI355X_MICROARCH.md, cycle constants)
-EXTRA = {"attn_flash.hip": _ATTN, "attn_flash8.hip": _ATTN + ["-fno-slp-vectorize"], "ff_geglu.hip": _ATTN + ["-fno-slp-vectorize"],
+EXTRA = {"attn_flash.hip": _ATTN, "attn_flash8.hip": _ATTN + ["-fno-slp-vectorize"], "attn_flash8m16.hip": _ATTN + ["-fno-slp-vectorize"], "ff_geglu.hip": _ATTN + ["-fno-slp-vectorize"],
          "linear_n320.hip": _ATTN + ["-fno-slp-vectorize"]}
 
 

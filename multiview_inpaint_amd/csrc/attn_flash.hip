@@ -386,6 +386,11 @@ template <typename T>
 int attn_flash8_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
                        float scale, bool q_log2, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs);
 
+// the same kernel on v_mfma_f32_16x16x32 (attn_flash8m16.hip; MVI_ATTN_MFMA16=1)
+template <typename T>
+int attn_flash8m16_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk,
+                          float scale, bool q_log2, hipStream_t st, int64_t q_rs, int64_t kv_rs, int64_t o_rs);
+
 // rowtile kernel (attn_rowtile.hip)
 template <typename T>
 int attn_rowtile_launch(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Sk, int D,
@@ -394,6 +399,9 @@ int unet_fail(int code, const char* msg);
 
 }  // namespace mvi
 
+#ifndef MVI_ATTN_MFMA16_DEFAULT
+#define MVI_ATTN_MFMA16_DEFAULT 0      // profiles/round6_attention_mfma16_ab.txt decides
+#endif
 extern "C" int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype) {
     return (dtype != MVI_DT_F32 && D == mvi::kFD && Sk > 32) ? 1 : 0;
 }
@@ -402,7 +410,10 @@ extern "C" int mvi_attention_kernel_variant(int32_t Sq, int32_t Sk, int32_t D, i
     if (mvi_attention_kernel_kind(Sq, Sk, D, dtype) != 1) return 0;
     // 256-row blocks pay off once there are enough of them and the padding of the last block is small
     static const int forced = getenv("MVI_ATTN_VARIANT") ? atoi(getenv("MVI_ATTN_VARIANT")) : 0;   // 4 / 8: force a kernel (A/B runs)
-    return (forced == 8 || (forced != 4 && Sq >= 1024 && Sk >= 256)) ? 8 : 4;
+    // 16: the 8-wave kernel on v_mfma_f32_16x16x32 (attn_flash8m16.hip) wherever the 8-wave kernel would run
+    static const int mfma16 = getenv("MVI_ATTN_MFMA16") ? atoi(getenv("MVI_ATTN_MFMA16")) : MVI_ATTN_MFMA16_DEFAULT;
+    const bool eight = forced == 8 || (forced != 4 && Sq >= 1024 && Sk >= 256);
+    return eight ? (mfma16 ? 16 : 8) : 4;
 }
 
 // q_log2: q carries softmax scale * log2(e) already (mvi_attention_forward_strided_qlog2); `scale` is then ln 2, what the kernels
@@ -426,7 +437,10 @@ static int attention_forward_impl(const void* q, const void* k, const void* v, v
     int rc;
     const int variant = mvi_attention_kernel_variant(Sq, Sk, D, dtype);
     if (variant != 0) {
-        if (variant == 8)
+        if (variant == 16)
+            rc = dtype == MVI_DT_BF16 ? mvi::attn_flash8m16_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_ts, kv_ts, o_ts)
+                                      : mvi::attn_flash8m16_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_ts, kv_ts, o_ts);
+        else if (variant == 8)
             rc = dtype == MVI_DT_BF16 ? mvi::attn_flash8_launch<__hip_bfloat16>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_ts, kv_ts, o_ts)
                                       : mvi::attn_flash8_launch<__half>(q, k, v, out, B, H, Sq, Sk, scale, q_log2, st, q_ts, kv_ts, o_ts);
         else {

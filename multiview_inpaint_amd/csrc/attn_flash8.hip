@@ -102,16 +102,15 @@ template <int N> __device__ __forceinline__ void wait_vm_then_barrier() {
 
 // kWaves = 8: one 512-thread block per CU (2 waves per SIMD, 256 query rows share a K/V tile). kLoaders = 4: waves 0 .. 3
 // move the LDS-DMA pieces, at the END of a tile (see issue_tile). The timing ablations, in-kernel stamps and block timeline
-// that led here (MVI_ATTN_EXPERIMENT, other kWaves / kLoaders) live in tools/attn_dev/attn_flash8_x.hip, not in this file.
+// that led here (other kWaves / kLoaders, static wave priority, DMA pieces spread over the quarters — all measured and not kept) are in
+// profiles/HISTORY.md rounds 2 - 5 and in this file's git history; the diagnostic build that exists today is generated from this file
+// (tools/attn_dev/build_stamped.sh), not kept beside it.
 // kExact: the softmax scale is applied to the fp32 scores (one v_mul per score) instead of being rounded into Q. Folding
 // scale * log2(e) into Q saves those 32 multiplies per wave and tile but rounds Q a second time to bf16: an error of
 // |logit| * 2^-9 in the exponent, i.e. a few per cent on P where two keys with logits of ~60 compete (2.7e-2 of the
 // output scale on the adversarial rows of tests/test_unet_ops_gpu.py, against 5e-3 with the exact form).
 constexpr int kWaves = 8;
-#ifndef MVI_ATTN_NLOADERS
-#define MVI_ATTN_NLOADERS 4
-#endif
-constexpr int kLoaders = MVI_ATTN_NLOADERS;
+constexpr int kLoaders = 4;
 
 template <typename T, bool kExact>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -136,7 +135,6 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, hh = lane >> 5;
     const int qrow = qb * kQB + wave * 32 + qcol;
-    const bool young = wave >= kWaves / 2;       // wave-uniform
 
     const float sc_mul = kExact ? scale_log2e : 1.0f;            // what a score is multiplied by on its way into exp2
     // ---- Q' = Q (exact form) or round(Q * scale * log2 e): B operand of S^T = K Q^T, element j of lane (qcol, hh), d-step s: Q[qrow][16 s + 8 hh + j]
@@ -197,20 +195,6 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                 r = r < Sk ? r : Sk - 1;
                 dma_piece(base, (uint32_t)r * row_bytes + 16u * p_chunk[i], p_dst[i] + ring_off);
             }
-        }
-    };
-    // one piece of tile tt (A/B build MVI_ATTN_SPREAD_DMA: the four pieces of a loader leave one per quarter instead of together at the
-    // end of the tile)
-    auto issue_piece = [&](int tt, int i) __attribute__((always_inline)) {
-        if (i >= n_pieces) return;
-        const uint32_t ring_off = (uint32_t)((tt & (kRing - 1)) * kTileBytes);
-        const char* const base = p_is_v[i] ? vbase : kbase;
-        if (tt < n_full) {
-            dma_piece(base + (int64_t)tt * kKT * row_bytes, p_voff[i], p_dst[i] + ring_off);
-        } else {
-            int r = tt * kKT + p_row[i];
-            r = r < Sk ? r : Sk - 1;
-            dma_piece(base, (uint32_t)r * row_bytes + 16u * p_chunk[i], p_dst[i] + ring_off);
         }
     };
     // counted waits: "at most `tiles_in_flight` tiles' worth of this wave's own pieces still outstanding", then the barrier
@@ -429,15 +413,9 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             Frags f2 = load_frags(next, 0, 0, has_next, slot, 32);
             quarter(pipe_c, fq0, true, 0, s1, 0, s0, pend, t > 0);          // (before tile 0 nothing is pending)
             __builtin_amdgcn_sched_barrier(0);
-#ifdef MVI_ATTN_SPREAD_DMA
-            if (has_next) issue_piece(t + 3, 0);
-#endif
             Frags f3 = load_frags(next, 0, 3, has_next, slot, 48);
             quarter(pipe_c, fq1, true, 3, s1, 1, s0, pend, true);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef MVI_ATTN_SPREAD_DMA
-            if (has_next) issue_piece(t + 3, 1);
-#endif
             if (ragged) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -447,19 +425,12 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
             if (has_next) fq0 = load_frags(next, 1, 0, true, next, 0);
             quarter(pipe_c, f2, has_next, 0, s0, 0, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef MVI_ATTN_SPREAD_DMA
-            if (has_next) issue_piece(t + 3, 2);
-#endif
             if (has_next) fq1 = load_frags(next, 1, 3, true, next, 16);
             quarter(pipe_c, f3, has_next, 3, s0, 1, s1, pend, true);
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) {
                 // slot (t + 3) % 4 held tile t - 1: nobody reads it after the barrier that opened this tile
-#ifdef MVI_ATTN_SPREAD_DMA
-                issue_piece(t + 3, 3);
-#else
                 issue_tile(t + 3);
-#endif
                 wait_tiles_then_barrier(std::integral_constant<int, 1>{});   // own pieces of tile t + 2 (and everything older) landed
             }
         };
@@ -487,10 +458,6 @@ void attn_flash8_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
 
     MVI_AS3 uint32_t* const redo_flag = (MVI_AS3 uint32_t*)(lds + kLdsBytes);
     if (tid == 0) *redo_flag = 0u;                               // ordered before any read by the barriers of run()
-#ifdef MVI_ATTN_YOUNG_PRIO
-    // (A/B build, HISTORY.md round 5) static priority for the second-dispatched half: the loser of the SIMD's VALU arbitration
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 64 * kWaves / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     run(std::false_type{});
     // block-wide vote (the waves share the K / V ring and its barriers, so they repeat together or not at all)
     // (f16: P itself is packed to f16, which ends at 65504 — a row sum of at most 2^15 proves that no P of the row was larger)

@@ -36,17 +36,6 @@ namespace mvi {
 int unet_fail(int code, const char* msg);
 namespace ln3 {
 
-#ifndef LN3_STAMPS
-#define LN3_STAMPS 0
-#endif
-#if LN3_STAMPS
-// DIAGNOSTIC BUILD ONLY (tools/build_variant.sh ... -DLN3_STAMPS=1): wave 0 of every block leaves s_memrealtime (100 MHz) at four places
-// and its hardware id in a buffer of its own; the launcher prints the mean phase lengths and the per-CU gaps between blocks to stderr.
-__device__ unsigned long long* g_stamps;
-#define LN3_STAMP(k) do { if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define LN3_STAMP(k) do { } while (0)
-#endif
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -65,13 +54,7 @@ constexpr int kKC = 64;                              // contraction elements per
 constexpr int kChunkBytes = kN * kKC * 2;            // 40960
 constexpr int kPieces = kChunkBytes / 1024;          // 40 LDS-DMA pieces of 1 KiB (8 W rows each)
 constexpr int kRing = 3;
-#ifndef LN3_LOADERS
-#define LN3_LOADERS 4
-#endif
-#ifndef LN3_AHEAD
-#define LN3_AHEAD 4
-#endif
-constexpr int kLoaders = LN3_LOADERS;
+constexpr int kLoaders = 4;
 constexpr int kPiecesPerLoader = kPieces / kLoaders; // 10
 constexpr int kLdsBytes = kRing * kChunkBytes + kWaves * 4096;
 
@@ -190,14 +173,6 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;       // the lane's row / column inside a 16 x 16 tile, its 8-element group of a 32-deep k-step
     int bid = blockIdx.x;
-    LN3_STAMP(0);
-#if LN3_STAMPS
-    if (tid == 0) {
-        uint32_t hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-        g_stamps[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
-    }
-#endif
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
     int part_col0 = 0, ks = 0;
     int gg = 0;                                      // kGeglu: the block's column group (160 outputs)
@@ -248,9 +223,6 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             for (int r = 0; r < 4; ++r) acc[t][j][r] = b;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the compiler's own loads are done before the hand-counted ones start
-#if LN3_STAMPS
-    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();      // (diagnostic: kernel arguments + bias have landed)
-#endif
 
     // ---- x: A operand of row tile t, k-step s (32 deep) of chunk c: element e of lane (n16, kg) = x[row0 + 16 t + n16][64 c + 32 s + 8 kg + e];
     // rows past the end read the last row (kConv: the base is the tensor and the lane offset absolute — a tap's row may lie before the
@@ -350,7 +322,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
     // One chunk: 40 W fragments, each for the two row tiles = 80 MFMAs (v_mfma_f32_16x16x32), fragments requested kAhead ahead.
     // Forty independent accumulator chains: no MFMA waits for the one before it.
-    constexpr int kAhead = LN3_AHEAD;
+    constexpr int kAhead = 4;
     auto chunk_fn = [&](uint32_t slot_base, u32x4 (&xr)[4], uint32_t (&keep)[2]) __attribute__((always_inline)) {
         if (kConv && __builtin_amdgcn_ballot_w64((keep[0] & keep[1]) == 0u) != 0ull) {
             // the fragment is an output of assembly the compiler believes complete: this statement (volatile, so it stays behind the
@@ -377,7 +349,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     // Round 5, tried and not kept: the eight waves as two groups half a chunk apart (the barrier at the END of a chunk for waves 0 - 3,
     // in the MIDDLE for waves 4 - 7), so that a SIMD's matrix pipe always has one wave in mid-chunk while the other sits at the barrier
     // and waits for its first fragments. Correct, and 2 - 3 % SLOWER on every shape (profiles/round5_n320_phased_ab.txt): the loop
-    // spends 3620 cycles per chunk on 2560 cycles of MFMAs at 1.89 GHz (in-kernel stamps, LN3_STAMPS) — the chip trades the idle
+    // spends 3620 cycles per chunk on 2560 cycles of MFMAs at 1.89 GHz (in-kernel stamps: tools/n320_dev/build_stamped.sh) — the chip trades the idle
     // cycles for clock, and filling them returns as a lower clock, not as time.
     // (The x registers are NOT operands of the wait: tied operands made the allocator copy them in front of it, i.e. before the
     // loads had landed. Nothing that uses them can move above the wait anyway: every MFMA also takes a W fragment read from LDS
@@ -404,10 +376,6 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
-    LN3_STAMP(1);
-#if LN3_STAMPS
-    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
-#endif
 
     auto next_slot = [&](uint32_t s) __attribute__((always_inline)) { return s + kChunkBytes == (uint32_t)(kRing * kChunkBytes) ? 0u : s + kChunkBytes; };
     uint32_t slot = 0;
@@ -426,10 +394,6 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     // trailing (unused) pieces and rows land before the block ends; mfma_settle: the last matrix instructions (8 passes each) have
     // written their accumulators before anything the compiler schedules reads one
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-    LN3_STAMP(2);
-#if LN3_STAMPS
-    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -612,10 +576,6 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             *reinterpret_cast<u32x4*>(op + (8 * i) * orow_bytes + st_off) = v;
         }
     }
-#if LN3_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) g_stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();      // this wave's stores acknowledged
-#endif
     if (kStats && gn.part) {
         // wave partials -> the wave's own 4 KiB output tile (its flush reads are issued: LDS operations of one wave execute in order):
         // [320 channels][2] floats = 2560 bytes; the four kg hold different rows of a column
@@ -707,54 +667,8 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
-#if LN3_STAMPS
-    unsigned long long* dbg = nullptr;
-    hipMalloc(&dbg, (size_t)n_blocks * 64);
-    hipMemset(dbg, 0, (size_t)n_blocks * 64);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dbg, sizeof dbg);
-#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
                        o_rs, (int)n_blocks, cg, part, gn, ln);
-#if LN3_STAMPS
-    {
-        hipStreamSynchronize(st);
-        unsigned long long* h = (unsigned long long*)malloc((size_t)n_blocks * 64);
-        hipMemcpy(h, dbg, (size_t)n_blocks * 64, hipMemcpyDeviceToHost);
-        hipFree(dbg);
-        double cyc = 0;
-        for (int64_t b = 0; b < n_blocks; ++b) cyc += (double)(h[b * 8 + 7] - h[b * 8 + 6]);
-        fprintf(stderr, "[ln3 stamps] loop: %.0f shader cycles per chunk, clock %.3f GHz\n", cyc / n_blocks / (K / kKC),
-                cyc / n_blocks / 1e3 / ([&] { double t = 0; for (int64_t b = 0; b < n_blocks; ++b) t += (double)(h[b * 8 + 2] - h[b * 8 + 1]); return t / n_blocks * 10; }()));
-        double ph[4] = {0, 0, 0, 0};
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (int64_t b = 0; b < n_blocks; ++b) {
-            const unsigned long long* q = h + b * 8;
-            ph[0] += (double)(q[3] - q[0]); ph[1] += (double)(q[2] - q[1]); ph[2] += (double)(q[1] - q[3]); ph[3] += (double)(q[5] - q[2]);
-            if (q[0] < t0) t0 = q[0];
-            if (q[5] > t1) t1 = q[5];
-        }
-        // per CU (xcc, se, sh, cu from the hardware id): blocks in start order, the gap between one block's last stamp and the next one's first
-        struct Ev { unsigned long long key, s, e; };
-        Ev* ev = (Ev*)malloc((size_t)n_blocks * sizeof(Ev));
-        for (int64_t b = 0; b < n_blocks; ++b) {
-            const unsigned long long id = h[b * 8 + 4];
-            ev[b] = {((id >> 32) << 16) | ((id >> 8) & 0xFFu) | (((id >> 13) & 7u) << 8) | (((id >> 12) & 1u) << 11), h[b * 8], h[b * 8 + 5]};
-        }
-        qsort(ev, (size_t)n_blocks, sizeof(Ev), [](const void* a, const void* b) {
-            const Ev *x = (const Ev*)a, *y = (const Ev*)b;
-            return x->key != y->key ? (x->key < y->key ? -1 : 1) : (x->s < y->s ? -1 : (x->s > y->s));
-        });
-        double gap = 0; int64_t gaps = 0, cus = n_blocks ? 1 : 0;
-        for (int64_t b = 1; b < n_blocks; ++b) {
-            if (ev[b].key == ev[b - 1].key) { gap += (double)ev[b].s - (double)ev[b - 1].e; ++gaps; } else ++cus;
-        }
-        fprintf(stderr, "[ln3 stamps] blocks %lld on %lld CUs, chunks %d: arguments + bias %.2f us, loop %.2f us, first x / W chunk + barrier %.2f us, epilogue + store ack %.2f us; "
-                        "gap to the next block on the CU %.2f us (%lld gaps); first stamp to last %.1f us\n",
-                (long long)n_blocks, (long long)cus, K / kKC, ph[0] / n_blocks / 100, ph[1] / n_blocks / 100, ph[2] / n_blocks / 100,
-                ph[3] / n_blocks / 100, gaps ? gap / gaps / 100 : 0.0, (long long)gaps, (double)(t1 - t0) / 100);
-        free(ev); free(h);
-    }
-#endif
     if (kSplit) {
         const int c_tot = cg.groups * kN;
         const int64_t threads = rows * (c_tot / 8), rows_pad = (rows + kRows - 1) / kRows * kRows;

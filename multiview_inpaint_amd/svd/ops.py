@@ -151,7 +151,7 @@ def attention_scale_fold_pays(x, dim_head):
     if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 3):
         return False
     from . import hip_ops
-    return hip_ops.attention_kernel_variant(x.shape[1], x.shape[1], dim_head, x.dtype) == 8
+    return hip_ops.attention_kernel_variant(x.shape[1], x.shape[1], dim_head, x.dtype) in (8, 16)
 
 
 def _unfold_q(q, heads, q_log2):

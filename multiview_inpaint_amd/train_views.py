@@ -213,6 +213,17 @@ class ViewShardedTrainer:
             g.optimizer.step()
             g.optimizer.zero_grad(set_to_none=True)
 
+    @torch.no_grad()
+    def render(self, cam, background: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Forward-only render of one camera on the stored parameters — what the reference's render() returns for the evaluation
+        renders (inpaint_rec.py:68-69, :169-172 `render_set`; :208-229 `training_report`): no collective, any rank may call it."""
+        from . import raster as R
+        p = self.params()
+        raw = [p[k].detach() for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")]
+        rs = _settings(R, cam, self.background if background is None else background, self.g.active_sh_degree)
+        image, radii, depth, _ = R.rasterize_forward_raw(rs, *raw)
+        return {"render": image, "depth": depth, "radii": radii, "visibility_filter": radii > 0}
+
     def replicas_identical(self) -> bool:
         """Debug / test aid: every rank holds bit-identical parameters (one small all-gather of per-tensor checksums)."""
         if self.world == 1:
@@ -237,6 +248,57 @@ class ViewShardedTrainer:
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # launcher: the reference's inpaint_rec.py, view-sharded
+
+def save_png(path: str, image: torch.Tensor):
+    """image [3 or 1, H, W] in [0, 1] -> 8-bit PNG (what torchvision.utils.save_image writes at inpaint_rec.py:256-259: clamp, x 255 +
+    0.5, truncate), with the standard library only — torchvision is not part of the ROCm image this runs on."""
+    import struct
+    import zlib
+    a = (image.detach().float().clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()
+    h, w, c = a.shape
+    rows = b"".join(b"\x00" + a[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 0, 0, 0, 0))
+                 + chunk(b"IDAT", zlib.compress(rows, 1)) + chunk(b"IEND", b""))
+
+
+def render_set(trainer: "ViewShardedTrainer", model_path: str, iteration: int, views: Sequence) -> int:
+    """inpaint_rec.py:244-259: renders of `views` and their ground truth under <model_path>/ours_<iteration>/{renders,gt}/%05d.png.
+    Forward-only calls of path A; the launcher runs it on rank 0 alone."""
+    rp, gp = (os.path.join(model_path, f"ours_{iteration}", d) for d in ("renders", "gt"))
+    os.makedirs(rp, exist_ok=True)
+    os.makedirs(gp, exist_ok=True)
+    for idx, view in enumerate(views):
+        out = trainer.render(view)
+        save_png(os.path.join(rp, f"{idx:05d}.png"), out["render"])
+        save_png(os.path.join(gp, f"{idx:05d}.png"), view.original_image[0:3])
+    return len(views)
+
+
+def training_report(trainer: "ViewShardedTrainer", iteration: int, scene, say=print) -> Dict[str, Dict[str, float]]:
+    """The evaluation half of inpaint_rec.py:200-241 at a test iteration (the tensorboard half is out of scope): mean L1 and PSNR of
+    the clamped render against the clamped image over the test cameras and over five training cameras (indices 5, 10, ..., 25,
+    modulo the list). Returns {'test' | 'train': {'l1', 'psnr'}} for the sets that exist."""
+    train = scene.getTrainCameras()
+    sets = (("test", scene.getTestCameras()), ("train", [train[i % len(train)] for i in range(5, 30, 5)] if train else []))
+    res = {}
+    for name, cams in sets:
+        if not cams:
+            continue
+        l1 = psnr = 0.0
+        for cam in cams:
+            img = trainer.render(cam)["render"].clamp(0.0, 1.0)
+            gt = cam.original_image.to(img.device).clamp(0.0, 1.0)[0:3]
+            l1 += float((img - gt).abs().mean())
+            mse = ((img - gt) ** 2).reshape(img.shape[0], -1).mean(1, keepdim=True)          # utils/image_utils.py: per channel, then mean
+            psnr += float((20 * torch.log10(1.0 / torch.sqrt(mse))).mean())
+        res[name] = dict(l1=l1 / len(cams), psnr=psnr / len(cams))
+        say(f"\n[ITER {iteration}] Evaluating {name}: L1 {res[name]['l1']} PSNR {res[name]['psnr']}")
+    return res
+
 
 def _pin_device():
     """Before ANY GPU call: make this process see exactly its GPU, so the reference's 87 hard-coded "cuda" / .cuda() land on it
@@ -287,7 +349,12 @@ def main(argv=None):
     parser.add_argument("--scene_id", default=None, type=str)
     parser.add_argument("--ctrl_id", default="-1", type=str)
     parser.add_argument("--reduce", choices=["sum", "mean"], default="sum")
+    parser.add_argument("--dry-run", dest="dry_run", type=int, default=0, metavar="N",
+                        help="rehearsal on a new node: N iterations instead of --iterations, with one test and one save iteration at the end")
     args = parser.parse_args(argv[1:])
+    if args.dry_run > 0:
+        args.iterations = args.dry_run
+        args.test_iterations, args.save_iterations = [args.dry_run], [args.dry_run]
     args.save_iterations.append(args.iterations)
     # general_utils.safe_state's seeding (utils/general_utils.py:132-134) without its `cuda:0` pin and stdout wrapper
     random.seed(0)
@@ -313,6 +380,12 @@ def main(argv=None):
     trainer = ViewShardedTrainer(gaussians, opt, lambda: scene.getInpaintTrainCameras(args.n_mode, args.ctrl_id), bg, scene.cameras_extent,
                                  reduce=args.reduce, white_background=dataset.white_background)
     ema = [0.0]
+    # inpaint_rec.py:68-69: the inpaint cameras rendered once before the loop — forward-only, rank 0 (the others meet it at the
+    # first exchange)
+    if rank == 0:
+        n0 = render_set(trainer, out_render, 0, scene.getInpaintCameras(args.n_mode, args.ctrl_id))
+        if not args.quiet:
+            print(f"[ITER 0] rendered {n0} inpaint cameras to {out_render}", flush=True)
 
     def on_iteration(iteration, loss3):
         if iteration % 10 == 0 or iteration in args.save_iterations:
@@ -326,6 +399,12 @@ def main(argv=None):
             scene.save(iteration, out_render)
         if rank == 0 and iteration in args.checkpoint_iterations:
             torch.save((gaussians.capture(), iteration), out_render + "/chkpnt" + str(iteration) + ".pth")
+        if rank == 0 and iteration in args.test_iterations:
+            # inpaint_rec.py:139-140 (training_report) and :169-172 (the validation renders: first and last two inpaint cameras + two
+            # training cameras)
+            training_report(trainer, iteration, scene)
+            ic = scene.getInpaintCameras(args.n_mode, args.ctrl_id)
+            render_set(trainer, out_render, iteration, list(ic[:2]) + list(ic[-2:]) + list(scene.getTrainCameras()[:2]))
 
     trainer.train(1, opt.iterations, on_iteration)
     if world > 1:

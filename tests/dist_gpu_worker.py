@@ -228,3 +228,39 @@ def entry_training(rank, world, port, queue, kwargs):
     except BaseException as e:
         import traceback
         queue.put((rank, False, [], lines + [traceback.format_exc(), repr(e)]))
+
+
+# ---- the LAUNCHER itself (multiview_inpaint_amd.train_views.main) under torchrun with two ranks over gloo, on the stand-in gs-simp
+# directory tests/gs_simp_standin: argument plumbing, device pinning, patching, rank-0 render sets / report / saves, the loop, the
+# replicas check and the exit code. Runs in a process forked by the clean forkserver (it starts a program: torchrun).
+def entry_launcher(rank, world, port, queue, kwargs):
+    import glob
+    import subprocess
+    import tempfile
+    lines = []
+    try:
+        out = tempfile.mkdtemp(prefix="mvi_launcher_")
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]),
+                   MVI_TRAIN_VIEWS_BACKEND="gloo", HIP_VISIBLE_DEVICES="0,0", CUDA_VISIBLE_DEVICES="0,0")    # both ranks pin to the one GPU
+        env.pop("MVI_TRAIN_VIEWS_NO_PIN", None)
+        n = int(kwargs.get("iterations", 12))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "multiview_inpaint_amd.train_views", os.path.join(ROOT, "tests", "gs_simp_standin"),
+               "-m", out, "--scene_id", "standin", "--n_mode", "2", "--dry-run", str(n), "--reduce", kwargs.get("reduce", "sum"),
+               "--checkpoint_iterations", str(n)]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        lines += ["$ " + " ".join(cmd[1:]), p.stdout[-3000:], p.stderr[-3000:]]
+        base = os.path.join(out, "2")
+        found = dict(
+            renders0=len(glob.glob(os.path.join(base, "ours_0", "renders", "*.png"))), gt0=len(glob.glob(os.path.join(base, "ours_0", "gt", "*.png"))),
+            rendersN=len(glob.glob(os.path.join(base, f"ours_{n}", "renders", "*.png"))),
+            saved=os.path.exists(os.path.join(base, f"point_cloud/iteration_{n}", "point_cloud.pt")),
+            ckpt=os.path.exists(os.path.join(base, f"chkpnt{n}.pth")))
+        lines.append(f"launcher rc {p.returncode}; files: {found}")
+        ok = (p.returncode == 0 and found == dict(renders0=4, gt0=4, rendersN=6, saved=True, ckpt=True)
+              and "Evaluating test: L1" in p.stdout and "Evaluating train: L1" in p.stdout and "Training complete." in p.stdout
+              and "patched:" in p.stderr and "the replicas diverged" not in p.stderr)
+        queue.put((rank, ok, [], lines))
+    except BaseException as e:
+        import traceback
+        queue.put((rank, False, [], lines + [traceback.format_exc(), repr(e)]))

@@ -58,3 +58,18 @@ def test_two_rank_view_sharded_training_equals_one_process_over_both_views(rank_
         ok, _, lines = results[r]
         print("\n".join(lines))
         assert ok, lines[-3:]
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_launcher_dry_run_under_torchrun_with_two_ranks(rank_launcher, reduce):
+    """`torchrun --nproc-per-node 2 -m multiview_inpaint_amd.train_views <gs-simp dir> ... --dry-run 12` with MVI_TRAIN_VIEWS_BACKEND=gloo
+    on the stand-in gs-simp directory (tests/gs_simp_standin): main() itself — the reference's argument groups on one parser, each
+    rank pinned to its entry of HIP_VISIBLE_DEVICES before anything touches a GPU, patch_gs_simp.install(), InpaintScene /
+    InpaintGaussianModel / training_setup, the inpaint cameras rendered before the loop on rank 0 (inpaint_rec.py:68-69), twelve
+    view-sharded iterations incl. two densifications, training_report + the validation renders + save + checkpoint at the test / save
+    iteration on rank 0 (:139-142, :165-172), replicas_identical, exit code 0."""
+    import dist_gpu_worker as W
+    results = _run_ranks(rank_launcher, W.entry_launcher, 1, dict(iterations=12, reduce=reduce))
+    ok, _, lines = results[0]
+    print("\n".join(lines))
+    assert ok, lines[-2:]

@@ -59,3 +59,42 @@ def test_trainer_rejects_an_unknown_reduction():
     import pytest
     with pytest.raises(ValueError):
         TV.ViewShardedTrainer(object(), object(), lambda: [], torch.zeros(3), 1.0, reduce="median", world=1)
+
+
+def test_render_sets_and_report_of_the_launcher(tmp_path):
+    """render_set (inpaint_rec.py:244-259) and the evaluation half of training_report (:200-241) on a fake trainer: file layout
+    ours_<iteration>/{renders,gt}/%05d.png, 8-bit values as torchvision.utils.save_image writes them, L1 / PSNR means over the test
+    cameras and over the five training cameras 5, 10, ..., 25 (modulo the list)."""
+    import struct
+    import zlib
+
+    class Cam:
+        def __init__(self, k):
+            self.original_image = torch.full((3, 4, 6), 0.1 * k)
+            self.k = k
+
+    class Trainer:
+        def render(self, cam, background=None):
+            return {"render": cam.original_image + 0.05}
+
+    class Scene:
+        def getTrainCameras(self):
+            return [Cam(k) for k in range(3)]
+
+        def getTestCameras(self):
+            return [Cam(5), Cam(6)]
+
+    cams = [Cam(k) for k in range(3)]
+    assert TV.render_set(Trainer(), str(tmp_path), 7, cams) == 3
+    for sub in ("renders", "gt"):
+        assert sorted(os.listdir(tmp_path / "ours_7" / sub)) == ["00000.png", "00001.png", "00002.png"]
+    raw = (tmp_path / "ours_7" / "renders" / "00002.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", raw[16:24]) == (6, 4)
+    idat = raw[raw.index(b"IDAT") + 4:raw.index(b"IEND") - 8]
+    px = zlib.decompress(idat)
+    assert len(px) == 4 * (1 + 6 * 3) and px[1] == int(0.25 * 255 + 0.5)          # filter byte, then the first pixel's red
+    said = []
+    res = TV.training_report(Trainer(), 7, Scene(), say=said.append)
+    assert set(res) == {"test", "train"} and abs(res["test"]["l1"] - 0.05) < 1e-6
+    assert abs(res["test"]["psnr"] - 20 * torch.log10(torch.tensor(1 / 0.05)).item()) < 1e-3
+    assert len(said) == 2 and "[ITER 7] Evaluating test: L1" in said[0] and "Evaluating train" in said[1]

@@ -934,7 +934,7 @@ def test_softmax_scale_folded_into_the_q_weights(ops, dtype):
             TR.FOLD_SCALE_INTO_WQ = fold
             try:
                 with torch.no_grad():
-                    w, q_log2 = m._packed_qkv_weight(dtype, fold=ops.attention_kernel_variant(S, S, 64, dtype) == 8)
+                    w, q_log2 = m._packed_qkv_weight(dtype, fold=ops.attention_kernel_variant(S, S, 64, dtype) in (8, 16))
                     assert q_log2 == (fold and S == 1280)
                     if q_log2:
                         want_q = (m.to_q.weight.float() * (0.125 * 1.4426950408889634)).to(dtype)
@@ -1084,7 +1084,7 @@ def test_hd64_nets_on_a_32x32_latent_run_the_8_wave_kernel_within_the_reference_
         log = list(hip_ops.ATTN_VARIANTS)
     finally:
         hip_ops.ATTN_VARIANTS = None
-    eight = [e for e in log if e[0] == 8]
+    eight = [e for e in log if e[0] in (8, 16)]
     four = [e for e in log if e[0] == 4]
     # level 0 holds one spatial self-attention per transformer: UNet 1 down + 2 up, ControlNet 1 down, controlled UNet 1 + 2
     assert len(eight) >= 7 and all(sq == 1024 and sk == 1024 for _, sq, sk in eight), log

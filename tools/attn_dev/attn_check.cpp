@@ -3,9 +3,7 @@
 //                                     -Lmultiview_inpaint_amd/csrc -lmvi_hip -Wl,-rpath,'$ORIGIN/../../multiview_inpaint_amd/csrc' -o tools/attn_dev/attn_check
 // Run:    MVI_ATTN_VARIANT=8 tools/attn_dev/attn_check            (4 = the 4-wave kernel, 8 = the 8-wave kernel)
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 #include <algorithm>
-#include <map>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -122,97 +120,100 @@ static void bench(int B, int H, int S, int iters) {
     std::vector<uint16_t> buf(n);
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (size_t i = 0; i < n; ++i) buf[i] = g_zero_data ? 0 : f2bf(nd(rng));
+    // MVI_ATTN_CHECK_QLOG2=1: the form the SVD modules run — q carries scale * log2(e) from its projection's weights
+    // (mvi_attention_forward_strided_qlog2: no scale multiply in the loop); the same logits as the plain call on the same seed
+    const bool qlog2 = getenv("MVI_ATTN_CHECK_QLOG2") && atoi(getenv("MVI_ATTN_CHECK_QLOG2"));
+    for (size_t i = 0; i < n; ++i) {
+        float x = nd(rng);
+        if (qlog2 && (i % (3 * (size_t)HD)) < (size_t)HD) x *= 0.125f * 1.4426950408889634f;
+        buf[i] = g_zero_data ? 0 : f2bf(x);
+    }
     uint16_t *d, *o;
     CK(hipMalloc(&d, n * 2)); CK(hipMalloc(&o, (size_t)B * S * HD * 2));
     CK(hipMemcpy(d, buf.data(), n * 2, hipMemcpyHostToDevice));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+    auto launch = [&]() {
+        if (qlog2) mvi_attention_forward_strided_qlog2(d, d + HD, d + 2 * HD, o, B, H, S, S, D, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+        else mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+    };
+    for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a, nullptr));
-    for (int i = 0; i < iters; ++i) mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+    for (int i = 0; i < iters; ++i) launch();
     CK(hipEventRecord(b, nullptr));
     CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     ms /= iters;
     const double fl = 4.0 * B * H * (double)S * S * D;
-    printf("bench B=%d H=%d S=%d: %.3f ms  %.1f TFLOP/s  (%.3f of 2.5 PF)\n", B, H, S, ms, fl / ms * 1e-9, fl / ms * 1e-9 / 2500.0);
+    printf("bench B=%d H=%d S=%d%s variant %d: %.3f ms  %.1f TFLOP/s  (%.3f of 2.5 PF)\n", B, H, S, qlog2 ? " qlog2" : "",
+           mvi_attention_kernel_variant(S, S, D, MVI_DT_BF16), ms, fl / ms * 1e-9, fl / ms * 1e-9 / 2500.0);
     CK(hipFree(d)); CK(hipFree(o));
 }
 
-// "timeline": needs the experiment build (tools/attn_dev/build_x.sh) and MVI_ATTN_EXPERIMENT=20. Every block records when it
-// entered, started / ended its tile loop and left (s_memrealtime, 10 ns ticks) and where it ran (HW_ID, XCC_ID); the host
-// reconstructs the per-CU schedule: how long a CU sits between two blocks, how much of a block is not the tile loop.
-static void timeline(int B, int H, int S) {
-    using fn_t = int (*)(uint64_t*, int);
-    fn_t rd = (fn_t)dlsym(RTLD_DEFAULT, "mvi_attn_debug_timeline");
-    if (!rd) { printf("timeline: this libmvi_hip.so is not the experiment build\n"); return; }
+// "clock": needs the STAMPED build (tools/attn_dev/build_stamped.sh: the product kernels with two stamps around the key loop written
+// past the end of the output). >= 2 s of back-to-back launches on random data, then the stamps of the last launch: cycles of the key
+// loop per block (s_memtime) and the in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+static void clock_mode(int B, int H, int S, int iters) {
     const int D = 64, HD = H * D;
     const size_t n = (size_t)B * S * 3 * HD;
     std::vector<uint16_t> buf(n);
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (size_t i = 0; i < n; ++i) buf[i] = f2bf(nd(rng));
-    uint16_t *d, *o;
-    CK(hipMalloc(&d, n * 2)); CK(hipMalloc(&o, (size_t)B * S * HD * 2));
-    CK(hipMemcpy(d, buf.data(), n * 2, hipMemcpyHostToDevice));
-    for (int i = 0; i < 6; ++i) mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
-    CK(hipDeviceSynchronize());
+    const bool qlog2 = getenv("MVI_ATTN_CHECK_QLOG2") && atoi(getenv("MVI_ATTN_CHECK_QLOG2"));
+    for (size_t i = 0; i < n; ++i) {
+        float x = nd(rng);
+        if (qlog2 && (i % (3 * (size_t)HD)) < (size_t)HD) x *= 0.125f * 1.4426950408889634f;
+        buf[i] = g_zero_data ? 0 : f2bf(x);
+    }
     const int nb = B * H * ((S + 255) / 256);
-    std::vector<uint64_t> t(8 * (size_t)std::min(nb, 8192));
-    if (rd(t.data(), nb)) { printf("timeline: read-back failed\n"); return; }
-    const int m = std::min(nb, 8192);
-    uint64_t t0 = ~0ull, t1 = 0;
-    for (int i = 0; i < m; ++i) { t0 = std::min(t0, t[8 * i]); t1 = std::max(t1, t[8 * i + 3]); }
-    std::map<uint32_t, std::vector<int>> cu;                       // (xcc, se, sh, cu) -> blocks
-    double pro = 0, loop = 0, epi = 0, clk = 0;
-    for (int i = 0; i < m; ++i) {
-        const uint32_t hw = (uint32_t)t[8 * i + 4], xcc = (uint32_t)t[8 * i + 5] & 15u;
-        cu[(xcc << 16) | (hw & 0xff00u)].push_back(i);           // cu_id [11:8], sh_id [12], se_id [15:13]
-        pro += (double)(t[8 * i + 1] - t[8 * i]); loop += (double)(t[8 * i + 2] - t[8 * i + 1]); epi += (double)(t[8 * i + 3] - t[8 * i + 2]);
-        clk += (double)t[8 * i + 6] / (double)(t[8 * i + 3] - t[8 * i]);
+    const size_t out_bytes = (size_t)B * S * HD * 2;
+    uint16_t *d; char* o;
+    CK(hipMalloc(&d, n * 2)); CK(hipMalloc(&o, out_bytes + 16 * (size_t)nb));
+    CK(hipMemcpy(d, buf.data(), n * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(o + out_bytes, 0, 16 * (size_t)nb));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) {
+        if (qlog2) mvi_attention_forward_strided_qlog2(d, d + HD, d + 2 * HD, o, B, H, S, S, D, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
+        else mvi_attention_forward_strided(d, d + HD, d + 2 * HD, o, B, H, S, S, D, 0.125f, MVI_DT_BF16, 3 * HD, 3 * HD, HD, nullptr);
     }
-    printf("timeline B=%d H=%d S=%d: %d blocks on %zu CUs; kernel span %.1f us\n", B, H, S, m, cu.size(), (t1 - t0) * 0.01);
-    printf("  mean per block: entry->loop %.2f us, tile loop %.2f us, loop->exit %.2f us; mean in-block clock %.0f MHz\n", pro / m * 0.01,
-           loop / m * 0.01, epi / m * 0.01, clk / m * 100.0);
-    double gap = 0, busy = 0, lead = 0, tail = 0; int ngap = 0, overlap = 0; size_t mn = 1 << 30, mx = 0;
-    std::vector<double> gaps;
-    for (auto& kv : cu) {
-        auto& v = kv.second;
-        std::sort(v.begin(), v.end(), [&](int a, int b) { return t[8 * a] < t[8 * b]; });
-        mn = std::min(mn, v.size()); mx = std::max(mx, v.size());
-        lead += (double)(t[8 * v.front()] - t0); tail += (double)(t1 - t[8 * v.back() + 3]);
-        for (size_t j = 0; j < v.size(); ++j) {
-            busy += (double)(t[8 * v[j] + 3] - t[8 * v[j]]);
-            if (j) {
-                const double g = (double)t[8 * v[j]] - (double)t[8 * v[j - 1] + 3];
-                if (g < 0) ++overlap;
-                gap += g; ++ngap; gaps.push_back(g);
-            }
-        }
-    }
-    std::sort(gaps.begin(), gaps.end());
-    printf("  blocks per CU %zu .. %zu; gap between consecutive blocks of a CU: mean %.2f us, median %.2f, p90 %.2f, max %.2f (%d overlapping pairs)\n",
-           mn, mx, gap / std::max(ngap, 1) * 0.01, gaps.empty() ? 0.0 : gaps[gaps.size() / 2] * 0.01, gaps.empty() ? 0.0 : gaps[gaps.size() * 9 / 10] * 0.01,
-           gaps.empty() ? 0.0 : gaps.back() * 0.01, overlap);
-    const double span = (double)(t1 - t0) * cu.size();
-    printf("  of CU x span: in blocks %.1f %%, of which tile loop %.1f %%; between blocks %.1f %%; before first block %.1f %%; after last block %.1f %%\n",
-           100 * busy / span, 100 * loop / span, 100 * gap / span, 100 * lead / span, 100 * tail / span);
+    CK(hipEventRecord(b, nullptr));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<uint64_t> st(2 * (size_t)nb);
+    CK(hipMemcpy(st.data(), o + out_bytes, 16 * (size_t)nb, hipMemcpyDeviceToHost));
+    std::vector<double> cyc, clk;
+    for (int i = 0; i < nb; ++i)
+        if (st[2 * i + 1]) { cyc.push_back((double)st[2 * i]); clk.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 100.0); }
+    if (cyc.empty()) { printf("clock: no stamps — this libmvi_hip.so is not the stamped build\n"); return; }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    const double fl = 4.0 * B * H * (double)S * S * D;
+    printf("clock B=%d H=%d S=%d%s%s variant %d: %d launches in %.0f ms (%.3f ms each, %.1f TFLOP/s = %.3f of 2.5 PF); key loop per block: median %.0f "
+           "shader cycles (p10 %.0f, p90 %.0f), %.1f cycles per 64-key tile; in-kernel clock median %.0f MHz (p10 %.0f, p90 %.0f)\n",
+           B, H, S, qlog2 ? " qlog2" : "", g_zero_data ? " ZERO operands" : "", mvi_attention_kernel_variant(S, S, D, MVI_DT_BF16), iters, ms, ms / iters,
+           fl / (ms / iters) * 1e-9, fl / (ms / iters) * 1e-9 / 2500.0, cyc[cyc.size() / 2], cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10],
+           cyc[cyc.size() / 2] / ((S + 63) / 64), clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10]);
     CK(hipFree(d)); CK(hipFree(o));
 }
 
 int main(int argc, char** argv) {
     const char* var = getenv("MVI_ATTN_VARIANT");
-    printf("MVI_ATTN_VARIANT=%s\n", var ? var : "(default)");
+    printf("MVI_ATTN_VARIANT=%s MVI_ATTN_MFMA16=%s\n", var ? var : "(default)", getenv("MVI_ATTN_MFMA16") ? getenv("MVI_ATTN_MFMA16") : "(default)");
     int fails = 0;
     if (argc >= 2 && !strcmp(argv[1], "bench0")) {
         g_zero_data = true;
         bench(28, 5, 9216, 10);
         return 0;
     }
-    if (argc >= 2 && !strcmp(argv[1], "timeline")) {
-        timeline(28, 5, 9216);
-        timeline(28, 10, 2304);
+    if (argc >= 2 && (!strcmp(argv[1], "clock") || !strcmp(argv[1], "clock0"))) {
+        g_zero_data = !strcmp(argv[1], "clock0");
+        clock_mode(28, 5, 9216, 700);
+        clock_mode(28, 10, 2304, 2800);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "benchlong")) {     // ~2 s of back-to-back launches per shape: the clock has settled (DVFS)
+        bench(28, 5, 9216, 80);
+        bench(28, 10, 2304, 400);
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "bench1")) {       // one shape, few launches: the target of the PMC passes

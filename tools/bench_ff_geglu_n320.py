@@ -15,7 +15,9 @@ bench_svd.enable_gemm_tuning()
 dev = torch.device("cuda")
 g = torch.Generator(device="cuda").manual_seed(0)
 for rows, K, inner, dtype in [(64512, 640, 2560, torch.bfloat16), (16128, 1280, 5120, torch.bfloat16), (64512, 640, 2560, torch.float16),
-                              (258048, 640, 2560, torch.bfloat16)]:
+                              (258048, 640, 2560, torch.bfloat16),
+                              # round 6: the level-0 shape (K = 320) through this form, against csrc/ff_geglu.hip's K = 320 kernel
+                              (258048, 320, 1280, torch.bfloat16), (258048, 320, 1280, torch.float16)]:
     x = (torch.randn(rows, K, device=dev, generator=g) * 1.2).to(dtype)
     w = (torch.randn(2 * inner, K, device=dev, generator=g) * K ** -0.5).to(dtype)
     b = (torch.randn(2 * inner, device=dev, generator=g) * 0.3).to(dtype)
@@ -29,6 +31,8 @@ for rows, K, inner, dtype in [(64512, 640, 2560, torch.bfloat16), (16128, 1280, 
     e_f = float((y[idx].double() - ref).abs().max()) / sc
     e_u = float((unf[idx].double() - ref).abs().max()) / sc
     fns = (lambda: hip_ops.ff_geglu_n320(x, w, b), lambda: hip_ops.geglu(F.linear(x, w, b)), lambda: F.linear(x, w, b))
+    if K == 320:                                             # the second column is the K = 320 kernel of csrc/ff_geglu.hip instead of the library
+        fns = (fns[0], lambda: hip_ops.ff_geglu(x, w, b), fns[2])
     ts = [[], [], []]
     for rnd in range(5):                                     # interleaved rounds: both forms see the same clock history
         for k, fn in enumerate(fns):
@@ -45,5 +49,5 @@ for rows, K, inner, dtype in [(64512, 640, 2560, torch.bfloat16), (16128, 1280, 
     med = [sorted(t)[len(t) // 2] for t in ts]
     fl = 4.0 * rows * K * inner
     print(f"rows {rows} K {K} inner {inner} {str(dtype)[6:]}: fused {med[0] * 1e3:7.1f} us ({fl / med[0] * 1e-9:6.1f} TFLOP/s; min {min(ts[0]) * 1e3:.1f})  "
-          f"library GEMM + geglu {med[1] * 1e3:7.1f} us (GEMM alone {med[2] * 1e3:.1f}, {fl / med[2] * 1e-9:.1f} TFLOP/s);  "
+          f"{'ff_geglu_k320 kernel' if K == 320 else 'library GEMM + geglu'} {med[1] * 1e3:7.1f} us (GEMM alone {med[2] * 1e3:.1f}, {fl / med[2] * 1e-9:.1f} TFLOP/s);  "
           f"max err / max |ref|: fused {e_f:.2e}  unfused {e_u:.2e}", flush=True)

@@ -1,5 +1,5 @@
-"""Phase lengths inside csrc/linear_n320.hip's blocks (diagnostic build: tools/build_variant.sh stamps .../linear_n320.hip -DLN3_STAMPS=1;
-MVI_HIP_LIB=ab/stamps.so python tools/experiments/n320_stamps.py). The launcher prints to stderr after every call."""
+"""Phase lengths inside csrc/linear_n320.hip's blocks (diagnostic build: tools/n320_dev/build_stamped.sh -> MVI_HIP_LIB=ab/n320_stamped.so;
+MVI_HIP_LIB=ab/n320_stamped.so python tools/experiments/n320_stamps.py). The launcher prints to stderr after every call."""
 import os
 import sys
 
