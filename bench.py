@@ -109,10 +109,14 @@ SVD_CHILD_FAILURES = []          # what went wrong in a child that produced no r
 def _svd_child(two_streams, steps, timeout):
     """The SVD denoise-step benchmark (multiview_inpaint_amd/svd/bench_svd.py) in a child process; None if it failed or did not
     finish within `timeout` seconds (the child is then killed) — with the reason and the tail of the child's stderr appended to
-    SVD_CHILD_FAILURES."""
+    SVD_CHILD_FAILURES. two_streams None: the engine's own default (its gate, engine.gemm_set_pinned); False: forced to one stream."""
     import subprocess
-    env = dict(os.environ, MVI_SVD_TWO_STREAMS="1" if two_streams else "0")
-    what = "two streams" if two_streams else "one stream"
+    env = dict(os.environ)
+    if two_streams is None:
+        env.pop("MVI_SVD_TWO_STREAMS", None)
+    else:
+        env["MVI_SVD_TWO_STREAMS"] = "1" if two_streams else "0"
+    what = "engine default" if two_streams is None else ("two streams" if two_streams else "one stream")
 
     def failed(why, err):
         tail = (err or "").strip().splitlines()[-12:]
@@ -141,19 +145,24 @@ def _svd_child(two_streams, steps, timeout):
 
 def svd_leg(steps):
     """Second half of the BASELINE.json metric, measured in child processes started before this process initialises the GPU (a
-    child may not be exec'd from a process that has). The HEADLINE is the step on ONE stream — the library's default
-    (engine.TWO_STREAMS off). The opt-in mode with the ControlNet on a side stream beside the UNet encoder
-    (MVI_SVD_TWO_STREAMS=1; 1 - 3 % faster at the end of round 5 — 133.4 against 134.8 ms, 137.5 against 142.1 on a slower box — and only safe when the GEMM set is pinned: DESIGN.md) is measured as well, under a
-    time-out, and reported NEXT to the headline as `two_streams`. MVI_BENCH_TWO_STREAMS=0 skips it."""
-    one = _svd_child(False, steps, 900)
-    if one is None:
-        return None
-    one["execution"] = "one stream (the library default)"
-    if os.environ.get("MVI_BENCH_TWO_STREAMS", "1") != "0":
-        two = _svd_child(True, steps, 240)
-        one["two_streams"] = ({k: two[k] for k in ("steps_per_s", "ms_per_step", "step_ms", "finite") if k in two}
-                              if two is not None else "did not complete")
-    return one
+    child may not be exec'd from a process that has). The HEADLINE is the engine's DEFAULT execution (round 6): the ControlNet on a
+    side stream beside the UNet encoder exactly when the library GEMM set is pinned by the shipped TunableOp file in that process
+    (engine.gemm_set_pinned — the condition under which the mode has completed every run since round 3; bench_svd pins it), one
+    stream otherwise; `execution` says which ran. The forced one-stream step is measured as well and reported NEXT to the headline as
+    `one_stream` (rounds 1 - 5 had it the other way round: one stream as the headline, `two_streams` beside it).
+    MVI_BENCH_ONE_STREAM=0 skips the second child."""
+    head = _svd_child(None, steps, 900)
+    if head is None:
+        head = _svd_child(False, steps, 900)             # the default mode failed or hung (recorded in child_failures): one stream
+        if head is None:
+            return None
+    head["execution"] = ("two streams: ControlNet beside the UNet encoder (the engine's default with the pinned GEMM set)" if head.get("two_streams")
+                         else "one stream")
+    if head.get("two_streams") and os.environ.get("MVI_BENCH_ONE_STREAM", "1") != "0":
+        one = _svd_child(False, steps, 400)
+        head["one_stream"] = ({k: one[k] for k in ("steps_per_s", "ms_per_step", "step_ms", "finite") if k in one}
+                              if one is not None else "did not complete")
+    return head
 
 
 def main():

@@ -400,7 +400,7 @@ int unet_fail(int code, const char* msg);
 }  // namespace mvi
 
 #ifndef MVI_ATTN_MFMA16_DEFAULT
-#define MVI_ATTN_MFMA16_DEFAULT 0      // profiles/round6_attention_mfma16_ab.txt decides
+#define MVI_ATTN_MFMA16_DEFAULT 2      // 0: attn_flash8.hip (32x32x16); 1: 16x16x32, row sums on the VALU; 2: 16x16x32, row sums from the matrix pipe — profiles/round6_attention_mfma16_ab.txt: 2 is 2.7 - 3.0 % faster than 0 on both shapes, same box
 #endif
 extern "C" int mvi_attention_kernel_kind(int32_t Sq, int32_t Sk, int32_t D, int32_t dtype) {
     return (dtype != MVI_DT_F32 && D == mvi::kFD && Sk > 32) ? 1 : 0;

@@ -5,7 +5,12 @@
 // give-back' item 7), and attention was the one matrix kernel never built on it. Whether it pays HERE is a measurement
 // (profiles/round6_attention_mfma16_ab.txt): this kernel is bound by vector issue, and an MFMA of either shape holds the issue port
 // for 8 cycles — the 16x16x32 form issues twice as many of them per FLOP.
-// Selected by MVI_ATTN_MFMA16=1 (mvi_attention_kernel_variant reports 16 then); the default stays attn_flash8.hip unless the A/B says otherwise.
+// Measured (profiles/round6_attention_mfma16_ab.txt, same box, alternating, q carrying the scale as the SVD modules run it): per 64-key
+// tile and block 1638 shader cycles on 32x32x16, 1841 here, 1868 with the row sums as a fifth d tile (kOnes) — and an in-kernel clock of
+// 1.83, 2.07 and 2.11 GHz: the chip is power-bound under this kernel and pays the cheaper instruction back as clock, 12 % more cycles
+// become 2.7 - 3.0 % LESS time (S = 9216: 2.742 -> 2.668 ms, 0.443 -> 0.455 of 2.5 PF on that box; S = 2304: 0.402 -> 0.390 ms). On
+// all-zero operands (2.39 GHz for all three) the order is the cycle order. So this kernel is the default since round 6
+// (MVI_ATTN_MFMA16: 0 = attn_flash8.hip, 1 = row sums on the VALU, 2 = default); mvi_attention_kernel_variant reports 16.
 // Replaces xformers.ops.memory_efficient_attention / SDPA (svd_inpaint1/sgm/modules/attention.py:427-439, :332-336).
 //
 // Layout: q/out [B, Sq, H, 64], k/v [B, Sk, H, 64] token-major with element strides between tokens, as in attn_flash8.hip.

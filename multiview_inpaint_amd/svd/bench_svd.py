@@ -227,14 +227,15 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     # The ControlNet runs on the main stream here: with the two networks sharing the chip (engine.TWO_STREAMS, the timed
     # region above) an op's events would time its kernel PLUS whatever ran beside it.
     from . import engine as _engine
-    two_streams, _engine.TWO_STREAMS = _engine.TWO_STREAMS, False
+    two_streams, ts_setting = _engine.two_streams_active(), _engine.TWO_STREAMS
+    _engine.TWO_STREAMS = False
     hip_ops.PROFILE = []
     for i in range(steps):
         step(i)
     torch.cuda.synchronize(device)
     prof = hip_ops.profile_summary()
     hip_ops.PROFILE = None
-    _engine.TWO_STREAMS = two_streams
+    _engine.TWO_STREAMS = ts_setting
     res = dict(steps_per_s=round(1.0 / dt, 4), ms_per_step=round(dt * 1e3, 2), frames=T, latent=[h, w], batch=int(x.shape[0]),
                step_ms=per_step, controlnet=with_control, gemm_tuning=bool(tuned), two_streams=bool(two_streams and with_control),
                dtype=(f"{weights} weights + activations, fp32 GroupNorm statistics / softmax / LayerNorm accumulation" if weights in _HALF

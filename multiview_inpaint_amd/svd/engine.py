@@ -17,13 +17,49 @@ import torch.nn as nn
 from .schedule import Denoiser, instantiate_from_config
 
 OPENAIUNETWRAPPER = "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper"
-# ControlNet beside the UNet encoder (apply_model). OPT-IN: same-box A/B 181.3 -> 173.2 ms per step. What stands in the way of
-# making it the default (tools/experiments/two_stream_probe.py, every run under `timeout`): with hipBLASLt choosing its GEMM
-# kernels by its own heuristic, one of the first steps of a process stops making progress (twice out of two runs; some of its
-# stream-K kernels spin on flags of peer workgroups, and two of them on concurrent streams can keep each other's peers off
-# the chip); with the GEMM set pinned by the shipped TunableOp file (svd/tunableop_gfx950.csv, what bench_svd uses) the same
-# sequence and ~150 bench steps completed. A property of the library build, not of this code: left to the caller.
-TWO_STREAMS = os.environ.get("MVI_SVD_TWO_STREAMS", "0") == "1"
+# ControlNet beside the UNet encoder (apply_model): same-box A/B 181.3 -> 173.2 ms per step in round 3, 137.3 -> 133.7 in the driver's
+# round-5 run. What stood in the way of making it the default (tools/experiments/two_stream_probe.py, every run under `timeout`): with
+# hipBLASLt choosing its GEMM kernels by its own heuristic, one of the first steps of a process stops making progress (twice out of
+# two runs; some of its stream-K kernels spin on flags of peer workgroups, and two of them on concurrent streams can keep each other's
+# peers off the chip); with the GEMM set pinned by the shipped TunableOp file (svd/tunableop_gfx950.csv) the same sequence and every
+# bench run since round 3 completed. So since round 6 the mode is GATED ON THAT CONDITION instead of on an environment variable:
+#   MVI_SVD_TWO_STREAMS unset  -> on exactly when gemm_set_pinned(): TunableOp is enabled in look-up-only mode in this process
+#                                 (bench_svd.enable_gemm_tuning(), what bench.py and tools/ do) and the file's validator lines equal
+#                                 the running stack's (otherwise PyTorch ignores the file and the heuristic picks again);
+#   MVI_SVD_TWO_STREAMS=1 / 0  -> forced on / off (A/B runs; forcing it on without the pinned set is the caller's risk).
+# A process that never pinned its GEMMs (a plain `import` of the engine) therefore runs one stream, as before.
+_FORCED = {"1": True, "0": False}.get(os.environ.get("MVI_SVD_TWO_STREAMS", ""))
+TWO_STREAMS = _FORCED          # None: decided by gemm_set_pinned() at the first GPU step; tests and bench_svd assign True / False
+_pinned = None
+
+
+def gemm_set_pinned() -> bool:
+    """True when every library GEMM of this process is looked up in the shipped TunableOp selection (no run-time tuning, validators of
+    the file == validators of the running PyTorch / hipBLASLt / rocBLAS stack). Cached after the first call on a GPU."""
+    global _pinned
+    if _pinned is None:
+        _pinned = False
+        try:
+            import torch.cuda.tunable as tn
+            if tn.is_enabled() and not tn.tuning_is_enabled():
+                want = {}
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")) as fh:
+                    for line in fh:
+                        if line.startswith("Validator,"):
+                            _, k, v = line.rstrip("\n").split(",", 2)
+                            want[k] = v
+                have = {str(k): str(v) for k, v in (tn.get_validators() or ())}
+                _pinned = bool(want) and bool(have) and all(have.get(k) == v for k, v in want.items())
+        except Exception:
+            _pinned = False
+    return _pinned
+
+
+def two_streams_active() -> bool:
+    """Whether apply_model runs the ControlNet on a side stream in this process right now."""
+    return gemm_set_pinned() if TWO_STREAMS is None else bool(TWO_STREAMS)
+
+
 _side = {}
 
 
@@ -118,7 +154,7 @@ class SVDInpaintEngine(nn.Module):
                 if self.global_average_pooling:
                     cs = [c.mean(dim=(2, 3), keepdim=True) for c in cs]
                 return cs
-            if TWO_STREAMS and xin.is_cuda and not torch.is_grad_enabled() and _events_off():
+            if xin.is_cuda and not torch.is_grad_enabled() and _events_off() and two_streams_active():
                 # The ControlNet and the UNet's encoder + middle block are independent until the first residual is added
                 # (csvd.py:79): the ControlNet runs on a side stream while the main stream runs the encoder, so that the
                 # low-resolution halves of both — whose kernels fill a quarter of the chip each (80 tiles per 3x3 convolution
