@@ -356,6 +356,29 @@ int mvi_attention_kernel_variant(int32_t Sq, int32_t Sk, int32_t D, int32_t dtyp
 
 const char* mvi_unet_last_error(void);
 
+/* ---- Round 6: first-stage (VAE) decoder convolutions at fp32 accuracy on the bf16 matrix pipe (split operands).
+ * Replaces the fp32 F.conv2d / F.conv3d calls behind sgm/modules/diffusionmodules/model.py:604-748 (Decoder: ResnetBlock conv1 / conv2,
+ * Upsample.conv) and sgm/modules/autoencoding/temporal_ae.py:16-81 (VideoResBlock.time_stack) that the reference runs with autocast
+ * disabled (configs/test/svd_f_est_ctrl_simp1.yaml:6, sgm/models/diffusion.py:194-212).
+ *   x2     [rows, 2 C] bf16: every fp32 activation as (hi | lo) halves, hi = round_bf16(v), lo = round_bf16(v - hi)
+ *          (mvi_groupnorm_silu_tok2tok_split writes it);
+ *   weight [C_out padded to whole groups of mvi_conv_split3_group(C_out) columns][taps x 3 C] bf16 in the kernel's contraction order,
+ *          logical channels (w_hi | w_lo | w_hi), padding rows zero (multiview_inpaint_amd/svd/hip_ops.py split3_weight);
+ *   out    [mvi_conv_split3_out_rows(rows), C_out] fp32 = x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, NO bias; rows >= N H W are scratch.
+ * 3x3 / stride 1 / padding 1 over N images of H x W tokens, or (3,1,1) / padding (1,0,0) over B videos of T frames of `pixels` tokens.
+ * rows x 2 C x 2 bytes must stay below 4 GiB (split the batch). Returns MVI_OK or a negative status (mvi_unet_last_error). */
+int mvi_conv_split3_group(int32_t C_out);
+int64_t mvi_conv_split3_out_rows(int64_t rows);
+int mvi_conv3x3_split3_f32(const void* x2, const void* weight, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t C_out,
+                           int64_t out_rows_capacity, void* stream);
+int mvi_conv3t_split3_f32(const void* x2, const void* weight, float* out, int64_t B, int32_t T, int32_t pixels, int32_t C, int32_t C_out,
+                          int64_t out_rows_capacity, void* stream);
+/* GroupNorm(+SiLU) of fp32 token-major x [N, S, C] written as split bf16 y2 [N, S, 2 C] = (hi | lo); frames > 1: statistics per video of
+ * `frames` consecutive samples; groups = 0: no normalisation (plain split). Workspace: mvi_groupnorm_tok2tok_workspace_bytes(.., MVI_DT_F32). */
+int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const float* weight, const float* bias, const float* chan_bias,
+                                     int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

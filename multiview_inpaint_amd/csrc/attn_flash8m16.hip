@@ -426,7 +426,12 @@ void attn_flash8m16_kernel(const T* __restrict__ q, const T* __restrict__ k, con
     if (tid == 0) *redo_flag = 0u;                               // ordered before any read by the barriers of run()
     run(std::false_type{});
     const float l_limit = std::is_same<T, __half>::value ? 0x1p15f : 0x1p100f;
-    const bool out_of_range = !(l[0] <= l_limit) || !(l[1] <= l_limit);      // also true for NaN
+    // Compared as BIT PATTERNS: with the row sums from the matrix pipe (kOnes) a probability that overflowed the type (f16: > 65504)
+    // gives 0 x inf = NaN in the rows of the ones tile that hold zeros, i.e. a NaN sum — and this file is compiled with
+    // -fno-honor-nans, under which `!(l <= limit)` may be folded to `l > limit` (false for NaN). Sums are >= 0: |bits| orders them,
+    // and every inf / NaN pattern is above every finite limit.
+    const uint32_t lim = __float_as_uint(l_limit);
+    const bool out_of_range = (__float_as_uint(l[0]) & 0x7FFFFFFFu) > lim || (__float_as_uint(l[1]) & 0x7FFFFFFFu) > lim;
     if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull && lane == 0) *redo_flag = 1u;
     __syncthreads();
     if (*redo_flag != 0u) {

@@ -205,6 +205,73 @@ __global__ __launch_bounds__(1024) void gt_apply_kernel(const T* __restrict__ x,
     }
 }
 
+// Round 6, the split-operand convolutions of the first-stage decoder (csrc/linear_n320.hip, mvi_conv3x3_split3_f32): the apply pass of an
+// fp32 tensor writes every value as TWO bf16 — y2 [N, S, 2 C] = (hi | lo), hi = round(v), lo = round(v - hi): 16 mantissa bits, the bytes
+// of the fp32 tensor — instead of one rounded value. scale_shift NULL: no normalisation (the plain split in front of Upsample.conv).
+__global__ __launch_bounds__(1024) void gt_apply_split_kernel(const float* __restrict__ x, __hip_bfloat16* __restrict__ y2, const float* __restrict__ scale_shift,
+                                                              int C, int64_t S, int vpr, int rp, int silu) {
+    constexpr int V = 4;
+    const int tid = threadIdx.x, v = tid % vpr, r0 = tid / vpr;
+    const int64_t n = blockIdx.y;
+    const int64_t row0 = (int64_t)blockIdx.x * (kGtPasses * rp);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        sc[k] = scale_shift ? scale_shift[(n * C + v * V + k) * 2] : 1.f;
+        sh[k] = scale_shift ? scale_shift[(n * C + v * V + k) * 2 + 1] : 0.f;
+    }
+    const float* xb = x + (n * S) * C + (int64_t)v * V;
+    __hip_bfloat16* yb = y2 + (n * S) * 2 * C + (int64_t)v * V;
+    float4 raw[kGtPasses];
+#pragma unroll
+    for (int p = 0; p < kGtPasses; ++p) {
+        const int64_t row = row0 + p * rp + r0;
+        raw[p] = *reinterpret_cast<const float4*>(xb + (row < S ? row : S - 1) * C);
+    }
+#pragma unroll
+    for (int p = 0; p < kGtPasses; ++p) {
+        const int64_t row = row0 + p * rp + r0;
+        if (row < S) {
+            const float t[V] = {raw[p].x, raw[p].y, raw[p].z, raw[p].w};
+            uint16_t hi[V], lo[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float u = t[k] * sc[k] + sh[k];
+                if (silu) u = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+                const __hip_bfloat16 h = __float2bfloat16(u);
+                const __hip_bfloat16 l = __float2bfloat16(u - __bfloat162float(h));
+                hi[k] = *reinterpret_cast<const uint16_t*>(&h);
+                lo[k] = *reinterpret_cast<const uint16_t*>(&l);
+            }
+            const uint2 ph = {(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+            const uint2 pl = {(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+            *reinterpret_cast<uint2*>(yb + row * 2 * C) = ph;
+            *reinterpret_cast<uint2*>(yb + row * 2 * C + C) = pl;
+        }
+    }
+}
+
+static int gt_launch_split(const float* x, void* y2, const float* w, const float* b, const float* cb, int64_t N, int C, int64_t S, int G, float eps,
+                           int silu, float* ws, hipStream_t st, int frames) {
+    constexpr int V = 4;
+    const int vpr = C / V, rp = gt_rows_per_pass(vpr);
+    const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
+    const dim3 grid((unsigned)chunks, (unsigned)N), block((unsigned)(vpr * rp));
+    float* ss = nullptr;
+    if (G > 0) {
+        int sets = (int)((int64_t)chunks * N / 768);
+        sets = sets < 1 ? 1 : (sets > 16 ? 16 : sets);
+        const int schunks = (chunks + sets - 1) / sets;
+        float* part = ws;
+        ss = ws + (size_t)N * chunks * G * 3;
+        const size_t lds = ((size_t)2 * rp * C + C) * sizeof(float);
+        hipLaunchKernelGGL((gt_stats_kernel<float>), dim3((unsigned)schunks, (unsigned)N), block, lds, st, x, cb, part, C, S, G, vpr, rp, schunks, sets);
+        hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)N), dim3(kGtMergeThreads), 0, st, part, w, b, cb, ss, C, G, schunks, eps, frames);
+    }
+    hipLaunchKernelGGL(gt_apply_split_kernel, grid, block, 0, st, x, (__hip_bfloat16*)y2, ss, C, S, vpr, rp, silu);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+
 template <typename T>
 static int gt_launch(const void* x, void* y, const float* w, const float* b, const float* cb, int64_t N, int C, int64_t S, int G, float eps,
                      int silu, float* ws, hipStream_t st, int frames = 1) {
@@ -309,4 +376,22 @@ extern "C" int mvi_groupnorm_silu_tok2tok_frames(const void* x, void* y, const f
                                                  int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps,
                                                  int32_t fuse_silu, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
     return tok2tok_impl(x, y, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, frames, dtype, workspace, workspace_bytes, stream);
+}
+
+// GroupNorm(+SiLU) of an fp32 token-major tensor x [N, S, C] written as split bf16 y2 [N, S, 2 C] = (hi | lo) (see gt_apply_split_kernel);
+// statistics over the `frames` consecutive samples of a video when frames > 1 (the temporal norms). groups = 0: no normalisation, the
+// plain split (weight / bias / chan_bias / workspace unused). Workspace as mvi_groupnorm_tok2tok_workspace_bytes(..., MVI_DT_F32).
+extern "C" int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const float* weight, const float* bias, const float* chan_bias,
+                                                int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps,
+                                                int32_t fuse_silu, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (!gt_geometry_ok(N, C, spatial, groups > 0 ? groups : 1, MVI_DT_F32))
+        return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: C must be a multiple of groups (<= 64) and of 4");
+    if (frames < 1 || N % frames) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: N must be a whole number of videos of `frames` samples");
+    if (!x || !y2 || (groups > 0 && (!weight || !bias || !workspace))) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: NULL pointer");
+    if (((uintptr_t)x | (uintptr_t)y2) % 16 || C % 4) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: x / y2 must be 16-byte aligned");
+    if (groups > 0 && workspace_bytes < mvi_groupnorm_tok2tok_workspace_bytes(N, C, spatial, groups, MVI_DT_F32))
+        return mvi::unet_fail(MVI_ENOMEM, "groupnorm_tok2tok_split: workspace too small");
+    const int rc = mvi::gt_launch_split(x, y2, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, (hipStream_t)stream, frames);
+    return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok_split: kernel launch failed") : MVI_OK;
 }

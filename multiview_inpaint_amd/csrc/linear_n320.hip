@@ -111,6 +111,11 @@ struct ConvGeom {
     int stride, Ho, Wo;                              // 1 or 2 (3x3 only); output height / width (= H, W at stride 1)
     int cc_major;                                    // K ordered (channel chunk, tap, 64 channels) instead of (tap, channel): see conv_k_order
     int frame_major;                                 // taps == 3: row blocks walked (pixel block, frame) instead of (frame, pixel block)
+    // Round 6, split-operand convolutions at fp32 accuracy (the first-stage decoder, svd/vae_split.py):
+    int dup3;                                        // the LOGICAL channel axis is (hi | hi | lo) over a PHYSICAL x row of (hi | lo): logical 64-channel
+                                                     // chunk cc of a tap reads physical chunk cc - cpc / 3 once cc >= cpc / 3 (cpc = 3 C / 64)
+    int out_cols;                                    // > 0 (with kSplit): the fp32 accumulators ARE the result — stored to `part` [ksplit][padded
+                                                     // rows][out_cols], columns >= out_cols (the padding of C_out to whole column groups) dropped, no reduction
 };
 
 // kStats: the GroupNorm that FOLLOWS this convolution gets its statistics from here (ResBlock out_layers[0] behind in_layers[2],
@@ -159,12 +164,18 @@ struct LnEpi {
     float eps;
 };
 
-template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false>
+// NOUT (round 6): the block's column count — 320 everywhere in the UNet; 256 for the first-stage decoder's 128 / 256 / 512-channel
+// convolutions (split operands, fp32 out). Everything below is written in terms of kN / kNT / kChunkBytes / kPieces..., re-derived here
+// from NOUT (the epilogues that know about 320 — kStats, kGeglu, kLn — are only instantiated with it).
+template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                         int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part, GnStats gn,
                         LnEpi ln = {nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, 0.f}) {
     using M = Mma<T>;
+    static_assert(NOUT == 320 || !(kStats || kGeglu || kLn), "the fused epilogues are written for 320 columns");
+    constexpr int kN = NOUT, kNT = kN / 16, kChunkBytes = kN * kKC * 2, kPieces = kChunkBytes / 1024, kPiecesPerLoader = kPieces / kLoaders;
+    static_assert(kNT % 4 == 0 && kPieces % kLoaders == 0, "column tiles leave four at a time; every loader moves the same number of pieces");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     MVI_AS3 char* const lds = (MVI_AS3 char*)smem;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -270,7 +281,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         const int tap_u = __builtin_amdgcn_readfirstlane(ld_tap), cc_u = __builtin_amdgcn_readfirstlane(ld_cc);
         const int dy = cg.taps == 9 ? tap_u / 3 - 1 : tap_u - 1, dx = cg.taps == 9 ? tap_u - 3 * (tap_u / 3) - 1 : 0;
         const int delta = (dy * cg.W + dx) * (int)(x_rs * 2);
-        const char* const base = xbase + cc_u * (kKC * 2);
+        const int third = cg.cpc / 3;
+        const int cc_phys = cg.dup3 && cc_u >= third ? cc_u - third : cc_u;       // (hi | hi | lo) read from (hi | lo)
+        const char* const base = xbase + cc_phys * (kKC * 2);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bool ok = (tap_ok[t] >> tap_u) & 1u;
@@ -401,14 +414,17 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
     if (kSplit) {
         // fp32 partial sums straight from the accumulators: register r of tile (t, j) = row 16 t + 4 kg + r, column 16 j + n16
-        const int64_t c_tot = (int64_t)cg.groups * kN, rows_pad = (int64_t)(n_blocks / (cg.groups * cg.ksplit)) * kRows;
+        const int64_t c_tot = cg.out_cols ? (int64_t)cg.out_cols : (int64_t)cg.groups * kN;
+        const int64_t rows_pad = (int64_t)(n_blocks / (cg.groups * cg.ksplit)) * kRows;
         float* const pbase = part + ((int64_t)ks * rows_pad + row0 + 4 * kg) * c_tot + part_col0 + n16;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < kNT; ++j)
+            for (int j = 0; j < kNT; ++j) {
+                if (cg.out_cols && part_col0 + 16 * j >= cg.out_cols) continue;        // (the zero rows C_out was padded with)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pbase[(16 * t + r) * c_tot + 16 * j] = acc[t][j][r];
+            }
         return;
     }
     // ---- outputs leave through the wave's LDS tile [32 rows][64 columns = 128 bytes] — four column tiles per flush — and from there as
@@ -650,7 +666,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace ln3
 
-template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false>
+template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
                               hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0}, float* part = nullptr,
                               ln3::GnStats gn = {nullptr, nullptr, 0, 0},
@@ -661,7 +677,8 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn>;
+    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn, NOUT>;
+    constexpr int kLdsBytes = kRing * NOUT * kKC * 2 + kWaves * 4096;
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
@@ -669,7 +686,7 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
                        o_rs, (int)n_blocks, cg, part, gn, ln);
-    if (kSplit) {
+    if (kSplit && !cg.out_cols) {
         const int c_tot = cg.groups * kN;
         const int64_t threads = rows * (c_tot / 8), rows_pad = (rows + kRows - 1) / kRows * kRows;
         hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, (T*)out,
@@ -911,4 +928,65 @@ extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* b
                                void* workspace, size_t workspace_bytes, void* stream) {
     return conv_taps_n320("conv3t_n320", x, weight, bias, out, B, T, pixels, 3, 1, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
                           workspace, workspace_bytes, stream);
+}
+
+// ---- Round 6: convolutions at fp32 ACCURACY on the bf16 matrix pipe — the first-stage (VAE) decoder's 128 / 256 / 512-channel 3x3 and
+// (3,1,1) convolutions, which the reference runs in fp32 (`disable_first_stage_autocast: True`, configs/test/svd_f_est_ctrl_simp1.yaml:6;
+// sgm/models/diffusion.py:194-212; sgm/modules/diffusionmodules/model.py:604-748; sgm/modules/autoencoding/temporal_ae.py:291-347).
+// Every fp32 operand is split into two bf16 values, v = hi + lo (hi = round(v), lo = round(v - hi): 16 mantissa bits together), and
+//     x . w  ~=  x_hi . w_hi  +  x_hi . w_lo  +  x_lo . w_hi          (fp32 accumulate; the dropped x_lo . w_lo term is 2^-16 of a product)
+// runs as ONE implicit GEMM of this kernel with a three times longer contraction: logical channel axis (hi | hi | lo) of the
+// activations against (w_hi | w_lo | w_hi) of the weights. The activations are stored once, as x2 [rows, 2 C] = (hi | lo) bf16 (what
+// mvi_groupnorm_silu_tok2tok_split writes: the bytes of the fp32 tensor), and the K loop reads the hi half twice (ConvGeom::dup3).
+// The fp32 accumulators are the result (ConvGeom::out_cols): out [padded rows, C_out] fp32, no bias (the callers fold it into the
+// next norm / the residual add, as the fp32 path of svd/vae.py does).
+//   weight: [C_out_padded][taps x 3 C] bf16 in this kernel's K order (svd/hip_ops.py split3_weight), C_out_padded = a whole number of
+//   column groups of mvi_conv_split3_group(C_out) columns (320 when C_out is a multiple of 320, else 256), the padding rows zero.
+extern "C" int mvi_conv_split3_group(int32_t C_out) { return C_out > 0 && C_out % 320 == 0 ? 320 : 256; }
+
+extern "C" int64_t mvi_conv_split3_out_rows(int64_t rows) { return (rows + mvi::ln3::kRows - 1) / mvi::ln3::kRows * mvi::ln3::kRows; }
+
+static int conv_split3(const char* what, const void* x2, const void* weight, float* out, int64_t N, int32_t H, int32_t W, int32_t taps,
+                       int32_t C, int32_t C_out, int64_t out_rows_capacity, void* stream) {
+    char msg[200];
+    auto fail = [&](const char* m) {
+        snprintf(msg, sizeof msg, "%s: %s", what, m);
+        return mvi::unet_fail(MVI_EINVAL, msg);
+    };
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 || C_out <= 0 || C_out % 16) return fail("needs C a multiple of 64 and C_out a multiple of 16");
+    const int64_t rows = N * H * W;
+    if (rows == 0) return MVI_OK;
+    if (!x2 || !weight || !out) return fail("NULL pointer");
+    if (((uintptr_t)x2 | (uintptr_t)weight | (uintptr_t)out) % 16) return fail("x2, weight and out must be 16-byte aligned");
+    if (out_rows_capacity < mvi_conv_split3_out_rows(rows)) return fail("out needs room for mvi_conv_split3_out_rows(rows) rows (whole 256-row blocks are stored)");
+    const int group = mvi_conv_split3_group(C_out);
+    const int groups = (C_out + group - 1) / group;
+    const int64_t x_rs = 2 * (int64_t)C;                          // physical row: (hi | lo)
+    if ((int64_t)group * taps * 3 * C * 2 > 0xFFFFFFFFll || rows * x_rs * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
+        return fail("weight group / activation tensor exceeds 32-bit byte offsets (split the batch)");
+    const int k_order = taps == 9 ? g_conv_k_order : 0;
+    const mvi::ln3::ConvGeom cg = {H, W, 3 * C / mvi::ln3::kKC, taps, groups, 1, 1, H, W, k_order,
+                                   (taps == 3 && g_conv_k_order && W % mvi::ln3::kRows == 0) ? 1 : 0, 1, C_out};
+    hipStream_t st = (hipStream_t)stream;
+    const int K = taps * 3 * C;
+    int rc;
+    if (group == 320)
+        rc = mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 320>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
+    else
+        rc = mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 256>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
+    if (rc) {
+        snprintf(msg, sizeof msg, "%s: kernel launch failed", what);
+        return mvi::unet_fail(rc, msg);
+    }
+    return MVI_OK;
+}
+
+extern "C" int mvi_conv3x3_split3_f32(const void* x2, const void* weight, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t C_out,
+                                      int64_t out_rows_capacity, void* stream) {
+    return conv_split3("conv3x3_split3_f32", x2, weight, out, N, H, W, 9, C, C_out, out_rows_capacity, stream);
+}
+
+extern "C" int mvi_conv3t_split3_f32(const void* x2, const void* weight, float* out, int64_t B, int32_t T, int32_t pixels, int32_t C,
+                                     int32_t C_out, int64_t out_rows_capacity, void* stream) {
+    return conv_split3("conv3t_split3_f32", x2, weight, out, B, T, pixels, 3, C, C_out, out_rows_capacity, stream);
 }

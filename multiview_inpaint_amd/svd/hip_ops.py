@@ -877,3 +877,80 @@ def attention_kernel_variant(Sq, Sk, D, dtype):
 
 def attention_kernel_kind(Sq, Sk, D, dtype):
     return int(_lib.lib().mvi_attention_kernel_kind(Sq, Sk, D, _DT[dtype]))
+
+
+# ---- Round 6: split-operand convolutions at fp32 accuracy (the first-stage decoder; csrc/linear_n320.hip, mvi_conv3x3_split3_f32) ------
+
+def split_hi_lo(v):
+    """fp32 -> (hi, lo) bf16 with hi + lo = v to 16 mantissa bits."""
+    hi = v.to(torch.bfloat16)
+    return hi, (v - hi.float()).to(torch.bfloat16)
+
+
+def split3_weight(weight):
+    """A convolution weight ([C_out, C_in, 3, 3] or [C_out, C_in, 3, 1, 1], any float type) for mvi_conv3x3_split3_f32 / mvi_conv3t_split3_f32:
+    bf16 [C_out padded to whole column groups][taps x 3 C_in] with the logical channel axis (w_hi | w_lo | w_hi) in the kernel's
+    contraction order, padding rows zero."""
+    w = weight.detach().float()
+    hi, lo = split_hi_lo(w)
+    w3 = torch.cat([hi, lo, hi], dim=1)
+    packed = conv3x3_n320_weight(w3) if w.dim() == 4 else conv3t_n320_weight(w3)
+    Co = packed.shape[0]
+    group = int(_lib.lib().mvi_conv_split3_group(Co))
+    pad = -Co % group
+    if pad:
+        packed = torch.cat([packed, packed.new_zeros(pad, packed.shape[1])])
+    return packed.contiguous()
+
+
+def group_norm_split(x, num_groups, weight, bias, eps, silu, chan_bias=None, frames=1):
+    """GroupNorm(+SiLU) of fp32 token-major x [N, S, C] -> split bf16 [N, S, 2 C] = (hi | lo) (mvi_groupnorm_silu_tok2tok_split).
+    num_groups = 0: no normalisation, the plain split."""
+    L = _lib.lib()
+    if x.dtype != torch.float32 or x.dim() != 3:
+        raise TypeError("group_norm_split: fp32 [N, S, C] expected")
+    xc = x if x.is_contiguous() else x.contiguous()
+    N, S, Cc = xc.shape
+    y2 = torch.empty(N, S, 2 * Cc, dtype=torch.bfloat16, device=x.device)
+    ws, nbytes, cb = None, 0, None
+    if num_groups:
+        nbytes = L.mvi_groupnorm_tok2tok_workspace_bytes(N, Cc, S, num_groups, 0)
+        if nbytes == 0:
+            raise ValueError(f"group_norm_split: unsupported shape {tuple(x.shape)} / {num_groups} groups")
+        ws = _workspace(x.device, nbytes)
+        if chan_bias is not None:
+            cb = chan_bias.detach().float().contiguous()
+            if cb.shape != (N, Cc):
+                raise ValueError(f"group_norm_split: chan_bias must be [{N}, {Cc}]")
+    with torch.cuda.device(x.device), _Timed("groupnorm_split", 2.0 * xc.numel() * 4, x.device):
+        _check(L.mvi_groupnorm_silu_tok2tok_split(xc.data_ptr(), y2.data_ptr(), None if not num_groups else _f32(weight).data_ptr(),
+                                                  None if not num_groups else _f32(bias).data_ptr(), None if cb is None else cb.data_ptr(), N,
+                                                  int(frames), Cc, S, int(num_groups), float(eps), int(bool(silu)),
+                                                  None if ws is None else ws.data_ptr(), nbytes, _stream(x.device)), "group_norm_split")
+    return y2
+
+
+def conv_split3(x2, w3, N, H, W, C_out, taps=9, _max_bytes=0xFFFFFFFF):
+    """x . w at fp32 accuracy on the bf16 matrix pipe: x2 [N H W, 2 C] split bf16 (group_norm_split), w3 from split3_weight ->
+    fp32 [N H W, C_out], no bias. taps = 9: 3x3 / padding 1 over N images of H x W tokens; taps = 3: (3,1,1) / padding (1,0,0) over N
+    videos of H frames of W tokens. The batch is cut so that every launch stays inside the kernel's 32-bit activation offsets."""
+    L = _lib.lib()
+    C2 = x2.shape[-1]
+    C = C2 // 2
+    rows = N * H * W
+    if x2.dtype != torch.bfloat16 or not x2.is_contiguous() or x2.numel() != rows * C2 or w3.shape[1] != taps * 3 * C or w3.dtype != torch.bfloat16:
+        raise ValueError("conv_split3: x2 contiguous bf16 [N H W, 2 C] and w3 bf16 [C_out padded, taps 3 C] expected")
+    x2 = x2.reshape(rows, C2)
+    per = H * W * C2 * 2                                       # bytes of one image / video
+    n_max = max(1, (_max_bytes // per))
+    if per > 0xFFFFFFFF:
+        raise ValueError("conv_split3: one image / video exceeds the kernel's 32-bit activation offsets")
+    cap = int(L.mvi_conv_split3_out_rows(rows)) + 256
+    out = torch.empty(cap, C_out, dtype=torch.float32, device=x2.device)
+    fn = L.mvi_conv3x3_split3_f32 if taps == 9 else L.mvi_conv3t_split3_f32
+    with torch.cuda.device(x2.device), _Timed("conv_split3", 2.0 * rows * taps * 3 * C * C_out, x2.device):
+        for n0 in range(0, N, n_max):
+            n = min(n_max, N - n0)
+            r0 = n0 * H * W
+            _check(fn(x2[r0:].data_ptr(), w3.data_ptr(), out[r0:].data_ptr(), n, H, W, C, C_out, cap - r0, _stream(x2.device)), "conv_split3")
+    return out[:rows]

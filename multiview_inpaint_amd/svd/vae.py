@@ -388,6 +388,12 @@ class Decoder(nn.Module):
 
     def forward(self, z, **kwargs):
         self.last_z_shape = z.shape
+        if kwargs.get("timesteps") is not None and not kwargs.get("skip_video"):
+            # fp32 accuracy on the bf16 matrix pipe (round 6, svd/vae_split.py): the shipped VideoDecoder configuration in fp32 on the GPU
+            # runs its 3x3 / (3,1,1) convolutions with split operands on token-major activations; anything else is the graph below
+            from . import vae_split
+            if vae_split.applies(self, z):
+                return vae_split.decode(self, z, kwargs["timesteps"])
         res_kw = kwargs if isinstance(self.mid.block_1, VideoResBlock) else {}
         h = self.conv_in(z)
         h = self.mid.block_1(h, None, **res_kw)
@@ -553,8 +559,10 @@ def decode_first_stage(first_stage_model, z, scale_factor: float = 0.18215, en_a
     temporal layers), fp32 (disable_first_stage_autocast: the reference's recipe and the default here).
     dtype = torch.bfloat16 / torch.float16 (or MVI_VAE_DECODE_DTYPE=bf16): an opt-in of this package — the decoder's weights and
     activations in that type, GroupNorm statistics and the softmax in fp32 as everywhere, fp32 frames returned. At 14 x 576x1024 the
-    fp32 decode is bound by the fp32 matrix rate (1.26 s, a quarter of a 25-step sample); in bf16 its error against the reference's
-    fp32 frames is that of the reference's OWN bf16-autocast decode (tests/test_vae_gpu.py, budget in tests/golden/vae_full.npz)."""
+    fp32 LIBRARY decode is bound by the fp32 matrix rate (0.92 - 1.26 s, a quarter of a 25-step sample); in bf16 its error against the
+    reference's fp32 frames is that of the reference's OWN bf16-autocast decode (tests/test_vae_gpu.py, budget in tests/golden/vae_full.npz).
+    Since round 6 the DEFAULT itself (dtype None: fp32 contract, 1e-4) runs its convolutions on the bf16 matrix pipe with split operands
+    (svd/vae_split.py, entered from VideoDecoder.forward; MVI_VAE_SPLIT=0 for the library path)."""
     dtype = DECODE_DTYPE if dtype is None else dtype
     if dtype in (None, torch.float32) or not z.is_cuda:
         dec_mod, cast = None, None

@@ -308,7 +308,9 @@ def _pin_device():
         return
     # ONE device id, derived from whichever list the job was given (HIP's wins when both are set), written to both variables:
     # two independently derived values could name different GPUs
-    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    # MVI_TRAIN_VIEWS_DEVICES: an explicit rank -> device list that the PARENT (torchrun) does not see as a visibility variable — torchrun
+    # itself counts devices, and refuses a HIP_VISIBLE_DEVICES list longer than ROCR_VISIBLE_DEVICES (e.g. "0,0": two ranks on one GPU)
+    vis = os.environ.get("MVI_TRAIN_VIEWS_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
     if vis:                                                   # a restricted list: this rank's entry of it
         ids = [v for v in vis.split(",") if v != ""]
         if int(lr) >= len(ids):

@@ -241,8 +241,9 @@ def entry_launcher(rank, world, port, queue, kwargs):
     try:
         out = tempfile.mkdtemp(prefix="mvi_launcher_")
         env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]),
-                   MVI_TRAIN_VIEWS_BACKEND="gloo", HIP_VISIBLE_DEVICES="0,0", CUDA_VISIBLE_DEVICES="0,0")    # both ranks pin to the one GPU
-        env.pop("MVI_TRAIN_VIEWS_NO_PIN", None)
+                   MVI_TRAIN_VIEWS_BACKEND="gloo", MVI_TRAIN_VIEWS_DEVICES="0,0")    # both ranks pin themselves to the one GPU
+        for var in ("MVI_TRAIN_VIEWS_NO_PIN", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            env.pop(var, None)
         n = int(kwargs.get("iterations", 12))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), "-m", "multiview_inpaint_amd.train_views", os.path.join(ROOT, "tests", "gs_simp_standin"),

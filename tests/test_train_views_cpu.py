@@ -31,7 +31,7 @@ def test_view_stack_gives_every_rank_the_same_draws_and_its_own_view():
 
 
 def test_launcher_pins_each_rank_to_its_own_gpu(monkeypatch):
-    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "MVI_TRAIN_VIEWS_NO_PIN"):
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "MVI_TRAIN_VIEWS_NO_PIN", "MVI_TRAIN_VIEWS_DEVICES"):
         monkeypatch.delenv(var, raising=False)
     monkeypatch.setenv("LOCAL_RANK", "3")
     TV._pin_device()
@@ -49,6 +49,10 @@ def test_launcher_pins_each_rank_to_its_own_gpu(monkeypatch):
     import pytest
     with pytest.raises(RuntimeError):
         TV._pin_device()
+    monkeypatch.setenv("MVI_TRAIN_VIEWS_DEVICES", "2,2,2,2")    # an explicit rank -> device map wins (two ranks on one GPU: the tests)
+    TV._pin_device()
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "2" and os.environ["CUDA_VISIBLE_DEVICES"] == "2"
+    monkeypatch.delenv("MVI_TRAIN_VIEWS_DEVICES")
     monkeypatch.delenv("LOCAL_RANK")
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
     TV._pin_device()

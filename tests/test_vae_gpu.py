@@ -189,6 +189,9 @@ def test_full_size_first_stage_matches_the_reference(golden_dir, ops):
     assert abs(float(y.double().mean()) - float(G["vdec_out_mean"])) < 1e-4 * float(G["vdec_out_absmax"])
     assert max(errs.values()) < 1e-4, errs
     assert {"groupnorm", "bias_residual", "softmax_rows", "tokens_to_planes_add"} <= kinds, kinds
+    # round 6: the DEFAULT decode (the fp32 contract above) ran its convolutions with split operands on the bf16 matrix pipe
+    assert {"conv_split3", "groupnorm_split"} <= kinds, kinds
+    H.report(f"full-size first stage (decoder convolutions on the bf16 matrix pipe, split operands): relative max errors { {k: f'{v:.2e}' for k, v in errs.items()} } (bar 1e-4)")
 
 
 @pytest.mark.parametrize("dt,bar", [(torch.bfloat16, 2.0), (torch.float16, 0.5)])
@@ -230,3 +233,56 @@ def test_full_size_first_stage_reduced_precision_decode_within_the_reference_aut
         worst = max(worst, e_max / b_max, e_rms / b_rms)
         assert e_max <= bar * b_max and e_rms <= bar * b_rms, (name, e_max, b_max, e_rms, b_rms)
     H.report(f"first-stage decode at full size in {dt}: worst ratio of its error to the reference's own bf16-autocast decode error = {worst:.2f}")
+
+
+@pytest.mark.parametrize("N,H,W,C,Co,taps", [(2, 24, 32, 128, 128, 9), (3, 9, 15, 64, 320, 9), (1, 40, 33, 256, 512, 9), (2, 16, 16, 512, 256, 9),
+                                             (2, 7, 300, 128, 128, 3), (1, 14, 256, 256, 256, 3), (3, 2, 40, 64, 64, 3)])
+def test_split_operand_convolution_has_fp32_accuracy(ops, N, H, W, C, Co, taps):
+    """mvi_conv3x3_split3_f32 / mvi_conv3t_split3_f32 behind hip_ops.conv_split3 (round 6): x . w ~= x_hi . w_hi + x_hi . w_lo + x_lo . w_hi
+    on the bf16 matrix pipe, fp32 accumulate, against F.conv2d / F.conv3d of the SAME fp32 operands in fp64 — 3x3 / padding 1 over
+    images, (3,1,1) / padding (1,0,0) over frames; C_out = 128 (padded to a 256-column group), 256, 512 (two groups), 320 (the 320-column
+    form), 64; ragged row counts; and the batch cut into launches (forced small here). Bar 3e-5 of the output scale: the dropped
+    x_lo . w_lo terms are 2^-16 of a product each (observed ~1e-5) — an order under the 1e-4 the decoder is held to."""
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C + taps)
+    x = torch.randn(N, H * W, C, generator=g) * torch.rand(1, 1, C, generator=g).mul(3).add(0.2)      # channels of different scales
+    if taps == 9:
+        w = torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5
+        want = F.conv2d(x.double().view(N, H, W, C).permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(N, H * W, Co)
+    else:                                                           # N videos of H frames of W pixels
+        w = torch.randn(Co, C, 3, 1, 1, generator=g) * (3 * C) ** -0.5
+        x5 = x.double().view(N, H, W, C).permute(0, 3, 1, 2)[..., None]                                  # b c t (pixels) 1
+        want = F.conv3d(x5, w.double(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(N, H * W, Co)
+    xd = x.to(DEV)
+    x2 = ops.group_norm_split(xd.view(N, H * W, C) if taps == 9 else xd.view(N * H, W, C), 0, None, None, 0.0, False)
+    hi, lo = ops.split_hi_lo(xd)
+    assert torch.equal(x2[..., :C].reshape(N, H * W, C), hi) and torch.equal(x2[..., C:].reshape(N, H * W, C), lo)
+    w3 = ops.split3_weight(w.to(DEV))
+    assert w3.shape == (-(-Co // ops._lib.lib().mvi_conv_split3_group(Co)) * ops._lib.lib().mvi_conv_split3_group(Co), taps * 3 * C)
+    got = ops.conv_split3(x2.reshape(-1, 2 * C), w3, N, H, W, Co, taps=taps).view(N, H * W, Co)
+    torch.cuda.synchronize()
+    e = rel(got, want)
+    assert e < 3e-5, e
+    if N > 1:                                                       # one image / video per launch: the same values
+        cut = ops.conv_split3(x2.reshape(-1, 2 * C), w3, N, H, W, Co, taps=taps, _max_bytes=H * W * 4 * C).view(N, H * W, Co)
+        assert torch.equal(cut, got)
+    assert rel(got, want) < 0.02 * rel(F.conv2d(hi.float().view(N, H, W, C).permute(0, 3, 1, 2), w.to(DEV).bfloat16().float(), padding=1)
+                                       .permute(0, 2, 3, 1).reshape(N, H * W, Co), want) if taps == 9 else True   # (two orders better than plain bf16)
+
+
+@pytest.mark.parametrize("N,S,C,frames,silu", [(4, 300, 128, 1, True), (6, 64, 256, 3, True), (2, 1000, 512, 2, False), (3, 77, 64, 1, True)])
+def test_group_norm_with_split_output(ops, N, S, C, frames, silu):
+    """mvi_groupnorm_silu_tok2tok_split: GroupNorm(32, eps 1e-6)(+SiLU) of an fp32 token-major tensor with per-sample channel bias,
+    statistics per video of `frames` samples, written as (hi | lo) bf16 halves: hi + lo against fp64 to 2^-15 of the scale (two bf16
+    roundings), hi == round_bf16(hi + lo)."""
+    g = torch.Generator().manual_seed(N + S + C)
+    x = torch.randn(N, S, C, generator=g) * 2 + 0.5
+    wgt, b = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    cb = 0.3 * torch.randn(N, C, generator=g)
+    xf = (x.double() + cb.double()[:, None, :]).reshape(N // frames, frames * S, C).transpose(1, 2)
+    want = F.group_norm(xf, 32, wgt.double(), b.double(), 1e-6)
+    want = (F.silu(want) if silu else want).transpose(1, 2).reshape(N, S, C)
+    y2 = ops.group_norm_split(x.to(DEV), 32, wgt.to(DEV), b.to(DEV), 1e-6, silu, chan_bias=cb.to(DEV), frames=frames)
+    torch.cuda.synchronize()
+    hi, lo = y2[..., :C].float(), y2[..., C:].float()
+    assert rel(hi + lo, want) < 2.0 ** -15
+    assert torch.equal((hi + lo).bfloat16().float(), hi)
