@@ -366,18 +366,27 @@ const char* mvi_unet_last_error(void);
  *          logical channels (w_hi | w_lo | w_hi), padding rows zero (multiview_inpaint_amd/svd/hip_ops.py split3_weight);
  *   out    [mvi_conv_split3_out_rows(rows), C_out] fp32 = x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, NO bias; rows >= N H W are scratch.
  * 3x3 / stride 1 / padding 1 over N images of H x W tokens, or (3,1,1) / padding (1,0,0) over B videos of T frames of `pixels` tokens.
- * rows x 2 C x 2 bytes must stay below 4 GiB (split the batch). Returns MVI_OK or a negative status (mvi_unet_last_error). */
+ * rows x (row bytes of x2) must stay below 4 GiB (split the batch). Returns MVI_OK or a negative status (mvi_unet_last_error).
+ * terms = 3 needs dtype MVI_DT_BF16. terms = 1 (dtype MVI_DT_BF16 or MVI_DT_F16): the same launch on ONE rounded value per operand —
+ * x2 [rows, C], weight [C_out padded][taps x C] of that type, fp32 accumulation and fp32 out: the arithmetic of an autocast convolution
+ * (the opt-in reduced-precision decode, multiview_inpaint_amd/svd/vae.py decode_first_stage(dtype=...)). */
 int mvi_conv_split3_group(int32_t C_out);
 int64_t mvi_conv_split3_out_rows(int64_t rows);
 int mvi_conv3x3_split3_f32(const void* x2, const void* weight, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t C_out,
-                           int64_t out_rows_capacity, void* stream);
+                           int32_t terms, int32_t dtype, int64_t out_rows_capacity, void* stream);
 int mvi_conv3t_split3_f32(const void* x2, const void* weight, float* out, int64_t B, int32_t T, int32_t pixels, int32_t C, int32_t C_out,
-                          int64_t out_rows_capacity, void* stream);
-/* GroupNorm(+SiLU) of fp32 token-major x [N, S, C] written as split bf16 y2 [N, S, 2 C] = (hi | lo); frames > 1: statistics per video of
- * `frames` consecutive samples; groups = 0: no normalisation (plain split). Workspace: mvi_groupnorm_tok2tok_workspace_bytes(.., MVI_DT_F32). */
+                          int32_t terms, int32_t dtype, int64_t out_rows_capacity, void* stream);
+/* GroupNorm(+SiLU) of fp32 token-major x [N, S, C] written as split bf16 y2 [N, S, 2 C] = (hi | lo) (out_mode 0) or as one rounded value per
+ * element, y2 [N, S, C] bf16 (out_mode 1) / f16 (out_mode 2); frames > 1: statistics per video of `frames` consecutive samples; groups = 0:
+ * no normalisation (plain split / rounding). Workspace: mvi_groupnorm_tok2tok_workspace_bytes(.., MVI_DT_F32). */
 int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const float* weight, const float* bias, const float* chan_bias,
                                      int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps, int32_t fuse_silu,
-                                     void* workspace, size_t workspace_bytes, void* stream);
+                                     int32_t out_mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[r][c] = a[r][c] + alpha * (b[r][c] + bias[c]) on fp32 rows [R, C], C a multiple of 4; out may alias a or b; bias may be NULL.
+ * The skip add of a ResnetBlock (model.py:156-158) and the blend x + alpha (h + bias) of VideoResBlock (temporal_ae.py:70-81) on the
+ * token-major fp32 activations of the split-operand first-stage decoder. */
+int mvi_rows_axpb_f32(const float* a, const float* b, const float* bias, float alpha, float* out, int64_t R, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(1024) void gt_apply_kernel(const T* __restrict__ x,
 // Round 6, the split-operand convolutions of the first-stage decoder (csrc/linear_n320.hip, mvi_conv3x3_split3_f32): the apply pass of an
 // fp32 tensor writes every value as TWO bf16 — y2 [N, S, 2 C] = (hi | lo), hi = round(v), lo = round(v - hi): 16 mantissa bits, the bytes
 // of the fp32 tensor — instead of one rounded value. scale_shift NULL: no normalisation (the plain split in front of Upsample.conv).
-__global__ __launch_bounds__(1024) void gt_apply_split_kernel(const float* __restrict__ x, __hip_bfloat16* __restrict__ y2, const float* __restrict__ scale_shift,
+// kMode 0: (hi | lo) bf16, rows of 2 C; 1: hi only, bf16, rows of C; 2: one f16 value, rows of C (the operands of the terms = 1 launches).
+template <int kMode>
+__global__ __launch_bounds__(1024) void gt_apply_split_kernel(const float* __restrict__ x, uint16_t* __restrict__ y2, const float* __restrict__ scale_shift,
                                                               int C, int64_t S, int vpr, int rp, int silu) {
     constexpr int V = 4;
     const int tid = threadIdx.x, v = tid % vpr, r0 = tid / vpr;
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(1024) void gt_apply_split_kernel(const float* __res
         sh[k] = scale_shift ? scale_shift[(n * C + v * V + k) * 2 + 1] : 0.f;
     }
     const float* xb = x + (n * S) * C + (int64_t)v * V;
-    __hip_bfloat16* yb = y2 + (n * S) * 2 * C + (int64_t)v * V;
+    constexpr int kRow = kMode == 0 ? 2 : 1;                       // output row = kRow C elements
+    uint16_t* yb = y2 + (n * S) * kRow * C + (int64_t)v * V;
     float4 raw[kGtPasses];
 #pragma unroll
     for (int p = 0; p < kGtPasses; ++p) {
@@ -238,21 +241,29 @@ __global__ __launch_bounds__(1024) void gt_apply_split_kernel(const float* __res
             for (int k = 0; k < V; ++k) {
                 float u = t[k] * sc[k] + sh[k];
                 if (silu) u = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
-                const __hip_bfloat16 h = __float2bfloat16(u);
-                const __hip_bfloat16 l = __float2bfloat16(u - __bfloat162float(h));
-                hi[k] = *reinterpret_cast<const uint16_t*>(&h);
-                lo[k] = *reinterpret_cast<const uint16_t*>(&l);
+                if (kMode == 2) {
+                    const __half h = __float2half(u);
+                    hi[k] = *reinterpret_cast<const uint16_t*>(&h);
+                    lo[k] = 0;
+                } else {
+                    const __hip_bfloat16 h = __float2bfloat16(u);
+                    const __hip_bfloat16 l = __float2bfloat16(u - __bfloat162float(h));
+                    hi[k] = *reinterpret_cast<const uint16_t*>(&h);
+                    lo[k] = *reinterpret_cast<const uint16_t*>(&l);
+                }
             }
             const uint2 ph = {(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
-            const uint2 pl = {(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
-            *reinterpret_cast<uint2*>(yb + row * 2 * C) = ph;
-            *reinterpret_cast<uint2*>(yb + row * 2 * C + C) = pl;
+            *reinterpret_cast<uint2*>(yb + row * kRow * C) = ph;
+            if (kMode == 0) {
+                const uint2 pl = {(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+                *reinterpret_cast<uint2*>(yb + row * 2 * C + C) = pl;
+            }
         }
     }
 }
 
 static int gt_launch_split(const float* x, void* y2, const float* w, const float* b, const float* cb, int64_t N, int C, int64_t S, int G, float eps,
-                           int silu, float* ws, hipStream_t st, int frames) {
+                           int silu, float* ws, hipStream_t st, int frames, int mode) {
     constexpr int V = 4;
     const int vpr = C / V, rp = gt_rows_per_pass(vpr);
     const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
@@ -268,7 +279,9 @@ static int gt_launch_split(const float* x, void* y2, const float* w, const float
         hipLaunchKernelGGL((gt_stats_kernel<float>), dim3((unsigned)schunks, (unsigned)N), block, lds, st, x, cb, part, C, S, G, vpr, rp, schunks, sets);
         hipLaunchKernelGGL(gt_merge_kernel, dim3((unsigned)N), dim3(kGtMergeThreads), 0, st, part, w, b, cb, ss, C, G, schunks, eps, frames);
     }
-    hipLaunchKernelGGL(gt_apply_split_kernel, grid, block, 0, st, x, (__hip_bfloat16*)y2, ss, C, S, vpr, rp, silu);
+    if (mode == 0) hipLaunchKernelGGL(gt_apply_split_kernel<0>, grid, block, 0, st, x, (uint16_t*)y2, ss, C, S, vpr, rp, silu);
+    else if (mode == 1) hipLaunchKernelGGL(gt_apply_split_kernel<1>, grid, block, 0, st, x, (uint16_t*)y2, ss, C, S, vpr, rp, silu);
+    else hipLaunchKernelGGL(gt_apply_split_kernel<2>, grid, block, 0, st, x, (uint16_t*)y2, ss, C, S, vpr, rp, silu);
     return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
 }
 
@@ -381,10 +394,12 @@ extern "C" int mvi_groupnorm_silu_tok2tok_frames(const void* x, void* y, const f
 // GroupNorm(+SiLU) of an fp32 token-major tensor x [N, S, C] written as split bf16 y2 [N, S, 2 C] = (hi | lo) (see gt_apply_split_kernel);
 // statistics over the `frames` consecutive samples of a video when frames > 1 (the temporal norms). groups = 0: no normalisation, the
 // plain split (weight / bias / chan_bias / workspace unused). Workspace as mvi_groupnorm_tok2tok_workspace_bytes(..., MVI_DT_F32).
+// out_mode 1 / 2: ONE rounded value per element instead, bf16 / f16, y2 [N, S, C] (the operands of the terms = 1 convolutions).
 extern "C" int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const float* weight, const float* bias, const float* chan_bias,
                                                 int64_t N, int32_t frames, int32_t C, int64_t spatial, int32_t groups, float eps,
-                                                int32_t fuse_silu, void* workspace, size_t workspace_bytes, void* stream) {
+                                                int32_t fuse_silu, int32_t out_mode, void* workspace, size_t workspace_bytes, void* stream) {
     if (N == 0 || spatial == 0) return MVI_OK;
+    if (out_mode < 0 || out_mode > 2) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: out_mode 0 (hi | lo bf16), 1 (bf16) or 2 (f16)");
     if (!gt_geometry_ok(N, C, spatial, groups > 0 ? groups : 1, MVI_DT_F32))
         return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: C must be a multiple of groups (<= 64) and of 4");
     if (frames < 1 || N % frames) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: N must be a whole number of videos of `frames` samples");
@@ -392,6 +407,6 @@ extern "C" int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const 
     if (((uintptr_t)x | (uintptr_t)y2) % 16 || C % 4) return mvi::unet_fail(MVI_EINVAL, "groupnorm_tok2tok_split: x / y2 must be 16-byte aligned");
     if (groups > 0 && workspace_bytes < mvi_groupnorm_tok2tok_workspace_bytes(N, C, spatial, groups, MVI_DT_F32))
         return mvi::unet_fail(MVI_ENOMEM, "groupnorm_tok2tok_split: workspace too small");
-    const int rc = mvi::gt_launch_split(x, y2, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, (hipStream_t)stream, frames);
+    const int rc = mvi::gt_launch_split(x, y2, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, (hipStream_t)stream, frames, out_mode);
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok_split: kernel launch failed") : MVI_OK;
 }

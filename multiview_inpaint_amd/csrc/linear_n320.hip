@@ -940,6 +940,9 @@ extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* b
 // mvi_groupnorm_silu_tok2tok_split writes: the bytes of the fp32 tensor), and the K loop reads the hi half twice (ConvGeom::dup3).
 // The fp32 accumulators are the result (ConvGeom::out_cols): out [padded rows, C_out] fp32, no bias (the callers fold it into the
 // next norm / the residual add, as the fp32 path of svd/vae.py does).
+// terms = 1: the same launch on ONE rounded value per operand (x [rows, C] bf16 or f16, weight [C_out_padded][taps x C]): products of
+// rounded operands accumulated in fp32 with an fp32 result — the arithmetic of an autocast convolution, for the opt-in
+// reduced-precision decode (svd/vae.py decode_first_stage(dtype=...)), whose residual stream and norms then stay fp32 like the default's.
 //   weight: [C_out_padded][taps x 3 C] bf16 in this kernel's K order (svd/hip_ops.py split3_weight), C_out_padded = a whole number of
 //   column groups of mvi_conv_split3_group(C_out) columns (320 when C_out is a multiple of 320, else 256), the padding rows zero.
 extern "C" int mvi_conv_split3_group(int32_t C_out) { return C_out > 0 && C_out % 320 == 0 ? 320 : 256; }
@@ -947,13 +950,16 @@ extern "C" int mvi_conv_split3_group(int32_t C_out) { return C_out > 0 && C_out 
 extern "C" int64_t mvi_conv_split3_out_rows(int64_t rows) { return (rows + mvi::ln3::kRows - 1) / mvi::ln3::kRows * mvi::ln3::kRows; }
 
 static int conv_split3(const char* what, const void* x2, const void* weight, float* out, int64_t N, int32_t H, int32_t W, int32_t taps,
-                       int32_t C, int32_t C_out, int64_t out_rows_capacity, void* stream) {
+                       int32_t C, int32_t C_out, int32_t terms, int32_t dtype, int64_t out_rows_capacity, void* stream) {
     char msg[200];
     auto fail = [&](const char* m) {
         snprintf(msg, sizeof msg, "%s: %s", what, m);
         return mvi::unet_fail(MVI_EINVAL, msg);
     };
     if (N < 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 || C_out <= 0 || C_out % 16) return fail("needs C a multiple of 64 and C_out a multiple of 16");
+    if (!((terms == 3 && dtype == MVI_DT_BF16) || (terms == 1 && (dtype == MVI_DT_BF16 || dtype == MVI_DT_F16))))
+        return fail("terms = 3 (split operands, bf16) or terms = 1 (plain bf16 / f16 operands)");
+    if (terms == 1 && taps * C < 2 * mvi::ln3::kKC) return fail("the contraction needs at least two chunks of 64");
     const int64_t rows = N * H * W;
     if (rows == 0) return MVI_OK;
     if (!x2 || !weight || !out) return fail("NULL pointer");
@@ -961,19 +967,21 @@ static int conv_split3(const char* what, const void* x2, const void* weight, flo
     if (out_rows_capacity < mvi_conv_split3_out_rows(rows)) return fail("out needs room for mvi_conv_split3_out_rows(rows) rows (whole 256-row blocks are stored)");
     const int group = mvi_conv_split3_group(C_out);
     const int groups = (C_out + group - 1) / group;
-    const int64_t x_rs = 2 * (int64_t)C;                          // physical row: (hi | lo)
-    if ((int64_t)group * taps * 3 * C * 2 > 0xFFFFFFFFll || rows * x_rs * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
+    const int64_t x_rs = (terms == 3 ? 2 : 1) * (int64_t)C;       // physical row: (hi | lo), or the one rounded value
+    if ((int64_t)group * taps * terms * C * 2 > 0xFFFFFFFFll || rows * x_rs * 2 > 0xFFFFFFFFll || (int64_t)H * W > 0x7FFFFFFFll)
         return fail("weight group / activation tensor exceeds 32-bit byte offsets (split the batch)");
     const int k_order = taps == 9 ? g_conv_k_order : 0;
-    const mvi::ln3::ConvGeom cg = {H, W, 3 * C / mvi::ln3::kKC, taps, groups, 1, 1, H, W, k_order,
-                                   (taps == 3 && g_conv_k_order && W % mvi::ln3::kRows == 0) ? 1 : 0, 1, C_out};
+    const mvi::ln3::ConvGeom cg = {H, W, terms * C / mvi::ln3::kKC, taps, groups, 1, 1, H, W, k_order,
+                                   (taps == 3 && g_conv_k_order && W % mvi::ln3::kRows == 0) ? 1 : 0, terms == 3 ? 1 : 0, C_out};
     hipStream_t st = (hipStream_t)stream;
-    const int K = taps * 3 * C;
+    const int K = taps * terms * C;
     int rc;
-    if (group == 320)
-        rc = mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 320>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
+    if (dtype == MVI_DT_BF16)
+        rc = group == 320 ? mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 320>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out)
+                          : mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 256>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
     else
-        rc = mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 256>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
+        rc = group == 320 ? mvi::linear_n320_launch<__half, true, true, false, false, false, 320>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out)
+                          : mvi::linear_n320_launch<__half, true, true, false, false, false, 256>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
     if (rc) {
         snprintf(msg, sizeof msg, "%s: kernel launch failed", what);
         return mvi::unet_fail(rc, msg);
@@ -982,11 +990,11 @@ static int conv_split3(const char* what, const void* x2, const void* weight, flo
 }
 
 extern "C" int mvi_conv3x3_split3_f32(const void* x2, const void* weight, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t C_out,
-                                      int64_t out_rows_capacity, void* stream) {
-    return conv_split3("conv3x3_split3_f32", x2, weight, out, N, H, W, 9, C, C_out, out_rows_capacity, stream);
+                                      int32_t terms, int32_t dtype, int64_t out_rows_capacity, void* stream) {
+    return conv_split3("conv3x3_split3_f32", x2, weight, out, N, H, W, 9, C, C_out, terms, dtype, out_rows_capacity, stream);
 }
 
 extern "C" int mvi_conv3t_split3_f32(const void* x2, const void* weight, float* out, int64_t B, int32_t T, int32_t pixels, int32_t C,
-                                     int32_t C_out, int64_t out_rows_capacity, void* stream) {
-    return conv_split3("conv3t_split3_f32", x2, weight, out, B, T, pixels, 3, C, C_out, out_rows_capacity, stream);
+                                     int32_t C_out, int32_t terms, int32_t dtype, int64_t out_rows_capacity, void* stream) {
+    return conv_split3("conv3t_split3_f32", x2, weight, out, B, T, pixels, 3, C, C_out, terms, dtype, out_rows_capacity, stream);
 }

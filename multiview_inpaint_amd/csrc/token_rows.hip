@@ -371,6 +371,33 @@ extern "C" int mvi_add_lerp(const void* x, const void* h, const void* base, cons
     return rc ? unet_fail(MVI_EHIP, "add_lerp: kernel launch failed") : MVI_OK;
 }
 
+// out[r][c] = a[r][c] + alpha * (b[r][c] + bias[c]) on fp32 rows [R, C] (round 6): the two adds that end a ResBlock of the first-stage
+// decoder on token-major fp32 activations (svd/vae_split.py) — skip + convolution output + its bias, and the AlphaBlender form
+// x + alpha (conv + bias) of temporal_ae.py:70-81 — as ONE pass (a, b read, out written) instead of two in-place PyTorch adds each.
+// out may alias a or b. bias may be NULL.
+__global__ __launch_bounds__(256) void rows_axpb_kernel(const float* a, const float* b, const float* __restrict__ bias, float* out, float alpha,
+                                                        int64_t n4, int c4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 av = reinterpret_cast<const float4*>(a)[i], bv = reinterpret_cast<const float4*>(b)[i];
+    float4 cv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) cv = reinterpret_cast<const float4*>(bias)[i % c4];
+    float4 o;
+    o.x = av.x + alpha * (bv.x + cv.x); o.y = av.y + alpha * (bv.y + cv.y); o.z = av.z + alpha * (bv.z + cv.z); o.w = av.w + alpha * (bv.w + cv.w);
+    reinterpret_cast<float4*>(out)[i] = o;
+}
+
+extern "C" int mvi_rows_axpb_f32(const float* a, const float* b, const float* bias, float alpha, float* out, int64_t R, int32_t C, void* stream) {
+    if (R < 0 || C <= 0 || C % 4) return unet_fail(MVI_EINVAL, "rows_axpb_f32: C must be a positive multiple of 4");
+    if (R == 0) return MVI_OK;
+    if (!a || !b || !out) return unet_fail(MVI_EINVAL, "rows_axpb_f32: NULL pointer");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)bias) % 16) return unet_fail(MVI_EINVAL, "rows_axpb_f32: pointers must be 16-byte aligned");
+    const int64_t n4 = R * (C / 4), blocks = (n4 + 255) / 256;
+    if (blocks > 0x7FFFFFFFll) return unet_fail(MVI_EINVAL, "rows_axpb_f32: too many rows for one launch");
+    hipLaunchKernelGGL(rows_axpb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, bias, out, alpha, n4, C / 4);
+    return hipGetLastError() == hipSuccess ? MVI_OK : unet_fail(MVI_EHIP, "rows_axpb_f32: kernel launch failed");
+}
+
 template <typename T>
 static int tokens_to_planes_launch(const void* tok, const void* x_in, void* out, int64_t N, int C, int64_t S, hipStream_t st,
                                    const float* bias = nullptr, const void* base = nullptr, const float* alpha = nullptr) {

@@ -891,13 +891,20 @@ def split_hi_lo(v):
     return hi, (v - hi.float()).to(torch.bfloat16)
 
 
-def split3_weight(weight):
+_OPERANDS = {"split3": (3, torch.bfloat16, 0), "bf16": (1, torch.bfloat16, 1), "f16": (1, torch.float16, 2)}    # mode -> (terms, dtype, GN out_mode)
+
+
+def split3_weight(weight, mode="split3"):
     """A convolution weight ([C_out, C_in, 3, 3] or [C_out, C_in, 3, 1, 1], any float type) for mvi_conv3x3_split3_f32 / mvi_conv3t_split3_f32:
-    bf16 [C_out padded to whole column groups][taps x 3 C_in] with the logical channel axis (w_hi | w_lo | w_hi) in the kernel's
-    contraction order, padding rows zero."""
+    [C_out padded to whole column groups][taps x terms C_in] in the kernel's contraction order, padding rows zero. mode "split3": bf16
+    with the logical channel axis (w_hi | w_lo | w_hi); "bf16" / "f16": the weight rounded once to that type (terms = 1)."""
+    terms, dt, _ = _OPERANDS[mode]
     w = weight.detach().float()
-    hi, lo = split_hi_lo(w)
-    w3 = torch.cat([hi, lo, hi], dim=1)
+    if terms == 3:
+        hi, lo = split_hi_lo(w)
+        w3 = torch.cat([hi, lo, hi], dim=1)
+    else:
+        w3 = w.to(dt)
     packed = conv3x3_n320_weight(w3) if w.dim() == 4 else conv3t_n320_weight(w3)
     Co = packed.shape[0]
     group = int(_lib.lib().mvi_conv_split3_group(Co))
@@ -907,15 +914,17 @@ def split3_weight(weight):
     return packed.contiguous()
 
 
-def group_norm_split(x, num_groups, weight, bias, eps, silu, chan_bias=None, frames=1):
-    """GroupNorm(+SiLU) of fp32 token-major x [N, S, C] -> split bf16 [N, S, 2 C] = (hi | lo) (mvi_groupnorm_silu_tok2tok_split).
-    num_groups = 0: no normalisation, the plain split."""
+def group_norm_split(x, num_groups, weight, bias, eps, silu, chan_bias=None, frames=1, mode="split3"):
+    """GroupNorm(+SiLU) of fp32 token-major x [N, S, C] -> the operand of conv_split3 in `mode`: split bf16 [N, S, 2 C] = (hi | lo)
+    ("split3") or one rounded value per element [N, S, C] ("bf16" / "f16") (mvi_groupnorm_silu_tok2tok_split).
+    num_groups = 0: no normalisation, the plain split / rounding."""
     L = _lib.lib()
+    terms, dt, out_mode = _OPERANDS[mode]
     if x.dtype != torch.float32 or x.dim() != 3:
         raise TypeError("group_norm_split: fp32 [N, S, C] expected")
     xc = x if x.is_contiguous() else x.contiguous()
     N, S, Cc = xc.shape
-    y2 = torch.empty(N, S, 2 * Cc, dtype=torch.bfloat16, device=x.device)
+    y2 = torch.empty(N, S, (2 if terms == 3 else 1) * Cc, dtype=dt, device=x.device)
     ws, nbytes, cb = None, 0, None
     if num_groups:
         nbytes = L.mvi_groupnorm_tok2tok_workspace_bytes(N, Cc, S, num_groups, 0)
@@ -929,32 +938,50 @@ def group_norm_split(x, num_groups, weight, bias, eps, silu, chan_bias=None, fra
     with torch.cuda.device(x.device), _Timed("groupnorm_split", 2.0 * xc.numel() * 4, x.device):
         _check(L.mvi_groupnorm_silu_tok2tok_split(xc.data_ptr(), y2.data_ptr(), None if not num_groups else _f32(weight).data_ptr(),
                                                   None if not num_groups else _f32(bias).data_ptr(), None if cb is None else cb.data_ptr(), N,
-                                                  int(frames), Cc, S, int(num_groups), float(eps), int(bool(silu)),
+                                                  int(frames), Cc, S, int(num_groups), float(eps), int(bool(silu)), out_mode,
                                                   None if ws is None else ws.data_ptr(), nbytes, _stream(x.device)), "group_norm_split")
     return y2
 
 
-def conv_split3(x2, w3, N, H, W, C_out, taps=9, _max_bytes=0xFFFFFFFF):
-    """x . w at fp32 accuracy on the bf16 matrix pipe: x2 [N H W, 2 C] split bf16 (group_norm_split), w3 from split3_weight ->
-    fp32 [N H W, C_out], no bias. taps = 9: 3x3 / padding 1 over N images of H x W tokens; taps = 3: (3,1,1) / padding (1,0,0) over N
-    videos of H frames of W tokens. The batch is cut so that every launch stays inside the kernel's 32-bit activation offsets."""
+def conv_split3(x2, w3, N, H, W, C_out, taps=9, mode="split3", _max_bytes=0xFFFFFFFF):
+    """x . w at fp32 accuracy on the bf16 matrix pipe (mode "split3": x2 [N H W, 2 C] split bf16 from group_norm_split, w3 from
+    split3_weight) — or with ONE rounded value per operand, fp32 accumulate (modes "bf16" / "f16": x2 [N H W, C]) -> fp32 [N H W, C_out],
+    no bias. taps = 9: 3x3 / padding 1 over N images of H x W tokens; taps = 3: (3,1,1) / padding (1,0,0) over N videos of H frames of W
+    tokens. The batch is cut so that every launch stays inside the kernel's 32-bit activation offsets."""
     L = _lib.lib()
-    C2 = x2.shape[-1]
-    C = C2 // 2
+    terms, dt, _ = _OPERANDS[mode]
+    Cx = x2.shape[-1]
+    C = Cx // 2 if terms == 3 else Cx
     rows = N * H * W
-    if x2.dtype != torch.bfloat16 or not x2.is_contiguous() or x2.numel() != rows * C2 or w3.shape[1] != taps * 3 * C or w3.dtype != torch.bfloat16:
-        raise ValueError("conv_split3: x2 contiguous bf16 [N H W, 2 C] and w3 bf16 [C_out padded, taps 3 C] expected")
-    x2 = x2.reshape(rows, C2)
-    per = H * W * C2 * 2                                       # bytes of one image / video
+    if x2.dtype != dt or not x2.is_contiguous() or x2.numel() != rows * Cx or w3.shape[1] != taps * terms * C or w3.dtype != dt:
+        raise ValueError(f"conv_split3 ({mode}): x2 contiguous {dt} [N H W, {'2 C' if terms == 3 else 'C'}] and w3 [C_out padded, taps {terms} C] expected")
+    x2 = x2.reshape(rows, Cx)
+    per = H * W * Cx * 2                                       # bytes of one image / video
     n_max = max(1, (_max_bytes // per))
     if per > 0xFFFFFFFF:
         raise ValueError("conv_split3: one image / video exceeds the kernel's 32-bit activation offsets")
     cap = int(L.mvi_conv_split3_out_rows(rows)) + 256
     out = torch.empty(cap, C_out, dtype=torch.float32, device=x2.device)
     fn = L.mvi_conv3x3_split3_f32 if taps == 9 else L.mvi_conv3t_split3_f32
-    with torch.cuda.device(x2.device), _Timed("conv_split3", 2.0 * rows * taps * 3 * C * C_out, x2.device):
+    with torch.cuda.device(x2.device), _Timed("conv_split3", 2.0 * rows * taps * terms * C * C_out, x2.device):
         for n0 in range(0, N, n_max):
             n = min(n_max, N - n0)
             r0 = n0 * H * W
-            _check(fn(x2[r0:].data_ptr(), w3.data_ptr(), out[r0:].data_ptr(), n, H, W, C, C_out, cap - r0, _stream(x2.device)), "conv_split3")
+            _check(fn(x2[r0:].data_ptr(), w3.data_ptr(), out[r0:].data_ptr(), n, H, W, C, C_out, terms, _DT[dt], cap - r0, _stream(x2.device)),
+                   "conv_split3")
     return out[:rows]
+
+
+def rows_axpb(a, b, bias, alpha=1.0, out=None):
+    """a + alpha * (b + bias[c]) for fp32 token-major a, b [..., C] in one pass (mvi_rows_axpb_f32); out may be a or b (default: b)."""
+    L = _lib.lib()
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise TypeError("rows_axpb: contiguous fp32 tensors of one shape expected")
+    out = b if out is None else out
+    Cc = a.shape[-1]
+    R = a.numel() // Cc
+    bf = None if bias is None else _f32(bias)
+    with torch.cuda.device(a.device), _Timed("rows_axpb", 3.0 * a.numel() * 4, a.device):
+        _check(L.mvi_rows_axpb_f32(a.data_ptr(), b.data_ptr(), None if bf is None else bf.data_ptr(), float(alpha), out.data_ptr(), R, Cc,
+                                   _stream(a.device)), "rows_axpb")
+    return out

@@ -564,17 +564,27 @@ def decode_first_stage(first_stage_model, z, scale_factor: float = 0.18215, en_a
     Since round 6 the DEFAULT itself (dtype None: fp32 contract, 1e-4) runs its convolutions on the bf16 matrix pipe with split operands
     (svd/vae_split.py, entered from VideoDecoder.forward; MVI_VAE_SPLIT=0 for the library path)."""
     dtype = DECODE_DTYPE if dtype is None else dtype
+    split_mode = None
     if dtype in (None, torch.float32) or not z.is_cuda:
         dec_mod, cast = None, None
     else:
-        dec_mod, cast = _decoder_in(first_stage_model, dtype), dtype
+        # round 6: where the split-operand walk applies (the shipped VideoDecoder), the reduced-precision decode is that walk with one
+        # rounded value per convolution operand — residual stream and norms stay fp32, no copy of the decoder, no library convolution
+        from . import vae_split
+        if vae_split.applies(first_stage_model.decoder, z.float()) and isinstance(first_stage_model.decoder, VideoDecoder):
+            split_mode, dec_mod, cast = {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype], None, None
+        else:
+            dec_mod, cast = _decoder_in(first_stage_model, dtype), dtype
     z = 1.0 / scale_factor * z
     n = z.shape[0] if en_and_decode_n_samples_a_time is None else en_and_decode_n_samples_a_time
     outs = []
     for r in range(math.ceil(z.shape[0] / n)):
         zc = z[r * n:(r + 1) * n]
         kw = {"timesteps": len(zc)} if isinstance(first_stage_model.decoder, VideoDecoder) else {}
-        if dec_mod is None:
+        if split_mode is not None:
+            from . import vae_split
+            outs.append(vae_split.decode(first_stage_model.decoder, zc.float(), kw["timesteps"], mode=split_mode))
+        elif dec_mod is None:
             outs.append(first_stage_model.decode(zc, **kw))
         else:
             outs.append(dec_mod(zc.to(cast), **kw).float())

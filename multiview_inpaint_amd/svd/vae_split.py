@@ -25,15 +25,15 @@ SPLIT_DECODE = os.environ.get("MVI_VAE_SPLIT", "1") != "0"      # 0: the fp32 li
 _w3_cache = {}
 
 
-def _w3(weight):
-    """split3_weight(weight), once per parameter version."""
+def _w3(weight, mode):
+    """split3_weight(weight, mode), once per parameter version and operand mode."""
     import weakref
     from . import hip_ops
-    key = id(weight)
+    key = (id(weight), mode)
     ver = (weight.data_ptr(), weight._version, weight.dtype, weight.device, int(hip_ops._lib.lib().mvi_conv3x3_n320_k_order(-1)))
     hit = _w3_cache.get(key)
     if hit is None or hit[0]() is not weight or hit[1] != ver:
-        hit = (weakref.ref(weight, lambda _r, k=key: _w3_cache.pop(k, None)), ver, hip_ops.split3_weight(weight))
+        hit = (weakref.ref(weight, lambda _r, k=key: _w3_cache.pop(k, None)), ver, hip_ops.split3_weight(weight, mode))
         _w3_cache[key] = hit
     return hit[2]
 
@@ -61,33 +61,33 @@ def _fire_hooks(module, h, N, H, W):
             hook(module, (), out)
 
 
-def _gn(h, norm, silu=True, chan_bias=None, frames=1):
+def _gn(h, norm, mode, silu=True, chan_bias=None, frames=1):
     from . import hip_ops
-    return hip_ops.group_norm_split(h, norm.num_groups, norm.weight, norm.bias, norm.eps, silu, chan_bias=chan_bias, frames=frames)
+    return hip_ops.group_norm_split(h, norm.num_groups, norm.weight, norm.bias, norm.eps, silu, chan_bias=chan_bias, frames=frames, mode=mode)
 
 
-def _resblock(blk, h, N, H, W, T, alpha):
+def _resblock(blk, h, N, H, W, T, alpha, mode):
     """vae.VideoResBlock.forward on token-major fp32 h [N, H W, C_in] -> [N, H W, C_out]."""
     from . import hip_ops
     S, Co = H * W, blk.out_channels
     # spatial ResnetBlock (model.py:96-158): norm1-SiLU-conv1, norm2(+conv1 bias)-SiLU-conv2, + shortcut
-    c = hip_ops.conv_split3(_gn(h, blk.norm1), _w3(blk.conv1.weight), N, H, W, Co).view(N, S, Co)
+    c = hip_ops.conv_split3(_gn(h, blk.norm1, mode), _w3(blk.conv1.weight, mode), N, H, W, Co, mode=mode).view(N, S, Co)
     e = blk.conv1.bias.float()[None].expand(N, -1).contiguous()
-    c = hip_ops.conv_split3(_gn(c, blk.norm2, chan_bias=e), _w3(blk.conv2.weight), N, H, W, Co).view(N, S, Co)
+    c = hip_ops.conv_split3(_gn(c, blk.norm2, mode, chan_bias=e), _w3(blk.conv2.weight, mode), N, H, W, Co, mode=mode).view(N, S, Co)
     if blk.in_channels != blk.out_channels:
         sk = blk.nin_shortcut
-        x = F.linear(h, sk.weight.reshape(Co, blk.in_channels), sk.bias + blk.conv2.bias)
-        x.add_(c)
+        x = F.linear(h, sk.weight.reshape(Co, blk.in_channels), sk.bias)
+        x = hip_ops.rows_axpb(x, c, blk.conv2.bias)                   # shortcut + (conv2 + bias), one pass, into c's storage
     else:
-        x = c.add_(blk.conv2.bias).add_(h)
+        x = hip_ops.rows_axpb(h, c, blk.conv2.bias)                   # h + (conv2 + bias)
     # temporal ResBlock over the frame axis (temporal_ae.py:41-54 -> openaimodel.py:328-354 with dims = 3, skip_t_emb), blended
     ts = blk.time_stack
     g0, g1, c1, c2 = ts.in_layers[0], ts.out_layers[0], ts.in_layers[2], ts.out_layers[3]
-    ct = hip_ops.conv_split3(_gn(x, g0, frames=T), _w3(c1.weight), N // T, T, S, Co, taps=3).view(N, S, Co)
+    ct = hip_ops.conv_split3(_gn(x, g0, mode, frames=T), _w3(c1.weight, mode), N // T, T, S, Co, taps=3, mode=mode).view(N, S, Co)
     e = c1.bias.float()[None].expand(N, -1).contiguous()
-    ct = hip_ops.conv_split3(_gn(ct, g1, chan_bias=e, frames=T), _w3(c2.weight), N // T, T, S, Co, taps=3).view(N, S, Co)
+    ct = hip_ops.conv_split3(_gn(ct, g1, mode, chan_bias=e, frames=T), _w3(c2.weight, mode), N // T, T, S, Co, taps=3, mode=mode).view(N, S, Co)
     # alpha * (x + ct + b) + (1 - alpha) * x = x + alpha * (ct + b)
-    return x.add_(ct.add_(c2.bias), alpha=alpha)
+    return hip_ops.rows_axpb(x, ct, c2.bias, alpha=alpha)
 
 
 def _attn(blk, h):
@@ -101,20 +101,24 @@ def _attn(blk, h):
     return h + F.linear(a, blk.proj_out.weight.reshape(C, C), blk.proj_out.bias)
 
 
-def _upsample(up, h, N, H, W):
+def _upsample(up, h, N, H, W, mode):
     """vae.Upsample.forward (model.py:57-71: nearest x2, then the 3x3 convolution) on tokens: the split halves are written at the LOW
     resolution and repeated (one bf16 copy), the convolution runs at the high one."""
     from . import hip_ops
     C = h.shape[-1]
-    t2 = hip_ops.group_norm_split(h, 0, None, None, 0.0, False)                       # plain split, [N, H W, 2 C]
-    t2 = t2.view(N, H, 1, W, 1, 2 * C).expand(N, H, 2, W, 2, 2 * C).reshape(N, 4 * H * W, 2 * C)
-    c = hip_ops.conv_split3(t2, _w3(up.conv.weight), N, 2 * H, 2 * W, C).view(N, 4 * H * W, C)
-    return c.add_(up.conv.bias)
+    t2 = hip_ops.group_norm_split(h, 0, None, None, 0.0, False, mode=mode)            # plain split / rounding, [N, H W, 2 C or C]
+    Cx = t2.shape[-1]
+    t2 = t2.view(N, H, 1, W, 1, Cx).expand(N, H, 2, W, 2, Cx).reshape(N, 4 * H * W, Cx)
+    c = hip_ops.conv_split3(t2, _w3(up.conv.weight, mode), N, 2 * H, 2 * W, C, mode=mode).view(N, 4 * H * W, C)
+    return c.add_(up.conv.bias)                                      # (one in-place pass; the next block reads it three times anyway)
 
 
 @torch.no_grad()
-def decode(decoder, z, timesteps):
-    """VideoDecoder.forward(z, timesteps=T) (temporal_ae.py:291-347 over model.py:604-748) -> [N, 3, 8 h, 8 w] fp32."""
+def decode(decoder, z, timesteps, mode="split3"):
+    """VideoDecoder.forward(z, timesteps=T) (temporal_ae.py:291-347 over model.py:604-748) -> [N, 3, 8 h, 8 w] fp32.
+    mode "split3" (the default decode: fp32 accuracy, split operands); "bf16" / "f16": the opt-in reduced-precision decode — the same
+    walk with ONE rounded value per convolution operand (the arithmetic of an autocast convolution: rounded products, fp32 accumulation),
+    residual stream, norms and attention in fp32 as here."""
     from . import layers
     N, _, H, W = z.shape
     T = int(timesteps)
@@ -123,19 +127,19 @@ def decode(decoder, z, timesteps):
     alpha = {id(b): a for b, a in zip(blocks, alphas)}
     h = decoder.conv_in(z)
     h = h.permute(0, 2, 3, 1).reshape(N, H * W, h.shape[1]).contiguous()             # token-major from here on
-    h = _resblock(decoder.mid.block_1, h, N, H, W, T, alpha[id(decoder.mid.block_1)])
+    h = _resblock(decoder.mid.block_1, h, N, H, W, T, alpha[id(decoder.mid.block_1)], mode)
     _fire_hooks(decoder.mid.block_1, h, N, H, W)
     h = _attn(decoder.mid.attn_1, h)
     _fire_hooks(decoder.mid.attn_1, h, N, H, W)
-    h = _resblock(decoder.mid.block_2, h, N, H, W, T, alpha[id(decoder.mid.block_2)])
+    h = _resblock(decoder.mid.block_2, h, N, H, W, T, alpha[id(decoder.mid.block_2)], mode)
     _fire_hooks(decoder.mid.block_2, h, N, H, W)
     for i_level in reversed(range(decoder.num_resolutions)):
         up = decoder.up[i_level]
         for blk in up.block:
-            h = _resblock(blk, h, N, H, W, T, alpha[id(blk)])
+            h = _resblock(blk, h, N, H, W, T, alpha[id(blk)], mode)
             _fire_hooks(blk, h, N, H, W)
         if i_level != 0:
-            h = _upsample(up.upsample, h, N, H, W) if up.upsample.with_conv else \
+            h = _upsample(up.upsample, h, N, H, W, mode) if up.upsample.with_conv else \
                 h.view(N, H, 1, W, 1, -1).expand(N, H, 2, W, 2, h.shape[-1]).reshape(N, 4 * H * W, -1)
             H, W = 2 * H, 2 * W
     no = decoder.norm_out

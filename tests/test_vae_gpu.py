@@ -254,6 +254,18 @@ def test_split_operand_convolution_has_fp32_accuracy(ops, N, H, W, C, Co, taps):
         want = F.conv3d(x5, w.double(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(N, H * W, Co)
     xd = x.to(DEV)
     x2 = ops.group_norm_split(xd.view(N, H * W, C) if taps == 9 else xd.view(N * H, W, C), 0, None, None, 0.0, False)
+    # the one-value forms (the opt-in reduced-precision decode): products of ROUNDED operands, accumulated in fp32 — against fp64 on the same
+    # rounded operands to fp32 summation accuracy
+    for mode, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        x1 = ops.group_norm_split(xd.view(N, H * W, C), 0, None, None, 0.0, False, mode=mode)
+        assert x1.dtype == dt and torch.equal(x1, xd.to(dt))
+        g1 = ops.conv_split3(x1.reshape(-1, C), ops.split3_weight(w.to(DEV), mode), N, H, W, Co, taps=taps, mode=mode).view(N, H * W, Co)
+        xr, wr = x.to(dt).double(), w.to(dt).double()
+        if taps == 9:
+            w1 = F.conv2d(xr.view(N, H, W, C).permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1).reshape(N, H * W, Co)
+        else:
+            w1 = F.conv3d(xr.view(N, H, W, C).permute(0, 3, 1, 2)[..., None], wr, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(N, H * W, Co)
+        assert rel(g1, w1) < 5e-6, (mode, rel(g1, w1))
     hi, lo = ops.split_hi_lo(xd)
     assert torch.equal(x2[..., :C].reshape(N, H * W, C), hi) and torch.equal(x2[..., C:].reshape(N, H * W, C), lo)
     w3 = ops.split3_weight(w.to(DEV))
@@ -286,3 +298,17 @@ def test_group_norm_with_split_output(ops, N, S, C, frames, silu):
     hi, lo = y2[..., :C].float(), y2[..., C:].float()
     assert rel(hi + lo, want) < 2.0 ** -15
     assert float((lo.abs() / hi.abs().clamp_min(1e-30)).max()) <= 2.0 ** -8         # lo is the rounding residue of hi: at most half an ulp of it
+
+
+def test_rows_axpb(ops):
+    """a + alpha (b + bias[c]) on fp32 token rows in one pass, also in place into either operand (bit-exact against the same fp32 formula)."""
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(3, 77, 128, generator=g).to(DEV), torch.randn(3, 77, 128, generator=g).to(DEV)
+    bias = torch.randn(128, generator=g).to(DEV)
+    want = a + 0.37 * (b + bias)
+    got = ops.rows_axpb(a, b.clone(), bias, alpha=0.37)
+    assert rel(got, want) < 1e-6
+    b2 = b.clone()
+    assert ops.rows_axpb(a, b2, bias, alpha=0.37) is b2 and torch.equal(b2, got)
+    a2 = a.clone()
+    assert torch.equal(ops.rows_axpb(a2, b, None, alpha=1.0, out=a2), a + b)
