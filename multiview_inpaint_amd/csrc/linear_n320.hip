@@ -944,8 +944,14 @@ extern "C" int mvi_conv3t_n320(const void* x, const void* weight, const float* b
 // rounded operands accumulated in fp32 with an fp32 result — the arithmetic of an autocast convolution, for the opt-in
 // reduced-precision decode (svd/vae.py decode_first_stage(dtype=...)), whose residual stream and norms then stay fp32 like the default's.
 //   weight: [C_out_padded][taps x 3 C] bf16 in this kernel's K order (svd/hip_ops.py split3_weight), C_out_padded = a whole number of
-//   column groups of mvi_conv_split3_group(C_out) columns (320 when C_out is a multiple of 320, else 256), the padding rows zero.
-extern "C" int mvi_conv_split3_group(int32_t C_out) { return C_out > 0 && C_out % 320 == 0 ? 320 : 256; }
+//   column groups of mvi_conv_split3_group(C_out) columns (320 when C_out is a multiple of 320, 128 up to 128 channels, else 256), the
+//   padding rows zero.
+// (128: the 128-channel level of the decoder — a 256-column block would compute 128 columns of zeros)
+static int g_split3_group128 = [] { const char* e = getenv("MVI_SPLIT3_GROUP128"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int mvi_conv_split3_group(int32_t C_out) {
+    if (C_out > 0 && C_out % 320 == 0) return 320;
+    return (g_split3_group128 && C_out > 0 && C_out <= 128) ? 128 : 256;
+}
 
 extern "C" int64_t mvi_conv_split3_out_rows(int64_t rows) { return (rows + mvi::ln3::kRows - 1) / mvi::ln3::kRows * mvi::ln3::kRows; }
 
@@ -976,12 +982,12 @@ static int conv_split3(const char* what, const void* x2, const void* weight, flo
     hipStream_t st = (hipStream_t)stream;
     const int K = taps * terms * C;
     int rc;
+#define MVI_SPLIT3_LAUNCH(T, N) mvi::linear_n320_launch<T, true, true, false, false, false, N>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out)
     if (dtype == MVI_DT_BF16)
-        rc = group == 320 ? mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 320>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out)
-                          : mvi::linear_n320_launch<__hip_bfloat16, true, true, false, false, false, 256>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
+        rc = group == 320 ? MVI_SPLIT3_LAUNCH(__hip_bfloat16, 320) : group == 256 ? MVI_SPLIT3_LAUNCH(__hip_bfloat16, 256) : MVI_SPLIT3_LAUNCH(__hip_bfloat16, 128);
     else
-        rc = group == 320 ? mvi::linear_n320_launch<__half, true, true, false, false, false, 320>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out)
-                          : mvi::linear_n320_launch<__half, true, true, false, false, false, 256>(x2, weight, nullptr, nullptr, rows, K, x_rs, 0, st, cg, out);
+        rc = group == 320 ? MVI_SPLIT3_LAUNCH(__half, 320) : group == 256 ? MVI_SPLIT3_LAUNCH(__half, 256) : MVI_SPLIT3_LAUNCH(__half, 128);
+#undef MVI_SPLIT3_LAUNCH
     if (rc) {
         snprintf(msg, sizeof msg, "%s: kernel launch failed", what);
         return mvi::unet_fail(rc, msg);
