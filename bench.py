@@ -480,7 +480,7 @@ def main():
                 # the roofline of path B's hand-written contraction, flat at the top level (attention FLOPs /
                 # summed launch time of the attention kernels / 2.5 PFLOP/s dense bf16)
                 out["roofline_svd_attention"] = {
-                    "bound": "mfma", "kernel": "attn_flash8_kernel (+ attn_flash_kernel for S < 1024)",
+                    "bound": "mfma", "kernel": "attn_flash8m16_kernel (8 waves, v_mfma_f32_16x16x32; + attn_flash_kernel for S < 1024)",
                     "achieved": am["TFLOPs"], "peak": bench_svd.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": am["frac_of_bf16_mfma_peak"], "calls_per_step": am["calls_per_step"], "ms_per_step": am["ms_per_step"],
                     "traffic": _traffic("attention")}

@@ -179,6 +179,39 @@ def run_sample_loop(eng, device, num_steps=25, T=14, h=72, w=128, weights="bf16"
                 finite=bool(torch.isfinite(out).all()))
 
 
+def run_first_stage_decode(device, T=14, h=72, w=128, iters=2):
+    """What follows the 25 steps of a sample: the first-stage decode of its T latent frames to 8 h x 8 w RGB frames
+    (sgm/models/diffusion.py:194-212; VideoDecoder of configs/test/svd_f_est_ctrl_simp1.yaml:131-159 at full width, seeded random
+    weights), in the DEFAULT configuration — the reference's fp32 contract (disable_first_stage_autocast), since round 6 with the
+    convolutions on the bf16 matrix pipe with split operands (svd/vae_split.py). Reported beside the denoise step, not part of it."""
+    from . import hip_ops, vae
+    full = dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    dec = vae.VideoDecoder(**full, video_kernel_size=[3, 1, 1]).eval()
+    g = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for k, p in sorted(dec.state_dict().items()):           # seeded like tests/svd_helpers.seeded_state_dict: unit-gain weights
+            if p.dtype.is_floating_point:
+                r = torch.randn(p.shape, generator=g)
+                p.copy_(r if k.endswith("mix_factor") else r / p[0].numel() ** 0.5 if p.ndim >= 2 else (1.0 + 0.1 * r if k.endswith("weight") else 0.1 * r))
+    eng = vae.AutoencodingEngine(encoder_config=torch.nn.Identity(), decoder_config=dec.to(device))
+    z = (torch.randn(T, 4, h, w, generator=g) * 0.18215).to(device)
+    with torch.no_grad():
+        y = vae.decode_first_stage(eng, z)                         # warm-up
+        torch.cuda.synchronize(device)
+        hip_ops.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            y = vae.decode_first_stage(eng, z)
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) * 1e3 / iters
+        kinds = sorted(set(k for k, *_ in hip_ops.PROFILE))
+        hip_ops.PROFILE = None
+    return dict(ms=round(ms, 1), frames=T, out_shape=list(y.shape), finite=bool(torch.isfinite(y).all()),
+                convolutions="split bf16 operands on the matrix pipe, fp32 accumulate (fp32 contract, 1e-4)" if "conv_split3" in kinds
+                else "fp32 library path", hip_ops=kinds)
+
+
 _HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
@@ -259,6 +292,12 @@ def run_gpu(device, steps=2, warmup=1, T=14, h=72, w=128, with_control=True, wei
     hip_ops.check_groupnorm_cluster(device)         # a benchmark number from a run with a timed-out GroupNorm wait is no number
     if sample_steps and with_control:
         res["sample_loop"] = run_sample_loop(eng, device, sample_steps, T, h, w, weights)
+        del eng
+        torch.cuda.empty_cache()
+        try:
+            res["first_stage_decode"] = run_first_stage_decode(device, T, h, w)
+        except Exception as e:                                   # reported beside the step: never takes the step's number down with it
+            res["first_stage_decode"] = {"error": repr(e)[:300]}
     return res
 
 

@@ -12,7 +12,7 @@ cp $f $OUT/kernel_stats.csv; rm -rf $OUT/trace
 N=$(python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$OUT/kernel_stats.csv")))
-c=[int(r["Calls"]) for r in rows if "attn_flash8_kernel" in r["Name"]]
+c=[int(r["Calls"]) for r in rows if "attn_flash8" in r["Name"]]
 print(sum(c)//14 if c else 12)
 PY
 )
