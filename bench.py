@@ -151,9 +151,9 @@ def svd_leg(steps):
     stream otherwise; `execution` says which ran. The forced one-stream step is measured as well and reported NEXT to the headline as
     `one_stream` (rounds 1 - 5 had it the other way round: one stream as the headline, `two_streams` beside it).
     MVI_BENCH_ONE_STREAM=0 skips the second child."""
-    head = _svd_child(None, steps, 900)
+    head = _svd_child(None, steps, 420)                  # (a normal run takes under a minute; the time-out is for a wedged child)
     if head is None:
-        head = _svd_child(False, steps, 900)             # the default mode failed or hung (recorded in child_failures): one stream
+        head = _svd_child(False, steps, 600)             # the default mode failed or hung (recorded in child_failures): one stream
         if head is None:
             return None
     head["execution"] = ("two streams: ControlNet beside the UNet encoder (the engine's default with the pinned GEMM set)" if head.get("two_streams")

@@ -355,3 +355,20 @@ def test_production_width_config_matches_reference_golden(golden_dir):
     assert rel(yc, G["cunet_out_f32"]) < RTOL
     assert rel(ctrls[-1], G["ctrl_last_f32"]) < RTOL
     assert 1e-3 < rel(G["unet_out_bf16ac"], G["unet_out_f32"]) < 0.1 and 1e-4 < rel(G["cunet_out_f16ac"], G["cunet_out_f32"]) < 0.1
+
+
+def test_two_stream_gate_is_off_without_a_pinned_gemm_set(monkeypatch):
+    """engine.two_streams_active (round 6): the ControlNet runs beside the UNet encoder only when the library GEMM set is pinned in the
+    process (TunableOp enabled in look-up-only mode with the shipped file's validators) or when forced; a process that never pinned it —
+    this one: no GPU, TunableOp untouched — runs one stream. MVI_SVD_TWO_STREAMS forces either way."""
+    from multiview_inpaint_amd.svd import engine as E
+    monkeypatch.setattr(E, "_pinned", None)
+    monkeypatch.setattr(E, "TWO_STREAMS", None)
+    assert E.gemm_set_pinned() is False and E.two_streams_active() is False
+    monkeypatch.setattr(E, "TWO_STREAMS", True)
+    assert E.two_streams_active() is True
+    monkeypatch.setattr(E, "TWO_STREAMS", False)
+    monkeypatch.setattr(E, "_pinned", True)
+    assert E.two_streams_active() is False
+    monkeypatch.setattr(E, "TWO_STREAMS", None)
+    assert E.two_streams_active() is True                      # gate open: the default follows it

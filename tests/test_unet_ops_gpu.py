@@ -1875,20 +1875,20 @@ def test_groupnorm_statistics_from_the_convolution_epilogue_with_a_large_common_
     fp64 variance of the stored tensor and the norm's output within the token norms' bar, equal to the three-launch form's to 1.5 x.
     (Raw moments lose ~R^2 2^-24 sqrt(n) of the variance: beyond R ~ 50 in f16 the standalone pass should be used — MVI_SVD_GN_STATS_FROM_CONV=0.)"""
     g = torch.Generator().manual_seed(17)
-    N, H, W, C, Co = 8, 64, 64, 320, 320                            # (128 blocks: the launch is not K-split and may leave statistics)
-    assert ops.conv_n320_gnstats_supported(N * H * W, 9, C, Co, H * W, 32)
-    tok = (1.0 + 0.02 * (9 * C) ** 0.5 * torch.randn(N, H * W, C, generator=g)).to(dtype).cuda()
+    N, Hh, Ww, C, Co = 8, 64, 64, 320, 320                            # (128 blocks: the launch is not K-split and may leave statistics)
+    assert ops.conv_n320_gnstats_supported(N * Hh * Ww, 9, C, Co, Hh * Ww, 32)
+    tok = (1.0 + 0.02 * (9 * C) ** 0.5 * torch.randn(N, Hh * Ww, C, generator=g)).to(dtype).cuda()
     wt = ops.conv3x3_n320_weight(torch.full((Co, C, 3, 3), 1.0 / (9 * C)).to(dtype).cuda())
     w, bb = (1.0 + 0.1 * torch.randn(Co, generator=g)).cuda(), (0.1 * torch.randn(Co, generator=g)).cuda()
-    out, stats = ops.conv3x3_n320(tok, wt, None, H, W, gn=(32, None))
+    out, stats = ops.conv3x3_n320(tok, wt, None, Hh, Ww, gn=(32, None))
     xf = out.double().cpu()
     R = float(xf.mean().abs() / xf.std())
     assert R > 8, R
-    part = stats.part.view(N, H * W // 256, 32, 3).double().cpu()
+    part = stats.part.view(N, Hh * Ww // 256, 32, 3).double().cpu()
     cnt, mean, m2 = part[..., 0], part[..., 1], part[..., 2]
     gmean = (cnt * mean).sum(1) / cnt.sum(1)
     gvar = (m2 + cnt * (mean - gmean[:, None]) ** 2).sum(1) / cnt.sum(1)
-    xg = xf.reshape(N, H * W, 32, Co // 32)
+    xg = xf.reshape(N, Hh * Ww, 32, Co // 32)
     want_var = xg.var(dim=(1, 3), unbiased=False)
     assert float(((gvar - want_var).abs() / want_var).max()) < 2e-3, float(((gvar - want_var).abs() / want_var).max())
     y = ops.group_norm_silu_tok2tok(out, 32, w, bb, 1e-5, True, partials=stats)
