@@ -957,9 +957,21 @@ def conv_split3(x2, w3, N, H, W, C_out, taps=9, mode="split3", _max_bytes=0xFFFF
         raise ValueError(f"conv_split3 ({mode}): x2 contiguous {dt} [N H W, {'2 C' if terms == 3 else 'C'}] and w3 [C_out padded, taps {terms} C] expected")
     x2 = x2.reshape(rows, Cx)
     per = H * W * Cx * 2                                       # bytes of one image / video
+    if per > _max_bytes and taps == 3 and W > 1:
+        # one video alone exceeds the offsets (e.g. 25 frames of 576 x 1024 at 128 channels): the (3,1,1) convolution is independent
+        # per pixel, so the pixel axis is cut (contiguous copies of the slices in, strided copies out: two extra passes, rare)
+        parts = -(-per // _max_bytes)
+        step = -(-W // parts)
+        res = torch.empty(N, H, W, C_out, dtype=torch.float32, device=x2.device)
+        xv = x2.view(N, H, W, Cx)
+        for w0 in range(0, W, step):
+            w1 = min(W, w0 + step)
+            res[:, :, w0:w1] = conv_split3(xv[:, :, w0:w1].contiguous().view(-1, Cx), w3, N, H, w1 - w0, C_out, taps=3, mode=mode,
+                                           _max_bytes=_max_bytes).view(N, H, w1 - w0, C_out)
+        return res.view(rows, C_out)
     n_max = max(1, (_max_bytes // per))
     if per > 0xFFFFFFFF:
-        raise ValueError("conv_split3: one image / video exceeds the kernel's 32-bit activation offsets")
+        raise ValueError("conv_split3: one image exceeds the kernel's 32-bit activation offsets")
     cap = int(L.mvi_conv_split3_out_rows(rows)) + 256
     out = torch.empty(cap, C_out, dtype=torch.float32, device=x2.device)
     fn = L.mvi_conv3x3_split3_f32 if taps == 9 else L.mvi_conv3t_split3_f32
