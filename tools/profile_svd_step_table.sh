@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R && export TMPDIR=/tmp
+# one stream: with the ControlNet on a side stream (the engine's default since round 6) a kernel's duration includes what ran beside it
+export MVI_SVD_TWO_STREAMS=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 -m multiview_inpaint_amd.svd.bench_svd --steps 5 --warmup 2 --sample-steps 0 --weights bf16 > $OUT/bench_under_trace.json 2> $OUT/err.log
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv; rm -rf $OUT/trace
