@@ -167,6 +167,29 @@ struct LnEpi {
 // NOUT (round 6): the block's column count — 320 everywhere in the UNet; 256 for the first-stage decoder's 128 / 256 / 512-channel
 // convolutions (split operands, fp32 out). Everything below is written in terms of kN / kNT / kChunkBytes / kPieces..., re-derived here
 // from NOUT (the epilogues that know about 320 — kStats, kGeglu, kLn — are only instantiated with it).
+// The same arithmetic on a PAIR of outputs with the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue
+// slot). Round 5 found them an anti-lever BESIDE MFMAs (csrc/ff_geglu.hip's interleaved epilogue); this kernel's GEGLU epilogue runs after
+// the last MFMA of the block, with nothing on the matrix pipe. The two values of a pair are adjacent accumulator registers (rows r, r + 1
+// of one tile), so no register moves are needed. |v| enters through the scalar fma's abs modifier (the packed forms have none).
+typedef float f32p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32p geglu2(f32p v, f32p g) {
+    const f32p d = {__builtin_fmaf(__builtin_fabsf(g.x), 0.3275911f * 0.70710678118654752f, 1.0f),
+                    __builtin_fmaf(__builtin_fabsf(g.y), 0.3275911f * 0.70710678118654752f, 1.0f)};
+    const f32p t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32p p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    p = p * t;
+    const f32p gg = g * g * (-0.5f * 1.4426950408889634f);
+    const f32p e = {__builtin_amdgcn_exp2f(gg.x), __builtin_amdgcn_exp2f(gg.y)};
+    const f32p erf_abs = 1.0f - p * e;
+    const f32p hg = 0.5f * g;
+    const f32p s = {__builtin_fmaf(__builtin_fabsf(hg.x), erf_abs.x, hg.x), __builtin_fmaf(__builtin_fabsf(hg.y), erf_abs.y, hg.y)};
+    return v * s;
+}
+static const int g_geglu_packed = [] { const char* e = getenv("MVI_GEGLU_PACKED"); return (e && e[0] == '0') ? 0 : 1; }();
+
 template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
@@ -459,6 +482,11 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; r += 2)
+                            if (cg.dup3) {           // (kGeglu launches carry the packed-erf switch in this otherwise unused field)
+                                const f32p o2 = geglu2(f32p{acc[t][j0 + jj][r], acc[t][j0 + jj][r + 1]},
+                                                       f32p{acc[t][j0 + jj + kNT / 2][r], acc[t][j0 + jj + kNT / 2][r + 1]});
+                                tile_put(t, jj, r, M::pack2(o2.x, o2.y));
+                            } else
                             tile_put(t, jj, r, M::pack2(geglu1(acc[t][j0 + jj][r], acc[t][j0 + jj + kNT / 2][r]),
                                                         geglu1(acc[t][j0 + jj][r + 1], acc[t][j0 + jj + kNT / 2][r + 1])));
                 }
@@ -772,7 +800,7 @@ extern "C" int mvi_ff_geglu_n320(const void* x, const void* weight, const float*
         ((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16)
         return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: x, weight and out rows must be 16-byte aligned");
     if (256 * x_row_stride * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: row block exceeds 32-bit byte offsets");
-    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, inner / (mvi::ln3::kN / 2), 1, 1, 0, 0, 0, 0};
+    const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, inner / (mvi::ln3::kN / 2), 1, 1, 0, 0, 0, 0, mvi::ln3::g_geglu_packed, 0};
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == MVI_DT_BF16
                        ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
