@@ -98,7 +98,7 @@ __device__ __forceinline__ float geglu1(float v, float g) {
 // kGeglu = false: out[r, j] = x . W[j] + b[j], j < inner (= the Linear's out_features); a step = 64 outputs (the same two 32-row
 //                 blocks of a W tile, both plain) — the bias-only projections of level 0 (packed q/k/v, to_out, proj_in / proj_out),
 //                 which the library runs at 0.36 - 0.5 PFLOP/s because at K = 320 they are short loops around a lot of output
-// (the timing ablations this kernel was tuned with — every MFMA removed, erf removed, stores removed: DESIGN.md §8.2b — were a second copy of
+// (the timing ablations this kernel was tuned with — every MFMA removed, erf removed, stores removed: DESIGN.md §9 item 2b — were a second copy of
 // this file under tools/ff_dev/ until round 6; it is in the git history (commit 93207b4), not kept beside a kernel it would drift from)
 template <typename T, bool kGeglu = true>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
