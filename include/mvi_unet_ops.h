@@ -388,6 +388,18 @@ int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const float* weig
  * token-major fp32 activations of the split-operand first-stage decoder. */
 int mvi_rows_axpb_f32(const float* a, const float* b, const float* bias, float alpha, float* out, int64_t R, int32_t C, void* stream);
 
+/* ---- Round 6: the elementwise tails of the UNet's blocks on TOKEN-MAJOR tensors [N, spatial, C], with the statistics of the GroupNorm
+ * that reads the result next (csrc/groupnorm_tokens.hip gt_fused_kernel):
+ *   mode 0: out = a + b + bias[c]      — ResBlock `skip_connection(x) + h` (openaimodel.py:354), SpatialTransformer `x + x_in` (attention.py:717-722)
+ *   mode 1: out = base + (1 - alpha[n]) (a + bias[c]) — the temporal ResBlock's skip add + AlphaBlender (video_model.py:67-81, util.py:358-372)
+ * groups > 0: part receives (count, mean, M2) per (sample, chunk, group) of `out` in the layout mvi_groupnorm_silu_tok2tok_pre merges
+ * (*chunks_per_sample chunks per sample): the next block's first norm (openaimodel.py:256-261, attention.py:700-707, video_model.py:41-54)
+ * then needs no statistics pass. Tensors of one dtype (fp32 / bf16 / f16), 16-byte aligned; bias [C], alpha [N] fp32. */
+size_t mvi_rows_gnstats_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups, int32_t dtype);
+int mvi_rows_fused_gnstats(int32_t mode, const void* a, const void* b, const void* base, const float* bias, const float* alpha, void* out,
+                           int64_t N, int32_t C, int32_t C_first, int64_t spatial, int32_t groups, int32_t dtype, float* part,
+                           size_t part_bytes, int32_t* chunks_per_sample, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,131 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
     }
 }
 
+// Round 6, the token-major residual stream (svd/layers.py TOKEN_STREAM): the elementwise passes that END a block — the ResBlock's skip add
+// (openaimodel.py:354), the temporal skip add + AlphaBlender (video_model.py:67-81, util.py:358-372), the transformer's `x + x_in`
+// (attention.py:717-722) — on token-major tensors, leaving behind the (count, mean, M2) partials of the GroupNorm that reads the result
+// next (the next block's in_layers[0] / SpatialTransformer.norm / the time stack's in_layers[0]) in gt_stats_kernel's layout: that norm then
+// runs merge + apply only (mvi_groupnorm_silu_tok2tok_pre) and its statistics pass over the tensor disappears. Thread layout, shifted sums
+// and the partials are gt_stats_kernel's; the value whose statistics are taken is the ROUNDED output (what the norm will read).
+//   kMode 0: out = a + b + bias[c]                       (b and / or bias may be NULL)
+//   kMode 1: out = base + (1 - alpha[n]) * (a + bias[c]) (alpha per sample: tokens_blend_to_planes_kernel's arithmetic)
+//   kMode 2: out = concat_channels(a [.., C1], b [.., C - C1] + base)   (the decoder's th.cat([h, hs.pop() + control.pop()], dim=1),
+//            csvd.py:84-91; base may be NULL) — the statistics are those of GroupNorm(G) over the C concatenated channels
+// G = 0: no statistics (the plain fused pass).
+template <typename T, int kMode>
+__global__ __launch_bounds__(1024) void gt_fused_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ base,
+                                                        const float* __restrict__ bias, const float* __restrict__ alpha, T* __restrict__ out,
+                                                        float* __restrict__ part, int C, int64_t S, int G, int vpr, int rp, int chunks, int sets,
+                                                        int C1, int parts) {
+    constexpr int V = Io<T>::kVec;
+    extern __shared__ float s_mem[];
+    float* s_1 = s_mem;                        // [rp][C], as in gt_stats_kernel
+    float* s_2 = s_mem + (size_t)rp * C;
+    float* s_0 = s_mem + (size_t)2 * rp * C;   // [C] the block's shift: its first row's OUTPUT
+    const int tid = threadIdx.x, v = tid % vpr, r0 = tid / vpr;
+    const int64_t n = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int rows_set = kGtPasses * rp;
+    const int64_t row0 = (int64_t)chunk * rows_set * sets;
+    const int64_t row_end = row0 + (int64_t)rows_set * sets < S ? row0 + (int64_t)rows_set * sets : S;
+    const int64_t off = (n * S) * C + (int64_t)v * V;
+    // this thread's operands: first (always there) and second (may be absent), each with its own row pitch
+    const T* first = a + off;
+    const T* second = (kMode == 1 ? base : b) ? (kMode == 1 ? base : b) + off : nullptr;
+    int pitch = C;
+    if (kMode == 2) {
+        const bool left = v * V < C1;
+        pitch = left ? C1 : C - C1;
+        const int64_t o2 = (n * S) * pitch + (int64_t)v * V - (left ? 0 : C1);
+        first = (left ? a : b) + o2;
+        second = !left && base ? base + o2 : nullptr;
+    }
+    float bv[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) bv[k] = bias ? bias[v * V + k] : 0.f;
+    const float one_minus = kMode == 1 ? 1.0f - alpha[n] : 0.f;
+    auto value = [&](const uint4& ra, const uint4& rb, float (&o)[V]) __attribute__((always_inline)) {
+        float ta[V], tb[V];
+        Io<T>::load(reinterpret_cast<const T*>(&ra), ta);
+        Io<T>::load(reinterpret_cast<const T*>(&rb), tb);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            o[k] = round_to<T>(kMode == 1 ? tb[k] + one_minus * (ta[k] + bv[k]) : (second ? ta[k] + bv[k] + tb[k] : ta[k] + bv[k]));
+    };
+    // the shift: the output of the block's first row, computed by every thread for its own channels (rows past the block's end are
+    // replaced by that row below: they add 0 to both sums and are not stored)
+    float x0[V], s1[V], s2[V];
+    {
+        const uint4 ra = *reinterpret_cast<const uint4*>(first + row0 * pitch);
+        const uint4 rb = second ? *reinterpret_cast<const uint4*>(second + row0 * pitch) : make_uint4(0, 0, 0, 0);
+        value(ra, rb, x0);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
+    constexpr int kHalf = kGtPasses / 2;                              // four rows in flight per operand
+    for (int st = 0; st < 2 * sets; ++st) {
+        const int64_t base_row = row0 + (int64_t)st * kHalf * rp;
+        uint4 ra[kHalf], rb[kHalf];
+#pragma unroll
+        for (int p = 0; p < kHalf; ++p) {
+            const int64_t row = base_row + p * rp + r0;
+            const int64_t rc = row < row_end ? row : row0;
+            ra[p] = *reinterpret_cast<const uint4*>(first + rc * pitch);
+            rb[p] = second ? *reinterpret_cast<const uint4*>(second + rc * pitch) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < kHalf; ++p) {
+            const int64_t row = base_row + p * rp + r0;
+            float o[V];
+            value(ra[p], rb[p], o);
+            if (row < row_end) Io<T>::store(out + off + row * C, o);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float d = o[k] - x0[k]; s1[k] += d; s2[k] += d * d; }
+        }
+    }
+    if (G == 0) return;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        s_1[(size_t)r0 * C + v * V + k] = s1[k];
+        s_2[(size_t)r0 * C + v * V + k] = s2[k];
+        if (r0 == 0) s_0[v * V + k] = x0[k];
+    }
+    __syncthreads();
+    // The block's (count, mean, M2) per group, in two short steps instead of one thread per group walking its C / G channels twice (at
+    // 1280 channels that walk was a third of the kernel): thread (g, part) merges the C / (G parts) channels of its part — a channel's
+    // `rows` values have mean x0 + S1 / rows and M2 = S2 - S1^2 / rows (shifted sums: nothing cancels) — by Chan's update for sets of
+    // equal size, then one thread per group merges the parts in a fixed order.
+    float* s_q = s_0 + C;                      // [G * parts][2]
+    const int Cg = C / G, Cp = Cg / parts;
+    const float rows = (float)(row_end - row0), inv_rows = 1.0f / rows;
+    if (tid < G * parts) {
+        const int c0 = tid / parts * Cg + tid % parts * Cp;
+        float mean = 0.f, m2 = 0.f;
+        for (int k = 0; k < Cp; ++k) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int r = 0; r < rp; ++r) { a1 += s_1[(size_t)r * C + c0 + k]; a2 += s_2[(size_t)r * C + c0 + k]; }
+            const float mc = s_0[c0 + k] + a1 * inv_rows, qc = a2 - a1 * a1 * inv_rows;
+            const float d = mc - mean, inv = 1.0f / (float)(k + 1);
+            mean += d * inv;
+            m2 += qc + d * d * (rows * (float)k * inv);
+        }
+        s_q[2 * tid] = mean; s_q[2 * tid + 1] = m2;
+    }
+    __syncthreads();
+    if (tid < G) {
+        const float n_part = rows * (float)Cp;
+        float mean = 0.f, m2 = 0.f;
+        for (int k = 0; k < parts; ++k) {
+            const float mb = s_q[2 * (tid * parts + k)], qb = s_q[2 * (tid * parts + k) + 1];
+            const float d = mb - mean, inv = 1.0f / (float)(k + 1);
+            mean += d * inv;
+            m2 += qb + d * d * (n_part * (float)k * inv);
+        }
+        float* p = part + ((n * chunks + chunk) * G + tid) * 3;
+        p[0] = rows * Cg; p[1] = mean; p[2] = m2 > 0.f ? m2 : 0.f;
+    }
+}
+
 // one block per sample: Chan merge per group, then per-channel scale / shift
 // frames > 1: the temporal GroupNorm of VideoResBlock.time_stack (statistics over the `frames` consecutive samples of a video,
 // video_model.py:71-75): a block merges the chunks of all its frames — they are consecutive in `part` — and writes every frame's
@@ -409,4 +534,74 @@ extern "C" int mvi_groupnorm_silu_tok2tok_split(const float* x, void* y2, const 
         return mvi::unet_fail(MVI_ENOMEM, "groupnorm_tok2tok_split: workspace too small");
     const int rc = mvi::gt_launch_split(x, y2, weight, bias, chan_bias, N, C, spatial, groups, eps, fuse_silu, (float*)workspace, (hipStream_t)stream, frames, out_mode);
     return rc ? mvi::unet_fail(MVI_EHIP, "groupnorm_tok2tok_split: kernel launch failed") : MVI_OK;
+}
+
+// ---- round 6: elementwise block tails on token-major tensors with the NEXT GroupNorm's statistics (gt_fused_kernel) --------------------
+namespace mvi {
+template <typename T>
+static int gt_fused_launch(int mode, const void* a, const void* b, const void* base, const float* bias, const float* alpha, void* out, float* part,
+                           int64_t N, int C, int64_t S, int G, int* chunks_out, hipStream_t st, int C1) {
+    constexpr int V = Io<T>::kVec;
+    const int vpr = C / V, rp = gt_rows_per_pass(vpr);
+    const int chunks = (int)((S + kGtPasses * rp - 1) / (kGtPasses * rp));
+    // blocks walk `sets` chunks each: ~6 blocks per CU (level 0 of the 576x1024 step, [28, 9216, 320]: 113 us at 3 per CU, 101 us at 6,
+    // 96 us at 12 — but every chunk is a partial the norm's merge walks, 14 frames' worth for the temporal norm)
+    int sets = (int)((int64_t)chunks * N / 1536);
+    sets = sets < 1 ? 1 : (sets > 16 ? 16 : sets);
+    const int schunks = (chunks + sets - 1) / sets;
+    if (chunks_out) *chunks_out = schunks;
+    // parts per group of the block's closing merge: the largest divisor of C / G that is <= 16 and leaves G parts <= the block's threads
+    int parts = 1;
+    if (G > 0)
+        for (int q = 2; q <= 16 && G * q <= vpr * rp; ++q)
+            if ((C / G) % q == 0) parts = q;
+    const size_t lds = G > 0 ? ((size_t)2 * rp * C + C + 2 * G * parts) * sizeof(float) : 0;
+    const dim3 grid((unsigned)schunks, (unsigned)N), block((unsigned)(vpr * rp));
+    if (mode == 0)
+        hipLaunchKernelGGL((gt_fused_kernel<T, 0>), grid, block, lds, st, (const T*)a, (const T*)b, (const T*)nullptr, bias, alpha, (T*)out, part, C, S, G, vpr, rp, schunks, sets, 0, parts);
+    else if (mode == 1)
+        hipLaunchKernelGGL((gt_fused_kernel<T, 1>), grid, block, lds, st, (const T*)a, (const T*)nullptr, (const T*)base, bias, alpha, (T*)out, part, C, S, G, vpr, rp, schunks, sets, 0, parts);
+    else
+        hipLaunchKernelGGL((gt_fused_kernel<T, 2>), grid, block, lds, st, (const T*)a, (const T*)b, (const T*)base, (const float*)nullptr, alpha, (T*)out, part, C, S, G, vpr, rp, schunks, sets, C1, parts);
+    return hipGetLastError() == hipSuccess ? 0 : MVI_EHIP;
+}
+}  // namespace mvi
+
+// Partials buffer of the fused passes below: [N * chunks * groups][3] floats with chunks <= the statistics pass's chunk count.
+extern "C" size_t mvi_rows_gnstats_bytes(int64_t N, int32_t C, int64_t spatial, int32_t groups, int32_t dtype) {
+    if (groups <= 0 || !gt_geometry_ok(N, C, spatial, groups, dtype)) return 0;
+    const int V = dtype == MVI_DT_F32 ? 4 : 8;
+    const int rp = mvi::gt_rows_per_pass(C / V);
+    if (((size_t)2 * rp * C + C + 2 * groups * 16) * sizeof(float) > 64 * 1024) return 0;      // (+ the parts of the closing merge)
+    const int64_t chunks = (spatial + mvi::kGtPasses * rp - 1) / (mvi::kGtPasses * rp);
+    return (size_t)(N * chunks * groups * 3) * sizeof(float);
+}
+
+// mode 0: out = a + b + bias[c] (b, bias optional); mode 1: out = base + (1 - alpha[n]) * (a + bias[c]) — token-major [N, spatial, C] tensors
+// of one dtype (bf16 / f16 / fp32), bias [C] / alpha [N] fp32; mode 2: out [N, spatial, C] = channels (a [.., C_first] | b [.., C - C_first]
+// + base), base optional, no bias (C_first is ignored by the other modes). groups > 0: also the (count, mean, M2) partials of GroupNorm(groups) of `out`
+// into part (mvi_rows_gnstats_bytes), *chunks_per_sample = their chunk count — what mvi_groupnorm_silu_tok2tok_pre takes; groups = 0: none.
+extern "C" int mvi_rows_fused_gnstats(int32_t mode, const void* a, const void* b, const void* base, const float* bias, const float* alpha,
+                                      void* out, int64_t N, int32_t C, int32_t C_first, int64_t spatial, int32_t groups, int32_t dtype, float* part,
+                                      size_t part_bytes, int32_t* chunks_per_sample, void* stream) {
+    if (N == 0 || spatial == 0) return MVI_OK;
+    if (mode < 0 || mode > 2) return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: mode 0 (add), 1 (blend) or 2 (concat)");
+    if (mode == 2 && (!b || bias || C_first <= 0 || C_first >= C || C_first % (dtype == MVI_DT_F32 ? 4 : 8) || (C - C_first) % (dtype == MVI_DT_F32 ? 4 : 8)))
+        return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: concat takes a [.., C_first] and b [.., C - C_first], both multiples of the 16-byte vector, and no bias");
+    if (!gt_geometry_ok(N, C, spatial, groups > 0 ? groups : 1, dtype))
+        return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: C must be a multiple of groups (<= 64) and of the 16-byte vector width");
+    if (!a || !out || (mode == 1 && (!base || !alpha))) return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: NULL pointer");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)base | (uintptr_t)out) % 16) return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: tensors must be 16-byte aligned");
+    if (groups > 0 && (!part || part_bytes < mvi_rows_gnstats_bytes(N, C, spatial, groups, dtype)))
+        return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: statistics buffer missing or too small (mvi_rows_gnstats_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    int rc, ch = 0;
+    switch (dtype) {
+        case MVI_DT_F32: rc = mvi::gt_fused_launch<float>(mode, a, b, base, bias, alpha, out, part, N, C, spatial, groups, &ch, st, C_first); break;
+        case MVI_DT_BF16: rc = mvi::gt_fused_launch<__hip_bfloat16>(mode, a, b, base, bias, alpha, out, part, N, C, spatial, groups, &ch, st, C_first); break;
+        case MVI_DT_F16: rc = mvi::gt_fused_launch<__half>(mode, a, b, base, bias, alpha, out, part, N, C, spatial, groups, &ch, st, C_first); break;
+        default: return mvi::unet_fail(MVI_EINVAL, "rows_fused_gnstats: unknown dtype");
+    }
+    if (chunks_per_sample) *chunks_per_sample = ch;
+    return rc ? mvi::unet_fail(MVI_EHIP, "rows_fused_gnstats: kernel launch failed") : MVI_OK;
 }

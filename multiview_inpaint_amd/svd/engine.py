@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .schedule import Denoiser, instantiate_from_config
+from .layers import to_planes
 
 OPENAIUNETWRAPPER = "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper"
 # ControlNet beside the UNet encoder (apply_model): same-box A/B 181.3 -> 173.2 ms per step in round 3, 137.3 -> 133.7 in the driver's
@@ -147,12 +148,14 @@ class SVDInpaintEngine(nn.Module):
         controls = None
         if hint is not None and self.control_model is not None:
             def run_control():
+                # (our ControlNet hands its residuals over token-major where it computed them so — layers.Tok — and the UNet consumes them so)
+                extra = dict(tokens_out=True) if getattr(self.control_model, "offers_token_residuals", False) else {}
                 cs = self.control_model(x=xin, hint=hint, timesteps=timesteps, context=context, y=y,
                                         time_context=time_context, num_video_frames=num_video_frames,
-                                        image_only_indicator=image_only_indicator)
+                                        image_only_indicator=image_only_indicator, **extra)
                 cs = [c if s == 1.0 else c * s for c, s in zip(cs, self.control_scales)]   # x * 1.0 is x: skip the pass
                 if self.global_average_pooling:
-                    cs = [c.mean(dim=(2, 3), keepdim=True) for c in cs]
+                    cs = [to_planes(c).mean(dim=(2, 3), keepdim=True) for c in cs]
                 return cs
             if xin.is_cuda and not torch.is_grad_enabled() and _events_off() and two_streams_active():
                 # The ControlNet and the UNet's encoder + middle block are independent until the first residual is added

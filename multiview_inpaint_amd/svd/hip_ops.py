@@ -997,3 +997,56 @@ def rows_axpb(a, b, bias, alpha=1.0, out=None):
         _check(L.mvi_rows_axpb_f32(a.data_ptr(), b.data_ptr(), None if bf is None else bf.data_ptr(), float(alpha), out.data_ptr(), R, Cc,
                                    _stream(a.device)), "rows_axpb")
     return out
+
+
+# ---- Round 6: block tails on token-major tensors with the next GroupNorm's statistics (csrc/groupnorm_tokens.hip gt_fused_kernel) -------
+
+def rows_gnstats_supported(N, C, S, groups, dtype):
+    return dtype in _DT and int(_lib.lib().mvi_rows_gnstats_bytes(int(N), int(C), int(S), int(groups), _DT[dtype])) > 0
+
+
+def rows_fused(a, b=None, bias=None, base=None, alpha=None, groups=0, concat=False):
+    """Token-major [N, S, C] tensors of one dtype. base None: a + b + bias[c] (b, bias optional) — the ResBlock's skip add, the
+    transformer's `x + x_in`. base and alpha given: base + (1 - alpha[n]) * (a + bias[c]) — the temporal skip add + AlphaBlender (alpha [N]
+    fp32). concat: channels (a | b + base) -> [N, S, Ca + Cb], base optional — the decoder's cat([h, skip + control], dim=1).
+    groups > 0: also returns GnPartials of GroupNorm(groups) of the result (no chan_bias) for group_norm_silu_tok2tok(partials=...), None
+    where the statistics kernel's geometry does not take the shape."""
+    L = _lib.lib()
+    if a.dim() != 3 or a.dtype not in _DT:
+        raise TypeError("rows_fused: token-major [N, S, C] fp32 / bf16 / f16 expected")
+    N, S, Ca = a.shape
+    ts = [t for t in (a, b, base) if t is not None]
+    if any(t.dtype != a.dtype or not t.is_contiguous() or t.shape[:2] != a.shape[:2] for t in ts):
+        raise ValueError("rows_fused: a, b, base must be contiguous [N, S, .] tensors of one dtype")
+    if concat:
+        if b is None or bias is not None or alpha is not None or (base is not None and base.shape != b.shape):
+            raise ValueError("rows_fused: concat takes a, b (and base shaped like b), no bias / alpha")
+        mode, Cc = 2, Ca + b.shape[2]
+    else:
+        if any(t.shape != a.shape for t in ts):
+            raise ValueError("rows_fused: a, b, base must share one shape")
+        mode, Cc = (0 if base is None else 1), Ca
+        if mode == 1 and (alpha is None or alpha.numel() != N):
+            raise ValueError(f"rows_fused: alpha must be [{N}]")
+    out = torch.empty(N, S, Cc, dtype=a.dtype, device=a.device)
+    part, nb = None, 0
+    if groups:
+        nb = int(L.mvi_rows_gnstats_bytes(N, Cc, S, int(groups), _DT[a.dtype]))
+        if nb == 0:
+            groups = 0
+        else:
+            part = torch.empty(nb // 4, dtype=torch.float32, device=a.device)
+    ch = C.c_int32(0)
+    al = None if alpha is None else alpha.detach().float().contiguous()
+    bf = None if bias is None else _f32(bias)
+    kind = ("rows_add", "rows_blend", "rows_concat")[mode]
+    nbytes = float(sum(t.numel() for t in ts) + out.numel()) * a.element_size()
+    with torch.cuda.device(a.device), _Timed(kind, nbytes, a.device):
+        _check(L.mvi_rows_fused_gnstats(mode, a.data_ptr(), None if b is None else b.data_ptr(), None if base is None else base.data_ptr(),
+                                        None if bf is None else bf.data_ptr(), None if al is None else al.data_ptr(), out.data_ptr(), N, Cc, Ca, S,
+                                        int(groups), _DT[a.dtype], None if part is None else part.data_ptr(), nb, C.byref(ch),
+                                        _stream(a.device)), "rows_fused")
+    if not groups:
+        return out, None
+    chunks = int(ch.value)
+    return out, GnPartials(part[:N * chunks * int(groups) * 3], chunks, int(groups), None)

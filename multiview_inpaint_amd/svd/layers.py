@@ -99,6 +99,84 @@ def norm_act(seq: nn.Sequential, x):
     return seq[0](x, silu=True)
 
 
+TOKEN_STREAM = os.environ.get("MVI_SVD_TOKEN_STREAM", "1") != "0"
+
+
+class Tok:
+    """The residual stream BETWEEN the blocks of the video UNet / ControlNet in token-major form (round 6, MVI_SVD_TOKEN_STREAM): the
+    activation `b c h w` of the reference held as t [N, H W, C], plus — when the kernel that produced it left them — the GroupNorm
+    statistics of t (hip_ops.GnPartials) for the norm that opens the next block. Every block of the SVD networks works on tokens
+    inside (implicit-GEMM convolutions, attention), so carrying tokens across the block boundary removes the two layout passes per
+    block and lets the block tails (skip add, AlphaBlender, `x + x_in`, the decoder's concatenation) be plain row kernels that
+    also take the next norm's statistics (csrc/groupnorm_tokens.hip gt_fused_kernel). `shape` is the LOGICAL b c h w shape, so
+    shape checks written for planes read the same."""
+    __slots__ = ("t", "H", "W", "stats")
+    takes_tokens = True
+
+    def __init__(self, t, H, W, stats=None):
+        self.t, self.H, self.W, self.stats = t, int(H), int(W), stats
+
+    @property
+    def shape(self):
+        return torch.Size((self.t.shape[0], self.t.shape[2], self.H, self.W))
+
+    dtype = property(lambda self: self.t.dtype)
+    device = property(lambda self: self.t.device)
+    is_cuda = property(lambda self: self.t.is_cuda)
+
+    def dim(self):
+        return 4
+
+    def gn_stats(self, groups):
+        """The producer's statistics if they are those of GroupNorm(groups) of t without a channel bias, else None."""
+        st = self.stats
+        return st if GN_STATS_FROM_TAILS and st is not None and st.groups == int(groups) and st.chan_bias is None else None
+
+    def planes(self):
+        """b c h w (one layout pass)."""
+        N, S, C = self.t.shape
+        if C % 8 == 0 and S % 8 == 0:
+            from . import hip_ops
+            return hip_ops.tokens_to_planes_add(self.t, None, spatial=(self.H, self.W))
+        return self.t.transpose(1, 2).reshape(N, C, self.H, self.W).contiguous()
+
+    def __mul__(self, s):
+        return Tok(self.t * s, self.H, self.W)
+
+    def record_stream(self, stream):
+        self.t.record_stream(stream)
+
+
+GN_STATS_FROM_TAILS = os.environ.get("MVI_SVD_GN_STATS_FROM_TAILS", "1") != "0"     # 0: the block tails leave no statistics (A/B)
+
+
+def token_stream_ok(x):
+    """Whether a forward pass on x may carry its residual stream token-major: the reduced-precision inference path on the GPU with the
+    implicit-GEMM convolutions on (every block then works on tokens inside)."""
+    return (TOKEN_STREAM and CONV_N320 and NHWC_CONVS and TIME_STACK_TOKENS and torch.is_tensor(x) and x.is_cuda and x.dim() == 4
+            and x.dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled())
+
+
+def to_tok(x):
+    """b c h w -> Tok (one layout pass); a Tok is returned as it is."""
+    if isinstance(x, Tok):
+        return x
+    from . import hip_ops
+    N, C, H, W = x.shape
+    if C % 8 == 0 and (H * W) % 8 == 0:
+        return Tok(hip_ops.planes_to_tokens(x), H, W)
+    return Tok(x.flatten(2).transpose(1, 2).contiguous(), H, W)
+
+
+def to_planes(x):
+    return x.planes() if isinstance(x, Tok) else x
+
+
+def _conv1x1_as_rows(conv):
+    return (isinstance(conv, nn.Conv2d) and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (0, 0) and conv.groups == 1)
+
+
 class Timestep(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -185,9 +263,18 @@ class Upsample(nn.Module):
         if use_conv:
             self.conv = conv_nd(dims, self.channels, self.out_channels, kernel_size, padding=padding)
 
+    takes_tokens = True
+
     def forward(self, x):
         assert x.shape[1] == self.channels
         s = self.scale_factor
+        if isinstance(x, Tok):
+            N, C, H, W = x.shape
+            if self.dims != 3 and s == 2 and self.use_conv and _conv_n320_route_ok(self.conv, N, C, 2 * H, 2 * W, x.dtype):
+                from . import hip_ops
+                up = x.t.view(N, H, 1, W, 1, C).expand(N, H, 2, W, 2, C).reshape(N, 4 * H * W, C)      # nearest-neighbour 2x on tokens
+                return Tok(hip_ops.conv3x3_n320(up, _tap_major_weight(self.conv.weight), self.conv.bias, 2 * H, 2 * W), 2 * H, 2 * W)
+            return to_tok(self.forward(x.planes()))
         if self.dims == 3:
             x = F.interpolate(x, ((s if self.third_up else 1) * x.shape[2], x.shape[3] * s, x.shape[4] * s), mode="nearest")
         else:
@@ -211,8 +298,17 @@ class Downsample(nn.Module):
             assert self.channels == self.out_channels
             self.op = avg_pool_nd(dims, kernel_size=stride, stride=stride)
 
+    takes_tokens = True
+
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if isinstance(x, Tok):
+            N, C, H, W = x.shape
+            if self.use_conv and _conv_n320_route_ok(self.op, N, C, H, W, x.dtype):
+                from . import hip_ops
+                Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                return Tok(hip_ops.conv3x3_n320(x.t, _tap_major_weight(self.op.weight), self.op.bias, H, W, stride=2), Ho, Wo)
+            return to_tok(self.forward(x.planes()))
         if self.use_conv:
             y = conv3x3_planes_via_tokens(self.op, x)                        # the stride-2 convolution on tokens
             if y is not None:
@@ -238,22 +334,33 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Sequential whose members declare, through `takes`, which conditioning they consume
     (openaimodel.py:72-104 dispatches on isinstance instead; same call signature)."""
 
+    @staticmethod
+    def _member(layer, x, a):
+        kind = getattr(layer, "takes", None)
+        if kind == "video_res":
+            return layer(x, a.emb, a.num_video_frames, a.image_only_indicator)
+        if kind == "video_attn":
+            return layer(x, a.context, a.time_context, a.num_video_frames, a.image_only_indicator)
+        if kind == "attn":
+            return layer(x, a.context)
+        if kind == "emb" or isinstance(layer, TimestepBlock):
+            return layer(x, a.emb)
+        if isinstance(layer, nn.Conv2d):
+            return conv_no_bias(layer, x, layer.bias)          # 1x1 convolutions of channels-last rows run as GEMMs
+        return layer(x)
+
     def forward(self, x, emb=None, context=None, image_only_indicator=None, time_context=None, num_video_frames=None):
         a = BlockArgs(emb, context, image_only_indicator, time_context, num_video_frames)
         for layer in self:
-            kind = getattr(layer, "takes", None)
-            if kind == "video_res":
-                x = layer(x, a.emb, a.num_video_frames, a.image_only_indicator)
-            elif kind == "video_attn":
-                x = layer(x, a.context, a.time_context, a.num_video_frames, a.image_only_indicator)
-            elif kind == "attn":
-                x = layer(x, a.context)
-            elif kind == "emb" or isinstance(layer, TimestepBlock):
-                x = layer(x, a.emb)
-            elif isinstance(layer, nn.Conv2d):
-                x = conv_no_bias(layer, x, layer.bias)          # 1x1 convolutions of channels-last rows run as GEMMs
+            if isinstance(x, Tok) and not getattr(layer, "takes_tokens", False):
+                # a member that knows planes only, inside a token-major stream: a 1x1 convolution (the ControlNet's zero convolutions,
+                # csvd.py:252-256) is a GEMM on the token rows; anything else sees b c h w and its result is turned back
+                if _conv1x1_as_rows(layer) and layer.weight.dtype == x.dtype:
+                    x = Tok(ops.linear(x.t, layer.weight.reshape(layer.out_channels, layer.in_channels), layer.bias), x.H, x.W)
+                else:
+                    x = to_tok(self._member(layer, x.planes(), a))
             else:
-                x = layer(x)
+                x = self._member(layer, x, a)
         return x
 
 
@@ -513,7 +620,7 @@ def _tap_major_weight(w):
     return hit[2]
 
 
-def conv3x3_planes_via_tokens(conv, x, upsample=1):
+def conv3x3_planes_via_tokens(conv, x, upsample=1, tokens_out=False):
     """`conv(x)` — or `conv(F.interpolate(x, scale_factor=2, mode="nearest"))` with upsample = 2 — for a 3x3 / padding 1 Conv2d of
     stride 1 or 2 on an NCHW tensor, evaluated on tokens: layout pass (the upsampling folded into it), the implicit-GEMM kernel of
     csrc/linear_n320.hip with the bias in its accumulators, layout pass back. None when the route does not apply: reduced precision
@@ -529,12 +636,28 @@ def conv3x3_planes_via_tokens(conv, x, upsample=1):
     stride = conv.stride[0]
     Hi, Wi = upsample * H, upsample * W
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    if not (C % 8 == 0 and (H * W) % 8 == 0 and (Ho * Wo) % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, x.dtype)
-            and N * Hi * Wi * C * 2 < 2 ** 32
-            and hip_ops.conv3x3_n320_fills_chip(N, Hi, Wi, C, conv.out_channels, CONV_N320_MIN_BLOCKS, stride=stride)):
+    if not ((H * W) % 8 == 0 and (Ho * Wo) % 8 == 0 and _conv_n320_shape_ok(conv, N, C, Hi, Wi, x.dtype)):
         return None
     t = hip_ops.conv3x3_n320(hip_ops.planes_to_tokens(x, upsample=upsample), _tap_major_weight(conv.weight), conv.bias, Hi, Wi, stride=stride)
+    if tokens_out:                                                       # (the caller carries the result token-major: layers.Tok)
+        return Tok(t, Ho, Wo)
     return hip_ops.tokens_to_planes_add(t, None, spatial=(Ho, Wo))
+
+
+def _conv_n320_shape_ok(conv, N, C, Hi, Wi, dtype):
+    """A 3x3 / padding 1 convolution of stride 1 or 2 over N images of Hi x Wi tokens with C channels: the shapes csrc/linear_n320.hip takes
+    and enough output pixels to fill the chip."""
+    from . import hip_ops
+    return (C % 8 == 0 and hip_ops.conv3x3_n320_supported(C, conv.out_channels, dtype) and N * Hi * Wi * C * 2 < 2 ** 32
+            and hip_ops.conv3x3_n320_fills_chip(N, Hi, Wi, C, conv.out_channels, CONV_N320_MIN_BLOCKS, stride=conv.stride[0]))
+
+
+def _conv_n320_route_ok(conv, N, C, Hi, Wi, dtype):
+    """conv3x3_planes_via_tokens' conditions for a token-major input (Tok) of N x (Hi Wi) x C."""
+    return (CONV_N320 and NHWC_CONVS and dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled()
+            and isinstance(conv, nn.Conv2d) and conv.weight.dtype == dtype and tuple(conv.kernel_size) == (3, 3)
+            and tuple(conv.stride) in ((1, 1), (2, 2)) and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and _conv_n320_shape_ok(conv, N, C, Hi, Wi, dtype))
 
 
 TIME_STACK_TOKENS = os.environ.get("MVI_SVD_TIME_STACK_TOKENS", "1") != "0"
@@ -687,7 +810,7 @@ class VideoResBlock(ResBlock):
                 and _tok2tok_ok(bt, co, h * w, ts.in_layers[0].num_groups, x.dtype)
                 and hip_ops.conv3t_n320_fills_chip(bt // t, t, h * w, co, co, CONV_N320_MIN_BLOCKS))
 
-    def _time_stack_tokens(self, xt, emb, T, blend, hw):
+    def _time_stack_tokens(self, xt, emb, T, blend, hw, stats_in=None, tokens_out=False):
         """_time_stack_frames on token-major xt [(b T), S, c] (the spatial ResBlock's output as tokens): temporal GroupNorm + SiLU with
         token-major input and output, the (3,1,1) convolutions as three-tap implicit GEMMs over the frame axis, and the skip add +
         AlphaBlender in the pass that restores b c h w. No channel-stacked tensor, no library convolution."""
@@ -695,7 +818,7 @@ class VideoResBlock(ResBlock):
         ts = self.time_stack
         g0, g1 = ts.in_layers[0], ts.out_layers[0]
         c1, c2 = ts.in_layers[2], ts.out_layers[3]
-        h = ops.group_norm_tok2tok(xt, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, frames=T)
+        h = ops.group_norm_tok2tok(xt, g0.num_groups, g0.weight, g0.bias, g0.eps, silu=True, frames=T, partials=stats_in)
         e = _emb_chan_bias(ts.emb_layers, emb, c1)                 # [(b T), c] fp32 incl. the first convolution's bias
         e = e if e.is_contiguous() else e.contiguous()
         stats = None
@@ -706,10 +829,52 @@ class VideoResBlock(ResBlock):
             h = hip_ops.conv3t_n320(h, _tap_major_weight(c1.weight), None, T)
         h = ops.group_norm_tok2tok(h, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, chan_bias=e, frames=T, partials=stats)
         h = hip_ops.conv3t_n320(ts.out_layers[2](h), _tap_major_weight(c2.weight), None, T)
+        if tokens_out:
+            # the token-major stream: skip add + AlphaBlender as a row pass that leaves the statistics of the next block's first norm
+            out, st = hip_ops.rows_fused(h, bias=c2.bias, base=xt, alpha=blend, groups=g0.num_groups if GN_STATS_FROM_TAILS else 0)
+            return Tok(out, hw[0], hw[1], st)
         return hip_ops.tokens_blend_to_planes(h, xt, c2.bias, blend, hw)
+
+    takes_tokens = True
+
+    def _forward_tok(self, x, emb, t, image_only_indicator):
+        """forward() on the token-major stream (Tok in, Tok out): first norm straight from tokens (its statistics, where the block
+        before left them, cost no pass), the spatial block's skip add as a row pass that takes the temporal norm's statistics, the
+        channel-changing skip convolution (1x1, openaimodel.py:300) as a GEMM on the token rows. None where a condition of the token
+        path (_tokens_path_ok) fails: the caller goes through planes."""
+        sk = self.skip_connection
+        g1, g2 = self.in_layers[0], self.out_layers[0]
+        N, C, H, W = x.shape
+        if not (self._tokens_path_ok(x, t) and (isinstance(sk, nn.Identity) or (_conv1x1_as_rows(sk) and sk.weight.dtype == x.dtype))
+                and _tok2tok_ok(N, C, H * W, g1.num_groups, x.dtype)):
+            return None
+        a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)
+        if a.ndim != 5:
+            return None
+        if a.size(0) != N // t:
+            a = self.time_mixer.get_alpha(image_only_indicator, rows=N // t)   # CFG-doubled batch (util.py:365-367)
+        from . import hip_ops
+        conv1, conv2 = self.in_layers[2], self.out_layers[3]
+        h = ops.group_norm_tok2tok(x.t, g1.num_groups, g1.weight, g1.bias, g1.eps, silu=True, partials=x.gn_stats(g1.num_groups))
+        e = _emb_chan_bias(self.emb_layers, emb, conv1)
+        e = e if e.is_contiguous() else e.contiguous()
+        h, stats = _conv_tokens(conv1, h, H, W, gn=(g2.num_groups, e))
+        h = ops.group_norm_tok2tok(h, g2.num_groups, g2.weight, g2.bias, g2.eps, silu=True, chan_bias=e, partials=stats)
+        h = _conv_tokens(conv2, self.out_layers[2](h), H, W)
+        if isinstance(sk, nn.Identity):
+            xs, sb = x.t, conv2.bias
+        else:
+            xs = ops.linear(x.t, sk.weight.reshape(sk.out_channels, sk.in_channels), None)
+            sb = sk.bias if conv2.bias is None else (conv2.bias if sk.bias is None else _sum_param(sk.bias, conv2.bias))
+        g0 = self.time_stack.in_layers[0]
+        xt, st0 = hip_ops.rows_fused(h, xs, bias=sb, groups=g0.num_groups if GN_STATS_FROM_TAILS else 0)
+        return self._time_stack_tokens(xt, emb, t, a.reshape(N), (H, W), stats_in=st0, tokens_out=True)
 
     def forward(self, x, emb, num_video_frames, image_only_indicator=None):
         t = int(num_video_frames)
+        if isinstance(x, Tok):
+            y = self._forward_tok(x, emb, t, image_only_indicator)
+            return y if y is not None else to_tok(self.forward(x.planes(), emb, num_video_frames, image_only_indicator))
         if x.dim() == 4 and self._tokens_path_ok(x, t):
             a = self.time_mixer.get_alpha(image_only_indicator)           # [b, 1, t, 1, 1] (or a scalar)
             if a.ndim == 5:

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import AlphaBlender, linear, maybe_checkpoint, timestep_embedding, zero_module
+from .layers import AlphaBlender, Tok, linear, maybe_checkpoint, timestep_embedding, to_tok, zero_module
 
 
 import os
@@ -241,20 +241,43 @@ class SpatialTransformer(nn.Module):
                                   checkpoint=use_checkpoint, sdp_backend=sdp_backend) for d in range(depth)])
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv2d(inner, in_channels, 1))
 
+    takes_tokens = True
+
+    def _norm_tokens(self, x):
+        """self.norm(x) as tokens b (h w) c: from planes the norm writes them directly; from the token-major stream (layers.Tok) it is
+        the token norm, without its statistics pass where the block before left them."""
+        if isinstance(x, Tok):
+            n = self.norm
+            return ops.group_norm_tok2tok(x.t, n.num_groups, n.weight, n.bias, n.eps, silu=False, partials=x.gn_stats(n.num_groups))
+        return self.norm.forward_tokens(x)
+
+    def _tok_route_ok(self, x):
+        from .layers import _tok2tok_ok
+        N, C, H, W = x.shape
+        return self.use_linear and _tok2tok_ok(N, C, H * W, self.norm.num_groups, x.dtype)
+
     def _tokens_in(self, x):
         if self.use_linear:
-            return ops.linear_module(self.proj_in, self.norm.forward_tokens(x))  # the norm writes b (h w) c directly
+            return ops.linear_module(self.proj_in, self._norm_tokens(x))
         h = self.proj_in(self.norm(x))
         return h.flatten(2).transpose(1, 2).contiguous()      # b c h w -> b (h w) c
 
     def _tokens_out(self, t, x_in):
         b, c, h, w = x_in.shape
+        if isinstance(x_in, Tok):
+            # `x + x_in` on token rows, with the statistics of the next block's first norm
+            from . import hip_ops
+            from .layers import GN_STATS_FROM_TAILS
+            out, st = hip_ops.rows_fused(ops.linear_module(self.proj_out, t), x_in.t, groups=self.norm.num_groups if GN_STATS_FROM_TAILS else 0)
+            return Tok(out, h, w, st)
         if self.use_linear:
             return ops.tokens_to_planes_add(ops.linear_module(self.proj_out, t), x_in)   # b (h w) c -> b c h w, + x_in, one pass
         t = t.transpose(1, 2).reshape(b, -1, h, w)
         return self.proj_out(t) + x_in
 
     def forward(self, x, context=None):
+        if isinstance(x, Tok) and not self._tok_route_ok(x):
+            return to_tok(self.forward(x.planes(), context))
         ctxs = context if isinstance(context, list) else [context]
         t = self._tokens_in(x)
         for i, blk in enumerate(self.transformer_blocks):
@@ -398,6 +421,8 @@ class SpatialVideoTransformer(SpatialTransformer):
         return pe
 
     def forward(self, x, context=None, time_context=None, timesteps=None, image_only_indicator=None):
+        if isinstance(x, Tok) and not self._tok_route_ok(x):
+            return to_tok(self.forward(x.planes(), context, time_context, timesteps, image_only_indicator))
         _, _, h, w = x.shape
         T = int(timesteps)
         # SVD configuration (use_spatial_context, one CLIP token): the temporal blocks run on the
@@ -416,7 +441,7 @@ class SpatialVideoTransformer(SpatialTransformer):
         n1 = None
         if in_place and self.use_linear:
             # the stem's projection carries the first block's norm1 (one kernel at the level-0 width)
-            n1, t, _ = ops.linear_add_layer_norm(self.norm.forward_tokens(x), self.proj_in, None, self.transformer_blocks[0].norm1)
+            n1, t, _ = ops.linear_add_layer_norm(self._norm_tokens(x), self.proj_in, None, self.transformer_blocks[0].norm1)
         else:
             t = self._tokens_in(x)
         emb = self.time_pos_embed(self._frame_embedding(T, x.shape[0] // T, x.device))[:, None, :]

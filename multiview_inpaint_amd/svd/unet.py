@@ -16,8 +16,8 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .layers import (Downsample, TimestepEmbedSequential, Timestep, Upsample, VideoResBlock, conv_nd, linear, prepare_emb_projections,
-                     norm_act, normalization, timestep_embedding, zero_module)
+from .layers import (Downsample, TimestepEmbedSequential, Timestep, Tok, Upsample, VideoResBlock, conv_nd, linear, prepare_emb_projections,
+                     norm_act, normalization, timestep_embedding, to_planes, to_tok, token_stream_ok, zero_module)
 from .transformer import SpatialVideoTransformer
 from . import ops
 
@@ -180,21 +180,60 @@ class VideoUNet(_Encoder):
         prepare_emb_projections(self, emb)                # all ResBlock embedding projections of this step as one GEMM per width
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
+        tokens = token_stream_ok(x)                        # the residual stream between the blocks held token-major (layers.Tok)
         hs, h = [], x
         for blk in self.input_blocks:
-            h = _input_conv(blk, h) if blk is self.input_blocks[0] else blk(h, emb, **kw)
+            if blk is self.input_blocks[0]:
+                h = _input_conv(blk, h)
+                h = to_tok(h) if tokens else h
+            else:
+                h = blk(h, emb, **kw)
             hs.append(h)
         h = self.middle_block(h, emb, **kw)
         if callable(control):
             control = control()                            # residuals produced on another stream: joined here (engine.py)
+        if tokens:
+            return self._decode_tokens(h, hs, control, emb, kw)
         if control is not None:
-            h = h + control.pop()                          # consumes the caller's list (csvd.py:79-91)
+            h = h + to_planes(control.pop())               # consumes the caller's list (csvd.py:79-91)
         for blk in self.output_blocks:
             skip = hs.pop()
-            h = blk(ops.concat_add(h, skip, control.pop() if control is not None else None), emb, **kw)
+            h = blk(ops.concat_add(h, skip, to_planes(control.pop()) if control is not None else None), emb, **kw)
         h = h.type(x.dtype)
         out = self.out[2](norm_act(self.out, h))
         return out
+
+    def _decode_tokens(self, h, hs, control, emb, kw):
+        """The second half of forward() on the token-major stream: `h + control.pop()`, the concatenations with the skip tensors and
+        their residuals (csvd.py:79-91) as row passes — the concatenation also takes the statistics of the GroupNorm that opens the
+        block it feeds — and the last norm + convolution, whose 4-channel result is returned b c h w."""
+        from . import hip_ops
+        from .layers import GN_STATS_FROM_TAILS, _channels_last_weight
+
+        def residual(like):
+            c = control.pop()
+            if not isinstance(c, Tok) and tuple(c.shape[2:]) != (like.H, like.W):
+                return c, False                            # (a pooled residual [N, C, 1, 1]: broadcast on planes below)
+            return to_tok(c), True
+
+        if control is not None:
+            c, same = residual(h)
+            h = Tok(hip_ops.rows_fused(h.t, c.t)[0], h.H, h.W) if same else to_tok(h.planes() + c)
+        for blk in self.output_blocks:
+            skip = hs.pop()
+            c, same = residual(skip) if control is not None else (None, True)
+            if not same:
+                skip, c = to_tok(skip.planes() + c), None
+            first = blk[0]
+            g = first.in_layers[0].num_groups if GN_STATS_FROM_TAILS and hasattr(first, "in_layers") else 0
+            t, st = hip_ops.rows_fused(h.t, skip.t, base=None if c is None else c.t, concat=True, groups=g)
+            h = blk(Tok(t, h.H, h.W, st), emb, **kw)
+        n, conv = self.out[0], self.out[2]
+        N, C, H, W = h.shape
+        t = ops.group_norm_tok2tok(h.t, n.num_groups, n.weight, n.bias, n.eps, silu=True, partials=h.gn_stats(n.num_groups))
+        y = torch.nn.functional.conv2d(t.view(N, H, W, C).permute(0, 3, 1, 2), _channels_last_weight(conv.weight), conv.bias, conv.stride,
+                                       conv.padding, conv.dilation, conv.groups)
+        return y.contiguous()
 
 
 class ControlledVideoUNet(VideoUNet):
@@ -230,13 +269,14 @@ class ControlNet(_Encoder):
         self.middle_block_out = self.make_zero_conv(ch)
         del self._mk_attn, self._mk_res
 
-    def _hint_stem(self, hint, emb, context):
+    def _hint_stem(self, hint, emb, context, tokens=False):
         """input_hint_block (csvd.py:234-250): convolution, SiLU, ..., convolution. On the GPU every convolution runs
         without its bias and `silu(h + bias)` is one fused pass (the tensors are up to 528 MB at 576x1024)."""
         layers_ = list(self.input_hint_block)
         plain = all(isinstance(m, (nn.Conv2d, nn.SiLU)) for m in layers_)
         if not (plain and hint.is_cuda and not torch.is_grad_enabled()):
-            return self.input_hint_block(hint, emb, context)
+            g = self.input_hint_block(hint, emb, context)
+            return to_tok(g) if tokens else g
         from . import hip_ops, ops
         from .layers import conv_no_bias
         h, i = hint, 0
@@ -250,10 +290,10 @@ class ControlNet(_Encoder):
                 i += 2
             else:
                 from .layers import conv3x3_planes_via_tokens
-                y = conv3x3_planes_via_tokens(conv, h)            # the last layer, 256 -> model_channels: the implicit-GEMM kernel
+                y = conv3x3_planes_via_tokens(conv, h, tokens_out=tokens)   # the last layer, 256 -> model_channels: the implicit-GEMM kernel
                 h = conv(h) if y is None else y
                 i += 1
-        return h
+        return to_tok(h) if tokens else h
 
     @contextlib.contextmanager
     def hint_cache(self):
@@ -269,39 +309,49 @@ class ControlNet(_Encoder):
         finally:
             self.__dict__.pop("_hint_slot", None)
 
-    def _hint_stem_cached(self, hint, emb, context):
+    def _hint_stem_cached(self, hint, emb, context, tokens=False):
         slot = self.__dict__.get("_hint_slot")
         plain = all(isinstance(m, (nn.Conv2d, nn.SiLU)) for m in self.input_hint_block)
         if slot is None or not plain or torch.is_grad_enabled() or not torch.is_tensor(hint):
-            return self._hint_stem(hint, emb, context)
-        key = (hint.data_ptr(), hint._version, tuple(hint.shape), hint.dtype) + tuple(
+            return self._hint_stem(hint, emb, context, tokens)
+        key = (hint.data_ptr(), hint._version, tuple(hint.shape), hint.dtype, bool(tokens)) + tuple(
             (p.data_ptr(), p._version) for p in self.input_hint_block.parameters())
         if slot[0] is not None and slot[0][0] == key:
             return slot[0][1]
-        guided = self._hint_stem(hint, emb, context)
+        guided = self._hint_stem(hint, emb, context, tokens)
         slot[0] = (key, guided, hint)               # holds the hint: its address cannot be reused meanwhile
         return guided
 
     def make_zero_conv(self, channels):
         return TimestepEmbedSequential(zero_module(conv_nd(self.dims, channels, channels, 1, padding=0)))
 
+    offers_token_residuals = True
+
     def forward(self, x, hint, timesteps, context=None, y=None, time_context=None, num_video_frames=None,
-                image_only_indicator=None):
+                image_only_indicator=None, tokens_out=False):
+        """tokens_out (not in the reference; SVDInpaintEngine.apply_model sets it): where this pass carried its residual stream
+        token-major, return the 13 residuals as they are (layers.Tok) for a ControlledVideoUNet that consumes them so — otherwise they
+        are returned b c h w, as the reference's."""
         emb = self._embed(x, timesteps, y)
         prepare_emb_projections(self, emb)
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
-        guided = self._hint_stem_cached(hint, emb, context)
+        tokens = token_stream_ok(x) and torch.is_tensor(hint)
+        guided = self._hint_stem_cached(hint, emb, context, tokens)
         outs, h = [], x
         for blk, zc in zip(self.input_blocks, self.zero_convs):
             h = _input_conv(blk, h) if blk is self.input_blocks[0] else blk(h, emb, **kw)
             if guided is not None:
-                h = h + guided                              # added once, after the first input block (:471-473)
+                if tokens:
+                    from . import hip_ops                  # b c h w + tokens -> tokens: the layout change rides on the add
+                    h = Tok(hip_ops.planes_add_to_tokens(h, guided.t), guided.H, guided.W)
+                else:
+                    h = h + guided                         # added once, after the first input block (:471-473)
                 guided = None
             outs.append(zc(h, emb, context))
         h = self.middle_block(h, emb, **kw)
         outs.append(self.middle_block_out(h, emb, context))
-        return outs
+        return outs if tokens_out else [to_planes(o) for o in outs]
 
     # ---- checkpoint helpers (models/csvd.py:500-564)
     @staticmethod

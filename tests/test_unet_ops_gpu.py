@@ -1106,8 +1106,9 @@ def test_hd64_nets_on_a_32x32_latent_run_the_8_wave_kernel_within_the_reference_
           f"error = {worst:.2f}")
 
 
+@pytest.mark.parametrize("stream", ["tokens", "planes"])
 @pytest.mark.parametrize("dtype,tag", [(torch.bfloat16, "bf16ac"), (torch.float16, "f16ac")])
-def test_production_width_nets_run_the_round3_kernels_within_the_reference_autocast_budget(golden_dir, strict, dtype, tag):
+def test_production_width_nets_run_the_round3_kernels_within_the_reference_autocast_budget(golden_dir, strict, dtype, tag, stream):
     """The round-3 kernels under the reference pin: model_channels = 320 and num_head_channels = 64 (the production widths,
     configs/test/svd_f_est_ctrl_simp1.yaml:18-31) on a 16x16 latent, so that INSIDE the module graphs of VideoUNet, ControlNet and
     ControlledVideoUNet the 3x3 convolutions (320 / 640 outputs, K split at this image size) and the (3,1,1) frame convolutions run
@@ -1118,7 +1119,9 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     Bar, in bf16 and in f16 (the reference's own GPU recipe): the build's error against the reference's fp32 output is at most SMALL_LATENT_BAR (1.6) x the
     error of the reference's OWN autocast run in that type, per tensor, in max norm and in rms (fixture tests/golden/sgm_c320.npz,
     generated from the imported reference by tools/gen_golden_sgm_c320.py) — for the three final tensors AND for four
-    intermediate block outputs of the UNet (first level-0 block, first level-1 block, middle block, an output block; round 4)."""
+    intermediate block outputs of the UNet (first level-0 block, first level-1 block, middle block, an output block; round 4).
+    stream (round 6): the residual stream between the blocks token-major (layers.Tok, the default: block tails as row passes that leave
+    the next norm's statistics, no layout pass per block) or b c h w (MVI_SVD_TOKEN_STREAM=0) — the same bar for both."""
     from sgm.modules.diffusionmodules.video_model import VideoUNet
     from models.csvd import ControlNet, ControlledVideoUNet
     from multiview_inpaint_amd import _lib
@@ -1141,16 +1144,17 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     ctx, vec, hint = inp["crossattn"].to(dtype), inp["vector"].to(dtype), inp["control_hint"].to(dtype)
     dt = 1 if dtype == torch.bfloat16 else 2
     assert _lib.lib().mvi_attention_temporal_kernel_variant(H.T_FRAMES, 5, 64, dt, 3 * 320, 320) == 1
-    old = LY.CONV_N320_MIN_BLOCKS
+    old = LY.CONV_N320_MIN_BLOCKS, LY.TOKEN_STREAM
     hip_ops.PROFILE = []
     try:
         LY.CONV_N320_MIN_BLOCKS = 1              # (a launch-size gate of the 576x1024 step: a 16x16 latent is far below it)
+        LY.TOKEN_STREAM = stream == "tokens"
         # intermediate block outputs of the UNet (same submodule names as the reference: the state-dict keys are identical),
         # subsampled like the fixture: a wrong block that later layers wash out must not pass on the final tensors alone
         probes, handles = {}, []
         for name in H.C320_PROBES:
             handles.append(unet.get_submodule(name).register_forward_hook(
-                lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[:, ::4, ::2, ::2].contiguous())))
+                lambda m, i, o, name=name: probes.__setitem__(name, LY.to_planes(o).detach().float()[:, ::4, ::2, ::2].contiguous())))
         with torch.no_grad():
             y = unet(xin, tt, ctx, vec, **kw)
             ctrls = cnet(xin, hint, tt, ctx, vec, **kw)
@@ -1158,18 +1162,33 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
         torch.cuda.synchronize()
         kinds = [rec[0] for rec in hip_ops.PROFILE]
     finally:
-        LY.CONV_N320_MIN_BLOCKS = old
+        LY.CONV_N320_MIN_BLOCKS, LY.TOKEN_STREAM = old
         hip_ops.PROFILE = None
         for hd in handles:
             hd.remove()
     count = lambda k: sum(1 for x in kinds if x == k)
     # per network: 5 VideoResBlocks (UNet: 2 down, middle 2, ... ) — every one token-major: 2 spatial + 2 frame convolutions each
     n_vrb = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ == "VideoResBlock")
-    assert count("conv3t_n320") == 2 * n_vrb and count("tokens_blend_to_planes") == n_vrb and count("planes_add_to_tokens") == n_vrb, kinds
+    n_svt = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ == "SpatialVideoTransformer")
     n_updown = sum(1 for net in (unet, cnet, cunet) for m in net.modules() if type(m).__name__ in ("Upsample", "Downsample"))
+    assert all(torch.is_tensor(c) and c.dim() == 4 for c in ctrls)                # a bare ControlNet call answers b c h w either way
+    assert count("conv3t_n320") == 2 * n_vrb
     # + Upsample.conv, Downsample.op and the last convolution of the ControlNet's hint stem (256 -> 320)
-    assert count("conv3x3_n320") == 2 * n_vrb + n_updown + 1 and count("planes_to_tokens") == n_updown + 1
-    assert count("attention_temporal") > 0 and count("groupnorm_tok2tok") == 3 * n_vrb
+    assert count("conv3x3_n320") == 2 * n_vrb + n_updown + 1 and count("attention_temporal") > 0
+    if stream == "tokens":
+        # every block tail a row pass: skip add + blend per VideoResBlock, `x + x_in` per transformer, the middle residual of the controlled
+        # UNet; one concatenation per output block; no planes form of a tail except the ControlNet's `h + guided_hint` (planes + tokens)
+        assert count("rows_blend") == n_vrb and count("rows_add") == n_vrb + n_svt + 1, kinds
+        assert count("rows_concat") == len(unet.output_blocks) + len(cunet.output_blocks)
+        assert count("tokens_blend_to_planes") == 0 and count("planes_add_to_tokens") == 1, kinds
+        # layout passes: each network's first convolution -> tokens (the ControlNet's rides on its hint add: the hint stem's last layer
+        # instead), the 13 residuals out of the bare ControlNet call and into the controlled UNet (the engine hands them over as tokens)
+        # (fewer where a level has under 8 tokens: PyTorch's transpose serves those)
+        assert 3 <= count("planes_to_tokens") <= 2 + 1 + len(ctrls), kinds
+        assert count("groupnorm_tok2tok") == 4 * n_vrb + n_svt + 2 and count("groupnorm_tokens") == 0, kinds
+    else:
+        assert count("tokens_blend_to_planes") == n_vrb and count("planes_add_to_tokens") == n_vrb, kinds
+        assert count("planes_to_tokens") == n_updown + 1 and count("groupnorm_tok2tok") == 3 * n_vrb and count("rows_add") == 0
     worst = 0.0
     assert set(probes) == set(H.C320_PROBES)
     for name, got in [("unet_out", y), ("cunet_out", yc), ("ctrl_last", ctrls[-1])] + [("probe_" + k, probes[k]) for k in H.C320_PROBES]:
@@ -1233,6 +1252,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     residual and four intermediate block outputs (subsampled in the fixture)."""
     from models.csvd import ControlNet, ControlledVideoUNet
     from multiview_inpaint_amd.svd import bench_svd, hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
     path = os.path.join(golden_dir, "sgm_full.npz")
     assert os.path.exists(path), "tests/golden/sgm_full.npz is missing (tools/gen_golden_sgm_full.py, build container only)"
     G = np.load(path)
@@ -1251,7 +1271,7 @@ def test_full_size_networks_match_the_reference_at_configs3_size(golden_dir, str
     probes, handles = {}, []
     for name in H.FULL_PROBES:
         handles.append(cunet.get_submodule(name).register_forward_hook(
-            lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[H.FULL_SUB].contiguous())))
+            lambda m, i, o, name=name: probes.__setitem__(name, LY.to_planes(o).detach().float()[H.FULL_SUB].contiguous())))
     hip_ops.PROFILE = []
     try:
         with torch.no_grad():
@@ -1330,6 +1350,7 @@ def test_full_size_networks_in_fp32_meet_the_north_star_tolerance(golden_dir, st
     temporal kernel) — and the vendor libraries for every GEMM and convolution (the MFMA kernels of this library are 16-bit by
     construction and their dtype gates decline fp32; that is a gate, not a fallback: strict mode stays on)."""
     from multiview_inpaint_amd.svd import bench_svd, hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
     G = np.load(os.path.join(golden_dir, "sgm_full.npz"))
     torch.backends.cudnn.benchmark = False
     bench_svd.use_shipped_miopen_db()
@@ -1346,7 +1367,7 @@ def test_full_size_networks_in_fp32_meet_the_north_star_tolerance(golden_dir, st
     probes, handles = {}, []
     for name in H.FULL_PROBES:
         handles.append(cunet.get_submodule(name).register_forward_hook(
-            lambda m, i, o, name=name: probes.__setitem__(name, o.detach().float()[H.FULL_SUB].contiguous())))
+            lambda m, i, o, name=name: probes.__setitem__(name, LY.to_planes(o).detach().float()[H.FULL_SUB].contiguous())))
     hip_ops.PROFILE = []
     try:
         with torch.no_grad():
@@ -1436,6 +1457,7 @@ def test_full_size_svd_step_properties(strict):
       * image_only_indicator = 1 => frames are independent: permuting the frames permutes the output;
       * the per-sample hint-stem cache does not change the result."""
     from multiview_inpaint_amd.svd import bench_svd, hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
     dev = torch.device("cuda")
     T, h, w = 14, 72, 128
     torch.backends.cudnn.benchmark = False                 # immediate-mode solvers: no minute-long search inside a test
@@ -1923,6 +1945,104 @@ def test_token_forms_of_the_resblock_adds(ops, dtype):
     assert (out.double() - ref.double()).abs().max().item() <= ulp * max(1.0, ref.abs().max().item())
     want = to_planes(base).double() + (1.0 - alpha.double()).view(N, 1, 1, 1) * (to_planes(t).double() + bias.double().view(1, C, 1, 1))
     assert (out.double() - want).abs().max().item() <= ulp * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_row_tails_of_the_token_stream_and_the_statistics_they_leave(ops, dtype):
+    """mvi_rows_fused_gnstats (csrc/groupnorm_tokens.hip gt_fused_kernel), the block tails of the token-major residual stream: add
+    (a + b + bias: openaimodel.py:354, attention.py:717-722), blend (base + (1 - alpha)(a + bias): video_model.py:67-81 after
+    util.py:358-372) and concat ((a | b + base): csvd.py:84-91) against fp64 to one rounding, on shapes whose row count ends inside a
+    chunk and inside a set; and the (count, mean, M2) partials they leave: GroupNorm(32) + SiLU from them equals the three-launch
+    norm of the same tensor (per sample, and with the statistics of the temporal norm over 3 frames) and fp64."""
+    g = torch.Generator().manual_seed(61)
+    ulp = {torch.float32: 2.0 ** -22, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    for (N, S, C) in [(6, 8 * 16, 320), (3, 36 * 64 - 8, 640), (6, 9 * 16, 1280)]:
+        mk = lambda *sh: (torch.randn(*sh, generator=g) * 1.5 + 0.7).to(dtype).cuda()
+        a, b, base = mk(N, S, C), mk(N, S, C), mk(N, S, C)
+        bias, alpha = torch.randn(C, generator=g).cuda(), torch.rand(N, generator=g).cuda()
+        w, bb = (torch.randn(C, generator=g) * 0.5 + 1).cuda(), torch.randn(C, generator=g).cuda()
+        d = lambda z: z.double().cpu()
+        cases = {
+            "add": (dict(b=b, bias=bias), d(a) + d(b) + d(bias)),
+            "add1": (dict(bias=bias), d(a) + d(bias)),
+            "blend": (dict(bias=bias, base=base, alpha=alpha), d(base) + (1.0 - d(alpha)).view(N, 1, 1) * (d(a) + d(bias))),
+            "concat": (dict(b=b, base=base, concat=True), torch.cat([d(a), d(b) + d(base)], -1)),
+            "concat1": (dict(b=b, concat=True), torch.cat([d(a), d(b)], -1)),
+        }
+        for name, (kw, want) in cases.items():
+            plain, none = ops.rows_fused(a, **kw)
+            assert none is None and plain.shape == want.shape
+            assert (d(plain) - want).abs().max().item() <= ulp * max(1.0, want.abs().max().item()), name
+            if dtype == torch.float32:
+                continue                                       # (the norm that takes producer statistics is the bf16 / f16 one)
+            Cc = want.shape[-1]
+            out, st = ops.rows_fused(a, groups=32, **kw)
+            assert torch.equal(out, plain) and st is not None and st.groups == 32 and st.chan_bias is None, name
+            wc, bc = (w, bb) if Cc == C else (torch.cat([w, w]), torch.cat([bb, bb]))
+            for frames in (1, 3):
+                y = ops.group_norm_silu_tok2tok(out, 32, wc, bc, 1e-5, True, frames=frames, partials=st)
+                y3 = ops.group_norm_silu_tok2tok(out, 32, wc, bc, 1e-5, True, frames=frames)
+                xf = d(out).reshape(N // frames, frames * S, Cc)
+                ref = F.silu(F.group_norm(xf.transpose(1, 2), 32, d(wc), d(bc), 1e-5)).transpose(1, 2).reshape(N, S, Cc)
+                scale = max(1.0, ref.abs().max().item())
+                e, e3 = (d(y) - ref).abs().max().item() / scale, (d(y3) - ref).abs().max().item() / scale
+                assert e <= ulp and e <= 1.5 * e3 + 1e-6, (name, frames, e, e3)
+    with pytest.raises(ValueError):
+        ops.rows_fused(a, b=b[:, :, :8].contiguous())
+    with pytest.raises(ValueError):
+        ops.rows_fused(a, base=base)                          # a blend needs its alpha
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4.0 / 128), (torch.float16, 4.0 / 1024)])
+def test_blocks_on_the_token_stream_equal_the_planes_stream(dtype, tol):
+    """The token-major residual stream (layers.Tok, MVI_SVD_TOKEN_STREAM): a TimestepEmbedSequential of VideoResBlock (channel-changing
+    1x1 skip as a GEMM on rows), SpatialVideoTransformer, VideoResBlock, Downsample, Upsample fed a Tok answers with a Tok whose
+    planes equal the same modules fed b c h w (each block's arithmetic is the same; the tails round once either way) and the fp64
+    evaluation; the statistics the tails leave are consumed (no standalone statistics for the norms that open blocks 2 and 3); a member
+    that knows planes only (a plain ResBlock, a 1x1 zero convolution) is served through planes / as a GEMM on the rows."""
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    from multiview_inpaint_amd.svd.transformer import SpatialVideoTransformer
+    g = torch.Generator().manual_seed(29)
+    T = 3
+    mk_res = lambda cin, cout: LY.VideoResBlock(cin, 256, 0.0, video_kernel_size=[3, 1, 1], out_channels=cout, merge_strategy="learned_with_images",
+                                                merge_factor=0.3)
+    svt = SpatialVideoTransformer(320, 5, 64, depth=1, context_dim=64, use_linear=True, use_spatial_context=True, time_depth=1, merge_strategy="learned_with_images",
+                                  merge_factor=0.5, ff_in=True, attn_mode="softmax-xformers", checkpoint=False)
+    seq = LY.TimestepEmbedSequential(mk_res(640, 320), svt, mk_res(320, 320), LY.ResBlock(320, 256, 0.0, out_channels=320),
+                                     LY.Downsample(320, True, out_channels=320), LY.Upsample(320, True, out_channels=320),
+                                     LY.zero_module(torch.nn.Conv2d(320, 320, 1))).eval()
+    with torch.no_grad():
+        for p in seq.parameters():
+            if p.dim() > 0:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.03 if p.dim() > 1 else 0.3))
+    x = torch.randn(2 * T, 640, 8, 16, generator=g)
+    emb, ctx = torch.randn(2 * T, 256, generator=g), torch.randn(2 * T, 1, 64, generator=g)
+    ind = torch.zeros(2, T)
+    ind[1, 1] = 1.0
+    with torch.no_grad():
+        ref = seq.double()(x.double(), emb.double(), ctx.double(), ind.double(), None, T)
+        seq = seq.to(dtype).cuda()
+        xs, es, cs, inds = x.to(dtype).cuda(), emb.to(dtype).cuda(), ctx.to(dtype).cuda(), ind.cuda()
+        old = LY.CONV_N320_MIN_BLOCKS
+        try:
+            LY.CONV_N320_MIN_BLOCKS = 1
+            planes = seq(xs, es, cs, inds, None, T)
+            hip_ops.PROFILE = []
+            tok = seq(LY.to_tok(xs), es, cs, inds, None, T)
+            torch.cuda.synchronize()
+            kinds = [rec[0] for rec in hip_ops.PROFILE]
+        finally:
+            LY.CONV_N320_MIN_BLOCKS = old
+            hip_ops.PROFILE = None
+    assert isinstance(tok, LY.Tok) and tuple(tok.shape) == tuple(ref.shape) and isinstance(planes, torch.Tensor)
+    count = lambda k: sum(1 for x in kinds if x == k)
+    # two VideoResBlocks: skip add + blend each; the transformer's exit; nothing of the planes forms of these
+    assert count("rows_add") == 3 and count("rows_blend") == 2 and count("tokens_blend_to_planes") == 0 and count("planes_add_to_tokens") == 0, kinds
+    # the plain ResBlock went through planes (one pass each way) — and only it
+    assert count("planes_to_tokens") == 2 and count("tokens_to_planes_add") >= 1, kinds       # (+ this test's own to_tok)
+    got = tok.planes()
+    assert rel(got, ref) < tol and rel(planes, ref) < tol and rel(got, planes.double()) < tol, (rel(got, ref), rel(planes, ref), rel(got, planes.double()))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4.0 / 128), (torch.float16, 4.0 / 1024)])
