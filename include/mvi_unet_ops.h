@@ -175,6 +175,13 @@ size_t mvi_conv3t_n320_workspace_bytes(int64_t B, int32_t T, int32_t pixels, int
 int mvi_conv3x3_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W, int32_t C_in,
                      int32_t C_out, int32_t stride, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* conv3x3(F.interpolate(x, scale_factor=2, mode="nearest")) of token-major x [N, h w, C_in] -> out [N, (2 h)(2 w), C_out]: Upsample.conv
+ * (openaimodel.py:107-150) with the upsampling in the kernel's addressing (round 6: the token-major residual stream). Conditions and
+ * out capacity as mvi_conv3x3_n320 at (N, 2 h, 2 w), stride 1. */
+int mvi_conv3x3_up2_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t h, int32_t w, int32_t C_in,
+                         int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int mvi_conv3t_n320(const void* x, const void* weight, const float* bias, void* out, int64_t B, int32_t T, int32_t pixels, int32_t C_in,
                     int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype, void* workspace,
                     size_t workspace_bytes, void* stream);

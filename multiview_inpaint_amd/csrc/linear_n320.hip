@@ -117,6 +117,9 @@ struct ConvGeom {
     int out_cols;                                    // > 0 (with kSplit): the fp32 accumulators ARE the result — stored to `part` [ksplit][padded
                                                      // rows][out_cols], columns >= out_cols (the padding of C_out to whole column groups) dropped, no reduction
 };
+// kUps (round 6, the token stream's Upsample.conv: openaimodel.py:107-150): cg.H, cg.W are those of the nearest-neighbour 2x UPSAMPLED image, x
+// holds the (H / 2) x (W / 2) source — pixel (y, x) reads source (y >> 1, x >> 1): the convolution of F.interpolate(x, scale_factor=2)
+// without the 4x tensor ever existing. An instantiation of its own (3 launches per step): the other convolutions carry none of its registers.
 
 // kStats: the GroupNorm that FOLLOWS this convolution gets its statistics from here (ResBlock out_layers[0] behind in_layers[2],
 // openaimodel.py:292-305, :339-343; the temporal twin, video_model.py:41-54): every block leaves, per GroupNorm group inside its 320
@@ -190,7 +193,8 @@ __device__ __forceinline__ f32p geglu2(f32p v, f32p g) {
 }
 static const int g_geglu_packed = [] { const char* e = getenv("MVI_GEGLU_PACKED"); return (e && e[0] == '0') ? 0 : 1; }();
 
-template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320>
+template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320,
+          bool kUps = false>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                         int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part, GnStats gn,
@@ -265,6 +269,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
                                     : reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
     uint32_t x_voff[2];
     uint32_t tap_ok[2] = {0x1FFu, 0x1FFu};           // bit 3 (dy + 1) + (dx + 1): that neighbour of the row's pixel is inside the image
+    uint32_t ups_par = 0;                            // kUps: bits 2 t + 1, 2 t = parity of row tile t's pixel (y, x) in the upsampled image
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int64_t row = row0 + 16 * t + n16;
@@ -276,6 +281,10 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             const int pix = (int)(rclamp - img * ((int64_t)cg.Ho * cg.Wo));
             const int py = pix / cg.Wo * cg.stride, px = (pix - pix / cg.Wo * cg.Wo) * cg.stride;  // the centre, in the input image
             if (cg.stride != 1) x_voff[t] = (uint32_t)(((img * cg.H + py) * cg.W + px) * x_rs * 2 + 16 * kg);
+            if (kUps) {
+                x_voff[t] = (uint32_t)(((img * (cg.H >> 1) + (py >> 1)) * (cg.W >> 1) + (px >> 1)) * x_rs * 2 + 16 * kg);
+                ups_par |= (uint32_t)(((py & 1) << 1) | (px & 1)) << (2 * t);
+            }
             if (cg.taps == 9) {
                 if (py == 0) tap_ok[t] &= ~0x007u;
                 if (py == cg.H - 1) tap_ok[t] &= ~0x1C0u;
@@ -310,7 +319,15 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bool ok = (tap_ok[t] >> tap_u) & 1u;
-            const uint32_t voff = ok ? x_voff[t] + (uint32_t)delta : x_voff[t];
+            int delta_t = delta;
+            if (kUps) {
+                // neighbour (y + dy, x + dx) of the upsampled image lives at source ((y + dy) >> 1, (x + dx) >> 1): one source row / pixel
+                // back only from an even y / x, one forward only from an odd one
+                const int py1 = (int)((ups_par >> (2 * t + 1)) & 1u), px1 = (int)((ups_par >> (2 * t)) & 1u);
+                const int ddy = dy < 0 ? py1 - 1 : (dy > 0 ? py1 : 0), ddx = dx < 0 ? px1 - 1 : (dx > 0 ? px1 : 0);
+                delta_t = (ddy * (cg.W >> 1) + ddx) * (int)(x_rs * 2);
+            }
+            const uint32_t voff = ok ? x_voff[t] + (uint32_t)delta_t : x_voff[t];
 #pragma unroll
             for (int s = 0; s < 2; ++s) xr[2 * t + s] = load16_async(base + 64 * s, voff);
             keep[t] = ok ? ~0u : 0u;
@@ -694,7 +711,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace ln3
 
-template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320>
+template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320,
+          bool kUps = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
                               hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0}, float* part = nullptr,
                               ln3::GnStats gn = {nullptr, nullptr, 0, 0},
@@ -705,7 +723,7 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn, NOUT>;
+    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn, NOUT, kUps>;
     constexpr int kLdsBytes = kRing * NOUT * kKC * 2 + kWaves * 4096;
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -863,7 +881,7 @@ static int conv_gnstats_ok(int64_t rows, int32_t taps, int32_t stride, int32_t C
 static int conv_taps_n320(const char* what, const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t H, int32_t W,
                           int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride,
                           int32_t dtype, void* workspace, size_t workspace_bytes, void* stream,
-                          mvi::ln3::GnStats gn = {nullptr, nullptr, 0, 0}) {
+                          mvi::ln3::GnStats gn = {nullptr, nullptr, 0, 0}, int32_t ups = 0) {
     char msg[160];
     auto fail = [&](const char* m) {
         snprintf(msg, sizeof msg, "%s: %s", what, m);
@@ -885,10 +903,16 @@ static int conv_taps_n320(const char* what, const void* x, const void* weight, c
     // the K split is taken when the caller brought its workspace (mvi_conv3x3_n320_workspace_bytes); without one the launch is unsplit
     int ks = conv_ksplit(rows, taps, C_in, C_out);
     if (ks > 1 && (!workspace || workspace_bytes < conv_workspace_bytes(rows, taps, C_in, C_out) || (uintptr_t)workspace % 16)) ks = 1;
-    const mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo, taps == 9 ? g_conv_k_order : 0,
-                                   (taps == 3 && g_conv_k_order && W % mvi::ln3::kRows == 0) ? 1 : 0};
+    mvi::ln3::ConvGeom cg = {H, W, C_in / mvi::ln3::kKC, taps, C_out / mvi::ln3::kN, ks, stride, Ho, Wo, taps == 9 ? g_conv_k_order : 0,
+                             (taps == 3 && g_conv_k_order && W % mvi::ln3::kRows == 0) ? 1 : 0};
     int rc;
-    if (gn.part) {
+    if (ups) {                                       // (H, W: the upsampled image — both even by construction; its own instantiation, never K-split)
+        if (taps != 9 || stride != 1 || gn.part || (H & 1) || (W & 1)) return fail("upsampling: 3x3, stride 1, no statistics");
+        cg.ksplit = 1;
+        rc = dtype == MVI_DT_BF16
+                 ? mvi::linear_n320_launch<__hip_bfloat16, true, false, false, false, false, 320, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg)
+                 : mvi::linear_n320_launch<__half, true, false, false, false, false, 320, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg);
+    } else if (gn.part) {
         if (!conv_gnstats_ok(rows, taps, stride, C_in, C_out, gn.S, gn.G)) return fail("this shape cannot leave GroupNorm statistics (mvi_conv_n320_gnstats_supported)");
         rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16, true, false, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg, nullptr, gn)
                                   : mvi::linear_n320_launch<__half, true, false, true>(x, weight, bias, out, rows, taps * C_in, C_in, out_row_stride, st, cg, nullptr, gn);
@@ -921,6 +945,17 @@ extern "C" int mvi_conv3x3_n320(const void* x, const void* weight, const float* 
                                 void* workspace, size_t workspace_bytes, void* stream) {
     return conv_taps_n320("conv3x3_n320", x, weight, bias, out, N, H, W, 9, stride, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
                           workspace, workspace_bytes, stream);
+}
+
+// conv3x3(F.interpolate(x, scale_factor=2, mode="nearest")) for token-major x [N, h w, C_in] -> out [N, (2 h)(2 w), C_out]: Upsample.conv
+// (openaimodel.py:107-150) with the upsampling in the kernel's addressing — the 4x tensor is neither written nor read. Workspace as for
+// mvi_conv3x3_n320 at (N, 2 h, 2 w).
+extern "C" int mvi_conv3x3_up2_n320(const void* x, const void* weight, const float* bias, void* out, int64_t N, int32_t h, int32_t w,
+                                    int32_t C_in, int32_t C_out, int64_t out_rows_capacity, int64_t out_row_stride, int32_t dtype,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (h <= 0 || w <= 0 || h > (1 << 29) || w > (1 << 29)) return mvi::unet_fail(MVI_EINVAL, "conv3x3_up2_n320: bad image size");
+    return conv_taps_n320("conv3x3_up2_n320", x, weight, bias, out, N, 2 * h, 2 * w, 9, 1, C_in, C_out, out_rows_capacity, out_row_stride, dtype,
+                          workspace, workspace_bytes, stream, {nullptr, nullptr, 0, 0}, 1);
 }
 
 extern "C" int mvi_conv_n320_gnstats_supported(int64_t rows, int32_t taps, int32_t stride, int32_t C_in, int32_t C_out, int64_t spatial,

@@ -489,7 +489,7 @@ def conv_n320_gnstats_supported(rows, taps, C_in, C_out, spatial, groups, stride
     return bool(_lib.lib().mvi_conv_n320_gnstats_supported(int(rows), int(taps), int(stride), int(C_in), int(C_out), int(spatial), int(groups)))
 
 
-def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split=True, gn=None):
+def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split=True, gn=None, up2=False):
     """tok: token-major activations of N images of H x W pixels (or, taps = 3, N videos of H frames of W pixels).
     gn = (groups, chan_bias [samples, C_out] fp32 or None): also leave the statistics of the GroupNorm that follows
     (mvi_conv3x3_n320_gnstats / mvi_conv3t_n320_gnstats) — returns (out, GnPartials); the caller asked
@@ -497,6 +497,10 @@ def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split
     L = _lib.lib()
     C = tok.shape[-1]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if up2:                                    # tok holds the H x W source of the 2x upsampled image the convolution runs over
+        if taps != 9 or stride != 1 or gn is not None:
+            raise ValueError(f"{kind}: upsampling goes with the plain 3x3 / stride 1 form")
+        Ho, Wo = 2 * H, 2 * W
     rows = N * Ho * Wo
     if tok.numel() != N * H * W * C or weight_taps.shape[1] != taps * C or weight_taps.dtype != tok.dtype:
         raise ValueError(f"{kind}: token-major activations [.., C_in] of N H W rows and weight [C_out, {taps} C_in] of one dtype expected")
@@ -524,7 +528,10 @@ def _conv_taps_n320(kind, tok, weight_taps, bias, N, H, W, taps, stride=1, split
                       _DT[tok.dtype], None if cb is None else cb.data_ptr(), int(groups), part.data_ptr(), nb, _stream(tok.device)), kind + " (gn stats)")
         return full[:rows], GnPartials(part, spatial // 256, groups, cb)
     with torch.cuda.device(tok.device), _Timed(kind, 2.0 * rows * taps * C * Co, tok.device):
-        if taps == 9:
+        if up2:
+            rc = L.mvi_conv3x3_up2_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co,
+                                        cap, full.stride(0), _DT[tok.dtype], wsp, ws_bytes, _stream(tok.device))
+        elif taps == 9:
             rc = L.mvi_conv3x3_n320(xc.data_ptr(), wc.data_ptr(), None if b is None else b.data_ptr(), full.data_ptr(), N, H, W, C, Co, stride,
                                     cap, full.stride(0), _DT[tok.dtype], wsp, ws_bytes, _stream(tok.device))
         else:
@@ -547,14 +554,15 @@ def conv3t_n320_fills_chip(B, T, S, C_in, C_out, min_blocks):
     return blocks >= min_blocks or int(_lib.lib().mvi_conv3t_n320_workspace_bytes(B, T, S, C_in, C_out)) > 0
 
 
-def conv3x3_n320(tok, weight_taps, bias, H, W, stride=1, split=True, gn=None):
+def conv3x3_n320(tok, weight_taps, bias, H, W, stride=1, split=True, gn=None, up2=False):
     """3x3 / padding 1 convolution (stride 1 or 2) to a multiple of 320 output channels of token-major activations tok [N, H W, C_in]
     (csrc/linear_n320.hip in its implicit-GEMM mode) -> [N, Ho Wo, C_out]; weight_taps from conv3x3_n320_weight.
-    gn = (groups, chan_bias): -> (out, GnPartials) for the GroupNorm that follows (see _conv_taps_n320)."""
+    gn = (groups, chan_bias): -> (out, GnPartials) for the GroupNorm that follows (see _conv_taps_n320).
+    up2: the convolution of the nearest-neighbour 2x upsampled image (mvi_conv3x3_up2_n320) -> [N, (2 H)(2 W), C_out]."""
     N, S, C = tok.shape
     if S != H * W:
         raise ValueError("conv3x3_n320: tok [N, H W, C_in] expected")
-    r = _conv_taps_n320("conv3x3_n320", tok, weight_taps, bias, N, H, W, 9, stride, split, gn=gn)
+    r = _conv_taps_n320("conv3x3_n320", tok, weight_taps, bias, N, H, W, 9, stride, split, gn=gn, up2=up2)
     if gn is not None:
         return r[0].view(N, -1, weight_taps.shape[0]), r[1]
     return r.view(N, -1, weight_taps.shape[0])

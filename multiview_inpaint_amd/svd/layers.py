@@ -271,9 +271,8 @@ class Upsample(nn.Module):
         if isinstance(x, Tok):
             N, C, H, W = x.shape
             if self.dims != 3 and s == 2 and self.use_conv and _conv_n320_route_ok(self.conv, N, C, 2 * H, 2 * W, x.dtype):
-                from . import hip_ops
-                up = x.t.view(N, H, 1, W, 1, C).expand(N, H, 2, W, 2, C).reshape(N, 4 * H * W, C)      # nearest-neighbour 2x on tokens
-                return Tok(hip_ops.conv3x3_n320(up, _tap_major_weight(self.conv.weight), self.conv.bias, 2 * H, 2 * W), 2 * H, 2 * W)
+                from . import hip_ops                   # (the upsampling is in the kernel's addressing: no 4x tensor)
+                return Tok(hip_ops.conv3x3_n320(x.t, _tap_major_weight(self.conv.weight), self.conv.bias, H, W, up2=True), 2 * H, 2 * W)
             return to_tok(self.forward(x.planes()))
         if self.dims == 3:
             x = F.interpolate(x, ((s if self.third_up else 1) * x.shape[2], x.shape[3] * s, x.shape[4] * s), mode="nearest")

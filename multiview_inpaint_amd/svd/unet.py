@@ -208,7 +208,7 @@ class VideoUNet(_Encoder):
         their residuals (csvd.py:79-91) as row passes — the concatenation also takes the statistics of the GroupNorm that opens the
         block it feeds — and the last norm + convolution, whose 4-channel result is returned b c h w."""
         from . import hip_ops
-        from .layers import GN_STATS_FROM_TAILS, _channels_last_weight
+        from .layers import GN_STATS_FROM_TAILS
 
         def residual(like):
             c = control.pop()
@@ -231,9 +231,9 @@ class VideoUNet(_Encoder):
         n, conv = self.out[0], self.out[2]
         N, C, H, W = h.shape
         t = ops.group_norm_tok2tok(h.t, n.num_groups, n.weight, n.bias, n.eps, silu=True, partials=h.gn_stats(n.num_groups))
-        y = torch.nn.functional.conv2d(t.view(N, H, W, C).permute(0, 3, 1, 2), _channels_last_weight(conv.weight), conv.bias, conv.stride,
-                                       conv.padding, conv.dilation, conv.groups)
-        return y.contiguous()
+        # 320 -> 4 channels: the library's b c h w convolution behind one layout pass (254 us at 576x1024) — its channels-last form on a
+        # view of the tokens is slower (318 us) and not in the shipped find-db (a process's first calls ran MIOpen's naive kernel, 3.3 ms)
+        return conv(Tok(t, H, W).planes())
 
 
 class ControlledVideoUNet(VideoUNet):

@@ -1682,6 +1682,33 @@ def test_conv3x3_n320_stride_2(dtype, tol, N, H, W, C, Co):
         assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+@pytest.mark.parametrize("N,H,W,C,Co", [(2, 12, 16, 320, 320), (1, 9, 15, 64, 640), (3, 4, 3, 128, 320), (1, 1, 1, 64, 320), (2, 7, 20, 192, 320),
+                                        (28, 36, 64, 640, 640)])
+def test_conv3x3_up2_n320_equals_conv2d_of_the_upsampled_image(dtype, tol, N, H, W, C, Co):
+    """Upsample.conv (openaimodel.py:107-150: F.interpolate(scale_factor=2, mode="nearest") then 3x3 / padding 1) with the upsampling in
+    the implicit-GEMM kernel's addressing (mvi_conv3x3_up2_n320, kUps): a row = a pixel (y, x) of the 2 H x 2 W image, its taps read
+    source pixel ((y + dy) >> 1, (x + dx) >> 1) of the H x W tokens; even and odd source sizes, one pixel, row blocks that straddle
+    images — against F.conv2d of the upsampled image in fp64 (the last case, the level 1 -> 0 shape of the 576x1024 step, against the
+    kernel's own plain form on the materialised upsampled tokens: bit for bit)."""
+    from multiview_inpaint_amd.svd import hip_ops
+    g = torch.Generator().manual_seed(N * 100 + H + W)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / (9 * C) ** 0.5)).to(dtype)
+    b = torch.randn(Co, generator=g)
+    tok = x.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous().cuda()
+    wt = hip_ops.conv3x3_n320_weight(w.cuda())
+    out = hip_ops.conv3x3_n320(tok, wt, b.cuda(), H, W, up2=True)
+    torch.cuda.synchronize()
+    assert out.shape == (N, 4 * H * W, Co)
+    up = tok.view(N, H, 1, W, 1, C).expand(N, H, 2, W, 2, C).reshape(N, 4 * H * W, C)
+    assert torch.equal(out, hip_ops.conv3x3_n320(up, wt, b.cuda(), 2 * H, 2 * W, split=False))     # same products, same order
+    if N * H * W <= 4096:
+        ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+        got = out.view(N, 2 * H, 2 * W, Co).permute(0, 3, 1, 2).double().cpu()
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_downsample_on_tokens_equals_the_library_route():
     from multiview_inpaint_amd.svd import hip_ops
     from multiview_inpaint_amd.svd import layers as LY

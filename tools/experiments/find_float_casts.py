@@ -44,6 +44,12 @@ class Watch(TorchDispatchMode):
             src = [a for a in args if torch.is_tensor(a) and a.dtype in (torch.bfloat16, torch.float16)]
             if src:
                 sites[name + " " + site()] += 1
+        # --big: every ATen op that writes a large tensor (a full-size pass over an activation that no HIP wrapper accounts for)
+        if "--big" in sys.argv and torch.is_tensor(out) and out.is_cuda and out.numel() >= (1 << 22) and "aten.empty" not in name \
+                and "view" not in name and "reshape" not in name and "permute" not in name and "expand" not in name and "slice" not in name \
+                and "select" not in name and "transpose" not in name and "detach" not in name and "alias" not in name and "as_strided" not in name \
+                and "unsqueeze" not in name and "squeeze" not in name and "split" not in name and "unbind" not in name and "chunk" not in name:
+            sites[f"BIG {name} {out.numel() * out.element_size() / 1e6:.0f} MB  " + site()] += 1
         return out
 
 
