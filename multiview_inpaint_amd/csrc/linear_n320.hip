@@ -194,13 +194,14 @@ __device__ __forceinline__ f32p geglu2(f32p v, f32p g) {
 static const int g_geglu_packed = [] { const char* e = getenv("MVI_GEGLU_PACKED"); return (e && e[0] == '0') ? 0 : 1; }();
 
 template <typename T, bool kConv, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320,
-          bool kUps = false>
+          bool kUps = false, bool kPersist = false>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                         int64_t rows, int K, int64_t x_rs, int64_t o_rs, int n_blocks, ConvGeom cg, float* __restrict__ part, GnStats gn,
                         LnEpi ln = {nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, 0.f}) {
     using M = Mma<T>;
     static_assert(NOUT == 320 || !(kStats || kGeglu || kLn), "the fused epilogues are written for 320 columns");
+    static_assert(!kPersist || !(kConv || kSplit || kStats || kLn), "the persistent form is written for the plain and the GEGLU projection");
     constexpr int kN = NOUT, kNT = kN / 16, kChunkBytes = kN * kKC * 2, kPieces = kChunkBytes / 1024, kPiecesPerLoader = kPieces / kLoaders;
     static_assert(kNT % 4 == 0 && kPieces % kLoaders == 0, "column tiles leave four at a time; every loader moves the same number of pieces");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -211,7 +212,22 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;       // the lane's row / column inside a 16 x 16 tile, its 8-element group of a 32-deep k-step
     int bid = blockIdx.x;
-    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
+    // kPersist (round 6): the grid is one block per CU (a multiple of 8) and a block walks tiles — tile = what a block of the plain grid
+    // computes — of its XCD's contiguous share of them: lo + l, lo + l + per, ... (l = the block's place among its XCD's blocks), so the
+    // blocks that run together on an XCD are still neighbouring row blocks. While a tile's last two chunks are computed the NEXT tile's
+    // first two W chunks and first x rows are requested in place of the re-loads of the last chunk the plain form issues there (same
+    // number of requests, same counted waits): the next tile starts behind the epilogue without a prologue.
+    int tile_hi = 0, tile_per = 0;
+    if (kPersist) {
+        tile_per = (int)(gridDim.x >> 3);
+        const int xcd = (int)(blockIdx.x & 7);
+        bid = (int)((int64_t)xcd * n_blocks / 8) + (int)(blockIdx.x >> 3);
+        tile_hi = (int)((int64_t)(xcd + 1) * n_blocks / 8);
+    } else if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // neighbouring row blocks on one XCD (W is shared by all)
+    int tile = bid;                                  // (kPersist: the tile in hand)
+    const T* const w_all = w;
+    T* const out_all = out;
+    const float* const bias_all = bias;
     int part_col0 = 0, ks = 0;
     int gg = 0;                                      // kGeglu: the block's column group (160 outputs)
     constexpr int kHalf = kN / 2;                    // 160
@@ -243,7 +259,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         const int pb = jj / cg.H, f = jj - pb * cg.H;
         bid = v * per_video + f * bpf + pb;
     }
-    const int64_t row0 = (int64_t)bid * kRows + wave * 32;                       // wave-uniform
+    int64_t row0 = (int64_t)bid * kRows + wave * 32;                             // wave-uniform
     // this block's chunks: c0 .. c0 + n_chunks - 1 of the K / 64 (all of them unless kSplit); chunk indices below are relative to c0
     const int c0 = kSplit ? (int)((int64_t)ks * (K / kKC) / cg.ksplit) : 0;
     const int n_chunks = kSplit ? (int)((int64_t)(ks + 1) * (K / kKC) / cg.ksplit) - c0 : K / kKC;
@@ -261,12 +277,16 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             for (int r = 0; r < 4; ++r) acc[t][j][r] = b;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the compiler's own loads are done before the hand-counted ones start
+    // kPersist: the bias of the NEXT tile waits in LDS (two 1 KiB pieces behind the waves' output tiles: plain — columns 0 .. 255 | 256 ..
+    // 319; kGeglu — the 160 value columns | the 160 gate columns), brought by wave 0 with the DMA during the tile before: a global load
+    // at the start of a tile would have to wait for the epilogue's stores (one counter for both)
+    constexpr uint32_t kBiasLds = (uint32_t)(kRing * kChunkBytes + kWaves * 4096);
 
     // ---- x: A operand of row tile t, k-step s (32 deep) of chunk c: element e of lane (n16, kg) = x[row0 + 16 t + n16][64 c + 32 s + 8 kg + e];
     // rows past the end read the last row (kConv: the base is the tensor and the lane offset absolute — a tap's row may lie before the
     // wave's first one)
-    const char* const xbase = kConv ? reinterpret_cast<const char*>(x)
-                                    : reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
+    const char* xbase = kConv ? reinterpret_cast<const char*>(x)
+                              : reinterpret_cast<const char*>(x + (row0 < rows ? row0 : rows - 1) * x_rs);   // wave-uniform
     uint32_t x_voff[2];
     uint32_t tap_ok[2] = {0x1FFu, 0x1FFu};           // bit 3 (dy + 1) + (dx + 1): that neighbour of the row's pixel is inside the image
     uint32_t ups_par = 0;                            // kUps: bits 2 t + 1, 2 t = parity of row tile t's pixel (y, x) in the upsampled image
@@ -348,10 +368,55 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         const uint32_t pc = (uint32_t)(wave + i * kLoaders);         // (meaningless for a wave that loads nothing)
         const uint32_t r = 8u * pc + (uint32_t)(lane >> 3), slot = (uint32_t)(lane & 7);
         // kGeglu: rows 0 .. 159 of the chunk image are W rows 160 g + r (values), rows 160 .. 319 W rows inner + 160 g + (r - 160) (gates)
-        const uint32_t wr = kGeglu ? (r < (uint32_t)kHalf ? (uint32_t)(gg * kHalf) + r : (uint32_t)(inner + gg * kHalf) + (r - (uint32_t)kHalf)) : r;
+        // (kPersist: the column group's 160 rows are part of wbase, which changes from tile to tile — the lane offsets do not)
+        const uint32_t ggr = kPersist ? 0u : (uint32_t)(gg * kHalf);
+        const uint32_t wr = kGeglu ? (r < (uint32_t)kHalf ? ggr + r : (uint32_t)inner + ggr + (r - (uint32_t)kHalf)) : r;
         p_voff[i] = wr * w_row_bytes + 16u * (slot ^ ((r >> 1) & 7u));
     }
-    const char* const wbase = reinterpret_cast<const char*>(w) + (int64_t)c0 * (kKC * 2);
+    const char* wbase = reinterpret_cast<const char*>(w) + (int64_t)c0 * (kKC * 2) + (kPersist && kGeglu ? (int64_t)gg * kHalf * K * 2 : 0);
+    // kPersist: the tile after this one (its x rows, W rows, and where its bias comes from), decoded while this one runs
+    const char* nx_xbase = xbase;
+    const char* nx_wbase = wbase;
+    uint32_t nx_x_voff[2] = {x_voff[0], x_voff[1]};
+    int64_t nx_row0 = row0;
+    int nx_g = 0;
+    bool has_next = false;
+    auto decode_next = [&]() __attribute__((always_inline)) {
+        const int nt = tile + tile_per;
+        has_next = nt < tile_hi;
+        if (!has_next) return;
+        const int g = nt % cg.groups, rb = nt / cg.groups;               // (column group, row block): as the plain grid's decode
+        nx_g = g;
+        nx_row0 = (int64_t)rb * kRows + wave * 32;
+        const int64_t rb0 = nx_row0 < rows ? nx_row0 : rows - 1;
+        nx_xbase = reinterpret_cast<const char*>(x + rb0 * x_rs);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t row = nx_row0 + 16 * t + n16;
+            nx_x_voff[t] = (uint32_t)((row < rows ? row - rb0 : 0) * x_rs * 2 + 16 * kg);
+        }
+        nx_wbase = reinterpret_cast<const char*>(w_all) + (int64_t)g * (kGeglu ? kHalf : kN) * K * 2;
+    };
+    // wave 0 asks for the next tile's bias (see kBiasLds); lanes past the piece's end read the piece's first bytes again (never used)
+    auto stage_next_bias = [&]() __attribute__((always_inline)) {
+        if (!bias_all || wave != 0) return;
+        const float* const pa = kGeglu ? bias_all + nx_g * kHalf : bias_all + nx_g * kN;
+        const float* const pb = kGeglu ? bias_all + inner + nx_g * kHalf : bias_all + nx_g * kN + 256;
+        const uint32_t na = kGeglu ? 40u : 64u, nb = kGeglu ? 40u : 16u;             // lanes with 16 valid bytes
+        dma_piece(pa, (uint32_t)lane < na ? 16u * (uint32_t)lane : 0u, __builtin_amdgcn_readfirstlane(lds0 + kBiasLds));
+        dma_piece(pb, (uint32_t)lane < nb ? 16u * (uint32_t)lane : 0u, __builtin_amdgcn_readfirstlane(lds0 + kBiasLds + 1024u));
+    };
+    auto acc_from_staged_bias = [&]() __attribute__((always_inline)) {
+        MVI_AS3 const float* const sb = (MVI_AS3 const float*)(lds + kBiasLds);
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            const float b = !bias_all ? 0.f : (kGeglu ? sb[(j < kNT / 2 ? 16 * j : 256 + 16 * (j - kNT / 2)) + n16] : sb[16 * j + n16]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][j][r] = b;
+        }
+    };
     auto issue_chunk = [&](int c) __attribute__((always_inline)) {
         // chunks past the end re-load the last one (never read): every call issues the same number of pieces, the counted wait stays valid
         const int cc = c < n_chunks ? c : n_chunks - 1;
@@ -432,6 +497,64 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
 
     auto next_slot = [&](uint32_t s) __attribute__((always_inline)) { return s + kChunkBytes == (uint32_t)(kRing * kChunkBytes) ? 0u : s + kChunkBytes; };
     uint32_t slot = 0;
+    uint32_t islot = (uint32_t)(2 * kChunkBytes);                    // kPersist: the ring slot of the next chunk to be requested (chunks 0, 1 are out)
+    // kPersist forms of load_x / close_chunk: chunk index ci of THIS tile, or — past its end — chunk ci - n_chunks of the next tile (the
+    // last tile of the block re-loads its last chunk, as the plain form does). The addresses are selected, never the loads: an
+    // asynchronous load inside a branch ends in a register copy of rows that have not landed (profiles/HISTORY.md, round 5).
+    auto load_x_p = [&](int ci, u32x4 (&xr)[4]) __attribute__((always_inline)) {
+        const bool nxt = ci >= n_chunks && has_next;
+        const char* const base = nxt ? nx_xbase + (int64_t)(ci - n_chunks) * (kKC * 2) : xbase + (int64_t)(ci < n_chunks ? ci : n_chunks - 1) * (kKC * 2);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t voff = nxt ? nx_x_voff[t] : x_voff[t];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) xr[2 * t + s2] = load16_async(base + 64 * s2, voff);
+        }
+    };
+    auto close_chunk_p = [&](int c) __attribute__((always_inline)) {
+        if (loader) {
+            const int ci = c + 2;
+            const bool nxt = ci >= n_chunks && has_next;
+            const char* const base = nxt ? nx_wbase + (int64_t)(ci - n_chunks) * (kKC * 2) : wbase + (int64_t)(ci < n_chunks ? ci : n_chunks - 1) * (kKC * 2);
+#pragma unroll
+            for (int i = 0; i < kPiecesPerLoader; ++i)
+                dma_piece(base, p_voff[i], __builtin_amdgcn_readfirstlane(lds0 + islot + 1024u * (uint32_t)(wave + i * kLoaders)));
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kPiecesPerLoader) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        islot = next_slot(islot);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // kPersist, behind a tile's epilogue: the decoded next tile becomes the tile in hand. Its W chunks 0, 1 and x rows of chunk 0 have
+    // landed (every wave's wait in front of the epilogue); the barrier makes the loaders' pieces every wave's.
+    auto advance_tile = [&]() __attribute__((always_inline)) {
+        tile += tile_per;
+        xbase = nx_xbase;
+        wbase = nx_wbase;
+        x_voff[0] = nx_x_voff[0];
+        x_voff[1] = nx_x_voff[1];
+        row0 = nx_row0;
+        out = out_all + nx_g * (kGeglu ? kHalf : kN);
+        acc_from_staged_bias();
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+  for (;;) {                                                         // (one pass unless kPersist)
+    if (kPersist) {
+        decode_next();
+        for (int c = 0; c + 1 < n_chunks; c += 2) {                  // (the host takes this form for an even number of chunks only)
+            load_x_p(c + 1, xb);
+            chunk_fn(slot, xa, ka_keep);
+            if (c == 0 && has_next) stage_next_bias();               // (behind the barrier that followed every wave's read of the staged bias)
+            close_chunk_p(c);
+            slot = next_slot(slot);
+            load_x_p(c + 2, xa);
+            chunk_fn(slot, xb, kb_keep);
+            close_chunk_p(c + 1);
+            slot = next_slot(slot);
+        }
+    } else {
     int c = 0;
     for (; c + 1 < n_chunks; c += 2) {
         load_x(c + 1, xb, kb_keep);                                  // (c + 1 < n_chunks)
@@ -444,6 +567,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         slot = next_slot(slot);
     }
     if (c < n_chunks) chunk_fn(slot, xa, ka_keep);                   // K / 64 odd: one chunk left
+    }
     // trailing (unused) pieces and rows land before the block ends; mfma_settle: the last matrix instructions (8 passes each) have
     // written their accumulators before anything the compiler schedules reads one
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
@@ -516,7 +640,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
                 if (!half || (lane & 7) < 4) *reinterpret_cast<u32x4*>(op + (8 * i) * grow_bytes + gst_off) = v;
             }
         }
-        return;
+        if (!kPersist || !has_next) return;
+        advance_tile();
+        continue;
     }
     char* const obase = reinterpret_cast<char*>(out + row0 * o_rs);
     const int64_t orow_bytes = o_rs * 2;
@@ -684,6 +810,9 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
             p[0] = rws * Cg; p[1] = mean; p[2] = m2 > 0.f ? m2 : 0.f;
         }
     }
+    if (!kPersist || !has_next) return;
+    advance_tile();
+  }
 }
 
 // out[r][c] = sum_s part[s][r][c] + bias[c], eight columns per thread
@@ -711,8 +840,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace ln3
 
+// The persistent form's grid: one block per CU of the current device, rounded down to a multiple of 8 (the XCDs take blocks in turn).
+static int persist_grid() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? (prop.multiProcessorCount / 8) * 8 : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+// Tiles walked by one block per CU with the next tile's first loads under the last chunks of the one in hand (kPersist): for launches of
+// more tiles than CUs and an even number of chunks >= 4. MVI_N320_PERSIST=0: the plain grid everywhere (same-box A/B runs).
+static bool persist_ok(int64_t n_tiles, int K) {
+    const char* const e = getenv("MVI_N320_PERSIST");             // (read per launch: the parity test compares both forms in one process)
+    const int g = e && e[0] == '0' ? 0 : persist_grid();
+    const int chunks = K / ln3::kKC;
+    return g >= 8 && n_tiles > (int64_t)g && n_tiles <= 0x7FFFFFFFll && chunks >= 4 && chunks % 2 == 0;
+}
+
 template <typename T, bool kConv = false, bool kSplit = false, bool kStats = false, bool kGeglu = false, bool kLn = false, int NOUT = 320,
-          bool kUps = false>
+          bool kUps = false, bool kPersist = false>
 static int linear_n320_launch(const void* x, const void* w, const float* bias, void* out, int64_t rows, int K, int64_t x_rs, int64_t o_rs,
                               hipStream_t st, ln3::ConvGeom cg = {0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0}, float* part = nullptr,
                               ln3::GnStats gn = {nullptr, nullptr, 0, 0},
@@ -723,14 +872,16 @@ static int linear_n320_launch(const void* x, const void* w, const float* bias, v
     static unsigned long long attr_set = 0;                      // per device and instantiation: the opt-in for > 64 KiB of dynamic LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MVI_EHIP;
-    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn, NOUT, kUps>;
-    constexpr int kLdsBytes = kRing * NOUT * kKC * 2 + kWaves * 4096;
+    auto kern = &linear_n320_kernel<T, kConv, kSplit, kStats, kGeglu, kLn, NOUT, kUps, kPersist>;
+    constexpr int kLdsBytes = kRing * NOUT * kKC * 2 + kWaves * 4096 + (kPersist ? 2048 : 0);       // (+ the staged bias of the next tile)
     if (!(attr_set >> dev & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return MVI_EHIP;
         attr_set |= 1ull << dev;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
+    // kPersist: one block per CU walks the tiles (the caller checked persist_ok: more tiles than CUs, an even number of chunks)
+    const unsigned grid = kPersist ? (unsigned)persist_grid() : (unsigned)n_blocks;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWaves), kLdsBytes, st, (const T*)x, (const T*)w, bias, (T*)out, rows, K, x_rs,
                        o_rs, (int)n_blocks, cg, part, gn, ln);
     if (kSplit && !cg.out_cols) {
         const int c_tot = cg.groups * kN;
@@ -766,6 +917,9 @@ extern "C" int mvi_linear_n320(const void* x, const void* weight, const float* b
     // out_features = 320 g (round 5): g column groups per row block, neighbours in the grid — the blocks of one row block read the same
     // x rows, the first from HBM and the others from L2 (the convolutions' column groups)
     const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, out_features / mvi::ln3::kN, 1, 1, 0, 0, 0, 0};
+    // (the persistent form — kPersist, taken by the GEGLU projection below — is 0 ... +5 % SLOWER here: this epilogue is 20 stores, nothing
+    // for the next tile's first loads to hide under, and the plain grid's dispatch already overlaps a block's drain with the next one's start:
+    // profiles/round6_n320_persistent.txt)
     const int rc = dtype == MVI_DT_BF16 ? mvi::linear_n320_launch<__hip_bfloat16>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
                                         : mvi::linear_n320_launch<__half>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
     return rc ? mvi::unet_fail(rc, "linear_n320: kernel launch failed") : MVI_OK;
@@ -820,9 +974,16 @@ extern "C" int mvi_ff_geglu_n320(const void* x, const void* weight, const float*
     if (256 * x_row_stride * 2 > 0xFFFFFFFFll) return mvi::unet_fail(MVI_EINVAL, "ff_geglu_n320: row block exceeds 32-bit byte offsets");
     const mvi::ln3::ConvGeom cg = {0, 0, 0, 0, inner / (mvi::ln3::kN / 2), 1, 1, 0, 0, 0, 0, mvi::ln3::g_geglu_packed, 0};
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dtype == MVI_DT_BF16
-                       ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
-                       : mvi::linear_n320_launch<__half, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
+    const int64_t n_tiles = (rows + mvi::ln3::kRows - 1) / mvi::ln3::kRows * cg.groups;
+    int rc;
+    if (mvi::persist_ok(n_tiles, K))
+        rc = dtype == MVI_DT_BF16
+                 ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, true, false, 320, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
+                 : mvi::linear_n320_launch<__half, false, false, false, true, false, 320, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
+    else
+        rc = dtype == MVI_DT_BF16
+                 ? mvi::linear_n320_launch<__hip_bfloat16, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg)
+                 : mvi::linear_n320_launch<__half, false, false, false, true>(x, weight, bias, out, rows, K, x_row_stride, out_row_stride, st, cg);
     return rc ? mvi::unet_fail(rc, "ff_geglu_n320: kernel launch failed") : MVI_OK;
 }
 

@@ -495,6 +495,32 @@ def test_ff_geglu_long_contraction(ops, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
+def test_ff_geglu_n320_persistent_grid_equals_the_plain_grid(ops, dtype, tol, monkeypatch):
+    """Round 6: launches of mvi_ff_geglu_n320 with more tiles than CUs run ONE block per CU that walks its tiles, the next tile's first W
+    chunks / x rows requested under the last chunks of the tile in hand and its bias staged in LDS (csrc/linear_n320.hip kPersist;
+    MVI_N320_PERSIST=0: the plain grid, read per launch). Same products in the same order: the two forms agree bit for bit — ragged row
+    counts (a last tile with rows past the end), with and without bias, K = 640 / 1280 / 128-chunk-pairs — and the persistent one
+    against fp64 on the rounded inputs."""
+    g = torch.Generator().manual_seed(47)
+    for rows, K, inner, with_bias in [(4200, 640, 2560, True), (9 * 256 + 5, 1280, 5120, False), (70000, 256, 640, True)]:
+        x = (torch.randn(rows, K, generator=g) * 1.2).to(dtype)
+        w = (torch.randn(2 * inner, K, generator=g) * K ** -0.5).to(dtype)
+        b = (torch.randn(2 * inner, generator=g) * 0.3).to(dtype) if with_bias else None
+        xc, wc, bc = x.cuda(), w.cuda(), None if b is None else b.cuda()
+        assert -(-rows // 256) * (inner // 160) > 256                      # more tiles than the chip has CUs
+        monkeypatch.setenv("MVI_N320_PERSIST", "0")
+        plain = ops.ff_geglu_n320(xc, wc, bc)
+        monkeypatch.setenv("MVI_N320_PERSIST", "1")
+        pers = ops.ff_geglu_n320(xc, wc, bc)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, pers), (rows, K, inner)
+        if rows <= 5000:
+            h = F.linear(x.double(), w.double(), None if b is None else b.double())
+            assert rel(pers, h[:, :inner] * F.gelu(h[:, inner:])) < tol
+    monkeypatch.delenv("MVI_N320_PERSIST")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.0 / 128), (torch.float16, 1.0 / 1024)])
 def test_stem_conv3x3_silu_kernel(ops, dtype, tol):
     """silu(conv2d(x, w, b, padding=1)) for 16 output channels and <= 16 input channels on the MFMA kernel of csrc/stem_conv.hip
     (the stride-1 layers of the ControlNet hint stem at its two finest resolutions): against fp64 on the rounded inputs, 7 / 16 / 3 / 9
