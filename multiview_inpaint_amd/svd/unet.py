@@ -198,7 +198,10 @@ class VideoUNet(_Encoder):
             h = h + to_planes(control.pop())               # consumes the caller's list (csvd.py:79-91)
         for blk in self.output_blocks:
             skip = hs.pop()
-            h = blk(ops.concat_add(h, skip, to_planes(control.pop()) if control is not None else None), emb, **kw)
+            c = to_planes(control.pop()) if control is not None else None
+            if c is not None and c.shape != skip.shape:    # (a pooled residual [N, C, 1, 1] — global_average_pooling, csvd.py:1263 — broadcasts)
+                skip, c = skip + c, None
+            h = blk(ops.concat_add(h, skip, c), emb, **kw)
         h = h.type(x.dtype)
         out = self.out[2](norm_act(self.out, h))
         return out

@@ -275,6 +275,56 @@ def test_sample_loop_on_gpu_matches_reference_golden_with_and_without_hint_cache
     assert dp < 1e-4 and dc < 1e-4                 # north_star: 1e-4 rel on UNet activations
 
 
+@pytest.mark.parametrize("pooled", [False, True])
+def test_engine_hands_the_control_residuals_over_as_tokens(pooled):
+    """SVDInpaintEngine.apply_model (models/csvd.py:1240-1269) with the token-major residual stream: the ControlNet's 13 residuals reach the
+    ControlledVideoUNet as layers.Tok (`tokens_out`), scaled by control_scales != 1 (csvd.py:1262) on the way and — pooled — averaged
+    over the image (`global_average_pooling`, :1263-1264: a [N, C, 1, 1] residual the token UNet adds by broadcast on planes).
+    One bf16 denoise step at production width on a 16x16 latent equals the same step with `b c h w` between the blocks
+    (MVI_SVD_TOKEN_STREAM=0) to the rounding of the tails. One stream: the side-stream mode is only safe with the pinned GEMM set
+    (svd/engine.py) — bench.py runs the same hand-over there."""
+    from models.csvd import ControlNet, ControlledVideoUNet, SVDInpaintEngine
+    from sgm.modules.diffusionmodules.denoiser import Denoiser
+    from multiview_inpaint_amd.svd import engine as EG
+    from multiview_inpaint_amd.svd import hip_ops
+    from multiview_inpaint_amd.svd import layers as LY
+    dtype = torch.bfloat16
+    cunet = ControlledVideoUNet(**H.SMALL_UNET320).eval()
+    cunet.load_state_dict(H.seeded_state_dict(cunet, 51))
+    cnet = ControlNet(**H.SMALL_CTRL320).eval()
+    cnet.load_state_dict(H.seeded_state_dict(cnet, 52))
+    n_res = len(cnet.zero_convs) + 1
+    eng = SVDInpaintEngine(cunet.cuda().to(dtype), cnet.cuda().to(dtype), Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}),
+                           None, control_scales=[0.5 + 0.1 * i for i in range(n_res)], global_average_pooling=pooled)
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(53, hw=H.LATENT_HW320, cfg=H.SMALL_UNET320).items()}
+    cond = dict(crossattn=inp["crossattn"].to(dtype), vector=inp["vector"].to(dtype), concat=inp["concat"].to(dtype), control_hint=inp["control_hint"].to(dtype))
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    old = LY.CONV_N320_MIN_BLOCKS, LY.TOKEN_STREAM, EG.TWO_STREAMS
+    outs = {}
+    try:
+        LY.CONV_N320_MIN_BLOCKS = 1
+        for stream in (True, False):
+            for two in (False,):
+                LY.TOKEN_STREAM, EG.TWO_STREAMS = stream, two
+                hip_ops.PROFILE = [] if not two else None         # (per-op events and the side stream exclude each other)
+                with torch.no_grad():
+                    outs[stream, two] = eng.denoise(inp["x"], inp["sigma"], cond, **kw).float()
+                torch.cuda.synchronize()
+                if not two:
+                    kinds = [rec[0] for rec in hip_ops.PROFILE]
+                    # tokens: the 13 residuals cross without a layout pass (the first convolutions' and, pooled, the residuals' own remain)
+                    assert (kinds.count("rows_concat") > 0) == stream and (kinds.count("concat_add") > 0) == (not stream), sorted(set(kinds))
+                    if stream and not pooled:
+                        assert kinds.count("planes_to_tokens") == 2 and kinds.count("tokens_to_planes_add") == 1, kinds
+    finally:
+        LY.CONV_N320_MIN_BLOCKS, LY.TOKEN_STREAM, EG.TWO_STREAMS = old
+        hip_ops.PROFILE = None
+    ref = outs[False, False]
+    assert torch.isfinite(ref).all() and ref.abs().max() > 0
+    for key, y in outs.items():
+        assert rel(y, ref.double()) < 2e-2, (key, rel(y, ref.double()))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-6), (torch.bfloat16, 2e-2)])
 def test_batched_embedding_projections_equal_the_per_block_ones(dtype, tol):
     """svd/layers.py prepare_emb_projections: one GEMM per output width for every ResBlock's Linear(SiLU(emb)) (+ the bias of
