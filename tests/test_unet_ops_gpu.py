@@ -276,7 +276,7 @@ def test_sample_loop_on_gpu_matches_reference_golden_with_and_without_hint_cache
 
 
 @pytest.mark.parametrize("pooled", [False, True])
-def test_engine_hands_the_control_residuals_over_as_tokens(pooled):
+def test_engine_hands_the_control_residuals_over_as_tokens(c320_nets, pooled):
     """SVDInpaintEngine.apply_model (models/csvd.py:1240-1269) with the token-major residual stream: the ControlNet's 13 residuals reach the
     ControlledVideoUNet as layers.Tok (`tokens_out`), scaled by control_scales != 1 (csvd.py:1262) on the way and — pooled — averaged
     over the image (`global_average_pooling`, :1263-1264: a [N, C, 1, 1] residual the token UNet adds by broadcast on planes).
@@ -289,12 +289,9 @@ def test_engine_hands_the_control_residuals_over_as_tokens(pooled):
     from multiview_inpaint_amd.svd import hip_ops
     from multiview_inpaint_amd.svd import layers as LY
     dtype = torch.bfloat16
-    cunet = ControlledVideoUNet(**H.SMALL_UNET320).eval()
-    cunet.load_state_dict(H.seeded_state_dict(cunet, 51))
-    cnet = ControlNet(**H.SMALL_CTRL320).eval()
-    cnet.load_state_dict(H.seeded_state_dict(cnet, 52))
+    cunet, cnet = c320_nets.get("cunet", dtype), c320_nets.get("cnet", dtype)
     n_res = len(cnet.zero_convs) + 1
-    eng = SVDInpaintEngine(cunet.cuda().to(dtype), cnet.cuda().to(dtype), Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}),
+    eng = SVDInpaintEngine(cunet, cnet, Denoiser({"target": "sgm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}),
                            None, control_scales=[0.5 + 0.1 * i for i in range(n_res)], global_average_pooling=pooled)
     inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(53, hw=H.LATENT_HW320, cfg=H.SMALL_UNET320).items()}
     cond = dict(crossattn=inp["crossattn"].to(dtype), vector=inp["vector"].to(dtype), concat=inp["concat"].to(dtype), control_hint=inp["control_hint"].to(dtype))
@@ -1182,9 +1179,41 @@ def test_hd64_nets_on_a_32x32_latent_run_the_8_wave_kernel_within_the_reference_
           f"error = {worst:.2f}")
 
 
+class _C320Nets:
+    """VideoUNet / ControlledVideoUNet (seed 51) and ControlNet (seed 52) of tests/golden/sgm_c320.npz: the 0.2 B seeded values per
+    network are drawn once (6 s each: a third of the suite's production-width tests was drawing them again) and kept on the GPU in
+    fp32; get(name, dtype) builds a fresh module over a copy in that type."""
+
+    def __init__(self):
+        self.master = {}
+
+    def get(self, name, dt):
+        from sgm.modules.diffusionmodules.video_model import VideoUNet
+        from models.csvd import ControlNet, ControlledVideoUNet
+        cls, cfg, seed = {"unet": (VideoUNet, H.SMALL_UNET320, 51), "cunet": (ControlledVideoUNet, H.SMALL_UNET320, 51),
+                          "cnet": (ControlNet, H.SMALL_CTRL320, 52)}[name]
+        key = "cnet" if name == "cnet" else "unet"             # (the two UNet classes share parameter names and seed)
+        if key not in self.master:
+            with torch.device("meta"):
+                m = cls(**cfg)
+            self.master[key] = {k: v.cuda() for k, v in H.seeded_state_dict(m, seed).items()}
+        with torch.device("meta"):
+            m = cls(**cfg)
+        m.load_state_dict({k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in self.master[key].items()}, strict=True, assign=True)
+        return m.eval()
+
+
+@pytest.fixture(scope="module")
+def c320_nets():
+    holder = _C320Nets()
+    yield holder
+    holder.master = {}
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("stream", ["tokens", "planes"])
 @pytest.mark.parametrize("dtype,tag", [(torch.bfloat16, "bf16ac"), (torch.float16, "f16ac")])
-def test_production_width_nets_run_the_round3_kernels_within_the_reference_autocast_budget(golden_dir, strict, dtype, tag, stream):
+def test_production_width_nets_run_the_round3_kernels_within_the_reference_autocast_budget(golden_dir, strict, c320_nets, dtype, tag, stream):
     """The round-3 kernels under the reference pin: model_channels = 320 and num_head_channels = 64 (the production widths,
     configs/test/svd_f_est_ctrl_simp1.yaml:18-31) on a 16x16 latent, so that INSIDE the module graphs of VideoUNet, ControlNet and
     ControlledVideoUNet the 3x3 convolutions (320 / 640 outputs, K split at this image size) and the (3,1,1) frame convolutions run
@@ -1204,13 +1233,7 @@ def test_production_width_nets_run_the_round3_kernels_within_the_reference_autoc
     from multiview_inpaint_amd.svd import hip_ops
     from multiview_inpaint_amd.svd import layers as LY
     G = np.load(os.path.join(golden_dir, "sgm_c320.npz"))
-    unet = VideoUNet(**H.SMALL_UNET320).eval()
-    unet.load_state_dict(H.seeded_state_dict(unet, 51))
-    cunet = ControlledVideoUNet(**H.SMALL_UNET320).eval()
-    cunet.load_state_dict(H.seeded_state_dict(cunet, 51))
-    cnet = ControlNet(**H.SMALL_CTRL320).eval()
-    cnet.load_state_dict(H.seeded_state_dict(cnet, 52))
-    unet, cunet, cnet = (m.cuda().to(dtype) for m in (unet, cunet, cnet))
+    unet, cunet, cnet = (c320_nets.get(n, dtype) for n in ("unet", "cunet", "cnet"))
     inp = H.seeded_inputs(53, hw=H.LATENT_HW320, cfg=H.SMALL_UNET320)
     inp["image_only_indicator"][0, 1] = 1.0
     inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
