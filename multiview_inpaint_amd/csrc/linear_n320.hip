@@ -86,13 +86,19 @@ template <> struct Mma<__half> {
     __device__ static float hi(uint32_t w) { f16x2 h = *reinterpret_cast<f16x2*>(&w); return (float)h[1]; }
 };
 
+// a pointer every lane of the wave holds the same value of, said to the compiler (the asynchronous loads take their base in scalar registers)
+__device__ __forceinline__ const char* wave_uniform(const char* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(wave_uniform((const char*)sbase)), "v"(voff), "s"(lds_addr) : "memory");
 }
 // 16 bytes per lane, invisible to the compiler's wait-count bookkeeping (see the header): whoever reads the result waits first
 __device__ __forceinline__ u32x4 load16_async(const void* sbase, uint32_t voff) {
     u32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(wave_uniform((const char*)sbase)) : "memory");
     return r;
 }
 
@@ -503,7 +509,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
     // asynchronous load inside a branch ends in a register copy of rows that have not landed (profiles/HISTORY.md, round 5).
     auto load_x_p = [&](int ci, u32x4 (&xr)[4]) __attribute__((always_inline)) {
         const bool nxt = ci >= n_chunks && has_next;
-        const char* const base = nxt ? nx_xbase + (int64_t)(ci - n_chunks) * (kKC * 2) : xbase + (int64_t)(ci < n_chunks ? ci : n_chunks - 1) * (kKC * 2);
+        const char* const base = (nxt ? nx_xbase + (int64_t)(ci - n_chunks) * (kKC * 2) : xbase + (int64_t)(ci < n_chunks ? ci : n_chunks - 1) * (kKC * 2));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint32_t voff = nxt ? nx_x_voff[t] : x_voff[t];
@@ -515,7 +521,7 @@ void linear_n320_kernel(const T* __restrict__ x, const T* __restrict__ w, const 
         if (loader) {
             const int ci = c + 2;
             const bool nxt = ci >= n_chunks && has_next;
-            const char* const base = nxt ? nx_wbase + (int64_t)(ci - n_chunks) * (kKC * 2) : wbase + (int64_t)(ci < n_chunks ? ci : n_chunks - 1) * (kKC * 2);
+            const char* const base = (nxt ? nx_wbase + (int64_t)(ci - n_chunks) * (kKC * 2) : wbase + (int64_t)(ci < n_chunks ? ci : n_chunks - 1) * (kKC * 2));
 #pragma unroll
             for (int i = 0; i < kPiecesPerLoader; ++i)
                 dma_piece(base, p_voff[i], __builtin_amdgcn_readfirstlane(lds0 + islot + 1024u * (uint32_t)(wave + i * kLoaders)));
