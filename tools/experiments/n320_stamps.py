@@ -22,4 +22,15 @@ for (rows, K) in [(28 * 9216, 1280), (28 * 9216, 320)]:
     print(f"linear {rows} x {K}", file=sys.stderr, flush=True)
     for _ in range(3):
         hip_ops.linear_n320(x, w, None)
+# round 6: the GEGLU form on the PLAIN grid (MVI_N320_PERSIST=0: a block = a tile, which is what the stamps record) — what the persistent
+# grid has to hide: the first x / W chunk of a tile (3.5 - 4.7 us beside a 17 - 18 us loop at K = 640). The GEGLU branch leaves before
+# the last stamp: its 'epilogue' and 'gap' columns are not meaningful, tile time - loop - first chunk is (6.6 us at K = 640)
+os.environ["MVI_N320_PERSIST"] = "0"
+for (rows, K, inner) in [(28 * 2304, 640, 2560), (28 * 576, 1280, 5120)]:
+    x = torch.randn(rows, K, device=dev, dtype=torch.bfloat16)
+    w = (torch.randn(2 * inner, K, device=dev) * K ** -0.5).bfloat16()
+    b = torch.randn(2 * inner, device=dev).bfloat16()
+    print(f"geglu {rows} x {K} -> 2 x {inner} (plain grid)", file=sys.stderr, flush=True)
+    for _ in range(3):
+        hip_ops.ff_geglu_n320(x, w, b)
 torch.cuda.synchronize()
