@@ -549,7 +549,8 @@ def test_ff_geglu_n320_persistent_grid_equals_the_plain_grid(ops, dtype, tol, mo
     counts (a last tile with rows past the end), with and without bias, K = 640 / 1280 / 128-chunk-pairs — and the persistent one
     against fp64 on the rounded inputs."""
     g = torch.Generator().manual_seed(47)
-    for rows, K, inner, with_bias in [(4200, 640, 2560, True), (9 * 256 + 5, 1280, 5120, False), (70000, 256, 640, True)]:
+    for rows, K, inner, with_bias in [(4200, 640, 2560, True), (9 * 256 + 5, 1280, 5120, False), (70000, 256, 640, True),
+                                      (4700, 640, 2400, True)]:      # (285 tiles: the eight XCD shares are 35 or 36 tiles)
         x = (torch.randn(rows, K, generator=g) * 1.2).to(dtype)
         w = (torch.randn(2 * inner, K, generator=g) * K ** -0.5).to(dtype)
         b = (torch.randn(2 * inner, generator=g) * 0.3).to(dtype) if with_bias else None
