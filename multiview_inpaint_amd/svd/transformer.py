@@ -456,7 +456,15 @@ class SpatialVideoTransformer(SpatialTransformer):
                     alpha = self.time_mixer.get_alpha(image_only_indicator)
                     if alpha.numel() > 1 and alpha.size(0) != t.size(0):
                         alpha = self.time_mixer.get_alpha(image_only_indicator, rows=t.size(0))   # the reference's CFG patch (util.py:365-367)
-                    alpha = alpha.reshape(-1).to(t.dtype)
+                    # alpha.to(x.dtype) of the reference (util.py:369), kept as the fp32 vector add_lerp takes: converted once per alpha
+                    # object (get_alpha hands out the same tensor while the indicator stands) instead of twice per call (two launches)
+                    hit = self.__dict__.get("_alpha_rows")
+                    if hit is None or hit[0] is not alpha or hit[1] != t.dtype or torch.is_grad_enabled():
+                        rows_alpha = alpha.reshape(-1).to(t.dtype)
+                        hit = (alpha, t.dtype, rows_alpha if torch.is_grad_enabled() else rows_alpha.float())
+                        if not torch.is_grad_enabled():
+                            self.__dict__["_alpha_rows"] = hit
+                    alpha = hit[2]
                 # alpha * spatial + (1 - alpha) * (f + x_t), with the temporal block's last residual add inside
                 t = ops.add_lerp(f if x_t is None else x_t, None if x_t is None else f, x_spatial, alpha)
             else:
