@@ -26,6 +26,96 @@ LOG2E = 1.4426950408889634
 # MVI_ATTN_WEIGHT_FOLD=0: the packed projection keeps to_q.weight as it is and the kernels apply the softmax scale (same-box A/B runs)
 FOLD_SCALE_INTO_WQ = os.environ.get("MVI_ATTN_WEIGHT_FOLD", "1") != "0"
 
+# Cross-attention to the ONE CLIP token of the SVD conditioning (CrossAttention.single_token: `to_out(to_v(ctx))`, a row per image that the
+# residual add broadcasts) was two 28-row GEMMs per layer: 92 launches of ~7.6 us per denoise step for 46 layers whose inputs are the same
+# tensor. prepare_single_token_rows batches them per network call: the row is linear in the token, row = ctx (W_out W_v)^T + b_out, so ONE
+# GEMM per kind against the layers' concatenated products W_out W_v (formed in fp32 once per parameter version, stored in the weights'
+# type: one rounding of the matrix instead of one of the intermediate to_v(ctx) — the same size of error) gives every layer's row; a
+# batched GEMM for the to_out's instead was 27 us per width and took the gain back (tools/experiments/token_rows_probe.py).
+# MVI_SVD_BATCHED_TOKEN_ROWS=0: per layer, as rounds 2 - 5.
+BATCHED_TOKEN_ROWS = os.environ.get("MVI_SVD_BATCHED_TOKEN_ROWS", "1") != "0"
+_row_plans = {}               # id(root) -> (weakref(root), signature, {"s": plan, "t": plan})
+_row_tables = []              # [(ctx, version, {id(attn2): row [n, 1, C]}, base context or None)], newest first
+
+
+def _row_plan(root):
+    """The cross-attention layers under `root` that meet the single context token — attn2 of every BasicTransformerBlock ("s": they see the
+    per-frame context) and of every VideoTransformerBlock ("t": the first frame's token per video) — with, per kind, the layers' products
+    W_out W_v concatenated (layers ordered by width), their to_out biases and where each width's rows sit. Rebuilt when a parameter changes."""
+    import weakref
+    kinds = {"s": [b.attn2 for b in root.modules() if isinstance(b, BasicTransformerBlock) and getattr(b, "attn2", None) is not None],
+             "t": [v.attn2 for v in root.modules() if isinstance(v, VideoTransformerBlock) and getattr(v, "attn2", None) is not None]}
+
+    def ok(a):
+        o = a.to_out
+        return (type(a.to_v) is nn.Linear and a.to_v.bias is None and isinstance(o, nn.Sequential) and len(o) == 2 and type(o[0]) is nn.Linear
+                and o[0].bias is not None and isinstance(o[1], nn.Dropout) and not (o[1].training and o[1].p > 0)
+                and o[0].in_features == a.to_v.out_features)
+    kinds = {k: [a for a in v if ok(a)] for k, v in kinds.items()}
+    params = [p for v in kinds.values() for a in v for p in (a.to_v.weight, a.to_out[0].weight, a.to_out[0].bias)]
+    if len(params) < 12 or any(p.requires_grad and torch.is_grad_enabled() for p in params):
+        return None
+    sig = tuple((id(p), p._version, p.data_ptr()) for p in params)
+    hit = _row_plans.get(id(root))
+    if hit is not None and hit[0]() is root and hit[1] == sig:
+        return hit[2]
+    plans = {}
+    with torch.no_grad():
+        for k, mods in kinds.items():
+            by_width = {}
+            for a in mods:
+                by_width.setdefault((a.to_out[0].out_features, a.to_v.out_features, a.to_v.in_features, a.to_v.weight.dtype, a.to_v.weight.device), []).append(a)
+            if len({(key[2], key[3], key[4]) for key in by_width}) != 1:
+                continue                                        # (one context width, dtype and device per kind, or the per-layer path)
+            order = [a for key in by_width for a in by_width[key]]
+            groups, off = [], 0
+            for (C, _, _, _, _), ms in by_width.items():
+                groups.append((C, off, [id(a) for a in ms]))
+                off += C * len(ms)
+            dt = order[0].to_v.weight.dtype
+            M = torch.cat([(a.to_out[0].weight.float() @ a.to_v.weight.float()).to(dt) for a in order], 0).contiguous()     # [sum C, D]
+            plans[k] = (M, torch.cat([a.to_out[0].bias for a in order], 0).contiguous(), groups)
+    key = id(root)
+    _row_plans[key] = (weakref.ref(root, lambda _r, kk=key: _row_plans.pop(kk, None)), sig, plans)
+    return plans
+
+
+def prepare_single_token_rows(root, context, T):
+    """Fills this step's table of CrossAttention.single_token rows for every eligible layer of `root` (see BATCHED_TOKEN_ROWS): the
+    spatial blocks' from `context` [N, 1, D], the temporal blocks' from the first frame's token of each video (context[::T],
+    video_attention.py:250-254 — the object frame_context_of() hands to SpatialVideoTransformer.forward)."""
+    if not (BATCHED_TOKEN_ROWS and torch.is_tensor(context) and context.is_cuda and context.dim() == 3 and context.shape[1] == 1) \
+            or torch.is_grad_enabled() or context.requires_grad or not T or context.shape[0] % int(T):
+        return
+    plans = _row_plan(root)
+    if not plans:
+        return
+    for kind, ctx, base in (("s", context, None), ("t", frame_context_of(context, T), context)):
+        plan = plans.get(kind)
+        if plan is None:
+            continue
+        M, b, groups = plan
+        if M.dtype != ctx.dtype or M.shape[1] != ctx.shape[-1]:
+            continue
+        n = ctx.shape[0]
+        R = F.linear(ctx.reshape(n, -1), M, b)                                       # [n, sum C]: every layer's to_out(to_v(ctx))
+        table = {}
+        for C, off, ids in groups:
+            out = R[:, off:off + C * len(ids)].reshape(n, len(ids), C).transpose(0, 1).contiguous()    # [L, n, C]: a layer's rows contiguous
+            for k, i in enumerate(ids):
+                table[i] = out[k].unsqueeze(1)
+        _row_tables.insert(0, (ctx, ctx._version, table, base))
+    del _row_tables[4:]                                          # (UNet + ControlNet, two kinds each; both key their temporal rows by ONE
+                                                                 # frame-context object: frame_context_of returns the one in the table)
+
+
+def frame_context_of(context, T):
+    """context[::T] — as the very object the step's table of temporal rows was computed from, when there is one."""
+    for c, ver, _, base in _row_tables:
+        if base is context and base._version == ver and c.shape[0] * int(T) == context.shape[0]:
+            return c
+    return context[::T]
+
 
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
@@ -147,7 +237,13 @@ class CrossAttention(nn.Module):
         return h if fuse is None else ops.finish_add_layer_norm(h, fuse)
 
     def single_token(self, ctx):
-        """Cross-attention to ONE context token: the projected value row (see forward)."""
+        """Cross-attention to ONE context token: the projected value row (see forward) — from this step's batched table when the
+        network prepared one (prepare_single_token_rows), else two small GEMMs here."""
+        for c, ver, table, _ in _row_tables:                    # (UNet and ControlNet see the same context: each has its own table)
+            if c is ctx and ver == ctx._version:
+                hit = table.get(id(self))
+                if hit is not None:
+                    return hit
         return self.to_out(self.to_v(ctx))
 
 
@@ -430,7 +526,7 @@ class SpatialVideoTransformer(SpatialTransformer):
         in_place = (self.use_spatial_context and context is not None and context.ndim == 3 and context.shape[1] == 1
                     and all(not m.disable_self_attn and not m.switch_temporal_ca_to_sa for m in self.time_stack))
         if in_place:
-            frame_context = context[::T]                                       # [b, 1, ctx_dim]
+            frame_context = frame_context_of(context, T)                       # [b, 1, ctx_dim]
         elif self.use_spatial_context:
             assert context.ndim == 3, f"n dims of spatial context should be 3 but are {context.ndim}"
             time_context = context[::T].repeat_interleave(h * w, dim=0)        # first frame's context per pixel

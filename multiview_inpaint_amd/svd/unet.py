@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .layers import (Downsample, TimestepEmbedSequential, Timestep, Tok, Upsample, VideoResBlock, conv_nd, linear, prepare_emb_projections,
                      norm_act, normalization, timestep_embedding, to_planes, to_tok, token_stream_ok, zero_module)
-from .transformer import SpatialVideoTransformer
+from .transformer import SpatialVideoTransformer, prepare_single_token_rows
 from . import ops
 
 STEM_CONV = os.environ.get("MVI_SVD_STEM_CONV", "1") != "0"     # csrc/stem_conv.hip for the 16-channel layers of the hint stem
@@ -178,6 +178,7 @@ class VideoUNet(_Encoder):
                 image_only_indicator=None, control: Optional[List[torch.Tensor]] = None):
         emb = self._embed(x, timesteps, y)
         prepare_emb_projections(self, emb)                # all ResBlock embedding projections of this step as one GEMM per width
+        prepare_single_token_rows(self, context, num_video_frames)   # every cross-attention row to the one CLIP token, batched
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
         tokens = token_stream_ok(x)                        # the residual stream between the blocks held token-major (layers.Tok)
@@ -337,6 +338,7 @@ class ControlNet(_Encoder):
         are returned b c h w, as the reference's."""
         emb = self._embed(x, timesteps, y)
         prepare_emb_projections(self, emb)
+        prepare_single_token_rows(self, context, num_video_frames)
         kw = dict(context=context, image_only_indicator=image_only_indicator, time_context=time_context,
                   num_video_frames=num_video_frames)
         tokens = token_stream_ok(x) and torch.is_tensor(hint)

@@ -275,6 +275,56 @@ def test_sample_loop_on_gpu_matches_reference_golden_with_and_without_hint_cache
     assert dp < 1e-4 and dc < 1e-4                 # north_star: 1e-4 rel on UNet activations
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2.0 ** -6)])
+def test_cross_attention_rows_to_the_single_clip_token_are_batched(c320_nets, dtype, tol):
+    """svd/transformer.py prepare_single_token_rows: `to_out(to_v(context))` of every cross-attention layer that meets the ONE CLIP token
+    (attention.py:332-336 with S_k = 1: the value row, video_attention.py:250-254 for the temporal blocks' first-frame token) computed per
+    network call as one GEMM over the concatenated to_v weights + one batched GEMM per width, against the per-layer rows: every eligible
+    layer is in the table, its row equals the layer's own to a rounding, the network output is unchanged to the rounding of those rows,
+    and changing a weight rebuilds the plan."""
+    from multiview_inpaint_amd.svd import layers as LY
+    from multiview_inpaint_amd.svd import transformer as TR
+    cunet = c320_nets.get("cunet", dtype)
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.seeded_inputs(53, hw=H.LATENT_HW320, cfg=H.SMALL_UNET320).items()}
+    kw = dict(num_video_frames=H.T_FRAMES, image_only_indicator=inp["image_only_indicator"])
+    xin = torch.cat([inp["x"], inp["concat"]], 1).to(dtype)
+    tt = 0.25 * inp["sigma"].log()
+    ctx, vec = inp["crossattn"].to(dtype), inp["vector"].to(dtype)
+    layers_s = [b.attn2 for b in cunet.modules() if isinstance(b, TR.BasicTransformerBlock)]
+    layers_t = [v.attn2 for v in cunet.modules() if isinstance(v, TR.VideoTransformerBlock)]
+    old = LY.CONV_N320_MIN_BLOCKS, TR.BATCHED_TOKEN_ROWS
+    try:
+        LY.CONV_N320_MIN_BLOCKS = 1
+        outs = {}
+        for mode in (False, True):
+            TR.BATCHED_TOKEN_ROWS = mode
+            del TR._row_tables[:]
+            with torch.no_grad():
+                outs[mode] = cunet(xin, tt, ctx, vec, **kw).float()
+            torch.cuda.synchronize()
+            assert len(TR._row_tables) == (2 if mode else 0)
+        tables = {(base is not None): (c, table) for c, _, table, base in TR._row_tables}
+        for temporal, mods in ((False, layers_s), (True, layers_t)):
+            c, table = tables[temporal]
+            assert c.shape[0] == (ctx.shape[0] // H.T_FRAMES if temporal else ctx.shape[0]) and set(table) == {id(a) for a in mods} and len(mods) >= 3
+            with torch.no_grad():
+                for a in mods:
+                    own = a.to_out(a.to_v(c)).float()
+                    assert (table[id(a)].float() - own).abs().max().item() <= tol * max(1.0, own.abs().max().item())
+        assert rel(outs[True], outs[False].double()) < (1e-4 if dtype == torch.float32 else 2e-2)
+        # a changed parameter: the plan is rebuilt, the rows follow
+        with torch.no_grad():
+            layers_s[0].to_out[0].bias.add_(1.0)
+            y2 = cunet(xin, tt, ctx, vec, **kw)
+            c, table = next((c, t) for c, _, t, base in TR._row_tables if base is None)
+            own = layers_s[0].to_out(layers_s[0].to_v(c)).float()
+            layers_s[0].to_out[0].bias.sub_(1.0)
+        assert (table[id(layers_s[0])].float() - own).abs().max().item() <= tol * max(1.0, own.abs().max().item()) and torch.isfinite(y2).all()
+    finally:
+        LY.CONV_N320_MIN_BLOCKS, TR.BATCHED_TOKEN_ROWS = old
+        del TR._row_tables[:]
+
+
 @pytest.mark.parametrize("pooled", [False, True])
 def test_engine_hands_the_control_residuals_over_as_tokens(c320_nets, pooled):
     """SVDInpaintEngine.apply_model (models/csvd.py:1240-1269) with the token-major residual stream: the ControlNet's 13 residuals reach the
