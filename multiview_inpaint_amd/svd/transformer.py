@@ -34,8 +34,9 @@ FOLD_SCALE_INTO_WQ = os.environ.get("MVI_ATTN_WEIGHT_FOLD", "1") != "0"
 # batched GEMM for the to_out's instead was 27 us per width and took the gain back (tools/experiments/token_rows_probe.py).
 # MVI_SVD_BATCHED_TOKEN_ROWS=0: per layer, as rounds 2 - 5.
 BATCHED_TOKEN_ROWS = os.environ.get("MVI_SVD_BATCHED_TOKEN_ROWS", "1") != "0"
+CACHE_FRAME_MLP = os.environ.get("MVI_SVD_CACHE_FRAME_MLP", "1") != "0"       # 0: time_pos_embed evaluated in every call (same-box A/B runs)
 _row_plans = {}               # id(root) -> (weakref(root), signature, {"s": plan, "t": plan})
-_row_tables = []              # [(ctx, version, {id(attn2): row [n, 1, C]}, base context or None)], newest first
+_row_tables = []              # [(ctx, version, {id(attn2): row [n, 1, C]}, base context or None, (id(root), plan signature))], newest first
 
 
 def _row_plan(root):
@@ -90,9 +91,14 @@ def prepare_single_token_rows(root, context, T):
     plans = _row_plan(root)
     if not plans:
         return
+    owner = (id(root), _row_plans[id(root)][1])
     for kind, ctx, base in (("s", context, None), ("t", frame_context_of(context, T), context)):
         plan = plans.get(kind)
         if plan is None:
+            continue
+        # the same context object, unchanged, met by the same network with the same parameters (the steps of a sample): its rows stand
+        old = next((e for e in _row_tables if e[0] is ctx and e[1] == ctx._version and e[3] is base and e[4] == owner), None)
+        if old is not None:
             continue
         M, b, groups = plan
         if M.dtype != ctx.dtype or M.shape[1] != ctx.shape[-1]:
@@ -104,14 +110,14 @@ def prepare_single_token_rows(root, context, T):
             out = R[:, off:off + C * len(ids)].reshape(n, len(ids), C).transpose(0, 1).contiguous()    # [L, n, C]: a layer's rows contiguous
             for k, i in enumerate(ids):
                 table[i] = out[k].unsqueeze(1)
-        _row_tables.insert(0, (ctx, ctx._version, table, base))
+        _row_tables.insert(0, (ctx, ctx._version, table, base, owner))
     del _row_tables[4:]                                          # (UNet + ControlNet, two kinds each; both key their temporal rows by ONE
                                                                  # frame-context object: frame_context_of returns the one in the table)
 
 
 def frame_context_of(context, T):
     """context[::T] — as the very object the step's table of temporal rows was computed from, when there is one."""
-    for c, ver, _, base in _row_tables:
+    for c, ver, _, base, _ in _row_tables:
         if base is context and base._version == ver and c.shape[0] * int(T) == context.shape[0]:
             return c
     return context[::T]
@@ -239,7 +245,7 @@ class CrossAttention(nn.Module):
     def single_token(self, ctx):
         """Cross-attention to ONE context token: the projected value row (see forward) — from this step's batched table when the
         network prepared one (prepare_single_token_rows), else two small GEMMs here."""
-        for c, ver, table, _ in _row_tables:                    # (UNet and ControlNet see the same context: each has its own table)
+        for c, ver, table, _, _ in _row_tables:                 # (UNet and ControlNet see the same context: each has its own table)
             if c is ctx and ver == ctx._version:
                 hit = table.get(id(self))
                 if hit is not None:
@@ -516,6 +522,22 @@ class SpatialVideoTransformer(SpatialTransformer):
             pe = cache[key] = pe.to(wd)
         return pe
 
+    def _frame_embedding_mlp(self, T, b, device):
+        """time_pos_embed(frame-index embedding)[:, None, :] (video_attention.py:256-266): its input depends on the shape only, so outside
+        autograd the MLP's output is kept until one of its parameters changes (two small GEMMs + SiLU per transformer and call: 69
+        launches per denoise step for 23 tensors that never change between steps)."""
+        pe = self._frame_embedding(T, b, device)
+        mlp = self.time_pos_embed
+        if not CACHE_FRAME_MLP or (torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters())):
+            return mlp(pe)[:, None, :]
+        key = (id(pe),) + tuple((p.data_ptr(), p._version) for p in mlp.parameters())
+        hit = self.__dict__.get("_pe_mlp")
+        if hit is None or hit[0] != key or hit[1] is not pe:
+            with torch.no_grad():
+                hit = (key, pe, mlp(pe)[:, None, :])
+            self.__dict__["_pe_mlp"] = hit
+        return hit[2]
+
     def forward(self, x, context=None, time_context=None, timesteps=None, image_only_indicator=None):
         if isinstance(x, Tok) and not self._tok_route_ok(x):
             return to_tok(self.forward(x.planes(), context, time_context, timesteps, image_only_indicator))
@@ -540,7 +562,7 @@ class SpatialVideoTransformer(SpatialTransformer):
             n1, t, _ = ops.linear_add_layer_norm(self._norm_tokens(x), self.proj_in, None, self.transformer_blocks[0].norm1)
         else:
             t = self._tokens_in(x)
-        emb = self.time_pos_embed(self._frame_embedding(T, x.shape[0] // T, x.device))[:, None, :]
+        emb = self._frame_embedding_mlp(T, x.shape[0] // T, x.device)
         alpha = None
         for blk, mix in zip(self.transformer_blocks, self.time_stack):
             if in_place:

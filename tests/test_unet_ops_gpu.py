@@ -303,7 +303,7 @@ def test_cross_attention_rows_to_the_single_clip_token_are_batched(c320_nets, dt
                 outs[mode] = cunet(xin, tt, ctx, vec, **kw).float()
             torch.cuda.synchronize()
             assert len(TR._row_tables) == (2 if mode else 0)
-        tables = {(base is not None): (c, table) for c, _, table, base in TR._row_tables}
+        tables = {(base is not None): (c, table) for c, _, table, base, _ in TR._row_tables}
         for temporal, mods in ((False, layers_s), (True, layers_t)):
             c, table = tables[temporal]
             assert c.shape[0] == (ctx.shape[0] // H.T_FRAMES if temporal else ctx.shape[0]) and set(table) == {id(a) for a in mods} and len(mods) >= 3
@@ -316,7 +316,7 @@ def test_cross_attention_rows_to_the_single_clip_token_are_batched(c320_nets, dt
         with torch.no_grad():
             layers_s[0].to_out[0].bias.add_(1.0)
             y2 = cunet(xin, tt, ctx, vec, **kw)
-            c, table = next((c, t) for c, _, t, base in TR._row_tables if base is None)
+            c, table = next((c, t) for c, _, t, base, _ in TR._row_tables if base is None)
             own = layers_s[0].to_out(layers_s[0].to_v(c)).float()
             layers_s[0].to_out[0].bias.sub_(1.0)
         assert (table[id(layers_s[0])].float() - own).abs().max().item() <= tol * max(1.0, own.abs().max().item()) and torch.isfinite(y2).all()
